@@ -1,0 +1,212 @@
+"""ctypes front end of the CPU oracle (TEST INFRASTRUCTURE -- see oracle/nmf_oracle.c).
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg import this
+module.  The shipped engine (``nmfgpu_amd``) never does.
+
+All matrices are numpy arrays in Fortran (column-major) order, like the reference's
+DeviceMatrix; ``ld`` is taken from the array's strides.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libnmf_oracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libnmfgpu_refhost.so")
+
+ALGORITHMS = {"mu": 0, "gdcls": 1, "als": 2, "acls": 3, "ahcls": 4, "nsnmf": 5}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle (and, if /root/reference is present, the reference host units)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                           for f in ("nmf_oracle.c", "nmf_oracle_impl.h"))):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if os.path.isdir("/root/reference/source/nmf") and not os.path.exists(_REF_PATH):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_num_threads.restype = C.c_int
+        _lib.oracle_summary_best_run.restype = C.c_uint
+        for sfx in ("f32", "f64"):
+            getattr(_lib, f"oracle_resolve_frobenius_{sfx}").restype = C.c_double
+            getattr(_lib, f"oracle_direct_frobenius_{sfx}").restype = C.c_double
+            getattr(_lib, f"oracle_run_{sfx}").restype = C.c_int
+    return _lib
+
+
+def ref_lib():
+    """The reference's own Algorithm.cpp / Summary.cpp (None when not built, e.g. on the GPU box)."""
+    if not os.path.exists(_REF_PATH):
+        if not os.path.isdir("/root/reference/source/nmf"):
+            return None
+        build()
+    r = C.CDLL(_REF_PATH)
+    r.ref_summary_best_run.restype = C.c_uint
+    return r
+
+
+def _sfx(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _f(a: np.ndarray) -> np.ndarray:
+    """Column-major, writable, contiguous-within-column view requirements."""
+    assert a.ndim == 2 and a.flags.f_contiguous, "oracle matrices must be Fortran-ordered 2-D arrays"
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ld(a: np.ndarray) -> int:
+    return a.strides[1] // a.itemsize if a.shape[1] > 1 else max(a.shape[0], 1)
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
+
+
+def seed_stream(seed: int, count: int) -> np.ndarray:
+    out = np.zeros(count, dtype=np.uint32)
+    lib().oracle_seed_stream(C.c_uint32(seed), C.c_int(count), _ptr(out))
+    return out
+
+
+def summary_best_run(frobenius) -> int:
+    f = np.ascontiguousarray(frobenius, dtype=np.float64)
+    return int(lib().oracle_summary_best_run(_ptr(f), C.c_int(len(f))))
+
+
+def gemm_tn(A, B):
+    """A^T B."""
+    s = _sfx(A.dtype); _f(A); _f(B)
+    out = np.zeros((A.shape[1], B.shape[1]), dtype=A.dtype, order="F")
+    getattr(lib(), f"oracle_gemm_tn_{s}")(A.shape[0], A.shape[1], B.shape[1], _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(out), _ld(out))
+    return out
+
+
+def gemm_nt(A, B):
+    """A B^T."""
+    s = _sfx(A.dtype); _f(A); _f(B)
+    out = np.zeros((A.shape[0], B.shape[0]), dtype=A.dtype, order="F")
+    getattr(lib(), f"oracle_gemm_nt_{s}")(A.shape[0], A.shape[1], B.shape[0], _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(out), _ld(out))
+    return out
+
+
+def gemm_nn(A, B):
+    s = _sfx(A.dtype); _f(A); _f(B)
+    out = np.zeros((A.shape[0], B.shape[1]), dtype=A.dtype, order="F")
+    getattr(lib(), f"oracle_gemm_nn_{s}")(A.shape[0], B.shape[1], A.shape[1], _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(out), _ld(out))
+    return out
+
+
+def multiply_divide(X, Num, Den):
+    """In place: X = X * Num / (Den + eps(T))."""
+    s = _sfx(X.dtype)
+    getattr(lib(), f"oracle_multiply_divide_{s}")(X.shape[0], X.shape[1], _ptr(_f(X)), _ld(X), _ptr(_f(Num)), _ld(Num), _ptr(_f(Den)), _ld(Den))
+    return X
+
+
+def normalize_columns(A):
+    s = _sfx(A.dtype)
+    getattr(lib(), f"oracle_normalize_columns_{s}")(A.shape[0], A.shape[1], _ptr(_f(A)), _ld(A))
+    return A
+
+
+def trace_multiplication(transpose_a: bool, A, B):
+    s = _sfx(A.dtype)
+    ps = np.zeros(B.shape[1], dtype=A.dtype)
+    getattr(lib(), f"oracle_trace_multiplication_{s}")(int(transpose_a), B.shape[1], B.shape[0], _ptr(_f(A)), _ld(A), _ptr(_f(B)), _ld(B), _ptr(ps))
+    return ps
+
+
+def vtv_sorted(V):
+    s = _sfx(V.dtype)
+    ps = np.zeros(V.shape[1], dtype=V.dtype)
+    getattr(lib(), f"oracle_vtv_sorted_{s}")(V.shape[0], V.shape[1], _ptr(_f(V)), _ld(V), _ptr(ps))
+    return ps
+
+
+def resolve_frobenius(vtv_sorted_, htwtv, hhtwtw) -> float:
+    s = _sfx(vtv_sorted_.dtype)
+    a = np.ascontiguousarray(vtv_sorted_); b = np.array(htwtv, dtype=a.dtype); c = np.array(hhtwtw, dtype=a.dtype)
+    return float(getattr(lib(), f"oracle_resolve_frobenius_{s}")(_ptr(a), len(a), _ptr(b), len(b), _ptr(c), len(c)))
+
+
+def direct_frobenius(V, W, H) -> float:
+    s = _sfx(V.dtype)
+    return float(getattr(lib(), f"oracle_direct_frobenius_{s}")(V.shape[0], V.shape[1], W.shape[1], _ptr(_f(V)), _ld(V), _ptr(_f(W)), _ld(W), _ptr(_f(H)), _ld(H)))
+
+
+def densify(fmt: str, rows: int, cols: int, values, a, b, base: int = 0, dtype=None):
+    """fmt 'csr': a=rowPtr b=colIdx; 'csc': a=colPtr b=rowIdx; 'coo': a=rowIdx b=colIdx."""
+    values = np.ascontiguousarray(values if dtype is None else np.asarray(values, dtype=dtype))
+    s = _sfx(values.dtype)
+    a = np.ascontiguousarray(a, dtype=np.int32); b = np.ascontiguousarray(b, dtype=np.int32)
+    out = np.zeros((rows, cols), dtype=values.dtype, order="F")
+    if fmt == "coo":
+        getattr(lib(), f"oracle_densify_coo_{s}")(rows, cols, _ptr(values), _ptr(a), _ptr(b), len(values), base, _ptr(out), _ld(out))
+    else:
+        getattr(lib(), f"oracle_densify_{fmt}_{s}")(rows, cols, _ptr(values), _ptr(a), _ptr(b), base, _ptr(out), _ld(out))
+    return out
+
+
+def qr_solve_left(A, X):
+    """X <- A^-1 X by Householder QR (A is overwritten with its factorisation)."""
+    s = _sfx(A.dtype)
+    getattr(lib(), f"oracle_qr_solve_left_{s}")(A.shape[0], _ptr(_f(A)), _ld(A), X.shape[1], _ptr(_f(X)), _ld(X))
+    return X
+
+
+def qr_solve_right(A, X):
+    """X <- X Q R^-T with A = Q R (for symmetric A this is X A^-1)."""
+    s = _sfx(A.dtype)
+    getattr(lib(), f"oracle_qr_solve_right_{s}")(A.shape[0], _ptr(_f(A)), _ld(A), X.shape[0], _ptr(_f(X)), _ld(X))
+    return X
+
+
+def run(algorithm: str, V, W, H, num_iterations: int, *, threshold_type: int = 0, threshold_value: float = 0.0,
+        const_w: bool = False, lam: float = 0.0, lambda_w: float = 0.0, lambda_h: float = 0.0,
+        alpha_w: float = 0.0, alpha_h: float = 0.0, theta: float = 0.0):
+    """One CopyExisting run of the reference's iteration loop.  W and H are updated in place.
+
+    Returns dict(iterations, frobenius, rmsd, history=[(frob, rmsd), ...])."""
+    s = _sfx(V.dtype)
+    assert W.dtype == V.dtype and H.dtype == V.dtype
+    m, n = V.shape
+    r = W.shape[1]
+    assert W.shape == (m, r) and H.shape == (r, n)
+    params = (C.c_double * 6)(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta)
+    frob = C.c_double(0.0); rmsd = C.c_double(0.0)
+    cap = num_iterations // 10 + 2
+    hist = np.zeros((cap, 2), dtype=np.float64)
+    hl = C.c_int(0)
+    it = getattr(lib(), f"oracle_run_{s}")(
+        ALGORITHMS[algorithm], m, n, r, _ptr(_f(V)), _ld(V), _ptr(_f(W)), _ld(W), _ptr(_f(H)), _ld(H),
+        num_iterations, threshold_type, C.c_double(threshold_value), int(const_w), params,
+        C.byref(frob), C.byref(rmsd), _ptr(hist), cap, C.byref(hl))
+    if it < 0:
+        raise ValueError("unknown algorithm")
+    return {"iterations": int(it), "frobenius": frob.value, "rmsd": rmsd.value,
+            "history": [tuple(x) for x in hist[: hl.value]]}

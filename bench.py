@@ -1,0 +1,159 @@
+"""bench.py -- NMF multiplicative-update iterations/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1: BASELINE config 2 -- dense V 10 000 x 5 000, r = 64, Lee-Seung MU (Frobenius), fp32, V resident
+in HBM; one step = one MU iteration (error terms evaluated every 10th iteration, as in the reference's
+loop, source/nmf/SingleGpuDispatcher.cpp:171-201).
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank holds one
+10 000 x 5 000 column shard (global V is 10 000 x 5 000 N), W replicated, one RCCL all-reduce of
+(V H^T | H H^T) per iteration; value = N * K shard-iterations / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, N_COLS, R = 10000, 5000, 64
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS spec"
+
+
+def make_problem(shard: int):
+    """V = U[0,1) fp32 from mt19937(1 + shard); W0, H0 = U(0,1] from seeds 2, 3."""
+    V = np.asfortranarray(np.random.RandomState(1 + shard).random_sample((N_COLS, M)).astype(np.float32).T)
+    W = np.asfortranarray((1.0 - np.random.RandomState(2).random_sample((R, M))).astype(np.float32).T)
+    H = np.asfortranarray((1.0 - np.random.RandomState(3 + 1000 * shard).random_sample((N_COLS, R))).astype(np.float32).T)
+    return V, W, H
+
+
+def cpu_baseline(V, W, H, budget_s: float = 20.0):
+    """The oracle (our CPU port of the reference's iteration) timed on this box's host cores."""
+    from oracle import oracle
+    Wc, Hc = W.copy(order="F"), H.copy(order="F")
+    t0 = time.perf_counter()
+    oracle.run("mu", V, Wc, Hc, 1)
+    first = time.perf_counter() - t0
+    iters = int(max(1, min(10, budget_s // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.run("mu", V, Wc, Hc, iters)
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{iters} MU iterations of the full 10000x5000 r=64 fp32 problem (oracle/nmf_oracle.c, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the factor-product launches with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import nmfgpu_amd as na
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    V, W, H = make_problem(rank)
+    K, Wm = args.steps, args.warmup
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms, kernel_launches = 0.0, 0
+    if not distributed:
+        eng = na.Engine(M, N_COLS, R, "mu", dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream)
+        eng.upload(V)
+        eng.set_factors(W, H)
+        eng.iterate(Wm, first_iteration=1, error_every=10)
+        eng.synchronize()
+        if not args.no_kernel_events:
+            eng.kernel_timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        eng.iterate(K, first_iteration=Wm + 1, error_every=10)
+        eng.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if not args.no_kernel_events:
+            kernel_ms, kernel_launches = eng.kernel_timing_read()
+            eng.kernel_timing(False)
+        frob = eng.frobenius
+        parallelism = "single GPU"
+    else:
+        from nmfgpu_amd.distributed import EngineShard, ShardedMU
+        shard = EngineShard(V, W, H)
+        drv = ShardedMU(shard, total_columns=N_COLS * world, rows=M)
+        drv.run(Wm, first_iteration=1, error_every=10)
+        shard.synchronize()
+        if not args.no_kernel_events:
+            shard.engine.kernel_timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        drv.run(K, first_iteration=Wm + 1, error_every=10)
+        shard.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if not args.no_kernel_events:
+            kernel_ms, kernel_launches = shard.engine.kernel_timing_read()
+        frob = drv.frobenius
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        parallelism = f"column shards x{world}, W replicated, RCCL all-reduce of (V H^T | H H^T) per iteration"
+
+    if rank == 0:
+        flops_per_launch = 2.0 * M * N_COLS * R               # one product against V (algorithmic, unpadded)
+        roofline = None
+        if kernel_launches > 0:
+            avg_s = kernel_ms / 1e3 / kernel_launches
+            achieved = flops_per_launch / avg_s / 1e12
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "k_factor_product_f32", "avg_launch_us": avg_s * 1e6, "launches": kernel_launches,
+                        "flops_per_launch": flops_per_launch}
+        out = {
+            "metric": "NMF MU iterations/sec, dense 10kx5k r=64",
+            "value": world * K / elapsed,
+            "unit": "iterations/s" if world == 1 else "shard-iterations/s (one 10000x5000 column shard per GPU)",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32",
+                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "parallelism": parallelism},
+            "frobenius_last": frob,
+            "iter_flops": 4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS),
+            "achieved_tflops_whole_iteration": (4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS)) * (K / elapsed) / 1e12,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(V, W, H)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

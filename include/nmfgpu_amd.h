@@ -1,0 +1,154 @@
+/* nmfgpu_amd.h -- C-ABI of the MI355X engine BELOW the nmfgpu.h boundary.
+ *
+ * nmfgpu.h (nmfgpu::compute and friends) is the drop-in boundary: host pointers in, host
+ * pointers out, one blocking call per factorisation.  This header exposes the same engine
+ * one level lower, for callers that want V to stay resident in HBM across calls (the benchmark
+ * harness, the column-sharded multi-GPU driver, the per-kernel parity tests).  Plain C: opaque
+ * handles, plain pointers and sizes, int status codes; no C++ or torch types.
+ *
+ * Each entry point names the reference code whose job it does (paths relative to the nmfgpu
+ * v0.2.3 tree).  All matrices are column-major; "ld" is a leading dimension in elements.
+ * The `_f32` / `_f64` suffix is the element type (the reference's NumericType = float / double).
+ */
+#ifndef NMFGPU_AMD_H
+#define NMFGPU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(NMFGPU_EXPORTING)
+#  define NMFAMD_API __attribute__((visibility("default")))
+#else
+#  define NMFAMD_API
+#endif
+
+/* status codes */
+enum {
+	NMFAMD_OK = 0,
+	NMFAMD_INVALID_ARGUMENT = 1,
+	NMFAMD_NO_DEVICE_MEMORY = 2,
+	NMFAMD_NO_HOST_MEMORY = 3,
+	NMFAMD_HIP_ERROR = 4,
+	NMFAMD_NO_DEVICE = 5
+};
+
+/* algorithm ids = nmfgpu::NmfAlgorithm (include/nmfgpu.h:107-114) */
+enum { NMFAMD_MU = 0, NMFAMD_GDCLS = 1, NMFAMD_ALS = 2, NMFAMD_ACLS = 3, NMFAMD_AHCLS = 4, NMFAMD_NSNMF = 5 };
+
+/* sparse formats = nmfgpu::StorageFormat (include/nmfgpu.h:177-186) */
+enum { NMFAMD_DENSE = 0, NMFAMD_CSR = 1, NMFAMD_CSC = 2, NMFAMD_COO = 3 };
+
+/* Algorithm parameters, the reference's name/value list (Interface.cpp:41-49, 249-326) as a struct. */
+typedef struct nmfamd_params {
+	double lambda;   /* GDCLS  "lambda"  */
+	double lambdaW;  /* ACLS / AHCLS "lambdaW" */
+	double lambdaH;  /* ACLS / AHCLS "lambdaH" */
+	double alphaW;   /* AHCLS "alphaW" */
+	double alphaH;   /* AHCLS "alphaH" */
+	double theta;    /* nsNMF "theta" */
+} nmfamd_params;
+
+typedef struct nmfamd_engine nmfamd_engine;  /* opaque; owns every device buffer of one factorisation */
+
+/* Number of visible HIP devices (0 when there is none), and the library's build description. */
+NMFAMD_API int nmfamd_device_count(void);
+NMFAMD_API const char* nmfamd_build_info(void);
+/* Text of the last failed HIP call on this thread's engine (diagnostics only). */
+NMFAMD_API const char* nmfamd_engine_last_error(const nmfamd_engine* e);
+
+/* Creates the device state for V (m x n) ~ W (m x r) H (r x n) on the CURRENT HIP device.
+ * Replaces IAlgorithm::allocateMemory (e.g. AlgorithmMultiplicativeFrobenius.h:85-128) minus the
+ * upload.  elem_bytes: 4 (float) or 8 (double).  stream: a hipStream_t (0 = the null stream);
+ * every kernel and copy of this engine is issued on it. */
+NMFAMD_API int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params* params,
+                                    int elem_bytes, void* stream, nmfamd_engine** out);
+NMFAMD_API void nmfamd_engine_destroy(nmfamd_engine* e);
+
+/* Upload V from host memory; builds V, its transpose and the sorted tr(V^T V) vector.
+ * Replaces DeviceMatrix::copyFrom(inputMatrix) + the trace kernel + host sort
+ * (AlgorithmMultiplicativeFrobenius.h:118-126; sparse -> dense with index base: Matrix.h:145-232). */
+NMFAMD_API int nmfamd_engine_upload_dense(nmfamd_engine* e, const void* V, long ld);
+/* format CSR: a = rowPtr (m+1), b = column indices; CSC: a = columnPtr (n+1), b = row indices;
+ * COO: a = row indices, b = column indices (nnz each).  base = 0 or 1. */
+NMFAMD_API int nmfamd_engine_upload_sparse(nmfamd_engine* e, int format, const void* values, const int* a, const int* b, long nnz, int base);
+
+/* W: m x r, H: r x n, host memory; a null pointer leaves that factor untouched.
+ * Replaces CopyStrategy (source/init/CopyStrategy.h:41-46) and storeFactorization. */
+NMFAMD_API int nmfamd_engine_set_factors(nmfamd_engine* e, const void* W, long ldw, const void* H, long ldh);
+NMFAMD_API int nmfamd_engine_get_factors(nmfamd_engine* e, void* W, long ldw, void* H, long ldh);
+/* Uniform (0,1] fill, the same seed for both factors (source/init/RandomValueStrategy.cpp:29-70). */
+NMFAMD_API int nmfamd_engine_randomize(nmfamd_engine* e, unsigned seed, int w, int h);
+
+/* `count` iterations of IAlgorithm::computeIteration (Algorithm.h:59).  Iterations are numbered
+ * first_iteration, first_iteration+1, ...; the error is evaluated when the number is a multiple of
+ * error_every (10 in the reference, SingleGpuDispatcher.h:37; 0 = never) or equals last_iteration
+ * (0 = no such iteration).  Returns after the work has been ENQUEUED, except that an error
+ * iteration synchronises (the reference does too). */
+NMFAMD_API int nmfamd_engine_iterate(nmfamd_engine* e, int count, int first_iteration, int error_every, int last_iteration, int constant_w);
+NMFAMD_API int nmfamd_engine_synchronize(nmfamd_engine* e);
+/* Frobenius norm / RMSD of the most recent error iteration (IAlgorithm::frobeniusNorm / rmsd). */
+NMFAMD_API double nmfamd_engine_frobenius(const nmfamd_engine* e);
+NMFAMD_API double nmfamd_engine_rmsd(const nmfamd_engine* e);
+
+/* Dominant-kernel timing.  When enabled every launch of the factor-product kernel (the two
+ * products against V, reference: gemm TN / NT at AlgorithmMultiplicativeFrobenius.h:187-188,240-241)
+ * is bracketed by HIP events on the engine's stream.  _read synchronises, returns the summed
+ * duration and the number of launches since the last read, and resets the counters. */
+NMFAMD_API int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable);
+NMFAMD_API int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches);
+
+/* Geometry the harness needs for its roofline arithmetic. */
+typedef struct nmfamd_geometry {
+	int m, n, r;
+	int padded_rank;       /* RP: factor rows as stored and multiplied */
+	long padded_m, padded_n;
+	int slabs_h, slabs_w;  /* split-K slices of the two factor products */
+	long exchange_count;   /* elements of the multi-GPU exchange buffer */
+} nmfamd_geometry;
+NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
+
+/* ---- column-sharded multi-GPU form of the multiplicative update ------------------------------
+ * Rank g holds V(:, J_g), H(:, J_g) and a full replica of W.  Per iteration:
+ *     nmfamd_engine_h_step        local: H(:, J_g) update, no communication
+ *     nmfamd_engine_w_products    local: exchange <- [ (V_g H_g^T)^T panel | H_g H_g^T ]
+ *     <all-reduce(sum) of `exchange` across ranks -- RCCL, done by the caller>
+ *     nmfamd_engine_w_finish      replicated: W update + column normalisation from the reduced sums
+ * `exchange` is a DEVICE pointer to exchange_count elements owned by the caller (so that the
+ * collective library can register it).  On error iterations h_step / w_finish leave the local
+ * error terms on the host: n_local per-column terms of tr(H^T W^T V), r terms of
+ * tr(H H^T W^T W) computed from the REDUCED H H^T, and the sorted local tr(V^T V) terms. */
+NMFAMD_API int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error);
+NMFAMD_API int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange);
+NMFAMD_API int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_error);
+/* which: 0 = sorted tr(V^T V) terms (n), 1 = tr(H^T W^T V) terms (n), 2 = tr(H H^T W^T W) terms (r).
+ * Returns the number of elements copied (<= capacity), negative on error. */
+NMFAMD_API long nmfamd_engine_error_terms(const nmfamd_engine* e, int which, void* out, long capacity);
+/* The host half of the error evaluation (source/nmf/FrobeniusResolver.cpp:29-51) on caller-supplied
+ * term vectors (the two latter ones are sorted in place). */
+NMFAMD_API double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw);
+NMFAMD_API double nmfamd_resolve_frobenius_f64(const double* vtv_sorted, long n_vtv, double* htwtv, long n_htwtv, double* hhtwtw, long n_hhtwtw);
+
+/* ---- single operations on host data (parity tests of the individual kernels) -----------------
+ * OUT (r x X) = F (r x Y) * A^T, A is X x Y: the factor product both big GEMMs are instances of.
+ * out_slabs (optional) receives the number of split-K slabs the MFMA kernel used.
+ * use_valu != 0 selects the generic VALU kernel (the fp64 path) instead of the fp32 MFMA kernel. */
+NMFAMD_API int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const float* F, long ldf, int r,
+                                            float* OUT, long ldo, int use_valu, int* out_slabs);
+NMFAMD_API int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r,
+                                            double* OUT, long ldo);
+/* G (r x r) = P P^T for a host r x len matrix P. */
+NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg);
+/* Ainv = (A + regulariser)^-1 for a host r x r matrix (offdiag / diag added as KernelFillMatrix.cu:29-45). */
+NMFAMD_API int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float diag, float* Ainv, long ldi);
+/* Test access to an engine's device intermediates in panel layout: which = 0 Wt, 1 H, 2 W^T W,
+ * 3 H H^T, 4 slabs, 5 inverse, 6 V, 7 Vt. */
+NMFAMD_API int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMFGPU_AMD_H */

@@ -1,0 +1,74 @@
+"""Build recipe of libnmfgpu64.so (the C-ABI shared library) for gfx950.
+
+    python -m nmfgpu_amd.build            # incremental
+    python -m nmfgpu_amd.build --force
+
+hipcc cross-compiles without a GPU.  The library is built IN TREE (nmfgpu_amd/lib/) so that it
+travels with the repository snapshot to the GPU box; it is git-ignored.  The file name is the
+reference's (source/CMakeLists.txt:78-92) so existing loaders find it.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
+SOURCES = ["kernels.hip", "engine.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
+ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",
+         "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the engine has no CPU fallback and cannot be built without ROCm")
+    return exe
+
+
+def _deps() -> float:
+    newest = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            newest = max(newest, os.path.getmtime(os.path.join(root, f)))
+    return newest
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps():
+        return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmd = [cc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {src} ---\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

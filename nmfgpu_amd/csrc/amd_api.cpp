@@ -1,0 +1,259 @@
+// amd_api.cpp -- the extern "C" entry points of include/nmfgpu_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/nmfgpu_amd.h"
+#include "engine.h"
+
+using namespace nmfamd;
+
+struct nmfamd_engine {
+	int elem_bytes;
+	std::unique_ptr<Engine<float>> f;
+	std::unique_ptr<Engine<double>> d;
+};
+
+namespace {
+template <typename Fn32, typename Fn64>
+int dispatch(nmfamd_engine* e, Fn32 f32, Fn64 f64) {
+	if (!e) return NMFAMD_INVALID_ARGUMENT;
+	return e->elem_bytes == 4 ? (int)f32(*e->f) : (int)f64(*e->d);
+}
+}
+
+namespace {
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 16); if (e == hipSuccess) e = hipMemset(p, 0, bytes ? bytes : 16); return e; }
+};
+
+template <typename T>
+int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, int r, T* OUT, long ldo, bool use_valu, int* out_slabs) {
+	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r);
+	const long Xp = pad128(X), Yp = pad128(Y);
+	int dev = 0; hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	FactorProductPlan plan = plan_factor_product((int)Xp, Y, RP, prop.multiProcessorCount);
+	const bool mfma = std::is_same<T, float>::value && !use_valu;
+	const int S = mfma ? plan.splits : 1;
+	DevBuf dA, dF, dS, dO;
+	const long slab_stride = (long)RP * Xp;
+	if (dA.alloc(sizeof(T) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(T) * RP * Yp) != hipSuccess ||
+	    dS.alloc(sizeof(T) * slab_stride * S) != hipSuccess || dO.alloc(sizeof(T) * slab_stride) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dA.p, Xp * sizeof(T), A, lda * sizeof(T), X * sizeof(T), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dF.p, RP * sizeof(T), F, ldf * sizeof(T), r * sizeof(T), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	hipError_t e;
+	if constexpr (std::is_same<T, float>::value) {
+		if (mfma) e = launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+		else e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
+	} else {
+		e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
+	}
+	if (e != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_reduce_slabs<T>((const T*)dS.p, S, slab_stride, (T*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(OUT, ldo * sizeof(T), dO.p, RP * sizeof(T), r * sizeof(T), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipDeviceSynchronize() != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (out_slabs) *out_slabs = S;
+	return NMFAMD_OK;
+}
+}
+
+extern "C" {
+
+int nmfamd_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+const char* nmfamd_build_info(void) {
+	return "nmfgpu-amd 0.2.3 (gfx950 HIP kernels: fp32 MFMA factor product, fused panel updates; no vendor BLAS)";
+}
+
+const char* nmfamd_engine_last_error(const nmfamd_engine* e) {
+	if (!e) return "";
+	return e->elem_bytes == 4 ? e->f->last_error() : e->d->last_error();
+}
+
+int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params* params, int elem_bytes, void* stream, nmfamd_engine** out) {
+	if (!out || (elem_bytes != 4 && elem_bytes != 8)) return NMFAMD_INVALID_ARGUMENT;
+	*out = nullptr;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	AlgorithmParams p;
+	if (params) { p.lambda = params->lambda; p.lambdaW = params->lambdaW; p.lambdaH = params->lambdaH; p.alphaW = params->alphaW; p.alphaH = params->alphaH; p.theta = params->theta; }
+	nmfamd_engine* e = new (std::nothrow) nmfamd_engine();
+	if (!e) return NMFAMD_NO_HOST_MEMORY;
+	e->elem_bytes = elem_bytes;
+	Status st;
+	try {
+		if (elem_bytes == 4) { e->f.reset(new Engine<float>(m, n, r, algorithm, p)); e->f->set_stream((hipStream_t)stream); st = e->f->allocate(); }
+		else { e->d.reset(new Engine<double>(m, n, r, algorithm, p)); e->d->set_stream((hipStream_t)stream); st = e->d->allocate(); }
+	} catch (const std::bad_alloc&) { delete e; return NMFAMD_NO_HOST_MEMORY; }
+	if (st != ST_OK) { delete e; return (int)st; }
+	*out = e;
+	return NMFAMD_OK;
+}
+
+void nmfamd_engine_destroy(nmfamd_engine* e) { delete e; }
+
+int nmfamd_engine_upload_dense(nmfamd_engine* e, const void* V, long ld) {
+	return dispatch(e, [&](Engine<float>& g) { return g.upload_dense((const float*)V, ld); },
+	                   [&](Engine<double>& g) { return g.upload_dense((const double*)V, ld); });
+}
+
+int nmfamd_engine_upload_sparse(nmfamd_engine* e, int format, const void* values, const int* a, const int* b, long nnz, int base) {
+	return dispatch(e, [&](Engine<float>& g) { return g.upload_sparse(format, (const float*)values, a, b, nnz, base); },
+	                   [&](Engine<double>& g) { return g.upload_sparse(format, (const double*)values, a, b, nnz, base); });
+}
+
+int nmfamd_engine_set_factors(nmfamd_engine* e, const void* W, long ldw, const void* H, long ldh) {
+	return dispatch(e, [&](Engine<float>& g) { return g.set_factors((const float*)W, ldw, (const float*)H, ldh); },
+	                   [&](Engine<double>& g) { return g.set_factors((const double*)W, ldw, (const double*)H, ldh); });
+}
+
+int nmfamd_engine_get_factors(nmfamd_engine* e, void* W, long ldw, void* H, long ldh) {
+	return dispatch(e, [&](Engine<float>& g) { return g.get_factors((float*)W, ldw, (float*)H, ldh); },
+	                   [&](Engine<double>& g) { return g.get_factors((double*)W, ldw, (double*)H, ldh); });
+}
+
+int nmfamd_engine_randomize(nmfamd_engine* e, unsigned seed, int w, int h) {
+	return dispatch(e, [&](Engine<float>& g) { return g.randomize_factors(seed, w != 0, h != 0); },
+	                   [&](Engine<double>& g) { return g.randomize_factors(seed, w != 0, h != 0); });
+}
+
+int nmfamd_engine_iterate(nmfamd_engine* e, int count, int first_iteration, int error_every, int last_iteration, int constant_w) {
+	auto run = [&](auto& g) -> Status {
+		for (int k = 0; k < count; ++k) {
+			const int it = first_iteration + k;
+			const bool err = (error_every > 0 && it % error_every == 0) || (last_iteration > 0 && it == last_iteration);
+			Status s = g.iterate(err, constant_w != 0);
+			if (s != ST_OK) return s;
+		}
+		return ST_OK;
+	};
+	return dispatch(e, run, run);
+}
+
+int nmfamd_engine_synchronize(nmfamd_engine* e) {
+	if (!e) return NMFAMD_INVALID_ARGUMENT;
+	hipStream_t s = e->elem_bytes == 4 ? e->f->stream() : e->d->stream();
+	return hipStreamSynchronize(s) == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+double nmfamd_engine_frobenius(const nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->frobenius() : e->d->frobenius()); }
+double nmfamd_engine_rmsd(const nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->rmsd() : e->d->rmsd()); }
+
+int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable) {
+	return dispatch(e, [&](Engine<float>& g) { g.enable_kernel_timing(enable != 0); return ST_OK; },
+	                   [&](Engine<double>& g) { g.enable_kernel_timing(enable != 0); return ST_OK; });
+}
+
+int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches) {
+	return dispatch(e, [&](Engine<float>& g) { g.dominant_stats(total_ms, launches); return ST_OK; },
+	                   [&](Engine<double>& g) { g.dominant_stats(total_ms, launches); return ST_OK; });
+}
+
+int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
+	if (!e || !out) return NMFAMD_INVALID_ARGUMENT;
+	auto fill = [&](const auto& g) {
+		out->m = g.m(); out->n = g.n(); out->r = g.r(); out->padded_rank = g.rp();
+		out->padded_m = pad128(g.m()); out->padded_n = pad128(g.n());
+		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
+	};
+	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
+	return NMFAMD_OK;
+}
+
+int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error) {
+	return dispatch(e, [&](Engine<float>& g) { return g.h_step(compute_error != 0); },
+	                   [&](Engine<double>& g) { return g.h_step(compute_error != 0); });
+}
+
+int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange) {
+	if (!exchange) return NMFAMD_INVALID_ARGUMENT;
+	return dispatch(e, [&](Engine<float>& g) { return g.w_products((float*)exchange); },
+	                   [&](Engine<double>& g) { return g.w_products((double*)exchange); });
+}
+
+int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_error) {
+	if (!exchange) return NMFAMD_INVALID_ARGUMENT;
+	return dispatch(e, [&](Engine<float>& g) { return g.w_finish((const float*)exchange, compute_error != 0); },
+	                   [&](Engine<double>& g) { return g.w_finish((const double*)exchange, compute_error != 0); });
+}
+
+long nmfamd_engine_error_terms(const nmfamd_engine* e, int which, void* out, long capacity) {
+	if (!e || !out || which < 0 || which > 2) return -1;
+	auto copy = [&](const auto& g) -> long {
+		const auto& v = which == 0 ? g.terms_vtv_sorted() : (which == 1 ? g.terms_htwtv() : g.terms_hhtwtw());
+		long cnt = std::min<long>((long)v.size(), capacity);
+		if (cnt > 0) std::memcpy(out, v.data(), sizeof(v[0]) * (size_t)cnt);
+		return cnt;
+	};
+	return e->elem_bytes == 4 ? copy(*e->f) : copy(*e->d);
+}
+
+double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw) {
+	std::vector<float> a(vtv_sorted, vtv_sorted + n_vtv), b(htwtv, htwtv + n_htwtv), c(hhtwtw, hhtwtw + n_hhtwtw);
+	double f = resolve_frobenius<float>(a, b, c);
+	std::copy(b.begin(), b.end(), htwtv); std::copy(c.begin(), c.end(), hhtwtw);
+	return f;
+}
+
+double nmfamd_resolve_frobenius_f64(const double* vtv_sorted, long n_vtv, double* htwtv, long n_htwtv, double* hhtwtw, long n_hhtwtw) {
+	std::vector<double> a(vtv_sorted, vtv_sorted + n_vtv), b(htwtv, htwtv + n_htwtv), c(hhtwtw, hhtwtw + n_hhtwtw);
+	double f = resolve_frobenius<double>(a, b, c);
+	std::copy(b.begin(), b.end(), htwtv); std::copy(c.begin(), c.end(), hhtwtw);
+	return f;
+}
+
+int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count) {
+	return dispatch(e, [&](Engine<float>& g) { return g.debug_read(which, (float*)out, count); },
+	                   [&](Engine<double>& g) { return g.debug_read(which, (double*)out, count); });
+}
+
+// ---- single operations on host data -------------------------------------------------------
+
+
+int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int use_valu, int* out_slabs) {
+	return op_factor_product<float>(A, lda, X, Y, F, ldf, r, OUT, ldo, use_valu != 0, out_slabs);
+}
+
+int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r, double* OUT, long ldo) {
+	return op_factor_product<double>(A, lda, X, Y, F, ldf, r, OUT, ldo, true, nullptr);
+}
+
+int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg) {
+	if (!P || !G || r <= 0 || len <= 0 || ldp < r || ldg < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r), parts = 64;
+	const long lp = pad128(len);
+	DevBuf dP, dPart, dG;
+	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dPart.alloc(sizeof(float) * (size_t)RP * RP * parts) != hipSuccess || dG.alloc(sizeof(float) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dP.p, RP * sizeof(float), P, ldp * sizeof(float), r * sizeof(float), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_gram<float>((const float*)dP.p, RP, len, parts, (float*)dPart.p, (float*)dG.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(G, ldg * sizeof(float), dG.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float diag, float* Ainv, long ldi) {
+	if (!A || !Ainv || r <= 0 || lda < r || ldi < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r);
+	DevBuf dA, dI, dW;
+	if (dA.alloc(sizeof(float) * RP * RP) != hipSuccess || dI.alloc(sizeof(float) * RP * RP) != hipSuccess || dW.alloc(sizeof(double) * 2 * (size_t)r * r) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dA.p, RP * sizeof(float), A, lda * sizeof(float), r * sizeof(float), r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_fill_small<float>((float*)dA.p, RP, r, 1, offdiag, diag, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_inverse_small<float>((const float*)dA.p, RP, r, (float*)dI.p, (double*)dW.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(Ainv, ldi * sizeof(float), dI.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+} // extern "C"

@@ -1,0 +1,467 @@
+// engine.cpp -- device-resident factorisation state and the per-iteration kernel sequences.
+//
+// Operation order per algorithm follows the reference's computeIteration bodies:
+//   MU     source/nmf/AlgorithmMultiplicativeFrobenius.h:150-248
+//   nsNMF  source/nmf/AlgorithmNonSmoothNMF.h:159-226
+//   GDCLS  source/nmf/AlgorithmGradientDescentConstrainedLeastSquares.h:159-272
+//   ACLS / AHCLS  source/nmf/AlgorithmAlternatingHoyerConstrainedLeastSquares.h:171-296
+//   ALS    source/nmf/AlgorithmAlternatingLeastSquares.h:146-224
+// but the eight vendor-BLAS calls + five custom kernels of one iteration collapse into the
+// fused kernels of kernels.hip (see DESIGN.md section 4 for the mapping).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <type_traits>
+
+namespace nmfamd {
+
+#define HIPX(call)                                        \
+	do {                                                  \
+		hipError_t e__ = (call);                          \
+		if (e__ != hipSuccess) return hip_fail(e__, #call); \
+	} while (0)
+
+template <typename T>
+double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw) {
+	std::sort(htwtv.begin(), htwtv.end());
+	std::sort(hhtwtw.begin(), hhtwtw.end());
+	double acc = 0.0;
+	const size_t mx = std::max(vtv_sorted.size(), std::max(htwtv.size(), hhtwtw.size()));
+	for (size_t j = 0; j < mx; ++j) {
+		if (j < vtv_sorted.size()) acc += vtv_sorted[j];
+		if (j < htwtv.size()) acc -= 2.f * htwtv[j];   // float literal: the product is formed in T, as in the reference
+		if (j < hhtwtw.size()) acc += hhtwtw[j];
+	}
+	return std::sqrt(acc);
+}
+template double resolve_frobenius<float>(const std::vector<float>&, std::vector<float>&, std::vector<float>&);
+template double resolve_frobenius<double>(const std::vector<double>&, std::vector<double>&, std::vector<double>&);
+
+template <typename T>
+Engine<T>::Engine(int m, int n, int r, int algorithm, const AlgorithmParams& params)
+	: m_(m), n_(n), r_(r), RP_(padded_rank(r)), alg_(algorithm), prm_(params), mpad_(pad128(m)), npad_(pad128(n)) {}
+
+template <typename T>
+Status Engine<T>::hip_fail(hipError_t e, const char* what) {
+	last_error_ = what;
+	(void)hipGetLastError();
+	return e == hipErrorOutOfMemory ? ST_NO_DEVICE_MEMORY : ST_HIP_ERROR;
+}
+
+template <typename T>
+Engine<T>::~Engine() {
+	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, psR_, stage_};
+	for (T* b : bufs) if (b) (void)hipFree(b);
+	if (inv_work_) (void)hipFree(inv_work_);
+	if (pin_psN_) (void)hipHostFree(pin_psN_);
+	if (pin_psR_) (void)hipHostFree(pin_psR_);
+	for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+}
+
+template <typename T>
+Status Engine<T>::allocate() {
+	if (m_ <= 0 || n_ <= 0 || r_ <= 0 || alg_ < 0 || alg_ > ALG_NSNMF) return ST_INVALID;
+	int dev = 0;
+	HIPX(hipGetDevice(&dev));
+	hipDeviceProp_t prop;
+	HIPX(hipGetDeviceProperties(&prop, dev));
+	num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+	planH_ = plan_factor_product((int)npad_, m_, RP_, num_cus_);
+	planW_ = plan_factor_product((int)mpad_, n_, RP_, num_cus_);
+	const bool mfma = std::is_same<T, float>::value && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
+	if (!mfma) { planH_.splits = 1; planW_.splits = 1; }
+	slab_stride_ = (long)RP_ * std::max(mpad_, npad_);
+	const long slab_elems = slab_stride_ * std::max(planH_.splits, planW_.splits);
+	const long panelW = (long)RP_ * mpad_, panelH = (long)RP_ * npad_, rr = (long)RP_ * RP_;
+
+	auto dalloc = [&](T** p, long elems) -> hipError_t {
+		hipError_t e = hipMalloc((void**)p, (size_t)elems * sizeof(T));
+		if (e != hipSuccess) return e;
+		return hipMemsetAsync(*p, 0, (size_t)elems * sizeof(T), stream_);
+	};
+	HIPX(dalloc(&V_, mpad_ * npad_));
+	HIPX(dalloc(&Vt_, npad_ * mpad_));
+	HIPX(dalloc(&Wt_, panelW));
+	HIPX(dalloc(&H_, panelH));
+	HIPX(dalloc(&slabs_, slab_elems));
+	HIPX(dalloc(&numW_, panelW));
+	HIPX(dalloc(&G_, rr));
+	HIPX(dalloc(&G2_, rr));
+	HIPX(dalloc(&HHt_, rr));
+	HIPX(dalloc(&Qinv_, rr));
+	HIPX(dalloc(&gram_part_, rr * gram_parts_));
+	HIPX(dalloc(&sumsq_part_, (mpad_ / panel_update_rows(RP_, sizeof(T))) * RP_));
+	HIPX(dalloc(&psN_, std::max<long>(npad_, RP_)));
+	HIPX(dalloc(&psR_, RP_));
+	HIPX(dalloc(&stage_, std::max(mpad_, npad_) * RP_));
+	if (alg_ == ALG_NSNMF) {
+		HIPX(dalloc(&Ws_, panelW));
+		HIPX(dalloc(&Hs_, panelH));
+	}
+	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
+		HIPX(dalloc(&Wold_, panelW));
+		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
+	}
+	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)std::max<long>(n_, r_)));
+	HIPX(hipHostMalloc((void**)&pin_psR_, sizeof(T) * (size_t)r_));
+	HIPX(hipStreamSynchronize(stream_));
+	return ST_OK;
+}
+
+// ---- upload / download --------------------------------------------------------------------
+
+template <typename T>
+Status Engine<T>::upload_dense(const T* V, long ld) {
+	if (!V || ld < m_) return ST_INVALID;
+	HIPX(hipMemcpy2DAsync(V_, mpad_ * sizeof(T), V, ld * sizeof(T), m_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_));
+	HIPX(launch_transpose<T>(V_, mpad_, m_, n_, Vt_, npad_, stream_));
+	HIPX(launch_column_sumsq<T>(V_, mpad_, m_, n_, psN_, stream_));
+	h_vtv_.resize(n_);
+	HIPX(hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	std::sort(h_vtv_.begin(), h_vtv_.end());
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const int* b, long nnz, int base) {
+	if (format < 1 || format > 3 || nnz < 0 || (nnz > 0 && (!values || !a || !b))) return ST_INVALID;
+	T* d_val = nullptr; int *d_a = nullptr, *d_b = nullptr;
+	const int outer = format == 1 ? m_ : n_;
+	const long na = format == 3 ? nnz : (long)outer + 1;
+	Status st = ST_OK;
+	do {
+		hipError_t e;
+		if ((e = hipMalloc((void**)&d_val, sizeof(T) * (size_t)std::max<long>(nnz, 1))) != hipSuccess ||
+		    (e = hipMalloc((void**)&d_a, sizeof(int) * (size_t)std::max<long>(na, 1))) != hipSuccess ||
+		    (e = hipMalloc((void**)&d_b, sizeof(int) * (size_t)std::max<long>(nnz, 1))) != hipSuccess) { st = hip_fail(e, "hipMalloc(sparse staging)"); break; }
+		if (nnz > 0) {
+			if ((e = hipMemcpyAsync(d_val, values, sizeof(T) * nnz, hipMemcpyHostToDevice, stream_)) != hipSuccess ||
+			    (e = hipMemcpyAsync(d_b, b, sizeof(int) * nnz, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse)"); break; }
+		}
+		if (na > 0 && (e = hipMemcpyAsync(d_a, a, sizeof(int) * na, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse ptr)"); break; }
+		if ((e = hipMemsetAsync(V_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_)) != hipSuccess) { st = hip_fail(e, "hipMemsetAsync(V)"); break; }
+		// CSR: ptr = a (rowPtr), idx = b (columns); CSC: ptr = a (columnPtr), idx = b (rows); COO: idx = a (rows), idx2 = b (columns)
+		if (format == 3) e = launch_densify<T>(3, d_val, nullptr, d_a, d_b, nnz, 0, base, V_, mpad_, m_, n_, stream_);
+		else e = launch_densify<T>(format, d_val, d_a, d_b, nullptr, nnz, outer, base, V_, mpad_, m_, n_, stream_);
+		if (e != hipSuccess) { st = hip_fail(e, "densify"); break; }
+		if ((e = launch_transpose<T>(V_, mpad_, m_, n_, Vt_, npad_, stream_)) != hipSuccess ||
+		    (e = launch_column_sumsq<T>(V_, mpad_, m_, n_, psN_, stream_)) != hipSuccess) { st = hip_fail(e, "transpose/sumsq"); break; }
+		h_vtv_.resize(n_);
+		if ((e = hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_)) != hipSuccess ||
+		    (e = hipStreamSynchronize(stream_)) != hipSuccess) { st = hip_fail(e, "sync(sparse upload)"); break; }
+		std::sort(h_vtv_.begin(), h_vtv_.end());
+	} while (0);
+	if (d_val) (void)hipFree(d_val);
+	if (d_a) (void)hipFree(d_a);
+	if (d_b) (void)hipFree(d_b);
+	return st;
+}
+
+template <typename T>
+Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
+	if (W) {
+		if (ldw < m_) return ST_INVALID;
+		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
+		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
+		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
+		HIPX(launch_transpose<T>(stage_, mpad_, m_, r_, Wt_, RP_, stream_));
+	}
+	if (H) {
+		if (ldh < r_) return ST_INVALID;
+		HIPX(hipMemsetAsync(H_, 0, sizeof(T) * (size_t)RP_ * npad_, stream_));
+		HIPX(hipMemcpy2DAsync(H_, RP_ * sizeof(T), H, ldh * sizeof(T), r_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_));
+	}
+	HIPX(hipStreamSynchronize(stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
+	if (W) {
+		if (ldw < m_) return ST_INVALID;
+		const T* src = Wt_;
+		if (alg_ == ALG_NSNMF) {
+			// storeFactorization returns W S (AlgorithmNonSmoothNMF.h:221-225)
+			const T off = (T)prm_.theta / (T)(unsigned)r_;
+			const T diag = (T)((1.0 - (T)prm_.theta) + off);
+			HIPX(launch_smooth_panel<T>(Wt_, Ws_, RP_, r_, mpad_, off, diag, stream_));
+			src = Ws_;
+		}
+		HIPX(launch_transpose<T>(src, RP_, r_, m_, stage_, mpad_, stream_));
+		HIPX(hipMemcpy2DAsync(W, ldw * sizeof(T), stage_, mpad_ * sizeof(T), m_ * sizeof(T), r_, hipMemcpyDeviceToHost, stream_));
+	}
+	if (H) {
+		if (ldh < r_) return ST_INVALID;
+		HIPX(hipMemcpy2DAsync(H, ldh * sizeof(T), H_, RP_ * sizeof(T), r_ * sizeof(T), n_, hipMemcpyDeviceToHost, stream_));
+	}
+	HIPX(hipStreamSynchronize(stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
+	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
+	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
+	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_));
+	return ST_OK;
+}
+
+// ---- the two big products ------------------------------------------------------------------
+
+template <typename T>
+void Engine<T>::record_begin() {
+	if (!timing_) return;
+	if (ev_used_ + 2 > ev_.size()) {
+		for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev_.push_back(e); }
+	}
+	(void)hipEventRecord(ev_[ev_used_], stream_);
+}
+
+template <typename T>
+void Engine<T>::record_end() {
+	if (!timing_ || ev_used_ + 2 > ev_.size()) return;
+	(void)hipEventRecord(ev_[ev_used_ + 1], stream_);
+	ev_used_ += 2;
+}
+
+template <typename T>
+void Engine<T>::dominant_stats(double* total_ms, long* launches) {
+	double tot = 0; long cnt = 0;
+	(void)hipStreamSynchronize(stream_);
+	for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+	}
+	ev_used_ = 0;
+	if (total_ms) *total_ms = tot;
+	if (launches) *launches = cnt;
+}
+
+template <typename T>
+Status Engine<T>::product_h(const T* F) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (planH_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+			record_begin();
+			HIPX(launch_factor_product_f32(planH_, Vt_, npad_, F, RP_, slabs_, slab_stride_, stream_));
+			record_end();
+			return ST_OK;
+		}
+	}
+	record_begin();
+	HIPX(launch_factor_product_valu<T>(Vt_, npad_, (int)npad_, m_, F, RP_, slabs_, stream_));
+	record_end();
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::product_w(const T* F) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (planW_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+			record_begin();
+			HIPX(launch_factor_product_f32(planW_, V_, mpad_, F, RP_, slabs_, slab_stride_, stream_));
+			record_end();
+			return ST_OK;
+		}
+	}
+	record_begin();
+	HIPX(launch_factor_product_valu<T>(V_, mpad_, (int)mpad_, n_, F, RP_, slabs_, stream_));
+	record_end();
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::normal_inverse(T* A, T offdiag, T diag) {
+	HIPX(launch_fill_small<T>(A, RP_, r_, 1, offdiag, diag, stream_));
+	HIPX(launch_inverse_small<T>(A, RP_, r_, Qinv_, inv_work_, stream_));
+	return ST_OK;
+}
+
+// ---- error terms ----------------------------------------------------------------------------
+
+template <typename T>
+Status Engine<T>::fetch_error_terms(int count_n) {
+	HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * count_n, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipMemcpyAsync(pin_psR_, psR_, sizeof(T) * r_, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	h_psN_.assign(pin_psN_, pin_psN_ + count_n);
+	h_psR_.assign(pin_psR_, pin_psR_ + r_);
+	return ST_OK;
+}
+
+template <typename T>
+void Engine<T>::resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements) {
+	frob_ = resolve_frobenius<T>(vtv_sorted, htwtv, hhtwtw);
+	rmsd_ = frob_ / std::sqrt((double)total_elements);
+}
+
+// ---- iteration --------------------------------------------------------------------------------
+
+template <typename T>
+Status Engine<T>::h_step(bool compute_error) {
+	const T eps = std::numeric_limits<T>::epsilon();
+	const T* F = Wt_;
+	if (alg_ == ALG_NSNMF) {
+		const T off = (T)prm_.theta / (T)(unsigned)r_;
+		const T diag = (T)((1.0 - (T)prm_.theta) + off);
+		HIPX(launch_smooth_panel<T>(Wt_, Ws_, RP_, r_, mpad_, off, diag, stream_));
+		F = Ws_;
+	}
+	HIPX(launch_gram<T>(F, RP_, m_, gram_parts_, gram_part_, G_, stream_));
+	if (Status s = product_h(F)) return s;
+	const int S = planH_.splits;
+	if (alg_ == ALG_MU || alg_ == ALG_NSNMF) {
+		HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, S, slab_stride_, G_, RP_, (int)npad_, eps,
+		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_));
+	} else {
+		T off = 0, diag = 0;
+		if (alg_ == ALG_GDCLS) diag = (T)prm_.lambda;
+		else if (alg_ == ALG_ACLS) diag = (T)prm_.lambdaH;
+		else if (alg_ == ALG_AHCLS) {
+			const T lam = (T)prm_.lambdaH, alpha = (T)prm_.alphaH;
+			T beta = (T)((1 - alpha) * std::sqrt((double)(unsigned)r_) + alpha);
+			beta *= beta;
+			off = -lam; diag = lam * beta - lam;
+		}
+		if (compute_error) HIPX(hipMemcpyAsync(G2_, G_, sizeof(T) * (size_t)RP_ * RP_, hipMemcpyDeviceToDevice, stream_));
+		if (Status s = normal_inverse(G_, off, diag)) return s;
+		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
+		                            nullptr, n_, nullptr, nullptr, stream_));
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::w_products(T* exchange) {
+	if (alg_ != ALG_MU) return ST_INVALID;
+	T* ex_hht = exchange + (long)RP_ * mpad_;
+	HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, ex_hht, stream_));
+	if (Status s = product_w(H_)) return s;
+	HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
+	if (alg_ != ALG_MU) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	const T* ex_hht = exchange + (long)RP_ * mpad_;
+	if (compute_error) {
+		HIPX(launch_trace_small<T>(ex_hht, G_, RP_, r_, psR_, stream_));
+		if (Status s = fetch_error_terms(n_)) return s;
+	}
+	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_));
+	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, (int)(mpad_ / panel_update_rows(RP_, sizeof(T))), stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::iterate(bool compute_error, bool constant_w) {
+	const T eps = std::numeric_limits<T>::epsilon();
+	const int norm_parts = (int)(mpad_ / panel_update_rows(RP_, sizeof(T)));
+	if (Status s = h_step(compute_error)) return s;
+
+	const bool ls_family = alg_ == ALG_ALS || alg_ == ALG_ACLS || alg_ == ALG_AHCLS;
+	int error_terms_n = n_;   // length of the tr(H^T W^T V) term vector
+
+	if (!(constant_w && !compute_error)) {
+		const T* Fh = H_;
+		if (alg_ == ALG_NSNMF) {
+			const T off = (T)prm_.theta / (T)(unsigned)r_;
+			const T diag = (T)((1.0 - (T)prm_.theta) + off);
+			HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, diag, stream_));
+			Fh = Hs_;
+		}
+		HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
+		if (compute_error) {
+			const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
+				HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
+				wtw = G2_;
+			} else if (alg_ != ALG_MU) wtw = G2_;               // LS algorithms: copy saved before the regulariser
+			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_));
+		}
+		if (!constant_w) {
+			if (Status s = product_w(Fh)) return s;
+			const int S = planW_.splits;
+			if (!ls_family) {
+				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
+				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
+				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_));
+				HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+				if (gd_err) {
+					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
+					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+					error_terms_n = r_;
+				}
+			} else {
+				T off = 0, diag = 0;
+				if (alg_ == ALG_ACLS) diag = (T)prm_.lambdaW;
+				else if (alg_ == ALG_AHCLS) {
+					const T lam = (T)prm_.lambdaW, alpha = (T)prm_.alphaW;
+					T beta = (T)((1 - alpha) * std::sqrt((double)(unsigned)r_) + alpha);
+					beta *= beta;
+					off = -lam; diag = lam * beta - lam;
+				}
+				if (Status s = normal_inverse(HHt_, off, diag)) return s;
+				if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
+				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
+				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_));
+				if (compute_error) {
+					// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
+					HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));
+					error_terms_n = r_;
+				}
+				HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+			}
+		} else if (compute_error && alg_ != ALG_MU && alg_ != ALG_NSNMF) {
+			// constant basis vectors, LS algorithms: the reference's trace reads W against itself
+			// (ALS/ACLS/AHCLS :199-205 with W never overwritten) or a stale buffer (GDCLS); here:
+			// ALS family as the reference, GDCLS the product the formula names.
+			if (ls_family) {
+				HIPX(launch_row_dot<T>(Wt_, Wt_, RP_, r_, mpad_, psN_, stream_));
+			} else {
+				if (Status s = product_w(Fh)) return s;
+				HIPX(launch_panel_update<T>(PANEL_SET, numW_, slabs_, planW_.splits, slab_stride_, HHt_, RP_, (int)mpad_, eps,
+				                            nullptr, m_, nullptr, nullptr, stream_));
+				HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+			}
+			error_terms_n = r_;
+		}
+	}
+	if (compute_error) {
+		if (Status s = fetch_error_terms(error_terms_n)) return s;
+		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::debug_read(int which, T* out, long count) {
+	const T* src = nullptr; long avail = 0;
+	switch (which) {
+	case 0: src = Wt_; avail = (long)RP_ * mpad_; break;
+	case 1: src = H_; avail = (long)RP_ * npad_; break;
+	case 2: src = G_; avail = (long)RP_ * RP_; break;
+	case 3: src = HHt_; avail = (long)RP_ * RP_; break;
+	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
+	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
+	case 6: src = V_; avail = mpad_ * npad_; break;
+	case 7: src = Vt_; avail = mpad_ * npad_; break;
+	default: return ST_INVALID;
+	}
+	if (count > avail) return ST_INVALID;
+	HIPX(hipMemcpyAsync(out, src, sizeof(T) * count, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	return ST_OK;
+}
+
+template class Engine<float>;
+template class Engine<double>;
+
+} // namespace nmfamd

@@ -1,0 +1,129 @@
+// engine.h -- device-resident state and per-iteration orchestration of one factorisation
+// (internal header).  This is the MI355X-native replacement of the reference's L2/L1 layers:
+// IAlgorithm + the five Algorithm*.h classes (source/nmf/Algorithm.h:38-77) and DeviceMatrix
+// (source/common/Matrix.h:446-645).  Everything stays in HBM between upload and download;
+// the host sees n + r partial sums on error iterations, exactly like the reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+enum Algorithm { ALG_MU = 0, ALG_GDCLS = 1, ALG_ALS = 2, ALG_ACLS = 3, ALG_AHCLS = 4, ALG_NSNMF = 5 };
+
+struct AlgorithmParams {
+	double lambda = 0, lambdaW = 0, lambdaH = 0, alphaW = 0, alphaH = 0, theta = 0;
+};
+
+// Status codes shared with nmfgpu_amd.h (NMFAMD_*).
+enum Status { ST_OK = 0, ST_INVALID = 1, ST_NO_DEVICE_MEMORY = 2, ST_NO_HOST_MEMORY = 3, ST_HIP_ERROR = 4, ST_NO_DEVICE = 5 };
+
+inline int padded_rank(int r) { return r <= 64 ? 64 : ((r + 127) / 128) * 128; }
+inline long pad128(long v) { return ((v + 127) / 128) * 128; }
+
+template <typename T>
+class Engine {
+public:
+	Engine(int m, int n, int r, int algorithm, const AlgorithmParams& params);
+	~Engine();
+
+	Status allocate();
+	void set_stream(hipStream_t s) { stream_ = s; }
+	hipStream_t stream() const { return stream_; }
+
+	// V: host, column-major / sparse.  Builds V, Vt and the sorted tr(V^T V) vector.
+	Status upload_dense(const T* V, long ld);
+	Status upload_sparse(int format, const T* values, const int* a, const int* b, long nnz, int base);
+
+	// W: host m x r (ld), H: host r x n (ld).  Either pointer may be null (leave as is).
+	Status set_factors(const T* W, long ldw, const T* H, long ldh);
+	Status get_factors(T* W, long ldw, T* H, long ldh);   // nsNMF returns W S, like the reference
+	Status randomize_factors(unsigned seed, bool w, bool h);
+
+	// One iteration.  With compute_error the frobenius()/rmsd() values are refreshed (host sync).
+	Status iterate(bool compute_error, bool constant_w);
+
+	// Split form for column-sharded multi-GPU runs (exchange = device buffer of exchange_count()
+	// elements: the local (V H^T)^T panel followed by the local H H^T):
+	//   h_step -> w_products(exchange) -> [all-reduce exchange across ranks] -> w_finish(exchange)
+	Status h_step(bool compute_error);
+	Status w_products(T* exchange);
+	Status w_finish(const T* exchange, bool compute_error);
+	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_; }
+	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
+	const std::vector<T>& terms_htwtv() const { return h_psN_; }
+	const std::vector<T>& terms_hhtwtw() const { return h_psR_; }
+	const std::vector<T>& terms_vtv_sorted() const { return h_vtv_; }
+	void resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);
+
+	double frobenius() const { return frob_; }
+	double rmsd() const { return rmsd_; }
+
+	// Timing of the dominant kernel (the factor product): when enabled, every launch is bracketed
+	// by HIP events on the engine's stream; dominant_stats reads them back (host sync).
+	void enable_kernel_timing(bool on) { timing_ = on; }
+	void dominant_stats(double* total_ms, long* launches);
+
+	int m() const { return m_; }
+	int n() const { return n_; }
+	int r() const { return r_; }
+	int rp() const { return RP_; }
+	int slabs_h() const { return planH_.splits; }
+	int slabs_w() const { return planW_.splits; }
+	const char* last_error() const { return last_error_; }
+
+	// test access to device intermediates (panel layout, host copies)
+	Status debug_read(int which, T* out, long count);
+
+private:
+	Status hip_fail(hipError_t e, const char* what);
+	Status product_h(const T* F);                    // slabs_ <- partials of F V   (r x n)
+	Status product_w(const T* F);                    // slabs_ <- partials of (V F^T)^T (r x m)
+	Status normal_inverse(T* A, T offdiag, T diag);  // A <- (A + regulariser)^-1
+	Status fetch_error_terms(int count_n);
+	void record_begin();
+	void record_end();
+
+	int m_, n_, r_, RP_, alg_;
+	AlgorithmParams prm_;
+	long mpad_, npad_;
+	int num_cus_ = 256;
+	hipStream_t stream_ = nullptr;
+	bool own_everything_ = false;
+	const char* last_error_ = "";
+
+	T *V_ = nullptr, *Vt_ = nullptr;
+	T *Wt_ = nullptr, *H_ = nullptr;          // factor panels
+	T *Ws_ = nullptr, *Hs_ = nullptr;         // nsNMF: smoothed copies (W S)^T and S H
+	T *slabs_ = nullptr;
+	T *numW_ = nullptr;                       // reduced (V H^T)^T panel (LS family error terms, sharded runs)
+	T *Wold_ = nullptr;                       // LS family: W before the update
+	T *G_ = nullptr, *G2_ = nullptr, *HHt_ = nullptr, *Qinv_ = nullptr, *gram_part_ = nullptr;
+	T *sumsq_part_ = nullptr;
+	T *psN_ = nullptr, *psR_ = nullptr;
+	double* inv_work_ = nullptr;
+	T* stage_ = nullptr;                      // upload/download staging (max(m, n) x r)
+	long slab_stride_ = 0;
+	int gram_parts_ = 64;
+	FactorProductPlan planH_, planW_;
+
+	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
+	std::vector<T> h_vtv_, h_psN_, h_psR_;
+	double frob_ = 0, rmsd_ = 0;
+
+	bool timing_ = false;
+	std::vector<hipEvent_t> ev_;
+	size_t ev_used_ = 0;
+};
+
+// Host-side part of the error evaluation: sorted, interleaved accumulation in double
+// (source/nmf/FrobeniusResolver.cpp:29-51).  The two iteration-dependent vectors are sorted here.
+template <typename T>
+double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw);
+
+} // namespace nmfamd

@@ -1,0 +1,78 @@
+// kernels.h -- launcher prototypes of the gfx950 kernels in kernels.hip (internal header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nmfamd {
+
+// How one factor product OUT(c, x) = sum_y F(c, y) A(x, y) is cut into workgroups.
+struct FactorProductPlan {
+	int xtiles;       // 128-row tiles of the output index x
+	int steps_total;  // reduction length in MFMA K-steps (two y per step)
+	int splits;       // workgroup slices of the reduction range = number of output slabs
+	int nb;           // 32-wide N-blocks per wave tile (2 or 4)
+	int chunks;       // launches needed to cover RP = chunks * 32 * nb factor rows
+};
+
+FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);
+
+// slabs: plan.splits partial results, slab s at slabs + s * slab_stride, panel layout [x][RP].
+hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                                     float* slabs, long slab_stride, hipStream_t stream);
+
+// Generic (VALU) form, writes the finished panel (no slabs).  Xpad multiple of 64, RP multiple of 32.
+template <typename T>
+hipError_t launch_factor_product_valu(const T* A, long lda, int Xpad, int Y, const T* F, int RP, T* out, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_reduce_slabs(const T* slabs, int S, long slab_stride, T* out, long count, hipStream_t stream);
+
+// G = P P^T over len panel columns; partial holds parts * RP * RP elements of scratch.
+template <typename T>
+hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G, hipStream_t stream);
+
+enum PanelMode { PANEL_MU = 0, PANEL_LS = 1, PANEL_SET = 2 };
+int panel_update_rows(int RP, size_t elem);
+
+// See k_panel_update.  sumsq_part needs (len_pad / panel_update_rows) * RP elements.
+template <typename T>
+hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_normalize_panel(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, hipStream_t stream);
+
+// work: 2 * r * r doubles
+template <typename T>
+hipError_t launch_inverse_small(const T* A, int RP, int r, T* Ainv, double* work, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_transpose(const T* src, long lds, int rows, int cols, T* dst, long ldd, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream);
+
+// format: 1 CSR (ptr = rowPtr, idx = column indices), 2 CSC (ptr = columnPtr, idx = row indices),
+// 3 COO (idx = row indices, idx2 = column indices); outer = rows (CSR) / columns (CSC).
+template <typename T>
+hipError_t launch_densify(int format, const T* values, const int* ptr, const int* idx, const int* idx2, long nnz, int outer, int base,
+                          T* V, long ldv, int rows, int cols, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
+
+} // namespace nmfamd

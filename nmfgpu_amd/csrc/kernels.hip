@@ -1,0 +1,786 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the NMF hot path and their launchers.
+//
+// Data layout in HBM:
+//   * V   : column-major m x n, leading dimension padded to 128 rows, zero padding.
+//   * Vt  : the transpose of V, column-major n x m, same padding.  V never changes during a
+//           factorisation, so both orientations are kept resident; every product against V
+//           then streams a matrix whose OUTPUT index is the contiguous one.
+//   * factor panels (Wt = W^T, H, and every r x len intermediate such as W^T V or (V H^T)^T):
+//           "panel layout" -- element (c, y) at P[y * RP + c], RP = padded rank, len padded to
+//           128, zero padding.
+//
+// The two big products of every algorithm (reference: cublas gemm-TN `W^T V` and gemm-NT
+// `V H^T`, source/common/Matrix.h:361-376 called from
+// source/nmf/AlgorithmMultiplicativeFrobenius.h:187-188,240-241) are one kernel here:
+//       OUT(c, x) = sum_y F(c, y) * A(x, y)          "factor product"
+//   W^T V     : A = Vt (x = column of V, y = row of V), F = Wt   -> OUT in H's layout
+//   (V H^T)^T : A = V  (x = row of V,    y = column of V), F = H -> OUT in Wt's layout
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// factor product, fp32 MFMA
+// ------------------------------------------------------------------------------------------
+//
+// One workgroup = 8 waves (two per SIMD, one workgroup per CU) = one 128-row x-tile times one
+// slice of the y (reduction) range; the slice is cut again into 8 contiguous pieces, one per
+// wave.  A wave keeps the whole 128 x (32*NB) output tile in 4*NB MFMA accumulators and
+// streams its y piece two columns per v_mfma_f32_32x32x2_f32:
+//
+//   A operand (32 x 2): lane l holds A(x0 + 4*(l&31) + b, y + (l>>5)) for b = 0..3 -- ONE 16-byte
+//       load per lane (512 contiguous bytes per half wave); component b feeds M-block b, i.e.
+//       MFMA row i of block b is matrix row x0 + 4*i + b (the row order inside a tile is free).
+//   B operand (2 x 32): lane l holds F(coff + NB*(l&31) + nb, y + (l>>5)) for nb = 0..NB-1 -- one
+//       4*NB-byte load; MFMA column j of N-block nb is factor row coff + NB*j + nb.
+//
+// No LDS and no barrier in the main loop: operands go global -> VGPR through a D-deep register
+// ring, the other wave on the SIMD covers what the ring does not.  The eight per-wave partial
+// tiles are then summed through LDS in a fixed order (wave 0..7) and written as one fp32 slab
+// per workgroup slice; slabs are summed in slice order by the consumer, so the result is
+// deterministic (no atomics).
+//
+// Numerics: every accumulator is a k-ordered fmaf chain (the MFMA is exact fp32), see
+// oracle_emulate_factor_product_f32 for the bit-exact restatement used by the tests.
+
+constexpr int FP_WAVES = 8;
+constexpr int FP_XT = 128;
+
+template <int NB> struct FVec;
+template <> struct FVec<2> { typedef f32x2 type; };
+template <> struct FVec<4> { typedef f32x4 type; };
+
+template <int NB> __device__ inline float fcomp(const typename FVec<NB>::type& v, int i);
+template <> __device__ inline float fcomp<2>(const f32x2& v, int i) { return v[i]; }
+template <> __device__ inline float fcomp<4>(const f32x4& v, int i) { return v[i]; }
+
+template <int NB, int D>
+__global__ __launch_bounds__(512, 2) void k_factor_product_f32(
+	const float* __restrict__ A, long lda,
+	const float* __restrict__ F, int RP, int coff,
+	float* __restrict__ slabs, long slab_stride,
+	int steps_total, int splits) {
+	typedef typename FVec<NB>::type fvec;
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+
+	const int xt = blockIdx.x;
+	const int sp = blockIdx.y;
+	// wave-uniform values are forced into SGPRs so that the address arithmetic of the main loop
+	// runs on the scalar unit and the loads take the saddr + 32-bit voffset form
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int half = lane >> 5;
+	const int l31 = lane & 31;
+
+	// this wave's piece of the reduction range, in K-steps of two y each
+	const int nw = splits * FP_WAVES;
+	const int widx = sp * FP_WAVES + wave;
+	const int s0 = (int)(((long)steps_total * widx) / nw);
+	const int s1 = (int)(((long)steps_total * (widx + 1)) / nw);
+	const int steps = s1 - s0;
+
+	f32x16 acc[4][NB];
+#pragma unroll
+	for (int b = 0; b < 4; ++b)
+#pragma unroll
+		for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
+
+	if (steps > 0) {
+		const float* abase = A + (long)(2 * s0) * lda + (long)xt * FP_XT;   // uniform
+		const float* fbase = F + (long)(2 * s0) * RP + coff;                 // uniform
+		const unsigned aoff = (unsigned)(half * lda + 4 * l31);              // per lane, elements
+		const unsigned foff = (unsigned)(half * RP + NB * l31);
+		const long astep = 2 * lda;
+		const long fstep = 2 * (long)RP;
+		const int last = steps - 1;
+
+		f32x4 va[D];
+		fvec fb[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int st = d < last ? d : last;
+			va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+			fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		int t = 0;
+		for (; t + D <= steps; t += D) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+#pragma unroll
+					for (int nb = 0; nb < NB; ++nb)
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][b], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
+				int st = t + D + d;
+				st = st < last ? st : last;
+				va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+				fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
+				// pin the order: the refill of ring slot d is issued right behind the MFMAs that
+				// consumed it, D-1 steps before its data is needed (hipcc otherwise sinks all loads
+				// to the end of the unrolled body and the first step waits a full memory latency)
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		const int rem = steps - t;
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			if (d < rem) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+#pragma unroll
+					for (int nb = 0; nb < NB; ++nb)
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][b], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
+			}
+		}
+	}
+
+	// ---- sum the eight per-wave tiles through LDS, four accumulator tiles per round ----------
+	// LDS image of a round: [src wave 8][tile 4][q 4][lane 64] float4  (128 KiB)
+	// C/D map of the 32x32 MFMA: register g of lane l is row (g&3) + 8*(g>>2) + 4*(l>>5), column l&31.
+	constexpr int TILES = 4 * NB;
+	constexpr int ROUNDS = TILES / 4;
+	constexpr int BPR = 4 / NB;          // M-blocks per round
+	constexpr int ITEMS = BPR * 4;       // (b_local, q) pairs handed out to the waves
+	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+	float* slab = slabs + (long)sp * slab_stride;
+#pragma unroll
+	for (int rd = 0; rd < ROUNDS; ++rd) {
+		if (rd > 0) __syncthreads();
+#pragma unroll
+		for (int tl = 0; tl < 4; ++tl) {
+			const int tix = rd * 4 + tl;
+			const int b = tix / NB, nb = tix % NB;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				f32x4 v;
+				v[0] = acc[b][nb][4 * q + 0]; v[1] = acc[b][nb][4 * q + 1];
+				v[2] = acc[b][nb][4 * q + 2]; v[3] = acc[b][nb][4 * q + 3];
+				l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+			}
+		}
+		__syncthreads();
+		for (int item = wave; item < ITEMS; item += FP_WAVES) {
+			const int bl = item >> 2, q = item & 3;
+			const int b = rd * BPR + bl;
+			f32x4 sum[NB];
+#pragma unroll
+			for (int nb = 0; nb < NB; ++nb) {
+				const int tl = bl * NB + nb;
+				f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+#pragma unroll
+				for (int src = 1; src < FP_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
+				sum[nb] = s;
+			}
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const int x = xt * FP_XT + 4 * (gi + 8 * q + 4 * half) + b;
+				fvec o;
+#pragma unroll
+				for (int nb = 0; nb < NB; ++nb) o[nb] = sum[nb][gi];
+				*reinterpret_cast<fvec*>(slab + (long)x * RP + coff + NB * l31) = o;
+			}
+		}
+	}
+}
+
+FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
+	FactorProductPlan p;
+	p.xtiles = (X + FP_XT - 1) / FP_XT;
+	p.steps_total = (Y + 1) / 2;
+	int splits = num_cus / p.xtiles;
+	if (splits < 1) splits = 1;
+	// keep at least 16 K-steps per wave, otherwise the prologue dominates
+	int max_splits = p.steps_total / (16 * FP_WAVES);
+	if (max_splits < 1) max_splits = 1;
+	if (splits > max_splits) splits = max_splits;
+	p.splits = splits;
+	p.nb = 2;                   // RP is a multiple of 64 (engine: padded_rank); the NB = 4 form needs 256 accumulator VGPRs and spills at two waves per SIMD
+	p.chunks = RP / (32 * p.nb);
+	return p;
+}
+
+template <int NB>
+static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                            float* slabs, long slab_stride, hipStream_t stream) {
+	constexpr int D = 6;
+	dim3 grid(p.xtiles, p.splits), block(512);
+	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
+	static bool attr_done = false;
+	if (!attr_done) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D>),
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		if (e != hipSuccess) return e;
+		attr_done = true;
+	}
+	for (int ch = 0; ch < p.chunks; ++ch)
+		hipLaunchKernelGGL((k_factor_product_f32<NB, D>), grid, block, lds_bytes, stream,
+		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits);
+	return hipGetLastError();
+}
+
+hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                                     float* slabs, long slab_stride, hipStream_t stream) {
+	return launch_fp<2>(p, A, lda, F, RP, slabs, slab_stride, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// factor product, generic VALU form (fp64, and the fp32 cross-check in the tests)
+// ------------------------------------------------------------------------------------------
+// One workgroup = 64 x by 32 c outputs, the whole y range; A and F tiles staged through LDS.
+// Thread (tx 0..15, tc 0..15) owns x = 4*tx..4*tx+3, c = 2*tc, 2*tc+1.
+template <typename T>
+__global__ __launch_bounds__(256) void k_factor_product_valu(
+	const T* __restrict__ A, long lda, const T* __restrict__ F, int RP,
+	T* __restrict__ out, int Y) {
+	constexpr int YT = 16;
+	__shared__ T sa[YT][64 + 1];
+	__shared__ T sf[YT][32 + 1];
+	const int x0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
+	const int tid = threadIdx.x, tx = tid & 15, tc = tid >> 4;
+	T acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+	for (int y0 = 0; y0 < Y; y0 += YT) {
+		for (int e = tid; e < YT * 64; e += 256) {
+			int yy = e / 64, xx = e % 64;
+			sa[yy][xx] = (y0 + yy < Y) ? A[(long)(y0 + yy) * lda + x0 + xx] : T(0);
+		}
+		for (int e = tid; e < YT * 32; e += 256) {
+			int yy = e / 32, cc = e % 32;
+			sf[yy][cc] = (y0 + yy < Y) ? F[(long)(y0 + yy) * RP + c0 + cc] : T(0);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int yy = 0; yy < YT; ++yy) {
+			T f0 = sf[yy][2 * tc], f1 = sf[yy][2 * tc + 1];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				T a = sa[yy][4 * tx + i];
+				acc[i][0] += a * f0;
+				acc[i][1] += a * f1;
+			}
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		out[(long)(x0 + 4 * tx + i) * RP + c0 + 2 * tc] = acc[i][0];
+		out[(long)(x0 + 4 * tx + i) * RP + c0 + 2 * tc + 1] = acc[i][1];
+	}
+}
+
+template <typename T>
+hipError_t launch_factor_product_valu(const T* A, long lda, int Xpad, int Y, const T* F, int RP, T* out, hipStream_t stream) {
+	dim3 grid(Xpad / 64, RP / 32), block(256);
+	hipLaunchKernelGGL((k_factor_product_valu<T>), grid, block, 0, stream, A, lda, F, RP, out, Y);
+	return hipGetLastError();
+}
+template hipError_t launch_factor_product_valu<float>(const float*, long, int, int, const float*, int, float*, hipStream_t);
+template hipError_t launch_factor_product_valu<double>(const double*, long, int, int, const double*, int, double*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// slab reduction: out = slab_0 + slab_1 + ... in slice order
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_reduce_slabs(const T* __restrict__ slabs, int S, long slab_stride, T* __restrict__ out, long count) {
+	long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= count) return;
+	T s = slabs[e];
+	for (int k = 1; k < S; ++k) s += slabs[(long)k * slab_stride + e];
+	out[e] = s;
+}
+
+template <typename T>
+hipError_t launch_reduce_slabs(const T* slabs, int S, long slab_stride, T* out, long count, hipStream_t stream) {
+	const int bs = 256;
+	hipLaunchKernelGGL((k_reduce_slabs<T>), dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, stream, slabs, S, slab_stride, out, count);
+	return hipGetLastError();
+}
+template hipError_t launch_reduce_slabs<float>(const float*, int, long, float*, long, hipStream_t);
+template hipError_t launch_reduce_slabs<double>(const double*, int, long, double*, long, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// Gram matrix of a factor panel: G(a, b) = sum_y P(a, y) P(b, y)
+// (reference: syrk / gemm for W^T W and H H^T, AlgorithmMultiplicativeFrobenius.h:168-178,208-209,231-232)
+// ------------------------------------------------------------------------------------------
+// Stage 1: workgroup p sums its slice of y into partial[p] (RP x RP, column-major, both
+// triangles, bitwise symmetric).  Stage 2 (k_reduce_slabs) adds the partials in order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ P, int RP, int len, int parts, T* __restrict__ partial) {
+	constexpr int YT = 16;
+	__shared__ T sa[YT][64 + 4];
+	__shared__ T sb[YT][64 + 4];
+	const int part = blockIdx.x;
+	const int a0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
+	const int y_begin = (int)(((long)len * part) / parts);
+	const int y_end = (int)(((long)len * (part + 1)) / parts);
+	const int tid = threadIdx.x, ta = tid & 15, tb = tid >> 4;
+	T acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+	for (int y0 = y_begin; y0 < y_end; y0 += YT) {
+		for (int e = tid; e < YT * 64; e += 256) {
+			int yy = e >> 6, cc = e & 63;
+			bool ok = y0 + yy < y_end;
+			sa[yy][cc] = ok ? P[(long)(y0 + yy) * RP + a0 + cc] : T(0);
+			sb[yy][cc] = ok ? P[(long)(y0 + yy) * RP + b0 + cc] : T(0);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int yy = 0; yy < YT; ++yy) {
+			T av[4], bv[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { av[i] = sa[yy][4 * ta + i]; bv[i] = sb[yy][4 * tb + i]; }
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+		}
+		__syncthreads();
+	}
+	T* out = partial + (long)part * RP * RP;
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) out[(long)(b0 + 4 * tb + j) * RP + a0 + 4 * ta + i] = acc[i][j];
+}
+
+template <typename T>
+hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G, hipStream_t stream) {
+	int blocks = RP / 64; // RP is a multiple of 64
+	hipLaunchKernelGGL((k_gram_partial<T>), dim3(parts, blocks, blocks), dim3(256), 0, stream, P, RP, len, parts, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return launch_reduce_slabs<T>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
+}
+template hipError_t launch_gram<float>(const float*, int, int, int, float*, float*, hipStream_t);
+template hipError_t launch_gram<double>(const double*, int, int, int, double*, double*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// panel update: the element-wise step of every algorithm, fused with the slab reduction, the
+// small r x r product and the partial sums that follow it in the reference.
+// ------------------------------------------------------------------------------------------
+//   num(c, y)  = sum_s slab_s(c, y)
+//   MODE_MU:  den = Q(c, :) . P(:, y);   P(c, y) <- P(c, y) * num / (den + eps)
+//             (reference: symm/gemm `RR * H` / `W * RR` + kernel::multiplyDivide,
+//              AlgorithmMultiplicativeFrobenius.h:181-191,235-244, KernelMultiplyDivide.cu:39-42)
+//   MODE_LS:  P(c, y) <- max(0, Q(c, :) . num(:, y))        Q = inverse of the normal matrix
+//             (reference: ormqr + trsm + setNegativeToZero, AlgorithmAlternatingLeastSquares.h:163-172)
+//   MODE_SET: P(c, y) <- num(c, y)                          plain reduction into a panel
+// Optional outputs:
+//   ps(y)            = sum_c P_new(c, y) * num(c, y)   -- diag(H^T (W^T V)), the per-column terms of
+//                      tr(H^T W^T V) (kernel::traceMultiplication, KernelTraceMultiplication.cu:43-80)
+//   sumsq_part(wg,c) = sum_{y in workgroup} P_new(c, y)^2  -- first half of kernel::normalizeColumns
+enum { MODE_MU = 0, MODE_LS = 1, MODE_SET = 2 };
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_panel_update(
+	T* __restrict__ P, const T* __restrict__ slabs, int S, long slab_stride,
+	const T* __restrict__ Q, int RP, T eps,
+	T* __restrict__ ps, int len_valid, T* __restrict__ sumsq_part, T* __restrict__ num_out, int YB) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* s_num = reinterpret_cast<T*>(smem_raw);       // [YB][RP]
+	T* s_old = s_num + YB * RP;                      // [YB][RP]  (old panel values, or new * num products)
+	const int y0 = blockIdx.x * YB;
+	const int tid = threadIdx.x;
+	const long base = (long)y0 * RP;
+
+	for (int e = tid; e < YB * RP; e += 256) {
+		T s = slabs[base + e];
+		for (int k = 1; k < S; ++k) s += slabs[(long)k * slab_stride + base + e];
+		s_num[e] = s;
+		if (num_out) num_out[base + e] = s;
+		if (MODE == MODE_MU) s_old[e] = P[base + e];
+	}
+	__syncthreads();
+
+	const int c = tid % RP;
+	const int ystride = 256 / RP > 0 ? 256 / RP : 1;
+	// RP <= 256: one thread per (c, y); RP > 256 is handled by the c-loop below
+	for (int cc = c; cc < RP; cc += 256) {
+		for (int yy = tid / RP; yy < YB; yy += ystride) {
+			T result;
+			if (MODE == MODE_SET) {
+				result = s_num[yy * RP + cc];
+			} else {
+				const T* vec = (MODE == MODE_MU) ? (s_old + yy * RP) : (s_num + yy * RP);
+				T dot = 0;
+				for (int k = 0; k < RP; ++k) dot += Q[(long)k * RP + cc] * vec[k];
+				if (MODE == MODE_MU) {
+					T value = s_old[yy * RP + cc];
+					result = value * s_num[yy * RP + cc] / (dot + eps);
+				} else {
+					result = dot > T(0) ? dot : T(0);
+				}
+			}
+			P[base + (long)yy * RP + cc] = result;
+		}
+	}
+	if (ps == nullptr && sumsq_part == nullptr) return;
+	__syncthreads();
+	// s_old <- new values (every thread re-reads what the workgroup just wrote)
+	for (int e = tid; e < YB * RP; e += 256) s_old[e] = P[base + e];
+	__syncthreads();
+	if (ps != nullptr && tid < YB) {
+		T s = 0;
+		for (int k = 0; k < RP; ++k) s += s_old[tid * RP + k] * s_num[tid * RP + k];
+		if (y0 + tid < len_valid) ps[y0 + tid] = s;
+	}
+	if (sumsq_part != nullptr) {
+		for (int cc = tid; cc < RP; cc += 256) {
+			T s = 0;
+			for (int yy = 0; yy < YB; ++yy) { T v = s_old[yy * RP + cc]; s += v * v; }
+			sumsq_part[(long)blockIdx.x * RP + cc] = s;
+		}
+	}
+}
+
+// panel columns per workgroup: 32, fewer when two [rows][RP] images would not fit 64 KiB of LDS
+int panel_update_rows(int RP, size_t elem) {
+	int yb = 32;
+	while (yb > 1 && 2 * (size_t)yb * RP * elem > 65536) yb >>= 1;
+	return yb;
+}
+
+template <typename T>
+hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream) {
+	const int yb = panel_update_rows(RP, sizeof(T));
+	dim3 grid(len_pad / yb), block(256);
+	size_t smem = 2 * (size_t)yb * RP * sizeof(T);
+	switch (mode) {
+	case MODE_MU: hipLaunchKernelGGL((k_panel_update<T, MODE_MU>), grid, block, smem, stream, P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, yb); break;
+	case MODE_LS: hipLaunchKernelGGL((k_panel_update<T, MODE_LS>), grid, block, smem, stream, P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, yb); break;
+	default: hipLaunchKernelGGL((k_panel_update<T, MODE_SET>), grid, block, smem, stream, P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, yb); break;
+	}
+	return hipGetLastError();
+}
+template hipError_t launch_panel_update<float>(int, float*, const float*, int, long, const float*, int, int, float, float*, int, float*, float*, hipStream_t);
+template hipError_t launch_panel_update<double>(int, double*, const double*, int, long, const double*, int, int, double, double*, int, double*, double*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// column normalisation of W (rows of the Wt panel): second half of kernel::normalizeColumns
+// (KernelNormalizeColumns.cu:37-58): sum > 0 ? x / sqrt(sum) : x
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_normalize_panel(T* __restrict__ P, int RP, const T* __restrict__ sumsq_part, int parts) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* s_norm = reinterpret_cast<T*>(smem_raw);
+	for (int c = threadIdx.x; c < RP; c += 256) {
+		T s = 0;
+		for (int p = 0; p < parts; ++p) s += sumsq_part[(long)p * RP + c];
+		s_norm[c] = s > T(0) ? (T)sqrt(s) : T(0);
+	}
+	__syncthreads();
+	const long base = (long)blockIdx.x * 32 * RP;
+	for (int e = threadIdx.x; e < 32 * RP; e += 256) {
+		T nrm = s_norm[e % RP];
+		if (nrm > T(0)) P[base + e] = P[base + e] / nrm;
+	}
+}
+
+template <typename T>
+hipError_t launch_normalize_panel(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream) {
+	hipLaunchKernelGGL((k_normalize_panel<T>), dim3(len_pad / 32), dim3(256), RP * sizeof(T), stream, P, RP, sumsq_part, parts);
+	return hipGetLastError();
+}
+template hipError_t launch_normalize_panel<float>(float*, int, int, const float*, int, hipStream_t);
+template hipError_t launch_normalize_panel<double>(double*, int, int, const double*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// nsNMF smoothing of a panel: out(:, y) = S P(:, y), S = (1-theta) I + (theta/r) 1 1^T
+// (reference: gemm with the explicit S matrix, AlgorithmNonSmoothNMF.h:131-134,175,194;
+//  here S is applied analytically: out(c) = offdiag * sum_c' P(c') + (diag - offdiag) * P(c))
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_smooth_panel(const T* __restrict__ P, T* __restrict__ out, int RP, int r, long len_pad, T offdiag, T diag) {
+	long y = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (y >= len_pad) return;
+	const T* p = P + y * RP;
+	T* o = out + y * RP;
+	T sum = 0;
+	for (int c = 0; c < r; ++c) sum += p[c];
+	for (int c = 0; c < r; ++c) o[c] = offdiag * (sum - p[c]) + diag * p[c];
+	for (int c = r; c < RP; ++c) o[c] = 0;
+}
+
+template <typename T>
+hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream) {
+	hipLaunchKernelGGL((k_smooth_panel<T>), dim3((unsigned)((len_pad + 255) / 256)), dim3(256), 0, stream, P, out, RP, r, len_pad, offdiag, diag);
+	return hipGetLastError();
+}
+template hipError_t launch_smooth_panel<float>(const float*, float*, int, int, long, float, float, hipStream_t);
+template hipError_t launch_smooth_panel<double>(const double*, double*, int, int, long, double, double, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// small r x r helpers (single workgroup)
+// ------------------------------------------------------------------------------------------
+// ps(d) = sum_i A(d, i) B(i, d): the r terms of tr(H H^T W^T W)
+// (kernel::traceMultiplication<false>, KernelTraceMultiplication.cu:43-80 at AlgorithmMultiplicativeFrobenius.h:212)
+template <typename T>
+__global__ void k_trace_small(const T* __restrict__ A, const T* __restrict__ B, int RP, int r, T* __restrict__ ps) {
+	for (int d = threadIdx.x; d < r; d += blockDim.x) {
+		T s = 0;
+		for (int i = 0; i < r; ++i) s += A[(long)i * RP + d] * B[(long)d * RP + i];
+		ps[d] = s;
+	}
+}
+
+template <typename T>
+hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream) {
+	hipLaunchKernelGGL((k_trace_small<T>), dim3(1), dim3(256), 0, stream, A, B, RP, r, ps);
+	return hipGetLastError();
+}
+template hipError_t launch_trace_small<float>(const float*, const float*, int, int, float*, hipStream_t);
+template hipError_t launch_trace_small<double>(const double*, const double*, int, int, double*, hipStream_t);
+
+// ps(d) = sum_y A(d, y) B(d, y) over two panels: the r terms of tr(W_old^T (V H^T)) used by the
+// least-squares family (AlgorithmAlternatingLeastSquares.h:199-205) and GDCLS (:259-264).
+// One workgroup per d-block would be overkill: r <= 256 rows, len <= ~1e5 -> one workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_dot(const T* __restrict__ A, const T* __restrict__ B, int RP, long len, T* __restrict__ ps) {
+	__shared__ T red[256];
+	const int d = blockIdx.x;
+	T s = 0;
+	for (long y = threadIdx.x; y < len; y += 256) s += A[y * RP + d] * B[y * RP + d];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) ps[d] = red[0];
+}
+
+template <typename T>
+hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream) {
+	hipLaunchKernelGGL((k_row_dot<T>), dim3(r), dim3(256), 0, stream, A, B, RP, len, ps);
+	return hipGetLastError();
+}
+template hipError_t launch_row_dot<float>(const float*, const float*, int, int, long, float*, hipStream_t);
+template hipError_t launch_row_dot<double>(const double*, const double*, int, int, long, double*, hipStream_t);
+
+// A(i, j) = [reuse] A(i, j) + (i == j ? diag : offdiag) on the r x r block
+// (kernel::fillMatrix / addConstantToMatrix, KernelFillMatrix.cu:29-45)
+template <typename T>
+__global__ void k_fill_small(T* __restrict__ A, int RP, int r, int reuse, T offdiag, T diag) {
+	for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+		int i = e % r, j = e / r;
+		T old = reuse ? A[(long)j * RP + i] : T(0);
+		A[(long)j * RP + i] = old + (i == j ? diag : offdiag);
+	}
+}
+
+template <typename T>
+hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, hipStream_t stream) {
+	hipLaunchKernelGGL((k_fill_small<T>), dim3(1), dim3(256), 0, stream, A, RP, r, reuse, offdiag, diag);
+	return hipGetLastError();
+}
+template hipError_t launch_fill_small<float>(float*, int, int, int, float, float, hipStream_t);
+template hipError_t launch_fill_small<double>(double*, int, int, int, double, double, hipStream_t);
+
+// Inverse of the r x r normal matrix by Householder QR, one workgroup, arithmetic in double.
+// (reference: cusolverDn geqrf, then ormqr + trsm per right-hand side, Matrix.h:565-618; here
+//  the factorisation is turned into an explicit inverse once, X = R^-1 Q^T, so that applying it
+//  to the r x n / m x r right-hand sides is a plain r x r product inside k_panel_update.)
+// work: 2 * r * r doubles of global scratch (QR image, and Q^T accumulated from the identity).
+template <typename T>
+__global__ __launch_bounds__(256) void k_inverse_small(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, double* __restrict__ work) {
+	__shared__ double red[256];
+	__shared__ double s_tau, s_beta;
+	double* M = work;              // r x r column-major
+	double* X = work + (long)r * r; // r x r column-major, starts as I, ends as R^-1 Q^T
+	const int tid = threadIdx.x;
+	for (int e = tid; e < r * r; e += 256) {
+		int i = e % r, j = e / r;
+		M[e] = (double)A[(long)j * RP + i];
+		X[e] = i == j ? 1.0 : 0.0;
+	}
+	__syncthreads();
+	for (int k = 0; k < r; ++k) {
+		// norm of the sub-column
+		double s = 0;
+		for (int i = k + 1 + tid; i < r; i += 256) { double v = M[(long)k * r + i]; s += v * v; }
+		red[tid] = s;
+		__syncthreads();
+		for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+		if (tid == 0) {
+			double alpha = M[(long)k * r + k], xnorm2 = red[0];
+			if (xnorm2 == 0.0) { s_tau = 0.0; s_beta = alpha; }
+			else {
+				double beta = sqrt(alpha * alpha + xnorm2);
+				if (alpha >= 0) beta = -beta;
+				s_tau = (beta - alpha) / beta;
+				s_beta = beta;
+				M[(long)k * r + k] = 1.0 / (alpha - beta); // scale, consumed below
+			}
+		}
+		__syncthreads();
+		const double tau = s_tau;
+		if (tau != 0.0) {
+			const double scale = M[(long)k * r + k];
+			__syncthreads();
+			for (int i = k + 1 + tid; i < r; i += 256) M[(long)k * r + i] *= scale;
+			if (tid == 0) M[(long)k * r + k] = s_beta;
+			__syncthreads();
+			// apply H_k to the trailing columns of M and to all columns of X: one thread per column
+			for (int j = tid; j < (r - k - 1) + r; j += 256) {
+				double* col = j < r - k - 1 ? (M + (long)(k + 1 + j) * r) : (X + (long)(j - (r - k - 1)) * r);
+				double w = col[k];
+				for (int i = k + 1; i < r; ++i) w += M[(long)k * r + i] * col[i];
+				w *= tau;
+				col[k] -= w;
+				for (int i = k + 1; i < r; ++i) col[i] -= w * M[(long)k * r + i];
+			}
+		}
+		__syncthreads();
+	}
+	// back substitution R Z = X (X currently holds Q^T), one thread per column
+	for (int j = tid; j < r; j += 256) {
+		double* x = X + (long)j * r;
+		for (int k = r - 1; k >= 0; --k) {
+			double s = x[k];
+			for (int p = k + 1; p < r; ++p) s -= M[(long)p * r + k] * x[p];
+			x[k] = s / M[(long)k * r + k];
+		}
+	}
+	__syncthreads();
+	for (int e = tid; e < RP * RP; e += 256) {
+		int i = e % RP, j = e / RP;
+		Ainv[e] = (i < r && j < r) ? (T)X[(long)j * r + i] : T(0);
+	}
+}
+
+template <typename T>
+hipError_t launch_inverse_small(const T* A, int RP, int r, T* Ainv, double* work, hipStream_t stream) {
+	hipLaunchKernelGGL((k_inverse_small<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv, work);
+	return hipGetLastError();
+}
+template hipError_t launch_inverse_small<float>(const float*, int, int, float*, double*, hipStream_t);
+template hipError_t launch_inverse_small<double>(const double*, int, int, double*, double*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// one-time data movement kernels (outside the iteration loop)
+// ------------------------------------------------------------------------------------------
+// dst(j, i) = src(i, j); src is rows x cols with leading dimension lds_, dst has leading dimension ldd.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, long lds_, int rows, int cols, T* __restrict__ dst, long ldd) {
+	__shared__ T tile[32][33];
+	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	for (int jj = ty; jj < 32; jj += 8) {
+		int i = i0 + tx, j = j0 + jj;
+		tile[jj][tx] = (i < rows && j < cols) ? src[(long)j * lds_ + i] : T(0);
+	}
+	__syncthreads();
+	for (int ii = ty; ii < 32; ii += 8) {
+		int i = i0 + ii, j = j0 + tx;
+		if (i < rows && j < cols) dst[(long)i * ldd + j] = tile[tx][ii];
+	}
+}
+
+template <typename T>
+hipError_t launch_transpose(const T* src, long lds_, int rows, int cols, T* dst, long ldd, hipStream_t stream) {
+	dim3 grid((rows + 31) / 32, (cols + 31) / 32), block(256);
+	hipLaunchKernelGGL((k_transpose<T>), grid, block, 0, stream, src, lds_, rows, cols, dst, ldd);
+	return hipGetLastError();
+}
+template hipError_t launch_transpose<float>(const float*, long, int, int, float*, long, hipStream_t);
+template hipError_t launch_transpose<double>(const double*, long, int, int, double*, long, hipStream_t);
+
+// ps(j) = sum_i V(i, j)^2 -- the per-column terms of tr(V^T V)
+// (kernel::traceMultiplication<true>(V, V), AlgorithmMultiplicativeFrobenius.h:119-121)
+template <typename T>
+__global__ __launch_bounds__(256) void k_column_sumsq(const T* __restrict__ V, long ldv, int rows, T* __restrict__ ps) {
+	__shared__ T red[256];
+	const T* col = V + (long)blockIdx.x * ldv;
+	T s = 0;
+	for (int i = threadIdx.x; i < rows; i += 256) s += col[i] * col[i];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) ps[blockIdx.x] = red[0];
+}
+
+template <typename T>
+hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream) {
+	hipLaunchKernelGGL((k_column_sumsq<T>), dim3(cols), dim3(256), 0, stream, V, ldv, rows, ps);
+	return hipGetLastError();
+}
+template hipError_t launch_column_sumsq<float>(const float*, long, int, int, float*, hipStream_t);
+template hipError_t launch_column_sumsq<double>(const double*, long, int, int, double*, hipStream_t);
+
+// Sparse -> dense on the device, honouring the index base
+// (reference: cusparse csr2dense / csc2dense / coo2csr+csr2dense, Matrix.h:145-232).
+// The destination has been zero-filled.  One thread per stored element.
+template <typename T>
+__global__ void k_densify(int format, const T* __restrict__ values, const int* __restrict__ ptr, const int* __restrict__ idx,
+                          const int* __restrict__ idx2, long nnz, int outer, int base, T* __restrict__ V, long ldv, int rows, int cols) {
+	long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nnz) return;
+	int i, j;
+	if (format == 3) { // COO: idx = row indices, idx2 = column indices
+		i = idx[p] - base; j = idx2[p] - base;
+	} else {
+		// find the row (CSR) / column (CSC) that owns element p: last o with ptr[o] - base <= p
+		int lo = 0, hi = outer; // ptr has outer + 1 entries
+		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if ((long)(ptr[mid] - base) <= p) lo = mid; else hi = mid; }
+		if (format == 1) { i = lo; j = idx[p] - base; } else { j = lo; i = idx[p] - base; }
+	}
+	if (i >= 0 && i < rows && j >= 0 && j < cols) V[(long)j * ldv + i] = values[p];
+}
+
+template <typename T>
+hipError_t launch_densify(int format, const T* values, const int* ptr, const int* idx, const int* idx2, long nnz, int outer, int base,
+                          T* V, long ldv, int rows, int cols, hipStream_t stream) {
+	if (nnz == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_densify<T>), dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, format, values, ptr, idx, idx2, nnz, outer, base, V, ldv, rows, cols);
+	return hipGetLastError();
+}
+template hipError_t launch_densify<float>(int, const float*, const int*, const int*, const int*, long, int, int, float*, long, int, int, hipStream_t);
+template hipError_t launch_densify<double>(int, const double*, const int*, const int*, const int*, long, int, int, double*, long, int, int, hipStream_t);
+
+// Uniform (0, 1] fill for AllRandomValues (reference: curandGenerateUniform with the XORWOW
+// default generator over ld * cols elements, source/init/RandomValueStrategy.cpp:29-49; cuRAND is
+// closed source, so only the distribution -- uniform on (0,1], same seed for W and H -- is
+// reproduced).  Counter-based generator: splitmix64 of (seed, element index).
+template <typename T>
+__global__ void k_fill_uniform(T* __restrict__ P, int RP, int r, long len, long len_pad, uint64_t seed) {
+	long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= len_pad * RP) return;
+	long y = e / RP; int c = (int)(e % RP);
+	T v = T(0);
+	if (y < len && c < r) {
+		uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(y * (long)r + c) + 0x632BE59BD9B4E019ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z = z ^ (z >> 31);
+		if (sizeof(T) == 4) v = (T)(((z >> 40) + 1) * (1.0f / 16777216.0f));          // 24 bits -> (0, 1]
+		else v = (T)(((z >> 11) + 1) * (1.0 / 9007199254740992.0));                    // 53 bits -> (0, 1]
+	}
+	P[e] = v;
+}
+
+template <typename T>
+hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream) {
+	long count = len_pad * RP;
+	hipLaunchKernelGGL((k_fill_uniform<T>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, P, RP, r, len, len_pad, seed);
+	return hipGetLastError();
+}
+template hipError_t launch_fill_uniform<float>(float*, int, int, long, long, uint64_t, hipStream_t);
+template hipError_t launch_fill_uniform<double>(double*, int, int, long, long, uint64_t, hipStream_t);
+
+} // namespace nmfamd

@@ -1,0 +1,117 @@
+"""Column-sharded multiplicative update across the GPUs of one node (one process per GPU).
+
+Rank g holds V(:, J_g), H(:, J_g) and a full replica of W (the reference is
+single-GPU, source/nmf/SingleGpuDispatcher.h:36, so this layer has no counterpart there).
+Per iteration:
+
+    h_step        local     H(:, J_g) <- H .* (W^T V_g) ./ (W^T W H + eps)            no communication
+    w_products    local     exchange <- [ (V_g H_g^T)^T | H_g H_g^T ]
+    all_reduce    RCCL      sum of `exchange` over the ranks (2.56 MB + 16 KB at 10000 x 5000, r = 64)
+    w_finish      replicated W <- W .* (V H^T) ./ (W H H^T + eps), column normalisation
+
+Every rank applies the identical W update to identical reduced sums, so the replicas stay
+bit-identical without a broadcast.  On error iterations the per-column terms of tr(H^T W^T V)
+are all-gathered so that the host-side sorted summation (source/nmf/FrobeniusResolver.cpp:29-51)
+sees the same vectors as a single-GPU run would.
+
+The class is backend-agnostic on purpose: the product backend is `EngineShard` (HIP engine +
+torch CUDA tensors + backend "nccl" = RCCL); the CPU tests drive the same orchestration with a
+test-only backend over gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class EngineShard:
+    """Product backend: one nmfgpu_amd.Engine on this rank's GPU, exchange buffer owned by torch."""
+
+    def __init__(self, V_local: np.ndarray, W: np.ndarray, H_local: np.ndarray, device=None):
+        import torch
+        from .engine import Engine
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("EngineShard needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        m, n = V_local.shape
+        r = W.shape[1]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.engine = Engine(m, n, r, "mu", dtype=V_local.dtype, stream=stream)
+        self.engine.upload(V_local)
+        self.engine.set_factors(W, H_local)
+        count = self.engine.geometry()["exchange_count"]
+        tdtype = torch.float32 if V_local.dtype == np.float32 else torch.float64
+        self.exchange = torch.zeros(count, dtype=tdtype, device=self.device)
+        self.dtype = V_local.dtype
+
+    def h_step(self, compute_error: bool):
+        self.engine.h_step(compute_error)
+
+    def w_products(self):
+        self.engine.w_products(self.exchange.data_ptr())
+
+    def w_finish(self, compute_error: bool):
+        self.engine.w_finish(self.exchange.data_ptr(), compute_error)
+
+    def error_terms(self, which: int) -> np.ndarray:
+        return self.engine.error_terms(which)
+
+    def resolve(self, vtv_sorted, htwtv, hhtwtw) -> float:
+        from .engine import resolve_frobenius
+        return resolve_frobenius(vtv_sorted, htwtv, hhtwtw)
+
+    def factors(self):
+        return self.engine.get_factors()
+
+    def synchronize(self):
+        self.engine.synchronize()
+
+
+class ShardedMU:
+    """Drives one backend per rank through the sharded iteration; `dist` is torch.distributed."""
+
+    def __init__(self, backend, total_columns: int, rows: int, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.backend = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.total_elements = int(np.uint32(rows) * np.uint32(total_columns))  # the reference multiplies unsigned ints
+        self.frobenius = 0.0
+        self.rmsd = 0.0
+        self._vtv_all = None
+
+    def _all_gather_host(self, local: np.ndarray) -> np.ndarray:
+        """Gathers equally sized host vectors of every rank (error iterations only)."""
+        if self.world == 1:
+            return local
+        torch, dist = self.torch, self.dist
+        t = torch.from_numpy(np.ascontiguousarray(local))
+        dev = getattr(self.backend, "device", None)
+        if dev is not None:
+            t = t.to(dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t, group=self.group)
+        return np.concatenate([o.cpu().numpy() for o in outs])
+
+    def iterate(self, compute_error: bool = False):
+        b = self.backend
+        b.h_step(compute_error)
+        b.w_products()
+        if self.world > 1:
+            self.dist.all_reduce(b.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
+        b.w_finish(compute_error)
+        if compute_error:
+            if self._vtv_all is None:
+                self._vtv_all = np.sort(self._all_gather_host(b.error_terms(0)))
+            htwtv = self._all_gather_host(b.error_terms(1))
+            hhtwtw = b.error_terms(2)
+            self.frobenius = b.resolve(self._vtv_all, htwtv, hhtwtw)
+            self.rmsd = self.frobenius / np.sqrt(float(self.total_elements))
+
+    def run(self, count: int, first_iteration: int = 1, error_every: int = 10, last_iteration: int = 0):
+        for k in range(count):
+            it = first_iteration + k
+            err = (error_every > 0 and it % error_every == 0) or (last_iteration > 0 and it == last_iteration)
+            self.iterate(err)

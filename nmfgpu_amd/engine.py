@@ -1,0 +1,211 @@
+"""ctypes wrapper of include/nmfgpu_amd.h: the device-resident engine and the single-kernel ops."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from ._lib import library
+
+ALGORITHMS = {"mu": 0, "gdcls": 1, "als": 2, "acls": 3, "ahcls": 4, "nsnmf": 5}
+_STATUS = {0: "ok", 1: "invalid argument", 2: "out of device memory", 3: "out of host memory", 4: "HIP error", 5: "no HIP device"}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        super().__init__(f"{what}: {_STATUS.get(status, status)}{(' (' + detail + ')') if detail else ''}")
+        self.status = status
+
+
+class _Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("lam", "lambdaW", "lambdaH", "alphaW", "alphaH", "theta")]
+
+
+class _Geometry(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("r", C.c_int), ("padded_rank", C.c_int),
+                ("padded_m", C.c_long), ("padded_n", C.c_long), ("slabs_h", C.c_int), ("slabs_w", C.c_int),
+                ("exchange_count", C.c_long)]
+
+
+def device_count() -> int:
+    fn = library().nmfamd_device_count
+    fn.restype = C.c_int
+    return int(fn())
+
+
+def _f(a: np.ndarray) -> np.ndarray:
+    if a.ndim != 2 or not a.flags.f_contiguous:
+        raise ValueError("matrices must be 2-D Fortran-ordered arrays")
+    return a
+
+
+def _ld(a: np.ndarray) -> int:
+    return a.strides[1] // a.itemsize if a.shape[1] > 1 else max(a.shape[0], 1)
+
+
+class Engine:
+    """One factorisation resident on the current HIP device (see include/nmfgpu_amd.h)."""
+
+    def __init__(self, m: int, n: int, r: int, algorithm: str = "mu", dtype=np.float32, stream: int = 0,
+                 lam=0.0, lambda_w=0.0, lambda_h=0.0, alpha_w=0.0, alpha_h=0.0, theta=0.0):
+        self._lib = library()
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("float32 or float64")
+        self.m, self.n, self.r = m, n, r
+        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta)
+        h = C.c_void_p()
+        st = self._lib.nmfamd_engine_create(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_engine_create")
+        self._h = h
+        self._lib.nmfamd_engine_frobenius.restype = C.c_double
+        self._lib.nmfamd_engine_rmsd.restype = C.c_double
+        self._lib.nmfamd_engine_last_error.restype = C.c_char_p
+        self._lib.nmfamd_engine_error_terms.restype = C.c_long
+
+    def _check(self, st: int, what: str):
+        if st != 0:
+            raise EngineError(st, what, (self._lib.nmfamd_engine_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, V: np.ndarray):
+        V = _f(V)
+        assert V.dtype == self.dtype and V.shape == (self.m, self.n)
+        self._check(self._lib.nmfamd_engine_upload_dense(self._h, C.c_void_p(V.ctypes.data), C.c_long(_ld(V))), "upload_dense")
+
+    def upload_sparse(self, fmt: int, values: np.ndarray, a: np.ndarray, b: np.ndarray, base: int = 0):
+        values = np.ascontiguousarray(values, dtype=self.dtype)
+        a = np.ascontiguousarray(a, dtype=np.int32); b = np.ascontiguousarray(b, dtype=np.int32)
+        self._check(self._lib.nmfamd_engine_upload_sparse(self._h, fmt, C.c_void_p(values.ctypes.data), C.c_void_p(a.ctypes.data),
+                                                          C.c_void_p(b.ctypes.data), C.c_long(len(values)), base), "upload_sparse")
+
+    def set_factors(self, W: Optional[np.ndarray], H: Optional[np.ndarray]):
+        wp = C.c_void_p(_f(W).ctypes.data) if W is not None else None
+        hp = C.c_void_p(_f(H).ctypes.data) if H is not None else None
+        self._check(self._lib.nmfamd_engine_set_factors(self._h, wp, C.c_long(_ld(W) if W is not None else 0),
+                                                        hp, C.c_long(_ld(H) if H is not None else 0)), "set_factors")
+
+    def get_factors(self):
+        W = np.zeros((self.m, self.r), dtype=self.dtype, order="F")
+        H = np.zeros((self.r, self.n), dtype=self.dtype, order="F")
+        self._check(self._lib.nmfamd_engine_get_factors(self._h, C.c_void_p(W.ctypes.data), C.c_long(self.m),
+                                                        C.c_void_p(H.ctypes.data), C.c_long(self.r)), "get_factors")
+        return W, H
+
+    def randomize(self, seed: int, w: bool = True, h: bool = True):
+        self._check(self._lib.nmfamd_engine_randomize(self._h, C.c_uint(seed), int(w), int(h)), "randomize")
+
+    def iterate(self, count: int, first_iteration: int = 1, error_every: int = 10, last_iteration: int = 0, constant_w: bool = False):
+        self._check(self._lib.nmfamd_engine_iterate(self._h, count, first_iteration, error_every, last_iteration, int(constant_w)), "iterate")
+
+    def synchronize(self):
+        self._check(self._lib.nmfamd_engine_synchronize(self._h), "synchronize")
+
+    @property
+    def frobenius(self) -> float:
+        return float(self._lib.nmfamd_engine_frobenius(self._h))
+
+    @property
+    def rmsd(self) -> float:
+        return float(self._lib.nmfamd_engine_rmsd(self._h))
+
+    def kernel_timing(self, enable: bool):
+        self._check(self._lib.nmfamd_engine_kernel_timing(self._h, int(enable)), "kernel_timing")
+
+    def kernel_timing_read(self):
+        ms = C.c_double(0); cnt = C.c_long(0)
+        self._check(self._lib.nmfamd_engine_kernel_timing_read(self._h, C.byref(ms), C.byref(cnt)), "kernel_timing_read")
+        return ms.value, cnt.value
+
+    def geometry(self) -> dict:
+        g = _Geometry()
+        self._check(self._lib.nmfamd_engine_geometry(self._h, C.byref(g)), "geometry")
+        return {k: getattr(g, k) for k, _ in _Geometry._fields_}
+
+    # ---- column-sharded form ----
+    def h_step(self, compute_error: bool = False):
+        self._check(self._lib.nmfamd_engine_h_step(self._h, int(compute_error)), "h_step")
+
+    def w_products(self, exchange_ptr: int):
+        self._check(self._lib.nmfamd_engine_w_products(self._h, C.c_void_p(exchange_ptr)), "w_products")
+
+    def w_finish(self, exchange_ptr: int, compute_error: bool = False):
+        self._check(self._lib.nmfamd_engine_w_finish(self._h, C.c_void_p(exchange_ptr), int(compute_error)), "w_finish")
+
+    def error_terms(self, which: int) -> np.ndarray:
+        cap = max(self.n, self.r)
+        out = np.zeros(cap, dtype=self.dtype)
+        cnt = self._lib.nmfamd_engine_error_terms(self._h, which, C.c_void_p(out.ctypes.data), C.c_long(cap))
+        if cnt < 0:
+            raise EngineError(1, "error_terms")
+        return out[:cnt]
+
+    def debug_read(self, which: int, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=self.dtype)
+        self._check(self._lib.nmfamd_engine_debug_read(self._h, which, C.c_void_p(out.ctypes.data), C.c_long(count)), "debug_read")
+        return out
+
+
+def resolve_frobenius(vtv_sorted: np.ndarray, htwtv: np.ndarray, hhtwtw: np.ndarray) -> float:
+    lib = library()
+    sfx = "f32" if vtv_sorted.dtype == np.float32 else "f64"
+    fn = getattr(lib, f"nmfamd_resolve_frobenius_{sfx}")
+    fn.restype = C.c_double
+    a = np.ascontiguousarray(vtv_sorted); b = np.array(htwtv, dtype=a.dtype); c = np.array(hhtwtw, dtype=a.dtype)
+    return float(fn(C.c_void_p(a.ctypes.data), C.c_long(len(a)), C.c_void_p(b.ctypes.data), C.c_long(len(b)),
+                    C.c_void_p(c.ctypes.data), C.c_long(len(c))))
+
+
+def op_factor_product(A: np.ndarray, F: np.ndarray, use_valu: bool = False):
+    """OUT (r x X) = F (r x Y) A^T for a host X x Y matrix A.  Returns (OUT, slabs)."""
+    A = _f(A); F = _f(F)
+    X, Y = A.shape
+    r = F.shape[0]
+    assert F.shape[1] == Y and A.dtype == F.dtype
+    out = np.zeros((r, X), dtype=A.dtype, order="F")
+    lib = library()
+    if A.dtype == np.float32:
+        slabs = C.c_int(0)
+        st = lib.nmfamd_op_factor_product_f32(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), X, Y, C.c_void_p(F.ctypes.data), C.c_long(_ld(F)), r,
+                                              C.c_void_p(out.ctypes.data), C.c_long(r), int(use_valu), C.byref(slabs))
+        if st != 0:
+            raise EngineError(st, "nmfamd_op_factor_product_f32")
+        return out, slabs.value
+    st = lib.nmfamd_op_factor_product_f64(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), X, Y, C.c_void_p(F.ctypes.data), C.c_long(_ld(F)), r,
+                                          C.c_void_p(out.ctypes.data), C.c_long(r))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_factor_product_f64")
+    return out, 1
+
+
+def op_gram(P: np.ndarray) -> np.ndarray:
+    P = _f(P)
+    r, length = P.shape
+    G = np.zeros((r, r), dtype=np.float32, order="F")
+    st = library().nmfamd_op_gram_f32(C.c_void_p(P.ctypes.data), C.c_long(_ld(P)), r, length, C.c_void_p(G.ctypes.data), C.c_long(r))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_gram_f32")
+    return G
+
+
+def op_inverse(A: np.ndarray, offdiag: float = 0.0, diag: float = 0.0) -> np.ndarray:
+    A = _f(A)
+    r = A.shape[0]
+    out = np.zeros((r, r), dtype=np.float32, order="F")
+    st = library().nmfamd_op_inverse_f32(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), r, C.c_float(offdiag), C.c_float(diag),
+                                         C.c_void_p(out.ctypes.data), C.c_long(r))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_inverse_f32")
+    return out

@@ -113,3 +113,41 @@ int oracle_num_threads(void) {
 	return 1;
 #endif
 }
+
+/* Bit-exact restatement of the engine's fp32 MFMA factor product (nmfgpu_amd/csrc/kernels.hip,
+ * k_factor_product_f32): OUT(c, x) = sum_y F(c, y) A(x, y), with the engine's summation order:
+ *   - the reduction range is cut into `splits` workgroup slices of 8 wave pieces each, piece
+ *     boundaries at floor(steps_total * i / (8 * splits)) K-steps of two y;
+ *   - inside a piece the v_mfma_f32_32x32x2_f32 accumulator is a y-ordered fmaf chain
+ *     (/opt/skills/guides/cdna_hip_programming.md, "FP32-input MFMA": D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)));
+ *   - the 8 pieces of a slice are added in wave order, the slices in slice order.
+ * A is X x Y (lda), F is r x Y (ldf), OUT is r x X (ldo), all column-major. */
+void oracle_emulate_factor_product_f32(int X, int Y, int r, const float* A, int lda, const float* F, int ldf,
+                                       int splits, float* OUT, int ldo) {
+	const int steps_total = (Y + 1) / 2;
+	const int nw = splits * 8;
+#pragma omp parallel for schedule(static)
+	for (int x = 0; x < X; ++x)
+		for (int c = 0; c < r; ++c) {
+			float total = 0.f;
+			for (int sp = 0; sp < splits; ++sp) {
+				float slab = 0.f;
+				for (int w = 0; w < 8; ++w) {
+					const int widx = sp * 8 + w;
+					const int s0 = (int)(((long)steps_total * widx) / nw);
+					const int s1 = (int)(((long)steps_total * (widx + 1)) / nw);
+					float acc = 0.f;
+					for (int st = s0; st < s1; ++st)
+						for (int k = 0; k < 2; ++k) {
+							const int y = 2 * st + k;
+							const float a = y < Y ? A[(size_t)y * lda + x] : 0.f;
+							const float f = y < Y ? F[(size_t)y * ldf + c] : 0.f;
+							acc = fmaf(a, f, acc);
+						}
+					slab = w == 0 ? acc : slab + acc;
+				}
+				total = sp == 0 ? slab : total + slab;
+			}
+			OUT[(size_t)x * ldo + c] = total;
+		}
+}

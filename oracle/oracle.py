@@ -210,3 +210,13 @@ def run(algorithm: str, V, W, H, num_iterations: int, *, threshold_type: int = 0
         raise ValueError("unknown algorithm")
     return {"iterations": int(it), "frobenius": frob.value, "rmsd": rmsd.value,
             "history": [tuple(x) for x in hist[: hl.value]]}
+
+
+def emulate_factor_product(A, F, splits: int):
+    """Bit-exact fp32 model of the engine's MFMA factor product: OUT (r x X) = F (r x Y) A^T."""
+    assert A.dtype == np.float32 and F.dtype == np.float32
+    X, Y = A.shape
+    r = F.shape[0]
+    out = np.zeros((r, X), dtype=np.float32, order="F")
+    lib().oracle_emulate_factor_product_f32(X, Y, r, _ptr(_f(A)), _ld(A), _ptr(_f(F)), _ld(F), splits, _ptr(out), _ld(out))
+    return out

@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libnmfgpu64.so) against the CPU oracle.
+
+Tolerances (fp32 unless noted; the reference's own summation order inside cuBLAS is unknowable,
+SURVEY.md section 8c, so floating-point parity is defined against the fp64 oracle):
+  * one product:            |gpu - fp64| <= 4e-7 * sum|a*b| per element (k-ordered fmaf chain bound)
+                            and BIT-EXACT against the oracle's model of the kernel's summation order
+  * factors after k iterations: relative Frobenius difference of W and of H <= 2e-4 (k <= 100)
+  * reported error:          relative 1e-5
+  * fp64 path:               1e-9 relative
+"""
+import numpy as np
+import pytest
+
+import nmfgpu_amd as na
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def F(a):
+    return np.asfortranarray(a)
+
+
+def problem(m, n, r, dtype, seed=1):
+    rng = np.random.default_rng(seed)
+    V = F(rng.random((m, n)).astype(dtype))
+    W = F((1.0 - rng.random((m, r))).astype(dtype))
+    H = F((1.0 - rng.random((r, n))).astype(dtype))
+    return V, W, H
+
+
+def rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-300)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _library_is_native():
+    assert na.device_count() >= 1, "GPU tests need a HIP device"
+    assert na.initialize() in (na.ResultType.Success, na.ResultType.ErrorAlreadyInitialized)
+    na.set_verbosity(na.Verbosity.Nothing)
+    yield
+    na.finalize()
+
+
+# ------------------------------------------------------------------ single kernels
+
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (200, 500, 8), (1000, 777, 64), (130, 2049, 33), (640, 4100, 64)])
+def test_factor_product_bit_exact_and_close(X, Y, r):
+    rng = np.random.default_rng(X + Y + r)
+    A = F(rng.random((X, Y)).astype(np.float32))
+    Fm = F(rng.random((r, Y)).astype(np.float32))
+    out, slabs = na.op_factor_product(A, Fm)
+    want64 = Fm.astype(np.float64) @ A.astype(np.float64).T
+    bound = 4e-7 * (np.abs(Fm).astype(np.float64) @ np.abs(A).astype(np.float64).T)
+    assert (np.abs(out - want64) <= bound + 1e-30).all()
+    model = oracle.emulate_factor_product(A, Fm, slabs)
+    assert np.array_equal(out, model), f"not bit-exact (slabs={slabs}, max diff {np.abs(out - model).max()})"
+
+
+def test_factor_product_asymmetric_identity_layout_check():
+    """A = I-like selector with an asymmetric factor: catches row/column swaps in the MFMA C/D map."""
+    X, Y, r = 256, 256, 64
+    A = F(np.eye(X, Y, dtype=np.float32))
+    Fm = F((np.arange(r)[:, None] * 1000 + np.arange(Y)[None, :]).astype(np.float32))
+    out, _ = na.op_factor_product(A, Fm)
+    assert np.array_equal(out, Fm[:, :X])
+
+
+def test_factor_product_valu_and_fp64_paths():
+    rng = np.random.default_rng(3)
+    A = F(rng.random((300, 210)).astype(np.float32)); Fm = F(rng.random((20, 210)).astype(np.float32))
+    out, _ = na.op_factor_product(A, Fm, use_valu=True)
+    np.testing.assert_allclose(out, Fm.astype(np.float64) @ A.astype(np.float64).T, rtol=2e-5)
+    A64, F64 = F(A.astype(np.float64)), F(Fm.astype(np.float64))
+    out64, _ = na.op_factor_product(A64, F64)
+    np.testing.assert_allclose(out64, F64 @ A64.T, rtol=1e-12)
+
+
+@pytest.mark.parametrize("r,length", [(8, 500), (64, 1000), (100, 333)])
+def test_gram(r, length):
+    rng = np.random.default_rng(r)
+    P = F(rng.random((r, length)).astype(np.float32))
+    G = na.op_gram(P)
+    np.testing.assert_allclose(G, P.astype(np.float64) @ P.astype(np.float64).T, rtol=3e-6)
+    assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("r", [3, 8, 64])
+def test_inverse_small(r):
+    rng = np.random.default_rng(r)
+    B = rng.random((4 * r, r))
+    A = F((B.T @ B).astype(np.float32))
+    inv = na.op_inverse(A, offdiag=-0.01, diag=0.05)
+    Areg = A.astype(np.float64) - 0.01 + np.eye(r) * (0.05 + 0.01)
+    np.testing.assert_allclose(inv.astype(np.float64) @ Areg, np.eye(r), atol=5e-4)
+
+
+# ------------------------------------------------------------------ whole iterations, engine level
+
+@pytest.mark.parametrize("m,n,r,iters", [(500, 200, 8, 60), (300, 700, 64, 30), (257, 131, 5, 40)])
+def test_mu_engine_matches_oracle(m, n, r, iters):
+    V, W, H = problem(m, n, r, np.float32)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert eng.rmsd == pytest.approx(ref["rmsd"], rel=1e-5)
+    assert (Wg >= 0).all() and (Hg >= 0).all()
+    np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+
+
+def test_mu_single_iteration_vs_fp32_oracle_tight():
+    V, W, H = problem(384, 256, 64, np.float32, seed=9)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    ref = oracle.run("mu", V, Wo, Ho, 1)
+    eng = na.Engine(384, 256, 64, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(1, first_iteration=1, error_every=10, last_iteration=1)
+    Wg, Hg = eng.get_factors()
+    np.testing.assert_allclose(Hg, Ho, rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(Wg, Wo, rtol=3e-5, atol=1e-7)
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=2e-5)
+
+
+@pytest.mark.parametrize("alg,kw", [
+    ("nsnmf", dict(theta=0.5)),
+    ("gdcls", dict(lam=0.01)),
+    ("als", dict()),
+    ("acls", dict(lambda_w=0.01, lambda_h=0.01)),
+    ("ahcls", dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01)),
+])
+def test_sibling_algorithms_match_oracle(alg, kw):
+    m, n, r, iters = 320, 200, 8, 20
+    V, W, H = problem(m, n, r, np.float32, seed=4)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)
+    eng = na.Engine(m, n, r, alg, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    tol = 2e-3 if alg in ("als", "acls", "ahcls", "gdcls") else 2e-4   # LS solves amplify fp32 rounding by cond(W^T W)
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=10 * tol)
+
+
+def test_fp64_engine_matches_fp64_oracle():
+    m, n, r, iters = 200, 150, 7, 30
+    V, W, H = problem(m, n, r, np.float64)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    ref = oracle.run("mu", V, Wo, Ho, iters)
+    eng = na.Engine(m, n, r, "mu", dtype=np.float64)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, Wo) < 1e-9 and rel(Hg, Ho) < 1e-9
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-9)
+
+
+@pytest.mark.parametrize("fmt,base", [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)])
+def test_sparse_upload_equals_dense_path_bit_exact(fmt, base):
+    """Integer-valued V: the densified matrix must be identical, hence identical factors."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(fmt * 10 + base)
+    m, n, r = 150, 90, 6
+    D = ((rng.random((m, n)) < 0.2) * rng.integers(1, 6, size=(m, n))).astype(np.float32)
+    _, W, H = problem(m, n, r, np.float32)
+    dense = na.Engine(m, n, r, "mu"); dense.upload(F(D)); dense.set_factors(W, H)
+    dense.iterate(10, last_iteration=10)
+    sparse = na.Engine(m, n, r, "mu")
+    if fmt == 1:
+        s = sp.csr_matrix(D); sparse.upload_sparse(1, s.data, s.indptr + base, s.indices + base, base)
+    elif fmt == 2:
+        s = sp.csc_matrix(D); sparse.upload_sparse(2, s.data, s.indptr + base, s.indices + base, base)
+    else:
+        s = sp.coo_matrix(D); sparse.upload_sparse(3, s.data, s.row + base, s.col + base, base)
+    sparse.set_factors(W, H)
+    sparse.iterate(10, last_iteration=10)
+    Wd, Hd = dense.get_factors(); Ws, Hs = sparse.get_factors()
+    assert np.array_equal(Wd, Ws) and np.array_equal(Hd, Hs)
+    assert dense.frobenius == sparse.frobenius
+    Vdev = sparse.debug_read(6, 256 * 128)  # V panel, ld = 256
+    assert np.array_equal(Vdev.reshape(128, 256).T[:m, :n], D)
+
+
+def test_determinism_bitwise_repeatable():
+    V, W, H = problem(400, 300, 64, np.float32, seed=12)
+    outs = []
+    for _ in range(2):
+        eng = na.Engine(400, 300, 64, "mu"); eng.upload(V); eng.set_factors(W, H)
+        eng.iterate(20, last_iteration=20)
+        outs.append(eng.get_factors() + (eng.frobenius,))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+# ------------------------------------------------------------------ through nmfgpu::compute (the drop-in boundary)
+
+def test_compute_config1_plumbing_and_summary():
+    """BASELINE config 1: dense 500 x 200, r = 8, MU Frobenius, through nmfgpu_compute_single."""
+    V, W, H = problem(500, 200, 8, np.float32)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, 100)
+    s = na.Summary()
+    out = []
+    res = na.compute(V, W, H, algorithm=na.NmfAlgorithm.Multiplicative, iterations=100, seed=7, summary=s, description_out=out)
+    assert res == na.ResultType.Success
+    assert rel(W, W64) < 2e-4 and rel(H, H64) < 2e-4
+    assert s.record_count() == 1 and s.best_run() == 0
+    rec = s.record(0)
+    assert rec.numIterations == 100
+    assert rec.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert rec.rmsd == pytest.approx(ref["rmsd"], rel=1e-5)
+    # the library writes the first draw of mt19937(seed) back into the caller's struct
+    assert out[0].seed == int(oracle.seed_stream(7, 1)[0])
+    # reference example's own check (example/main.cpp:133-146): direct residual next to the reported one
+    direct = oracle.direct_frobenius(V, W, H)
+    assert direct == pytest.approx(rec.frobenius, rel=2e-2)
+
+
+def test_compute_threshold_stop_matches_oracle_iteration_count():
+    V, W, H = problem(200, 120, 4, np.float32, seed=5)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, 2000, threshold_value=1e-2)
+    s = na.Summary()
+    res = na.compute(V, W, H, iterations=2000, threshold=1e-2, summary=s)
+    assert res == na.ResultType.Success
+    assert abs(int(s.record(0).numIterations) - ref["iterations"]) <= 10
+    assert s.record(0).numIterations % 10 == 0
+
+
+def test_compute_error_behaviour():
+    V, W, H = problem(60, 40, 5, np.float32)
+    assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.nsNMF, iterations=5) == na.ResultType.ErrorInvalidArgument  # theta missing
+    assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.AHCLS, iterations=5, parameters={"lambdaW": 0.1, "lambdaH": 0.1, "alphaW": 0.1}) == na.ResultType.ErrorInvalidArgument
+    Wbig = F(np.ones((60, 41), dtype=np.float32)); Hbig = F(np.ones((41, 40), dtype=np.float32))
+    assert na.compute(V, Wbig, Hbig, iterations=5) == na.ResultType.ErrorInvalidArgument  # features > columns
+    calls = {"n": 0}
+
+    def interrupt():
+        calls["n"] += 1
+        return calls["n"] > 3
+    assert na.compute(V, W, H, iterations=50, interrupt=interrupt) == na.ResultType.ErrorUserInterrupt
+    assert calls["n"] == 4
+
+
+def test_compute_multiple_runs_random_init_keeps_best():
+    V, _, _ = problem(120, 80, 4, np.float32)
+    W = F(np.zeros((120, 4), dtype=np.float32)); H = F(np.zeros((4, 80), dtype=np.float32))
+    s = na.Summary()
+    res = na.compute(V, W, H, init=na.NmfInitializationMethod.AllRandomValues, iterations=30, runs=4, seed=3, summary=s)
+    assert res == na.ResultType.Success
+    assert 1 <= s.record_count() <= 4
+    frobs = [s.record(i).frobenius for i in range(s.record_count())]
+    assert s.best_run() == oracle.summary_best_run(frobs)
+    assert frobs == sorted(frobs, reverse=True)  # only improving runs are stored
+    # the stored factors are the best run's: the direct residual is close to the best reported error
+    assert oracle.direct_frobenius(V, W, H) == pytest.approx(min(frobs), rel=5e-2)
+    assert (W > 0).any() and (H > 0).any()
+
+
+@pytest.mark.parametrize("alg,params", [
+    (na.NmfAlgorithm.nsNMF, {"theta": 0.5}),
+    (na.NmfAlgorithm.GDCLS, {"lambda": 0.01}),
+    (na.NmfAlgorithm.AHCLS, {"lambdaW": 0.01, "lambdaH": 0.01, "alphaW": 0.01, "alphaH": 0.01}),
+])
+def test_compute_dispatches_sibling_algorithms_double(alg, params):
+    """The reference example's configuration in miniature: double precision, parameters by name."""
+    V, W, H = problem(160, 66, 6, np.float64, seed=8)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    name = {na.NmfAlgorithm.nsNMF: "nsnmf", na.NmfAlgorithm.GDCLS: "gdcls", na.NmfAlgorithm.AHCLS: "ahcls"}[alg]
+    kw = {"theta": params.get("theta", 0.0), "lam": params.get("lambda", 0.0), "lambda_w": params.get("lambdaW", 0.0),
+          "lambda_h": params.get("lambdaH", 0.0), "alpha_w": params.get("alphaW", 0.0), "alpha_h": params.get("alphaH", 0.0)}
+    ref = oracle.run(name, V, Wo, Ho, 20, **kw)
+    s = na.Summary()
+    assert na.compute(V, W, H, algorithm=alg, iterations=20, parameters=params, summary=s) == na.ResultType.Success
+    assert rel(W, Wo) < 1e-6 and rel(H, Ho) < 1e-6
+    assert s.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-6)
+
+
+def test_kmeans_and_host_init_methods_run():
+    V, _, _ = problem(90, 150, 5, np.float32, seed=2)
+    C_ = F(np.zeros((90, 5), dtype=np.float32))
+    res, memb = na.compute_kmeans(V, C_, iterations=50, seed=1)
+    assert res == na.ResultType.Success and memb.max() < 5
+    # every centroid is the mean of its members
+    for c in range(5):
+        if (memb == c).any():
+            np.testing.assert_allclose(C_[:, c], V[:, memb == c].mean(axis=1), rtol=1e-4)
+    for init in (na.NmfInitializationMethod.MeanColumns, na.NmfInitializationMethod.KMeansAndRandomValues,
+                 na.NmfInitializationMethod.KMeansAndNonNegativeWTV, na.NmfInitializationMethod.EInNMF):
+        W = F(np.zeros((90, 5), dtype=np.float32)); H = F(np.zeros((5, 150), dtype=np.float32))
+        s = na.Summary()
+        assert na.compute(V, W, H, init=init, iterations=20, seed=4, summary=s) == na.ResultType.Success
+        assert np.isfinite(s.record(0).frobenius) and s.record(0).frobenius < np.linalg.norm(V)

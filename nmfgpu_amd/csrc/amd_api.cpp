@@ -233,7 +233,7 @@ int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const 
 int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg) {
 	if (!P || !G || r <= 0 || len <= 0 || ldp < r || ldg < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
-	const int RP = padded_rank(r), parts = 64;
+	const int RP = padded_rank(r), parts = 128;
 	const long lp = pad128(len);
 	DevBuf dP, dPart, dG;
 	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dPart.alloc(sizeof(float) * (size_t)RP * RP * parts) != hipSuccess || dG.alloc(sizeof(float) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;

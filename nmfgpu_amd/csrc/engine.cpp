@@ -356,14 +356,14 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_));
-	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, (int)(mpad_ / panel_update_rows(RP_, sizeof(T))), stream_));
+	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
 }
 
 template <typename T>
 Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	const T eps = std::numeric_limits<T>::epsilon();
-	const int norm_parts = (int)(mpad_ / panel_update_rows(RP_, sizeof(T)));
+	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 	if (Status s = h_step(compute_error)) return s;
 
 	const bool ls_family = alg_ == ALG_ALS || alg_ == ALG_ACLS || alg_ == ALG_AHCLS;

@@ -109,7 +109,7 @@ private:
 	double* inv_work_ = nullptr;
 	T* stage_ = nullptr;                      // upload/download staging (max(m, n) x r)
 	long slab_stride_ = 0;
-	int gram_parts_ = 64;
+	int gram_parts_ = 128;
 	FactorProductPlan planH_, planW_;
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;

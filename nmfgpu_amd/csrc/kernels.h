@@ -35,6 +35,17 @@ hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G,
 
 enum PanelMode { PANEL_MU = 0, PANEL_LS = 1, PANEL_SET = 2 };
 int panel_update_rows(int RP, size_t elem);
+// number of per-workgroup sum-of-squares partials launch_panel_update writes for a panel of len_pad columns
+int panel_update_parts(int RP, size_t elem, int len_pad);
+
+// fp32 / padded rank 64 specialisations (kernels_fast.hip); the generic launchers dispatch to them
+hipError_t launch_gram64_f32(const float* P, int len, int parts, float* partial, float* G, hipStream_t stream);
+hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
+                                     float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
+template <typename T>
+hipError_t launch_reduce_partials(const T* partial, int parts, long stride, T* out, long count, hipStream_t stream);
+template <typename T>
+hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream);
 
 // See k_panel_update.  sumsq_part needs (len_pad / panel_update_rows) * RP elements.
 template <typename T>

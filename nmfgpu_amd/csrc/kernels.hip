@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace nmfamd {
@@ -357,11 +359,14 @@ __global__ __launch_bounds__(256) void k_gram_partial(const T* __restrict__ P, i
 
 template <typename T>
 hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G, hipStream_t stream) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (RP == 64) return launch_gram64_f32(P, len, parts, partial, G, stream);
+	}
 	int blocks = RP / 64; // RP is a multiple of 64
 	hipLaunchKernelGGL((k_gram_partial<T>), dim3(parts, blocks, blocks), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	return launch_reduce_slabs<T>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
+	return launch_reduce_partials<T>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
 }
 template hipError_t launch_gram<float>(const float*, int, int, int, float*, float*, hipStream_t);
 template hipError_t launch_gram<double>(const double*, int, int, int, double*, double*, hipStream_t);
@@ -452,9 +457,18 @@ int panel_update_rows(int RP, size_t elem) {
 	return yb;
 }
 
+int panel_update_parts(int RP, size_t elem, int len_pad) {
+	if (elem == 4 && RP == 64) return len_pad / 128;       // k_panel_update64_f32
+	return len_pad / panel_update_rows(RP, elem);
+}
+
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
                                T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (RP == 64 && mode != MODE_SET)
+			return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+	}
 	const int yb = panel_update_rows(RP, sizeof(T));
 	dim3 grid(len_pad / yb), block(256);
 	size_t smem = 2 * (size_t)yb * RP * sizeof(T);
@@ -491,8 +505,7 @@ __global__ __launch_bounds__(256) void k_normalize_panel(T* __restrict__ P, int 
 
 template <typename T>
 hipError_t launch_normalize_panel(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream) {
-	hipLaunchKernelGGL((k_normalize_panel<T>), dim3(len_pad / 32), dim3(256), RP * sizeof(T), stream, P, RP, sumsq_part, parts);
-	return hipGetLastError();
+	return launch_normalize_panel_v2<T>(P, RP, len_pad, sumsq_part, parts, stream);
 }
 template hipError_t launch_normalize_panel<float>(float*, int, int, const float*, int, hipStream_t);
 template hipError_t launch_normalize_panel<double>(double*, int, int, const double*, int, hipStream_t);

@@ -105,12 +105,25 @@ double oracle_direct_frobenius_f32(int m, int n, int r, const float* V, int ldv,
 	return sqrt(acc);
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
-	extern int omp_get_max_threads(void);
 	return omp_get_max_threads();
 #else
 	return 1;
+#endif
+}
+
+/* The GPU box exposes far more hardware threads than its CPU share allows; the Python front end
+ * sizes the team to the share (and to 1 for small problems, where fork/join dominates). */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+	omp_set_num_threads(n > 0 ? n : 1);
+#else
+	(void)n;
 #endif
 }
 

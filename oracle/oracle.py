@@ -35,10 +35,21 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def cpu_share() -> int:
+    """Threads this process may use: its affinity mask, capped at 16 (a GPU box's CPU share per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("NMF_ORACLE_MAX_THREADS", "16"))))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_num_threads.restype = C.c_int
         _lib.oracle_summary_best_run.restype = C.c_uint
@@ -85,6 +96,13 @@ def _ld(a: np.ndarray) -> int:
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+def set_threads_for(work: float) -> int:
+    """One thread for small problems (fork/join would dominate), the CPU share otherwise."""
+    n = 1 if work < 2e7 else cpu_share()
+    lib().oracle_set_num_threads(n)
+    return n
 
 
 def seed_stream(seed: int, count: int) -> np.ndarray:
@@ -198,6 +216,7 @@ def run(algorithm: str, V, W, H, num_iterations: int, *, threshold_type: int = 0
     r = W.shape[1]
     assert W.shape == (m, r) and H.shape == (r, n)
     params = (C.c_double * 6)(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta)
+    set_threads_for(float(m) * n * r)
     frob = C.c_double(0.0); rmsd = C.c_double(0.0)
     cap = num_iterations // 10 + 2
     hist = np.zeros((cap, 2), dtype=np.float64)
@@ -218,5 +237,6 @@ def emulate_factor_product(A, F, splits: int):
     X, Y = A.shape
     r = F.shape[0]
     out = np.zeros((r, X), dtype=np.float32, order="F")
+    set_threads_for(float(X) * Y * r)
     lib().oracle_emulate_factor_product_f32(X, Y, r, _ptr(_f(A)), _ld(A), _ptr(_f(F)), _ld(F), splits, _ptr(out), _ld(out))
     return out

@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the factor-product launches with HIP events")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
+    ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,7 @@ def main():
         eng.iterate(Wm, first_iteration=1, error_every=10)
         eng.synchronize()
         if not args.no_kernel_events:
-            eng.kernel_timing(True)
+            eng.kernel_timing(args.event_stride)
         barrier()
         t0 = time.perf_counter()
         eng.iterate(K, first_iteration=Wm + 1, error_every=10)
@@ -100,7 +101,7 @@ def main():
         elapsed = time.perf_counter() - t0
         if not args.no_kernel_events:
             kernel_ms, kernel_launches = eng.kernel_timing_read()
-            eng.kernel_timing(False)
+            eng.kernel_timing(0)
         frob = eng.frobenius
         parallelism = "single GPU"
     else:
@@ -110,7 +111,7 @@ def main():
         drv.run(Wm, first_iteration=1, error_every=10)
         shard.synchronize()
         if not args.no_kernel_events:
-            shard.engine.kernel_timing(True)
+            shard.engine.kernel_timing(1)
         barrier()
         t0 = time.perf_counter()
         drv.run(K, first_iteration=Wm + 1, error_every=10)

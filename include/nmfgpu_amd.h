@@ -86,18 +86,21 @@ NMFAMD_API int nmfamd_engine_randomize(nmfamd_engine* e, unsigned seed, int w, i
 /* `count` iterations of IAlgorithm::computeIteration (Algorithm.h:59).  Iterations are numbered
  * first_iteration, first_iteration+1, ...; the error is evaluated when the number is a multiple of
  * error_every (10 in the reference, SingleGpuDispatcher.h:37; 0 = never) or equals last_iteration
- * (0 = no such iteration).  Returns after the work has been ENQUEUED, except that an error
- * iteration synchronises (the reference does too). */
+ * (0 = no such iteration).  Returns after the work has been ENQUEUED; the error terms of an error
+ * iteration travel to the host asynchronously and nmfamd_engine_frobenius / _rmsd wait for them
+ * (nmfgpu::compute reads them after every error iteration, like the reference's dispatcher). */
 NMFAMD_API int nmfamd_engine_iterate(nmfamd_engine* e, int count, int first_iteration, int error_every, int last_iteration, int constant_w);
 NMFAMD_API int nmfamd_engine_synchronize(nmfamd_engine* e);
 /* Frobenius norm / RMSD of the most recent error iteration (IAlgorithm::frobeniusNorm / rmsd). */
-NMFAMD_API double nmfamd_engine_frobenius(const nmfamd_engine* e);
-NMFAMD_API double nmfamd_engine_rmsd(const nmfamd_engine* e);
+NMFAMD_API double nmfamd_engine_frobenius(nmfamd_engine* e);
+NMFAMD_API double nmfamd_engine_rmsd(nmfamd_engine* e);
 
-/* Dominant-kernel timing.  When enabled every launch of the factor-product kernel (the two
+/* Dominant-kernel timing.  enable = k > 0: every launch of the factor-product kernel (the two
  * products against V, reference: gemm TN / NT at AlgorithmMultiplicativeFrobenius.h:187-188,240-241)
- * is bracketed by HIP events on the engine's stream.  _read synchronises, returns the summed
- * duration and the number of launches since the last read, and resets the counters. */
+ * in every k-th iteration is bracketed by HIP events on the engine's stream (k = 1: all launches;
+ * an event pair costs a few microseconds of stream time, so the harness samples).  enable = 0: off.
+ * _read synchronises, returns the summed duration and the number of launches timed since the last
+ * read, and resets the counters. */
 NMFAMD_API int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable);
 NMFAMD_API int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches);
 
@@ -126,7 +129,7 @@ NMFAMD_API int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange);
 NMFAMD_API int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_error);
 /* which: 0 = sorted tr(V^T V) terms (n), 1 = tr(H^T W^T V) terms (n), 2 = tr(H H^T W^T W) terms (r).
  * Returns the number of elements copied (<= capacity), negative on error. */
-NMFAMD_API long nmfamd_engine_error_terms(const nmfamd_engine* e, int which, void* out, long capacity);
+NMFAMD_API long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capacity);
 /* The host half of the error evaluation (source/nmf/FrobeniusResolver.cpp:29-51) on caller-supplied
  * term vectors (the two latter ones are sorted in place). */
 NMFAMD_API double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw);

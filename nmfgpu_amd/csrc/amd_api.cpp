@@ -148,12 +148,13 @@ int nmfamd_engine_synchronize(nmfamd_engine* e) {
 	return hipStreamSynchronize(s) == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
-double nmfamd_engine_frobenius(const nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->frobenius() : e->d->frobenius()); }
-double nmfamd_engine_rmsd(const nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->rmsd() : e->d->rmsd()); }
+double nmfamd_engine_frobenius(nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->frobenius() : e->d->frobenius()); }
+double nmfamd_engine_rmsd(nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->rmsd() : e->d->rmsd()); }
 
 int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable) {
-	return dispatch(e, [&](Engine<float>& g) { g.enable_kernel_timing(enable != 0); return ST_OK; },
-	                   [&](Engine<double>& g) { g.enable_kernel_timing(enable != 0); return ST_OK; });
+	// enable: 0 = off, k > 0 = bracket the launches of every k-th iteration
+	return dispatch(e, [&](Engine<float>& g) { g.enable_kernel_timing(enable != 0, enable); return ST_OK; },
+	                   [&](Engine<double>& g) { g.enable_kernel_timing(enable != 0, enable); return ST_OK; });
 }
 
 int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches) {
@@ -189,9 +190,9 @@ int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_e
 	                   [&](Engine<double>& g) { return g.w_finish((const double*)exchange, compute_error != 0); });
 }
 
-long nmfamd_engine_error_terms(const nmfamd_engine* e, int which, void* out, long capacity) {
+long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capacity) {
 	if (!e || !out || which < 0 || which > 2) return -1;
-	auto copy = [&](const auto& g) -> long {
+	auto copy = [&](auto& g) -> long {
 		const auto& v = which == 0 ? g.terms_vtv_sorted() : (which == 1 ? g.terms_htwtv() : g.terms_hhtwtw());
 		long cnt = std::min<long>((long)v.size(), capacity);
 		if (cnt > 0) std::memcpy(out, v.data(), sizeof(v[0]) * (size_t)cnt);

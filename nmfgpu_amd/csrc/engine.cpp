@@ -57,6 +57,10 @@ Engine<T>::~Engine() {
 	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, psR_, stage_};
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
+	if (gramW_part_) (void)hipFree(gramW_part_);
+	if (gramH_part_) (void)hipFree(gramH_part_);
+	if (scale_) (void)hipFree(scale_);
+	if (err_event_) (void)hipEventDestroy(err_event_);
 	if (pin_psN_) (void)hipHostFree(pin_psN_);
 	if (pin_psR_) (void)hipHostFree(pin_psR_);
 	for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
@@ -107,8 +111,14 @@ Status Engine<T>::allocate() {
 		HIPX(dalloc(&Wold_, panelW));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
 	}
+	if (fused_capable()) {
+		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 128)));
+		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 128)));
+		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
+	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)std::max<long>(n_, r_)));
 	HIPX(hipHostMalloc((void**)&pin_psR_, sizeof(T) * (size_t)r_));
+	HIPX(hipEventCreateWithFlags(&err_event_, hipEventDisableTiming));
 	HIPX(hipStreamSynchronize(stream_));
 	return ST_OK;
 }
@@ -167,6 +177,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
+		fused_ready_ = false; w_pending_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -183,6 +194,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 
 template <typename T>
 Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
+	if (Status s = materialize_w()) return s;
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
 		const T* src = Wt_;
@@ -207,6 +219,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
+	if (w) { fused_ready_ = false; w_pending_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_));
 	return ST_OK;
@@ -216,7 +229,7 @@ Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
 
 template <typename T>
 void Engine<T>::record_begin() {
-	if (!timing_) return;
+	if (!timing_ || !timing_now_) return;
 	if (ev_used_ + 2 > ev_.size()) {
 		for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev_.push_back(e); }
 	}
@@ -225,7 +238,7 @@ void Engine<T>::record_begin() {
 
 template <typename T>
 void Engine<T>::record_end() {
-	if (!timing_ || ev_used_ + 2 > ev_.size()) return;
+	if (!timing_ || !timing_now_ || ev_used_ + 2 > ev_.size()) return;
 	(void)hipEventRecord(ev_[ev_used_ + 1], stream_);
 	ev_used_ += 2;
 }
@@ -244,11 +257,12 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches) {
 }
 
 template <typename T>
-Status Engine<T>::product_h(const T* F) {
+Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (planH_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planH_, Vt_, npad_, F, RP_, slabs_, slab_stride_, stream_));
+			HIPX(launch_factor_product_f32(planH_, Vt_, npad_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -260,11 +274,12 @@ Status Engine<T>::product_h(const T* F) {
 }
 
 template <typename T>
-Status Engine<T>::product_w(const T* F) {
+Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (planW_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planW_, V_, mpad_, F, RP_, slabs_, slab_stride_, stream_));
+			HIPX(launch_factor_product_f32(planW_, V_, mpad_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -286,12 +301,28 @@ Status Engine<T>::normal_inverse(T* A, T offdiag, T diag) {
 
 template <typename T>
 Status Engine<T>::fetch_error_terms(int count_n) {
+	finalize_error(false);   // the pinned buffers are about to be reused; an older fetch is long complete
 	HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * count_n, hipMemcpyDeviceToHost, stream_));
 	HIPX(hipMemcpyAsync(pin_psR_, psR_, sizeof(T) * r_, hipMemcpyDeviceToHost, stream_));
-	HIPX(hipStreamSynchronize(stream_));
-	h_psN_.assign(pin_psN_, pin_psN_ + count_n);
-	h_psR_.assign(pin_psR_, pin_psR_ + r_);
+	HIPX(hipEventRecord(err_event_, stream_));
+	err_pending_ = true;
+	err_count_ = count_n;
 	return ST_OK;
+}
+
+template <typename T>
+void Engine<T>::finalize_error(bool resolve) {
+	if (err_pending_) {
+		(void)hipEventSynchronize(err_event_);
+		h_psN_.assign(pin_psN_, pin_psN_ + err_count_);
+		h_psR_.assign(pin_psR_, pin_psR_ + r_);
+		err_pending_ = false;
+		err_unresolved_ = true;
+	}
+	if (resolve && err_unresolved_) {
+		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
+		err_unresolved_ = false;
+	}
 }
 
 template <typename T>
@@ -305,6 +336,8 @@ void Engine<T>::resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, s
 template <typename T>
 Status Engine<T>::h_step(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
+	if (Status s = materialize_w()) return s;
+	if (timing_ && timing_stride_ == 1) timing_now_ = true;
 	const T* F = Wt_;
 	if (alg_ == ALG_NSNMF) {
 		const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -361,8 +394,57 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 }
 
 template <typename T>
+bool Engine<T>::fused_capable() const {
+	return std::is_same<T, float>::value && RP_ == 64 && alg_ == ALG_MU &&
+	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
+}
+
+template <typename T>
+Status Engine<T>::materialize_w() {
+	if constexpr (std::is_same<T, float>::value) {
+		if (w_pending_) {
+			// column norms from the partial Grams of the unnormalised W, then W <- W diag(scale)
+			GramReduceArgs rg = {gramW_part_, (int)(mpad_ / 128), G2_, scale_, 1};
+			HIPX(launch_mu64_gram_reduce(rg, stream_));
+			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
+			w_pending_ = false;
+			fused_ready_ = false;
+		}
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::iterate_mu64(bool compute_error) {
+	if constexpr (std::is_same<T, float>::value) {
+		const float eps = std::numeric_limits<float>::epsilon();
+		if (!fused_ready_) {
+			HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
+			normalize_next_ = 0;
+			fused_ready_ = true;
+		}
+		GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 128), G_, scale_, normalize_next_};
+		if (Status s = product_h(Wt_, &rgW)) return s;
+		HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
+		                        compute_error ? 1 : 0, stream_));
+		GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 128), HHt_, nullptr, 0};
+		if (Status s = product_w(H_, &rgH)) return s;
+		HIPX(launch_mu64_update(1, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
+		                        compute_error ? 1 : 0, stream_));
+		normalize_next_ = 1;
+		w_pending_ = true;
+		if (compute_error) {
+			if (Status s = fetch_error_terms(n_)) return s;
+		}
+	}
+	return ST_OK;
+}
+
+template <typename T>
 Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	const T eps = std::numeric_limits<T>::epsilon();
+	timing_now_ = timing_ && (timing_iter_++ % timing_stride_ == 0);
+	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 	if (Status s = h_step(compute_error)) return s;
 
@@ -436,7 +518,6 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	}
 	if (compute_error) {
 		if (Status s = fetch_error_terms(error_terms_n)) return s;
-		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
 	}
 	return ST_OK;
 }
@@ -445,7 +526,7 @@ template <typename T>
 Status Engine<T>::debug_read(int which, T* out, long count) {
 	const T* src = nullptr; long avail = 0;
 	switch (which) {
-	case 0: src = Wt_; avail = (long)RP_ * mpad_; break;
+	case 0: if (Status st = materialize_w()) return st; src = Wt_; avail = (long)RP_ * mpad_; break;
 	case 1: src = H_; avail = (long)RP_ * npad_; break;
 	case 2: src = G_; avail = (long)RP_ * RP_; break;
 	case 3: src = HHt_; avail = (long)RP_ * RP_; break;

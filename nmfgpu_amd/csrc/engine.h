@@ -56,17 +56,21 @@ public:
 	Status w_finish(const T* exchange, bool compute_error);
 	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_; }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
-	const std::vector<T>& terms_htwtv() const { return h_psN_; }
-	const std::vector<T>& terms_hhtwtw() const { return h_psR_; }
+	const std::vector<T>& terms_htwtv() { finalize_error(false); return h_psN_; }
+	const std::vector<T>& terms_hhtwtw() { finalize_error(false); return h_psR_; }
 	const std::vector<T>& terms_vtv_sorted() const { return h_vtv_; }
 	void resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);
 
-	double frobenius() const { return frob_; }
-	double rmsd() const { return rmsd_; }
+	// Error of the most recent error iteration.  The n + r partial sums travel to the host
+	// asynchronously; the first reader waits for them and does the sorted summation, so a caller
+	// that does not look at the error every time (the benchmark loop) never stalls the stream.
+	double frobenius() { finalize_error(true); return frob_; }
+	double rmsd() { finalize_error(true); return rmsd_; }
 
 	// Timing of the dominant kernel (the factor product): when enabled, every launch is bracketed
 	// by HIP events on the engine's stream; dominant_stats reads them back (host sync).
-	void enable_kernel_timing(bool on) { timing_ = on; }
+	// stride: time the launches of every stride-th iteration only (1 = all)
+	void enable_kernel_timing(bool on, int stride = 1) { timing_ = on; timing_stride_ = stride > 0 ? stride : 1; timing_iter_ = 0; }
 	void dominant_stats(double* total_ms, long* launches);
 
 	int m() const { return m_; }
@@ -82,10 +86,14 @@ public:
 
 private:
 	Status hip_fail(hipError_t e, const char* what);
-	Status product_h(const T* F);                    // slabs_ <- partials of F V   (r x n)
-	Status product_w(const T* F);                    // slabs_ <- partials of (V F^T)^T (r x m)
+	Status product_h(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of F V   (r x n)
+	Status product_w(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of (V F^T)^T (r x m)
+	bool fused_capable() const;                      // fp32, padded rank 64, MU
+	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
+	Status materialize_w();                          // fold the pending column scale into Wt_
 	Status normal_inverse(T* A, T offdiag, T diag);  // A <- (A + regulariser)^-1
-	Status fetch_error_terms(int count_n);
+	Status fetch_error_terms(int count_n);            // enqueue the copies, do not wait
+	void finalize_error(bool resolve);
 	void record_begin();
 	void record_end();
 
@@ -105,6 +113,10 @@ private:
 	T *Wold_ = nullptr;                       // LS family: W before the update
 	T *G_ = nullptr, *G2_ = nullptr, *HHt_ = nullptr, *Qinv_ = nullptr, *gram_part_ = nullptr;
 	T *sumsq_part_ = nullptr;
+	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
+	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
+	bool fused_ready_ = false, w_pending_ = false;
+	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;
 	double* inv_work_ = nullptr;
 	T* stage_ = nullptr;                      // upload/download staging (max(m, n) x r)
@@ -113,10 +125,16 @@ private:
 	FactorProductPlan planH_, planW_;
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
+	hipEvent_t err_event_ = nullptr;
+	bool err_pending_ = false, err_unresolved_ = false;
+	int err_count_ = 0;
 	std::vector<T> h_vtv_, h_psN_, h_psR_;
 	double frob_ = 0, rmsd_ = 0;
 
 	bool timing_ = false;
+	int timing_stride_ = 1;
+	long timing_iter_ = 0;
+	bool timing_now_ = false;
 	std::vector<hipEvent_t> ev_;
 	size_t ev_used_ = 0;
 };

@@ -18,9 +18,34 @@ struct FactorProductPlan {
 
 FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);
 
+// Optional passenger of a factor-product launch (rank-64 MU fast path, kernels_mu64.hip): reduce
+// `parts` partial 64 x 64 Gram matrices into G, optionally turning its diagonal into column scales.
+struct GramReduceArgs {
+	const float* partials;  // [parts][4096]
+	int parts;
+	float* G;               // [4096]
+	float* scale;           // [64] or nullptr
+	int normalize;          // 1: scale = 1/sqrt(diag), G scaled on both sides; 0: scale = 1
+};
+constexpr int GRAM_REDUCE_BLOCKS = 16;
+
 // slabs: plan.splits partial results, slab s at slabs + s * slab_stride, panel layout [x][RP].
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
-                                     float* slabs, long slab_stride, hipStream_t stream);
+                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
+
+// Rank-64 fp32 multiplicative-update fast path (kernels_mu64.hip).
+// Partial Gram matrices of a panel, one per 128 panel columns ([len_pad/128][4096]), no reduction.
+hipError_t launch_mu64_gram_partials(const float* P, int len_pad, float* partial, hipStream_t stream);
+// Stand-alone form of the Gram reduction (used outside the iteration loop).
+hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream);
+// Fused update (slab reduction, r x r product, element-wise update, error terms, partial Gram of the
+// result).  is_w = 0: H panel, numerator scaled by `scale`; is_w = 1: Wt panel kept UNNORMALISED,
+// old values scaled by `scale`; ps = tr(H^T W^T V) terms (H) / tr(H H^T W^T W) terms (W, needs Gprev).
+hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
+                              float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
+                              int compute_error, hipStream_t stream);
+// P(c, y) *= scale(c)
+hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream);
 
 // Generic (VALU) form, writes the finished panel (no slabs).  Xpad multiple of 64, RP multiple of 32.
 template <typename T>

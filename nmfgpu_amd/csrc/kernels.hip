@@ -63,14 +63,81 @@ template <int NB> __device__ inline float fcomp(const typename FVec<NB>::type& v
 template <> __device__ inline float fcomp<2>(const f32x2& v, int i) { return v[i]; }
 template <> __device__ inline float fcomp<4>(const f32x4& v, int i) { return v[i]; }
 
+// Extra workgroups of the factor-product launch (blockIdx.y == splits) reduce the partial Gram
+// matrices the previous update kernel left behind -- work that has no dependence on the product
+// itself and would otherwise cost its own launch on the critical path.  See kernels_mu64.hip.
+//   Gu = sum_p partial[p]  (fixed order: two halves of p, then added)
+//   normalize: scale(c) = Gu(c,c) > 0 ? 1/sqrt(Gu(c,c)) : 1, else scale = 1      (column norms of W)
+//   G(a,b) = Gu(a,b) * scale(a) * scale(b)
+// Every reduce workgroup derives the 64 scales itself, so no workgroup waits for another.
+__device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, float* lds) {
+	const int tid = threadIdx.x;
+	float* s_scale = lds;        // [64]
+	float* s_tmp = lds + 64;     // [2][256]
+	const int parts = rg.parts;
+	if (rg.normalize) {
+		if (tid < 128) {
+			const int c = tid & 63, g = tid >> 6;
+			const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
+			float sum = 0.f;
+			int p = p0;
+			for (; p + 8 <= p1; p += 8) {
+				float v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) v[u] = rg.partials[(long)(p + u) * 4096 + c * 65];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) sum += v[u];
+			}
+			for (; p < p1; ++p) sum += rg.partials[(long)p * 4096 + c * 65];
+			s_tmp[g * 64 + c] = sum;
+		}
+		__syncthreads();
+		if (tid < 64) {
+			const float d = s_tmp[tid] + s_tmp[64 + tid];
+			s_scale[tid] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+		}
+	} else if (tid < 64) {
+		s_scale[tid] = 1.0f;
+	}
+	__syncthreads();
+	{
+		const int el = tid & 255, g = tid >> 8;
+		const int e = blk * 256 + el;
+		const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
+		float sum = 0.f;
+		int p = p0;
+		for (; p + 8 <= p1; p += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = rg.partials[(long)(p + u) * 4096 + e];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) sum += v[u];
+		}
+		for (; p < p1; ++p) sum += rg.partials[(long)p * 4096 + e];
+		s_tmp[g * 256 + el] = sum;
+	}
+	__syncthreads();
+	if (tid < 256) {
+		const int e = blk * 256 + tid;
+		const float v = s_tmp[tid] + s_tmp[256 + tid];
+		rg.G[e] = (v * s_scale[e & 63]) * s_scale[e >> 6];
+	}
+	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
+}
+
 template <int NB, int D>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long lda,
 	const float* __restrict__ F, int RP, int coff,
 	float* __restrict__ slabs, long slab_stride,
-	int steps_total, int splits) {
+	int steps_total, int splits, GramReduceArgs rg) {
 	typedef typename FVec<NB>::type fvec;
 	extern __shared__ __attribute__((aligned(16))) float lds[];
+
+	if (blockIdx.y == (unsigned)splits) {   // the reduce row of the grid (only launched when rg.partials != nullptr)
+		if (blockIdx.x < GRAM_REDUCE_BLOCKS) gram_reduce_block(rg, blockIdx.x, lds);
+		return;
+	}
 
 	const int xt = blockIdx.x;
 	const int sp = blockIdx.y;
@@ -213,9 +280,12 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
 
 template <int NB>
 static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
-                            float* slabs, long slab_stride, hipStream_t stream) {
+                            float* slabs, long slab_stride, const GramReduceArgs* rg, hipStream_t stream) {
 	constexpr int D = 6;
-	dim3 grid(p.xtiles, p.splits), block(512);
+	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
+	const bool with_reduce = rg != nullptr && rg->partials != nullptr && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
+	if (rg != nullptr && rg->partials != nullptr && !with_reduce) return hipErrorInvalidValue;
+	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
 	if (!attr_done) {
@@ -226,13 +296,13 @@ static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda
 	}
 	for (int ch = 0; ch < p.chunks; ++ch)
 		hipLaunchKernelGGL((k_factor_product_f32<NB, D>), grid, block, lds_bytes, stream,
-		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits);
+		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none);
 	return hipGetLastError();
 }
 
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
-                                     float* slabs, long slab_stride, hipStream_t stream) {
-	return launch_fp<2>(p, A, lda, F, RP, slabs, slab_stride, stream);
+                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
+	return launch_fp<2>(p, A, lda, F, RP, slabs, slab_stride, rg, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -541,17 +611,20 @@ template hipError_t launch_smooth_panel<double>(const double*, double*, int, int
 // ps(d) = sum_i A(d, i) B(i, d): the r terms of tr(H H^T W^T W)
 // (kernel::traceMultiplication<false>, KernelTraceMultiplication.cu:43-80 at AlgorithmMultiplicativeFrobenius.h:212)
 template <typename T>
-__global__ void k_trace_small(const T* __restrict__ A, const T* __restrict__ B, int RP, int r, T* __restrict__ ps) {
-	for (int d = threadIdx.x; d < r; d += blockDim.x) {
-		T s = 0;
-		for (int i = 0; i < r; ++i) s += A[(long)i * RP + d] * B[(long)d * RP + i];
-		ps[d] = s;
-	}
+__global__ __launch_bounds__(256) void k_trace_small(const T* __restrict__ A, const T* __restrict__ B, int RP, int r, T* __restrict__ ps) {
+	// one wave per diagonal element, lanes stride the inner index, butterfly sum (fixed order)
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int d = blockIdx.x * 4 + wave;
+	if (d >= r) return;
+	T s = 0;
+	for (int i = lane; i < r; i += 64) s += A[(long)i * RP + d] * B[(long)d * RP + i];
+	for (int w = 32; w > 0; w >>= 1) s += __shfl_xor(s, w);
+	if (lane == 0) ps[d] = s;
 }
 
 template <typename T>
 hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream) {
-	hipLaunchKernelGGL((k_trace_small<T>), dim3(1), dim3(256), 0, stream, A, B, RP, r, ps);
+	hipLaunchKernelGGL((k_trace_small<T>), dim3((r + 3) / 4), dim3(256), 0, stream, A, B, RP, r, ps);
 	return hipGetLastError();
 }
 template hipError_t launch_trace_small<float>(const float*, const float*, int, int, float*, hipStream_t);

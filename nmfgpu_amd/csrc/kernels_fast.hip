@@ -168,12 +168,40 @@ __global__ __launch_bounds__(256) void k_panel_update64_f32(
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const long off = ybase + 32 * cb + 8 * q + 4 * half;
-			f32x4 s = *reinterpret_cast<const f32x4*>(slabs + off);
-			for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + off);
-			numv[cb][q] = s;
-			if (num_out) *reinterpret_cast<f32x4*>(num_out + off) = s;
+			numv[cb][q] = *reinterpret_cast<const f32x4*>(slabs + off);
 			if (MODE == PANEL_MU) oldv[cb][q] = *reinterpret_cast<const f32x4*>(P + off);
 		}
+	for (int k = 1; k < S; ++k) {
+		f32x4 t[2][4];
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) t[cb][q] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + ybase + 32 * cb + 8 * q + 4 * half);
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) numv[cb][q] += t[cb][q];
+	}
+	if (num_out) {
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(num_out + ybase + 32 * cb + 8 * q + 4 * half) = numv[cb][q];
+	}
+
+	// all 64 A operands (Q) are requested up front, next to the numerator loads: one memory latency
+	// for the whole product instead of one per group of MFMAs
+	float qa[2][32];
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const int cp = 32 * cb + 8 * q + 4 * half + gi;
+				qa[0][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + l31];
+				qa[1][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + 32 + l31];
+			}
 
 	f32x16 acc[2];
 #pragma unroll
@@ -181,21 +209,13 @@ __global__ __launch_bounds__(256) void k_panel_update64_f32(
 #pragma unroll
 	for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			float qa[2][4];
-#pragma unroll
-			for (int gi = 0; gi < 4; ++gi) {
-				const int cp = 32 * cb + 8 * q + 4 * half + gi;
-				qa[0][gi] = Q[(long)cp * 64 + l31];
-				qa[1][gi] = Q[(long)cp * 64 + 32 + l31];
-			}
+		for (int q = 0; q < 4; ++q)
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) {
 				const float b = (MODE == PANEL_MU) ? oldv[cb][q][gi] : numv[cb][q][gi];
-				acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0][gi], b, acc[0], 0, 0, 0);
-				acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[1][gi], b, acc[1], 0, 0, 0);
+				acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0][cb * 16 + q * 4 + gi], b, acc[0], 0, 0, 0);
+				acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[1][cb * 16 + q * 4 + gi], b, acc[1], 0, 0, 0);
 			}
-		}
 
 	float psum = 0.f;
 #pragma unroll
@@ -268,10 +288,30 @@ __global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, i
 		s_norm[c] = s > T(0) ? (T)sqrt(s) : T(0);
 	}
 	__syncthreads();
+	// 128 panel columns x RP rows, four elements per thread and step, eight steps in flight
 	const long base = (long)blockIdx.x * 128 * RP;
-	for (int e = threadIdx.x; e < 128 * RP; e += 256) {
-		const T nrm = s_norm[e % RP];
-		if (nrm > T(0)) P[base + e] = P[base + e] / nrm;
+	const int quads = 128 * RP / 4;
+	for (int e0 = threadIdx.x; e0 < quads; e0 += 256 * 8) {
+		T v[8][4];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int e = e0 + u * 256;
+			if (e < quads) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) v[u][k] = P[base + 4 * (long)e + k];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int e = e0 + u * 256;
+			if (e < quads) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const T nrm = s_norm[(4 * e + k) % RP];
+					if (nrm > T(0)) P[base + 4 * (long)e + k] = v[u][k] / nrm;
+				}
+			}
+		}
 	}
 }
 

@@ -1,0 +1,275 @@
+// kernels_mu64.hip -- the multiplicative-update iteration at padded rank 64, fp32, as FOUR launches.
+//
+// Reference sequence per iteration (source/nmf/AlgorithmMultiplicativeFrobenius.h:165-248):
+//   syrk W^T W, symm (W^T W) H, gemm W^T V, multiplyDivide(H), [trace kernels],
+//   syrk H H^T, symm W (H H^T), gemm V H^T, multiplyDivide(W), normalizeColumns(W)
+// Here:
+//   K_H  factor product  slabs <- Wu^T V (split-K)          + passenger: G, scale <- partial Grams of Wu
+//   U_H  k_mu64_update<false>   H <- H .* (scale .* sum slabs) ./ (G H + eps); tr terms; partial Grams of H
+//   K_W  factor product  slabs <- (V H^T)^T                 + passenger: H H^T <- partial Grams of H
+//   U_W  k_mu64_update<true>    Wu <- (Wu scale) .* (sum slabs) ./ ((Wu scale) H H^T + eps); partial Grams of Wu
+//
+// Column normalisation of W (kernel::normalizeColumns, KernelNormalizeColumns.cu:37-58) is carried
+// as a 64-entry scale vector instead of a pass over W: W = Wu diag(scale), scale(c) = 1/||Wu(:,c)||
+// (1 when the norm is 0, the reference's `sum > 0` guard).  Everything that consumes W applies it:
+//   W^T W = diag(scale) (Wu^T Wu) diag(scale)      (Gram reduction passenger)
+//   W^T V = diag(scale) (Wu^T V)                   (numerator scaling in U_H)
+//   W itself                                       (old-value scaling in U_W, Engine::materialize_w)
+// Up to fp32 rounding (a multiplication by 1/norm instead of a division by norm, applied after
+// instead of before the products) this is the reference's arithmetic; tolerances in tests/.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One wave = 32 panel columns; workgroup = 4 waves = 128 panel columns = one contiguous 32 KiB
+// tile of the panel.  Global traffic is fully coalesced: every array tile (slabs, old panel
+// values, result) moves as 16 B per lane over consecutive lanes, the slabs are summed in that
+// linear order, and the row-per-lane order the MFMA wants is produced by a pass through LDS
+// (a row-per-lane pattern straight from global memory is texture-addresser bound: 64 cache lines
+// per wave instruction).  MFMA operand maps as in k_panel_update64_f32 (kernels_fast.hip): the C/D
+// register layout of lane (y, k) doubles as the B operand of the r x r product.
+template <bool IS_W>
+__global__ __launch_bounds__(256) void k_mu64_update(
+	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
+	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
+	float* __restrict__ ps, int len_valid, float* __restrict__ gram_partial,
+	const float* __restrict__ Gprev, int compute_error) {
+	// one [y][c] tile with padded rows, used three times: numerator, old values, new values
+	__shared__ __attribute__((aligned(16))) float s_val[128][68];
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const long tile = (long)blockIdx.x * 128 * 64;
+	const int ycol = blockIdx.x * 128 + wave * 32 + l31;
+	const int c4 = (4 * tid) & 63;          // this thread's four panel rows in the linear pass
+	const int yl0 = tid >> 4;               // its panel column in step j is yl0 + 16 j
+
+	// ---- linear pass: slab sum, pending scale, into LDS ---------------------------------------
+	f32x4 nl[8], ol[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const long e = tile + 4 * (tid + 256 * j);
+		nl[j] = *reinterpret_cast<const f32x4*>(slabs + e);
+		ol[j] = *reinterpret_cast<const f32x4*>(P + e);
+	}
+	const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
+	// A operands of the r x r product (Q), requested now so that they arrive during the slab sum
+	float qa[2][32];
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const int cp = 32 * cb + 8 * q + 4 * half + gi;
+				qa[0][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + l31];
+				qa[1][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + 32 + l31];
+			}
+	for (int k = 1; k < S; k += 2) {        // two slabs in flight per step, added in slab order
+		f32x4 t0[8], t1[8];
+		const bool two = k + 1 < S;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const long e = tile + 4 * (tid + 256 * j);
+			t0[j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + e);
+			t1[j] = *reinterpret_cast<const f32x4*>(slabs + (long)(two ? k + 1 : k) * slab_stride + e);
+		}
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			nl[j] += t0[j];
+			if (two) nl[j] += t1[j];
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		// the pending column scale of W goes on the numerator W^T V (H update) or on W itself (W update)
+		if (IS_W) ol[j] *= sc; else nl[j] *= sc;
+		*reinterpret_cast<f32x4*>(&s_val[yl0 + 16 * j][c4]) = nl[j];
+	}
+	__syncthreads();
+	const int yrow = wave * 32 + l31;
+	f32x4 numv[2][4], oldv[2][4];
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) numv[cb][q] = *reinterpret_cast<const f32x4*>(&s_val[yrow][32 * cb + 8 * q + 4 * half]);
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(&s_val[yl0 + 16 * j][c4]) = ol[j];
+	__syncthreads();
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) oldv[cb][q] = *reinterpret_cast<const f32x4*>(&s_val[yrow][32 * cb + 8 * q + 4 * half]);
+
+	// ---- MFMA pass: den = Q * old, element-wise update -----------------------------------------
+	f32x16 acc[2];
+#pragma unroll
+	for (int g = 0; g < 16; ++g) { acc[0][g] = 0.f; acc[1][g] = 0.f; }
+#pragma unroll
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const float b = oldv[cb][q][gi];
+				acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0][cb * 16 + q * 4 + gi], b, acc[0], 0, 0, 0);
+				acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[1][cb * 16 + q * 4 + gi], b, acc[1], 0, 0, 0);
+			}
+
+	float psum = 0.f;
+#pragma unroll
+	for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			f32x4 o;
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				o[gi] = oldv[mb][q][gi] * numv[mb][q][gi] / (acc[mb][4 * q + gi] + eps);
+				psum += o[gi] * numv[mb][q][gi];
+			}
+			// each lane overwrites exactly the LDS words it read; other waves touch other rows
+			*reinterpret_cast<f32x4*>(&s_val[yrow][32 * mb + 8 * q + 4 * half]) = o;
+		}
+	if (!IS_W && compute_error) {
+		// per-column terms of tr(H^T W^T V) (kernel::traceMultiplication, AlgorithmMultiplicativeFrobenius.h:194-197)
+		psum += __shfl_xor(psum, 32);
+		if (half == 0 && ycol < len_valid) ps[ycol] = psum;
+	}
+	if (IS_W && compute_error && blockIdx.x == 0) {
+		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (:212)
+		for (int d = wave * 16; d < wave * 16 + 16; ++d) {
+			float v = Q[(long)lane * 64 + d] * Gprev[(long)d * 64 + lane];
+			for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w);
+			if (lane == 0) ps[d] = v;
+		}
+	}
+	__syncthreads();
+
+	// ---- result out (coalesced) and partial Gram of the 128 new columns ------------------------
+#pragma unroll
+	for (int j = 0; j < 8; ++j)
+		*reinterpret_cast<f32x4*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4*>(&s_val[yl0 + 16 * j][c4]);
+	const int ab = wave >> 1, bb = wave & 1;   // wave (ab, bb) computes one 32 x 32 block over all 128 columns
+	f32x16 g;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) g[i] = 0.f;
+#pragma unroll 8
+	for (int x = 0; x < 128; x += 2) {
+		const float a = s_val[x + half][ab * 32 + l31];
+		const float b = s_val[x + half][bb * 32 + l31];
+		g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, g, 0, 0, 0);
+	}
+	float* out = gram_partial + (long)blockIdx.x * 4096;
+#pragma unroll
+	for (int q = 0; q < 4; ++q)
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi) out[(long)(ab * 32 + gi + 8 * q + 4 * half) * 64 + bb * 32 + l31] = g[4 * q + gi];
+}
+
+hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
+                              float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
+                              int compute_error, hipStream_t stream) {
+	dim3 grid(len_pad / 128), block(256);
+	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
+	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
+	return hipGetLastError();
+}
+
+// Partial Gram matrices of an existing panel in the layout k_mu64_update produces (one per 128
+// panel columns): used once after W has been (re)initialised.
+__global__ __launch_bounds__(256) void k_mu64_gram_partials(const float* __restrict__ P, float* __restrict__ partial) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int ab = wave >> 1, bb = wave & 1;
+	const float* p = P + (long)blockIdx.x * 128 * 64;
+	f32x16 g;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) g[i] = 0.f;
+#pragma unroll 8
+	for (int x = 0; x < 128; x += 2) {
+		const float a = p[(long)(x + half) * 64 + ab * 32 + l31];
+		const float b = p[(long)(x + half) * 64 + bb * 32 + l31];
+		g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, g, 0, 0, 0);
+	}
+	float* out = partial + (long)blockIdx.x * 4096;
+#pragma unroll
+	for (int q = 0; q < 4; ++q)
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi) out[(long)(ab * 32 + gi + 8 * q + 4 * half) * 64 + bb * 32 + l31] = g[4 * q + gi];
+}
+
+hipError_t launch_mu64_gram_partials(const float* P, int len_pad, float* partial, hipStream_t stream) {
+	hipLaunchKernelGGL(k_mu64_gram_partials, dim3(len_pad / 128), dim3(256), 0, stream, P, partial);
+	return hipGetLastError();
+}
+
+// Stand-alone Gram reduction with the same arithmetic (and summation order) as the passenger
+// workgroups of the factor-product launch.
+__global__ __launch_bounds__(512) void k_mu64_gram_reduce(GramReduceArgs rg) {
+	__shared__ float lds[64 + 512];
+	const int tid = threadIdx.x, blk = blockIdx.x;
+	float* s_scale = lds;
+	float* s_tmp = lds + 64;
+	const int parts = rg.parts;
+	if (rg.normalize) {
+		if (tid < 128) {
+			const int c = tid & 63, g = tid >> 6;
+			const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
+			float sum = 0.f;
+			for (int p = p0; p < p1; ++p) sum += rg.partials[(long)p * 4096 + c * 65];
+			s_tmp[g * 64 + c] = sum;
+		}
+		__syncthreads();
+		if (tid < 64) {
+			const float d = s_tmp[tid] + s_tmp[64 + tid];
+			s_scale[tid] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+		}
+	} else if (tid < 64) {
+		s_scale[tid] = 1.0f;
+	}
+	__syncthreads();
+	{
+		const int el = tid & 255, g = tid >> 8;
+		const int e = blk * 256 + el;
+		const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
+		float sum = 0.f;
+		for (int p = p0; p < p1; ++p) sum += rg.partials[(long)p * 4096 + e];
+		s_tmp[g * 256 + el] = sum;
+	}
+	__syncthreads();
+	if (tid < 256) {
+		const int e = blk * 256 + tid;
+		const float v = s_tmp[tid] + s_tmp[256 + tid];
+		rg.G[e] = (v * s_scale[e & 63]) * s_scale[e >> 6];
+	}
+	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
+}
+
+hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream) {
+	hipLaunchKernelGGL(k_mu64_gram_reduce, dim3(GRAM_REDUCE_BLOCKS), dim3(512), 0, stream, rg);
+	return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mu64_apply_scale(float* __restrict__ P, long count4, const float* __restrict__ scale) {
+	const long e = (long)blockIdx.x * 256 + threadIdx.x;
+	if (e >= count4) return;
+	f32x4 v = *reinterpret_cast<f32x4*>(P + 4 * e);
+	const f32x4 s = *reinterpret_cast<const f32x4*>(scale + (4 * e) % 64);
+	v *= s;
+	*reinterpret_cast<f32x4*>(P + 4 * e) = v;
+}
+
+hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream) {
+	const long count4 = (long)len_pad * 64 / 4;
+	hipLaunchKernelGGL(k_mu64_apply_scale, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, stream, P, count4, scale);
+	return hipGetLastError();
+}
+
+} // namespace nmfamd

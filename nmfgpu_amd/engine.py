@@ -121,8 +121,9 @@ class Engine:
     def rmsd(self) -> float:
         return float(self._lib.nmfamd_engine_rmsd(self._h))
 
-    def kernel_timing(self, enable: bool):
-        self._check(self._lib.nmfamd_engine_kernel_timing(self._h, int(enable)), "kernel_timing")
+    def kernel_timing(self, every: int):
+        """every = k > 0: time the factor-product launches of every k-th iteration; 0: off."""
+        self._check(self._lib.nmfamd_engine_kernel_timing(self._h, int(every)), "kernel_timing")
 
     def kernel_timing_read(self):
         ms = C.c_double(0); cnt = C.c_long(0)

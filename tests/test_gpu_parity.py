@@ -113,6 +113,51 @@ def test_mu_engine_matches_oracle(m, n, r, iters):
     np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
 
 
+def test_mu_generic_kernel_path_matches_oracle(monkeypatch):
+    """The rank-generic kernels (kernels.hip / kernels_fast.hip) instead of the fused rank-64 MU path."""
+    monkeypatch.setenv("NMFAMD_NO_FUSED_MU", "1")
+    m, n, r, iters = 500, 200, 8, 60
+    V, W, H = problem(m, n, r, np.float32)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+
+
+def test_mu_large_rank_uses_chunked_product():
+    """r = 100 -> padded rank 128: two 64-row chunks of the factor product, generic update kernels."""
+    m, n, r, iters = 260, 300, 100, 10
+    V, W, H = problem(m, n, r, np.float32, seed=21)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+
+
+def test_mu_fused_path_interleaved_with_downloads():
+    """get_factors() in the middle of a run folds the pending column scale into W and the run continues."""
+    m, n, r = 640, 2300, 64   # 18 x-tiles on the H side: the Gram reduction rides in the product launch
+    V, W, H = problem(m, n, r, np.float32, seed=13)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    oracle.run("mu", V64, W64, H64, 7)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(3, first_iteration=1, error_every=0)
+    W3, _ = eng.get_factors()
+    np.testing.assert_allclose(np.linalg.norm(W3.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+    eng.iterate(4, first_iteration=4, error_every=0)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 1e-4 and rel(Hg, H64) < 1e-4
+
+
 def test_mu_single_iteration_vs_fp32_oracle_tight():
     V, W, H = problem(384, 256, 64, np.float32, seed=9)
     Wo, Ho = W.copy(order="F"), H.copy(order="F")

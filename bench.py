@@ -132,8 +132,12 @@ def main():
         if kernel_launches > 0:
             avg_s = kernel_ms / 1e3 / kernel_launches
             achieved = flops_per_launch / avg_s / 1e12
+            traffic = None   # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
+            tpath = os.path.join(ROOT, "profiles", "traffic_factor_product.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                         "kernel": "k_factor_product_f32", "avg_launch_us": avg_s * 1e6, "launches": kernel_launches,
                         "flops_per_launch": flops_per_launch}
         out = {

@@ -143,6 +143,11 @@ NMFAMD_API int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int
                                             float* OUT, long ldo, int use_valu, int* out_slabs);
 NMFAMD_API int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r,
                                             double* OUT, long ldo);
+/* Tuning / diagnosis of the factor-product kernel (rank 64) on synthetic device data: average of
+ * `reps` back-to-back launches; optionally (stamps_out != NULL) one launch of the diagnostic build that
+ * records 8 uint64 per wave: shader clock at entry / first MFMA / loop end / kernel end, 100 MHz
+ * real-time counter at entry / end, K-steps, XCC id. */
+NMFAMD_API int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned long long* stamps_out, long stamps_capacity, long* stamps_count);
 /* G (r x r) = P P^T for a host r x len matrix P. */
 NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg);
 /* Ainv = (A + regulariser)^-1 for a host r x r matrix (offdiag / diag added as KernelFillMatrix.cu:29-45). */

@@ -223,6 +223,41 @@ int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count)
 // ---- single operations on host data -------------------------------------------------------
 
 
+// Tuning / diagnosis of the dominant kernel on synthetic device data: `reps` back-to-back launches
+// timed with one event pair; optionally one more launch of the stamped build.
+int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned long long* stamps_out, long stamps_capacity, long* stamps_count) {
+	if (X <= 0 || Y <= 0 || reps <= 0 || !avg_us) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = 64;
+	const long Xp = pad128(X), Yp = pad128(Y);
+	int dev = 0; hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	FactorProductPlan plan = plan_factor_product((int)Xp, Y, RP, prop.multiProcessorCount);
+	DevBuf dA, dF, dS, dT;
+	const long slab_stride = (long)RP * Xp;
+	const long nwaves = (long)plan.xtiles * plan.splits * 8;
+	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * RP * Yp) != hipSuccess ||
+	    dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess || dT.alloc(sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (launch_fill_uniform<float>((float*)dA.p, (int)Xp, (int)Xp, Yp, Yp, 1, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;   // Xp x Yp uniform (0,1]
+	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	hipEvent_t e0, e1;
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+	for (int i = 0; i < 3; ++i) launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	(void)hipEventRecord(e0, nullptr);
+	for (int i = 0; i < reps; ++i) launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	(void)hipEventRecord(e1, nullptr);
+	if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+	float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+	*avg_us = ms * 1e3 / reps;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	if (stamps_out && stamps_capacity >= 8 * nwaves) {
+		if (launch_factor_product_f32_stamped(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, (unsigned long long*)dT.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (stamps_count) *stamps_count = nwaves;
+	} else if (stamps_count) *stamps_count = 0;
+	return NMFAMD_OK;
+}
+
 int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int use_valu, int* out_slabs) {
 	return op_factor_product<float>(A, lda, X, Y, F, ldf, r, OUT, ldo, use_valu != 0, out_slabs);
 }

@@ -112,8 +112,8 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
 	}
 	if (fused_capable()) {
-		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 128)));
-		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 128)));
+		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
+		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
 	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)std::max<long>(n_, r_)));
@@ -404,7 +404,7 @@ Status Engine<T>::materialize_w() {
 	if constexpr (std::is_same<T, float>::value) {
 		if (w_pending_) {
 			// column norms from the partial Grams of the unnormalised W, then W <- W diag(scale)
-			GramReduceArgs rg = {gramW_part_, (int)(mpad_ / 128), G2_, scale_, 1};
+			GramReduceArgs rg = {gramW_part_, (int)(mpad_ / 64), G2_, scale_, 1};
 			HIPX(launch_mu64_gram_reduce(rg, stream_));
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
 			w_pending_ = false;
@@ -423,11 +423,11 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 			normalize_next_ = 0;
 			fused_ready_ = true;
 		}
-		GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 128), G_, scale_, normalize_next_};
+		GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
 		if (Status s = product_h(Wt_, &rgW)) return s;
 		HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
 		                        compute_error ? 1 : 0, stream_));
-		GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 128), HHt_, nullptr, 0};
+		GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), HHt_, nullptr, 0};
 		if (Status s = product_w(H_, &rgH)) return s;
 		HIPX(launch_mu64_update(1, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
 		                        compute_error ? 1 : 0, stream_));

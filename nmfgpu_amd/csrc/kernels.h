@@ -33,8 +33,13 @@ constexpr int GRAM_REDUCE_BLOCKS = 16;
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 
+// Diagnostic build of the same kernel with in-kernel clock stamps (8 x uint64 per wave:
+// shader clock at entry / first MFMA / loop end / kernel end, 100 MHz real time at entry / end, steps, XCC id).
+hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                                             float* slabs, long slab_stride, unsigned long long* stamps, hipStream_t stream);
+
 // Rank-64 fp32 multiplicative-update fast path (kernels_mu64.hip).
-// Partial Gram matrices of a panel, one per 128 panel columns ([len_pad/128][4096]), no reduction.
+// Partial Gram matrices of a panel, one per 64 panel columns ([len_pad/64][4096]), no reduction.
 hipError_t launch_mu64_gram_partials(const float* P, int len_pad, float* partial, hipStream_t stream);
 // Stand-alone form of the Gram reduction (used outside the iteration loop).
 hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
 #include <type_traits>
 
 #include "kernels.h"
@@ -125,12 +126,17 @@ __device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, floa
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
-template <int NB, int D>
+template <int NB, int D, bool STAMP>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long lda,
 	const float* __restrict__ F, int RP, int coff,
 	float* __restrict__ slabs, long slab_stride,
-	int steps_total, int splits, GramReduceArgs rg) {
+	int steps_total, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
+	// STAMP: diagnostic build only (nmfamd_tune_factor_product): per-wave shader-clock and 100 MHz
+	// real-time stamps at kernel entry, first MFMA, end of the main loop and end of the epilogue,
+	// written to a buffer of their own; the production instantiation has STAMP = false.
+	unsigned long long t_entry = 0, r_entry = 0, t_loop0 = 0, t_loop1 = 0;
+	if (STAMP) { t_entry = __builtin_amdgcn_s_memtime(); r_entry = __builtin_amdgcn_s_memrealtime(); }
 	typedef typename FVec<NB>::type fvec;
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 			fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
 		}
 		__builtin_amdgcn_sched_barrier(0);
+		if (STAMP) { t_loop0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 		int t = 0;
 		for (; t + D <= steps; t += D) {
 #pragma unroll
@@ -212,6 +219,8 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 			}
 		}
 	}
+
+	if (STAMP) { __builtin_amdgcn_sched_barrier(0); t_loop1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 
 	// ---- sum the eight per-wave tiles through LDS, four accumulator tiles per round ----------
 	// LDS image of a round: [src wave 8][tile 4][q 4][lane 64] float4  (128 KiB)
@@ -260,6 +269,16 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 			}
 		}
 	}
+	if (STAMP) {
+		__builtin_amdgcn_s_waitcnt(0);   // stores done
+		const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+		if (lane == 0) {
+			unsigned long long* o = stamps + 8 * ((long)(blockIdx.y * gridDim.x + blockIdx.x) * FP_WAVES + wave);
+			o[0] = t_entry; o[1] = t_loop0; o[2] = t_loop1; o[3] = t_end; o[4] = r_entry; o[5] = r_end; o[6] = steps;
+			unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			o[7] = xcc;
+		}
+	}
 }
 
 FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
@@ -278,10 +297,9 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
 	return p;
 }
 
-template <int NB>
-static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
-                            float* slabs, long slab_stride, const GramReduceArgs* rg, hipStream_t stream) {
-	constexpr int D = 6;
+template <int NB, int D, bool STAMP>
+static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                              float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
 	const bool with_reduce = rg != nullptr && rg->partials != nullptr && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
 	if (rg != nullptr && rg->partials != nullptr && !with_reduce) return hipErrorInvalidValue;
@@ -289,15 +307,43 @@ static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
 	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D>),
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D, STAMP>),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		if (e != hipSuccess) return e;
 		attr_done = true;
 	}
 	for (int ch = 0; ch < p.chunks; ++ch)
-		hipLaunchKernelGGL((k_factor_product_f32<NB, D>), grid, block, lds_bytes, stream,
-		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none);
+		hipLaunchKernelGGL((k_factor_product_f32<NB, D, STAMP>), grid, block, lds_bytes, stream,
+		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
+}
+
+// Register-ring depth of the main loop: 8 unless NMFAMD_FP_DEPTH selects another instantiation (tuning).
+static int fp_depth() {
+	static int d = -1;
+	if (d < 0) {
+		const char* e = getenv("NMFAMD_FP_DEPTH");
+		d = e ? atoi(e) : 8;
+		if (d != 4 && d != 6 && d != 8 && d != 10 && d != 12) d = 8;
+	}
+	return d;
+}
+
+template <int NB>
+static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                            float* slabs, long slab_stride, const GramReduceArgs* rg, hipStream_t stream) {
+	switch (fp_depth()) {
+	case 4: return launch_fp_d<NB, 4, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	case 8: return launch_fp_d<NB, 8, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	case 10: return launch_fp_d<NB, 10, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	case 12: return launch_fp_d<NB, 12, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	default: return launch_fp_d<NB, 6, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	}
+}
+
+hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+                                             float* slabs, long slab_stride, unsigned long long* stamps, hipStream_t stream) {
+	return launch_fp_d<2, 6, true>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 }
 
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,

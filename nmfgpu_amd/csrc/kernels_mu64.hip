@@ -27,123 +27,127 @@ namespace nmfamd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One wave = 32 panel columns; workgroup = 4 waves = 128 panel columns = one contiguous 32 KiB
-// tile of the panel.  Global traffic is fully coalesced: every array tile (slabs, old panel
-// values, result) moves as 16 B per lane over consecutive lanes, the slabs are summed in that
-// linear order, and the row-per-lane order the MFMA wants is produced by a pass through LDS
-// (a row-per-lane pattern straight from global memory is texture-addresser bound: 64 cache lines
-// per wave instruction).  MFMA operand maps as in k_panel_update64_f32 (kernels_fast.hip): the C/D
-// register layout of lane (y, k) doubles as the B operand of the r x r product.
+// Workgroup = 4 waves = 64 panel columns = one contiguous 16 KiB tile of the panel.
+// Global traffic is fully coalesced: every array tile (slabs, old panel values, result) moves as
+// 16 B per lane over consecutive lanes, up to six slabs in flight at once and summed in slab order,
+// and the row-per-lane order the MFMA wants is produced by a pass through LDS (a row-per-lane
+// pattern straight from global memory is texture-addresser bound: 64 cache lines per instruction).
+// MFMA pass: wave w = (ct = w & 1: which 32 columns, mb = w >> 1: which 32 rows of the result);
+//   A operand: lane (i = l & 31, k = l >> 5) holds Q(mb*32 + i, c'_k(t))
+//   B operand: lane (y = l & 31, k = l >> 5) holds old(c'_k(t), y),  c'_k(t) = 32*cb + 8*q + 4*k + gi
+// i.e. the K order is chosen so that the B operands are the float4 groups the C/D register map
+// of the MFMA gives lane (y, k): one LDS image serves the product and the element-wise step.
 template <bool IS_W>
 __global__ __launch_bounds__(256) void k_mu64_update(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
 	float* __restrict__ ps, int len_valid, float* __restrict__ gram_partial,
 	const float* __restrict__ Gprev, int compute_error) {
-	// one [y][c] tile with padded rows, used three times: numerator, old values, new values
-	__shared__ __attribute__((aligned(16))) float s_val[128][68];
+	__shared__ __attribute__((aligned(16))) float s_num[64][68];   // reduced numerator, later the new values
+	__shared__ __attribute__((aligned(16))) float s_old[64][68];   // old values (scaled for the W update)
+	__shared__ float s_ps[2][64];
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int half = lane >> 5, l31 = lane & 31;
-	const long tile = (long)blockIdx.x * 128 * 64;
-	const int ycol = blockIdx.x * 128 + wave * 32 + l31;
+	const int ct = wave & 1, mb = wave >> 1;
+	const long tile = (long)blockIdx.x * 64 * 64;
 	const int c4 = (4 * tid) & 63;          // this thread's four panel rows in the linear pass
 	const int yl0 = tid >> 4;               // its panel column in step j is yl0 + 16 j
 
-	// ---- linear pass: slab sum, pending scale, into LDS ---------------------------------------
-	f32x4 nl[8], ol[8];
+	// ---- linear pass: slab sum (slab order), pending scale, into LDS ---------------------------
+	f32x4 nl[4], ol[4];
+	{
+		f32x4 t[5][4];
 #pragma unroll
-	for (int j = 0; j < 8; ++j) {
-		const long e = tile + 4 * (tid + 256 * j);
-		nl[j] = *reinterpret_cast<const f32x4*>(slabs + e);
-		ol[j] = *reinterpret_cast<const f32x4*>(P + e);
+		for (int j = 0; j < 4; ++j) {
+			const long e = tile + 4 * (tid + 256 * j);
+			nl[j] = *reinterpret_cast<const f32x4*>(slabs + e);
+			ol[j] = *reinterpret_cast<const f32x4*>(P + e);
+#pragma unroll
+			for (int u = 0; u < 5; ++u) {
+				const int k = 1 + u < S ? 1 + u : 0;   // clamped duplicate, discarded below
+				t[u][j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + e);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 5; ++u)
+			if (1 + u < S) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) nl[j] += t[u][j];
+			}
+		for (int k0 = 6; k0 < S; k0 += 5) {      // more than six slabs: further batches of five
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int u = 0; u < 5; ++u) {
+					const int k = k0 + u < S ? k0 + u : 0;
+					t[u][j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + tile + 4 * (tid + 256 * j));
+				}
+#pragma unroll
+			for (int u = 0; u < 5; ++u)
+				if (k0 + u < S) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) nl[j] += t[u][j];
+				}
+		}
 	}
 	const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
-	// A operands of the r x r product (Q), requested now so that they arrive during the slab sum
-	float qa[2][32];
+	// A operands of the r x r product (Q rows of this wave's M-block), in flight during the LDS pass
+	float qa[32];
 #pragma unroll
 	for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
 		for (int q = 0; q < 4; ++q)
 #pragma unroll
-			for (int gi = 0; gi < 4; ++gi) {
-				const int cp = 32 * cb + 8 * q + 4 * half + gi;
-				qa[0][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + l31];
-				qa[1][cb * 16 + q * 4 + gi] = Q[(long)cp * 64 + 32 + l31];
-			}
-	for (int k = 1; k < S; k += 2) {        // two slabs in flight per step, added in slab order
-		f32x4 t0[8], t1[8];
-		const bool two = k + 1 < S;
+			for (int gi = 0; gi < 4; ++gi) qa[cb * 16 + q * 4 + gi] = Q[(long)(32 * cb + 8 * q + 4 * half + gi) * 64 + 32 * mb + l31];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			const long e = tile + 4 * (tid + 256 * j);
-			t0[j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + e);
-			t1[j] = *reinterpret_cast<const f32x4*>(slabs + (long)(two ? k + 1 : k) * slab_stride + e);
-		}
-#pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			nl[j] += t0[j];
-			if (two) nl[j] += t1[j];
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < 8; ++j) {
+	for (int j = 0; j < 4; ++j) {
 		// the pending column scale of W goes on the numerator W^T V (H update) or on W itself (W update)
 		if (IS_W) ol[j] *= sc; else nl[j] *= sc;
-		*reinterpret_cast<f32x4*>(&s_val[yl0 + 16 * j][c4]) = nl[j];
+		*reinterpret_cast<f32x4*>(&s_num[yl0 + 16 * j][c4]) = nl[j];
+		*reinterpret_cast<f32x4*>(&s_old[yl0 + 16 * j][c4]) = ol[j];
 	}
 	__syncthreads();
-	const int yrow = wave * 32 + l31;
-	f32x4 numv[2][4], oldv[2][4];
-#pragma unroll
-	for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) numv[cb][q] = *reinterpret_cast<const f32x4*>(&s_val[yrow][32 * cb + 8 * q + 4 * half]);
-	__syncthreads();
-#pragma unroll
-	for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(&s_val[yl0 + 16 * j][c4]) = ol[j];
-	__syncthreads();
-#pragma unroll
-	for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) oldv[cb][q] = *reinterpret_cast<const f32x4*>(&s_val[yrow][32 * cb + 8 * q + 4 * half]);
 
-	// ---- MFMA pass: den = Q * old, element-wise update -----------------------------------------
-	f32x16 acc[2];
+	// ---- MFMA pass: den = Q * old, element-wise update of this wave's 32 x 32 block --------------
+	const int yrow = ct * 32 + l31;
+	f32x4 oldv[2][4], numv[4];
 #pragma unroll
-	for (int g = 0; g < 16; ++g) { acc[0][g] = 0.f; acc[1][g] = 0.f; }
+	for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) oldv[cb][q] = *reinterpret_cast<const f32x4*>(&s_old[yrow][32 * cb + 8 * q + 4 * half]);
+#pragma unroll
+	for (int q = 0; q < 4; ++q) numv[q] = *reinterpret_cast<const f32x4*>(&s_num[yrow][32 * mb + 8 * q + 4 * half]);
+	f32x16 acc;
+#pragma unroll
+	for (int g = 0; g < 16; ++g) acc[g] = 0.f;
 #pragma unroll
 	for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
 		for (int q = 0; q < 4; ++q)
 #pragma unroll
-			for (int gi = 0; gi < 4; ++gi) {
-				const float b = oldv[cb][q][gi];
-				acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[0][cb * 16 + q * 4 + gi], b, acc[0], 0, 0, 0);
-				acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[1][cb * 16 + q * 4 + gi], b, acc[1], 0, 0, 0);
-			}
+			for (int gi = 0; gi < 4; ++gi)
+				acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[cb * 16 + q * 4 + gi], oldv[cb][q][gi], acc, 0, 0, 0);
 
 	float psum = 0.f;
 #pragma unroll
-	for (int mb = 0; mb < 2; ++mb)
+	for (int q = 0; q < 4; ++q) {
+		f32x4 o;
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			f32x4 o;
-#pragma unroll
-			for (int gi = 0; gi < 4; ++gi) {
-				o[gi] = oldv[mb][q][gi] * numv[mb][q][gi] / (acc[mb][4 * q + gi] + eps);
-				psum += o[gi] * numv[mb][q][gi];
-			}
-			// each lane overwrites exactly the LDS words it read; other waves touch other rows
-			*reinterpret_cast<f32x4*>(&s_val[yrow][32 * mb + 8 * q + 4 * half]) = o;
+		for (int gi = 0; gi < 4; ++gi) {
+			const float old = mb == 0 ? oldv[0][q][gi] : oldv[1][q][gi];
+			o[gi] = old * numv[q][gi] / (acc[4 * q + gi] + eps);
+			psum += o[gi] * numv[q][gi];
 		}
+		// each (row, 32-row block) of s_num is read and then overwritten by exactly one wave
+		*reinterpret_cast<f32x4*>(&s_num[yrow][32 * mb + 8 * q + 4 * half]) = o;
+	}
 	if (!IS_W && compute_error) {
-		// per-column terms of tr(H^T W^T V) (kernel::traceMultiplication, AlgorithmMultiplicativeFrobenius.h:194-197)
 		psum += __shfl_xor(psum, 32);
-		if (half == 0 && ycol < len_valid) ps[ycol] = psum;
+		if (half == 0) s_ps[mb][yrow] = psum;
 	}
 	if (IS_W && compute_error && blockIdx.x == 0) {
-		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (:212)
+		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (AlgorithmMultiplicativeFrobenius.h:212)
 		for (int d = wave * 16; d < wave * 16 + 16; ++d) {
 			float v = Q[(long)lane * 64 + d] * Gprev[(long)d * 64 + lane];
 			for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w);
@@ -151,19 +155,24 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 		}
 	}
 	__syncthreads();
+	if (!IS_W && compute_error && tid < 64) {
+		// per-column terms of tr(H^T W^T V) (kernel::traceMultiplication, AlgorithmMultiplicativeFrobenius.h:194-197)
+		const int ycol = blockIdx.x * 64 + tid;
+		if (ycol < len_valid) ps[ycol] = s_ps[0][tid] + s_ps[1][tid];
+	}
 
-	// ---- result out (coalesced) and partial Gram of the 128 new columns ------------------------
+	// ---- result out (coalesced) and partial Gram of the 64 new columns --------------------------
 #pragma unroll
-	for (int j = 0; j < 8; ++j)
-		*reinterpret_cast<f32x4*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4*>(&s_val[yl0 + 16 * j][c4]);
-	const int ab = wave >> 1, bb = wave & 1;   // wave (ab, bb) computes one 32 x 32 block over all 128 columns
+	for (int j = 0; j < 4; ++j)
+		*reinterpret_cast<f32x4*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4*>(&s_num[yl0 + 16 * j][c4]);
+	const int ab = wave >> 1, bb = wave & 1;   // wave (ab, bb) computes one 32 x 32 block over the 64 columns
 	f32x16 g;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) g[i] = 0.f;
 #pragma unroll 8
-	for (int x = 0; x < 128; x += 2) {
-		const float a = s_val[x + half][ab * 32 + l31];
-		const float b = s_val[x + half][bb * 32 + l31];
+	for (int x = 0; x < 64; x += 2) {
+		const float a = s_num[x + half][ab * 32 + l31];
+		const float b = s_num[x + half][bb * 32 + l31];
 		g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, g, 0, 0, 0);
 	}
 	float* out = gram_partial + (long)blockIdx.x * 4096;
@@ -176,24 +185,24 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                               float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
                               int compute_error, hipStream_t stream) {
-	dim3 grid(len_pad / 128), block(256);
+	dim3 grid(len_pad / 64), block(256);
 	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
 	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
 	return hipGetLastError();
 }
 
-// Partial Gram matrices of an existing panel in the layout k_mu64_update produces (one per 128
+// Partial Gram matrices of an existing panel in the layout k_mu64_update produces (one per 64
 // panel columns): used once after W has been (re)initialised.
 __global__ __launch_bounds__(256) void k_mu64_gram_partials(const float* __restrict__ P, float* __restrict__ partial) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int half = lane >> 5, l31 = lane & 31;
 	const int ab = wave >> 1, bb = wave & 1;
-	const float* p = P + (long)blockIdx.x * 128 * 64;
+	const float* p = P + (long)blockIdx.x * 64 * 64;
 	f32x16 g;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) g[i] = 0.f;
 #pragma unroll 8
-	for (int x = 0; x < 128; x += 2) {
+	for (int x = 0; x < 64; x += 2) {
 		const float a = p[(long)(x + half) * 64 + ab * 32 + l31];
 		const float b = p[(long)(x + half) * 64 + bb * 32 + l31];
 		g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, g, 0, 0, 0);
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256) void k_mu64_gram_partials(const float* __restr
 }
 
 hipError_t launch_mu64_gram_partials(const float* P, int len_pad, float* partial, hipStream_t stream) {
-	hipLaunchKernelGGL(k_mu64_gram_partials, dim3(len_pad / 128), dim3(256), 0, stream, P, partial);
+	hipLaunchKernelGGL(k_mu64_gram_partials, dim3(len_pad / 64), dim3(256), 0, stream, P, partial);
 	return hipGetLastError();
 }
 

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
     args = ap.parse_args()
@@ -85,7 +86,7 @@ def main():
         torch.cuda.synchronize()
 
     kernel_ms, kernel_launches = 0.0, 0
-    if not distributed:
+    if not distributed and not args.sharded:
         eng = na.Engine(M, N_COLS, R, "mu", dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream)
         eng.upload(V)
         eng.set_factors(W, H)
@@ -121,9 +122,10 @@ def main():
         if not args.no_kernel_events:
             kernel_ms, kernel_launches = shard.engine.kernel_timing_read()
         frob = drv.frobenius
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         parallelism = f"column shards x{world}, W replicated, RCCL all-reduce of (V H^T | H H^T) per iteration"
 
     if rank == 0:

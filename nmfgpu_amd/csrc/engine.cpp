@@ -336,8 +336,23 @@ void Engine<T>::resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, s
 template <typename T>
 Status Engine<T>::h_step(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
-	if (Status s = materialize_w()) return s;
 	if (timing_ && timing_stride_ == 1) timing_now_ = true;
+	if constexpr (std::is_same<T, float>::value) {
+		if (fused_capable()) {
+			// sharded form of the four-launch iteration (kernels_mu64.hip): K_H + U_H here
+			if (!fused_ready_) {
+				HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
+				normalize_next_ = 0;
+				fused_ready_ = true;
+			}
+			GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
+			if (Status s = product_h(Wt_, &rgW)) return s;
+			HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
+			                        compute_error ? 1 : 0, stream_));
+			return ST_OK;
+		}
+	}
+	if (Status s = materialize_w()) return s;
 	const T* F = Wt_;
 	if (alg_ == ALG_NSNMF) {
 		const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -373,6 +388,16 @@ template <typename T>
 Status Engine<T>::w_products(T* exchange) {
 	if (alg_ != ALG_MU) return ST_INVALID;
 	T* ex_hht = exchange + (long)RP_ * mpad_;
+	if constexpr (std::is_same<T, float>::value) {
+		if (fused_capable()) {
+			// K_W with the local H H^T reduced straight into the exchange buffer by the passenger
+			// workgroups, then the local split-K slabs summed into the exchange panel
+			GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), ex_hht, nullptr, 0};
+			if (Status s = product_w(H_, &rgH)) return s;
+			HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
+			return ST_OK;
+		}
+	}
 	HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, ex_hht, stream_));
 	if (Status s = product_w(H_)) return s;
 	HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
@@ -384,6 +409,17 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	if (alg_ != ALG_MU) return ST_INVALID;
 	const T eps = std::numeric_limits<T>::epsilon();
 	const T* ex_hht = exchange + (long)RP_ * mpad_;
+	if constexpr (std::is_same<T, float>::value) {
+		if (fused_capable()) {
+			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T
+			HIPX(launch_mu64_update(1, Wt_, exchange, 1, 0, ex_hht, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
+			                        compute_error ? 1 : 0, stream_));
+			normalize_next_ = 1;
+			w_pending_ = true;
+			if (compute_error) { if (Status s = fetch_error_terms(n_)) return s; }
+			return ST_OK;
+		}
+	}
 	if (compute_error) {
 		HIPX(launch_trace_small<T>(ex_hht, G_, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;

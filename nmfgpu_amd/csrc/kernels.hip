@@ -126,7 +126,7 @@ __device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, floa
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
-template <int NB, int D, bool STAMP>
+template <int NB, int D, bool STAMP, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long lda,
 	const float* __restrict__ F, int RP, int coff,
@@ -199,8 +199,14 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][b], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
 				int st = t + D + d;
 				st = st < last ? st : last;
-				va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
-				fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
+				// DIAG (stamped diagnostic builds only): 1 = no refill at all (pure MFMA issue rate),
+				// 2 = refill A only, 3 = refill F only
+				if (DIAG == 0 || DIAG == 2) va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+				if (DIAG == 0 || DIAG == 3) fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
+				// keep the operand that was NOT reloaded opaque to the optimiser (never the reloaded one:
+				// an asm use would wait for the load right behind its issue)
+				if (DIAG == 1 || DIAG == 3) { asm volatile("" : "+v"(va[d])); }
+				if (DIAG == 1 || DIAG == 2) { asm volatile("" : "+v"(fb[d])); }
 				// pin the order: the refill of ring slot d is issued right behind the MFMAs that
 				// consumed it, D-1 steps before its data is needed (hipcc otherwise sinks all loads
 				// to the end of the unrolled body and the first step waits a full memory latency)
@@ -297,7 +303,7 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
 	return p;
 }
 
-template <int NB, int D, bool STAMP>
+template <int NB, int D, bool STAMP, int DIAG = 0>
 static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
                               float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -307,13 +313,13 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long l
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
 	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D, STAMP>),
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D, STAMP, DIAG>),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		if (e != hipSuccess) return e;
 		attr_done = true;
 	}
 	for (int ch = 0; ch < p.chunks; ++ch)
-		hipLaunchKernelGGL((k_factor_product_f32<NB, D, STAMP>), grid, block, lds_bytes, stream,
+		hipLaunchKernelGGL((k_factor_product_f32<NB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
 		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
@@ -343,7 +349,14 @@ static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda
 
 hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
                                              float* slabs, long slab_stride, unsigned long long* stamps, hipStream_t stream) {
-	return launch_fp_d<2, 6, true>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	static int diag = -1;
+	if (diag < 0) { const char* e = getenv("NMFAMD_FP_DIAG"); diag = e ? atoi(e) : 0; }
+	switch (diag) {
+	case 1: return launch_fp_d<2, 8, true, 1>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	case 2: return launch_fp_d<2, 8, true, 2>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	case 3: return launch_fp_d<2, 8, true, 3>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	default: return launch_fp_d<2, 8, true, 0>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	}
 }
 
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,

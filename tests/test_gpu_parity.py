@@ -340,3 +340,72 @@ def test_kmeans_and_host_init_methods_run():
         s = na.Summary()
         assert na.compute(V, W, H, init=init, iterations=20, seed=4, summary=s) == na.ResultType.Success
         assert np.isfinite(s.record(0).frobenius) and s.record(0).frobenius < np.linalg.norm(V)
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes
+
+def _config2(dtype=np.float32):
+    V = F(np.random.RandomState(1).random_sample((5000, 10000)).astype(dtype).T)
+    W = F((1.0 - np.random.RandomState(2).random_sample((64, 10000))).astype(dtype).T)
+    H = F((1.0 - np.random.RandomState(3).random_sample((5000, 64))).astype(dtype).T)
+    return V, W, H
+
+
+def test_config2_full_size_factor_product_properties():
+    """10 000 x 5 000, r = 64: sampled entries against fp64 dot products, the sum identity
+    sum_{c,x} OUT = sum_y (sum_c F)(sum_x A), and linearity in F."""
+    V, W, H = _config2()
+    out, slabs = na.op_factor_product(V, H)            # (V H^T)^T, 64 x 10000
+    rng = np.random.default_rng(0)
+    xs = rng.integers(0, 10000, 200); cs = rng.integers(0, 64, 200)
+    want = np.einsum("ij,ij->i", V[xs, :].astype(np.float64), H[cs, :].astype(np.float64))
+    np.testing.assert_allclose(out[cs, xs], want, rtol=2e-6)
+    total = float(out.astype(np.float64).sum())
+    ident = float(H.astype(np.float64).sum(axis=0) @ V.astype(np.float64).sum(axis=0))
+    assert total == pytest.approx(ident, rel=1e-6)
+    H2 = F(np.roll(H, 7, axis=1) * np.float32(0.5))
+    out2, _ = na.op_factor_product(V, H2)
+    out12, _ = na.op_factor_product(V, F(H + H2))
+    np.testing.assert_allclose(out12, out + out2, rtol=5e-6)
+    # a 200-row stripe bit-exact against the summation-order model (the full model is 6.4 GFLOP of fmaf)
+    stripe = slice(4000, 4200)
+    model = oracle.emulate_factor_product(F(V[stripe, :]), H, slabs)
+    assert np.array_equal(out[:, stripe], model)
+
+
+def test_config2_full_size_mu_matches_oracle_and_invariants():
+    V, W, H = _config2()
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    iters = 10
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    eng = na.Engine(10000, 5000, 64, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters - 1, first_iteration=1, error_every=0)
+    Wprev, _ = eng.get_factors()
+    eng.iterate(1, first_iteration=iters, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 1e-4 and rel(Hg, H64) < 1e-4
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert (Wg >= 0).all() and (Hg >= 0).all()
+    np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+    # the reported value is ||V - W_{k-1} H_k||_F (SURVEY 3.3 item 2), checked directly at full size
+    assert oracle.direct_frobenius(V, Wprev, Hg) == pytest.approx(eng.frobenius, rel=2e-5)
+
+
+@pytest.mark.parametrize("alg,kw,tol", [
+    ("ahcls", dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01), 5e-3),
+    ("gdcls", dict(lam=0.01), 5e-3),
+    ("nsnmf", dict(theta=0.5), 2e-4),
+])
+def test_config5_full_size_algorithm_dispatch(alg, kw, tol):
+    """BASELINE config 5: AHCLS / GDCLS (and nsNMF) at 10 000 x 5 000, r = 64, fp32 vs the fp64 oracle."""
+    V, W, H = _config2()
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    iters = 5
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)
+    eng = na.Engine(10000, 5000, 64, alg, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=10 * tol)

@@ -646,19 +646,21 @@ template hipError_t launch_normalize_panel<double>(double*, int, int, const doub
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_smooth_panel(const T* __restrict__ P, T* __restrict__ out, int RP, int r, long len_pad, T offdiag, T diag) {
-	long y = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	// one wave per panel column y: lanes stride the factor rows (coalesced), butterfly sum
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long y = (long)blockIdx.x * 4 + wave;
 	if (y >= len_pad) return;
 	const T* p = P + y * RP;
 	T* o = out + y * RP;
 	T sum = 0;
-	for (int c = 0; c < r; ++c) sum += p[c];
-	for (int c = 0; c < r; ++c) o[c] = offdiag * (sum - p[c]) + diag * p[c];
-	for (int c = r; c < RP; ++c) o[c] = 0;
+	for (int c = lane; c < r; c += 64) sum += p[c];
+	for (int w = 32; w > 0; w >>= 1) sum += __shfl_xor(sum, w);
+	for (int c = lane; c < RP; c += 64) o[c] = c < r ? offdiag * (sum - p[c]) + diag * p[c] : T(0);
 }
 
 template <typename T>
 hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream) {
-	hipLaunchKernelGGL((k_smooth_panel<T>), dim3((unsigned)((len_pad + 255) / 256)), dim3(256), 0, stream, P, out, RP, r, len_pad, offdiag, diag);
+	hipLaunchKernelGGL((k_smooth_panel<T>), dim3((unsigned)((len_pad + 3) / 4)), dim3(256), 0, stream, P, out, RP, r, len_pad, offdiag, diag);
 	return hipGetLastError();
 }
 template hipError_t launch_smooth_panel<float>(const float*, float*, int, int, long, float, float, hipStream_t);
@@ -806,8 +808,104 @@ __global__ __launch_bounds__(256) void k_inverse_small(const T* __restrict__ A, 
 	}
 }
 
+// Fast form for r <= 64: Gauss-Jordan elimination with partial pivoting on the augmented matrix
+// [A | I] (A embedded in a 64 x 64 block-diagonal with an identity tail), double precision,
+// REGISTER resident: 256 threads as a 16 x 16 grid, thread (ti, tj) owns rows 4ti..4ti+3 and
+// columns 8tj..8tj+7 (32 doubles).  Per elimination step only the pivot column and the scaled pivot
+// row travel through (double-buffered) LDS: two barriers per step, no row swaps -- the pivot row
+// stays where it is and the row permutation is undone when the result is written
+// (left half ends as a permutation matrix P = E A, right half E, so A^-1 row k = E row p_k).
+// The step loop is unrolled by 8 so that every register index is static.
+// Same result as the QR route (cusolver geqrf + ormqr + trsm, Matrix.h:565-618) up to rounding for
+// the non-singular normal matrices the LS algorithms produce.
+template <typename T>
+__global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv) {
+	__shared__ double s_col[2][64];
+	__shared__ double s_row[2][128];
+	__shared__ int s_inv[64];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int ti = tid >> 4, tj = tid & 15;
+	double M[4][8];
+#pragma unroll
+	for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+		for (int cc = 0; cc < 8; ++cc) {
+			const int i = 4 * ti + rr, j = 8 * tj + cc;
+			double v;
+			if (j < 64) v = (i < r && j < r) ? (double)A[(long)j * RP + i] : (i == j ? 1.0 : 0.0);
+			else v = (j - 64 == i) ? 1.0 : 0.0;
+			M[rr][cc] = v;
+		}
+	unsigned long long used = 0ull;
+	// 8 (rolled) x 8 (unrolled) steps: the register index of pivot column k inside its owner's
+	// block (k % 8) is static, while the code stays small enough for the instruction cache
+	// (all 64 steps unrolled run ~7x slower on instruction fetch).
+#pragma unroll 1
+	for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+	for (int kc = 0; kc < 8; ++kc) {
+		const int k = 8 * kg + kc;
+		const int b = kc & 1;
+		if (tj == kg) {
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr) s_col[b][4 * ti + rr] = M[rr][kc];
+		}
+		__syncthreads();
+		// pivot: (near-)largest |column k| among the rows not used yet; every wave computes the same
+		// answer.  One 32-bit key per lane -- the float bits of |value| with the low six bits replaced
+		// by 63 - lane -- so the wave reduction is six single shuffles (the first of equal maxima wins).
+		unsigned key = 0u;
+		if (!((used >> lane) & 1ull)) key = (__float_as_uint((float)fabs(s_col[b][lane])) & ~63u) | (unsigned)(63 - lane);
+		for (int w = 32; w > 0; w >>= 1) { const unsigned o = __shfl_xor(key, w); key = o > key ? o : key; }
+		const int p = 63 - (int)(key & 63u);
+		const double pivinv = 1.0 / s_col[b][p];
+		if (ti == (p >> 2)) {
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr)
+				if (rr == (p & 3)) {
+#pragma unroll
+					for (int cc = 0; cc < 8; ++cc) s_row[b][8 * tj + cc] = M[rr][cc] * pivinv;
+				}
+		}
+		if (tid == 0) s_inv[p] = k;
+		used |= 1ull << p;
+		__syncthreads();
+		double prow[8];
+#pragma unroll
+		for (int cc = 0; cc < 8; ++cc) prow[cc] = s_row[b][8 * tj + cc];
+#pragma unroll
+		for (int rr = 0; rr < 4; ++rr) {
+			const int i = 4 * ti + rr;
+			const double f = s_col[b][i];
+#pragma unroll
+			for (int cc = 0; cc < 8; ++cc) M[rr][cc] = (i == p) ? prow[cc] : M[rr][cc] - f * prow[cc];
+		}
+	}
+	__syncthreads();
+	if (tj >= 8) {
+#pragma unroll
+		for (int rr = 0; rr < 4; ++rr) {
+			const int kk = s_inv[4 * ti + rr];
+#pragma unroll
+			for (int cc = 0; cc < 8; ++cc) {
+				const int j = 8 * tj + cc - 64;
+				if (kk < r && j < r) Ainv[(long)j * RP + kk] = (T)M[rr][cc];
+			}
+		}
+	}
+	// zero padding of the RP x RP output outside the r x r block
+	for (int e = tid; e < RP * RP; e += 256) {
+		const int i = e % RP, j = e / RP;
+		if (i >= r || j >= r) Ainv[e] = T(0);
+	}
+}
+
 template <typename T>
 hipError_t launch_inverse_small(const T* A, int RP, int r, T* Ainv, double* work, hipStream_t stream) {
+	if (r <= 64) {
+		hipLaunchKernelGGL((k_inverse_gj64<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL((k_inverse_small<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv, work);
 	return hipGetLastError();
 }

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
@@ -70,12 +71,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or na.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank on a real node
+    torch.cuda.set_device(device_index)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     V, W, H = make_problem(rank)
     K, Wm = args.steps, args.warmup
@@ -123,7 +128,7 @@ def main():
             kernel_ms, kernel_launches = shard.engine.kernel_timing_read()
         frob = drv.frobenius
         if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         parallelism = f"column shards x{world}, W replicated, RCCL all-reduce of (V H^T | H H^T) per iteration"

@@ -52,7 +52,13 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 	if (hipMemcpy2D(dF.p, RP * sizeof(T), F, ldf * sizeof(T), r * sizeof(T), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 	hipError_t e;
 	if constexpr (std::is_same<T, float>::value) {
-		if (mfma) e = launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+		if (mfma) {
+			DevBuf dT;   // x-tiled image of A for the MFMA kernel
+			if (dT.alloc(sizeof(T) * Xp * Yp) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+			e = launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, 128 * Yp, false, nullptr);
+			if (e == hipSuccess) e = launch_factor_product_f32(plan, (const float*)dT.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+			if (e == hipSuccess) e = hipDeviceSynchronize();
+		}
 		else e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
 	} else {
 		e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
@@ -242,16 +248,16 @@ int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned 
 	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	hipEvent_t e0, e1;
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
-	for (int i = 0; i < 3; ++i) launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	for (int i = 0; i < 3; ++i) launch_factor_product_f32(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
 	(void)hipEventRecord(e0, nullptr);
-	for (int i = 0; i < reps; ++i) launch_factor_product_f32(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	for (int i = 0; i < reps; ++i) launch_factor_product_f32(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
 	(void)hipEventRecord(e1, nullptr);
 	if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
 	float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
 	*avg_us = ms * 1e3 / reps;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	if (stamps_out && stamps_capacity >= 8 * nwaves) {
-		if (launch_factor_product_f32_stamped(plan, (const float*)dA.p, Xp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, (unsigned long long*)dT.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (launch_factor_product_f32_stamped(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, (unsigned long long*)dT.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 		if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 		if (stamps_count) *stamps_count = nwaves;
 	} else if (stamps_count) *stamps_count = 0;

@@ -79,6 +79,7 @@ Status Engine<T>::allocate() {
 	planW_ = plan_factor_product((int)mpad_, n_, RP_, num_cus_);
 	const bool mfma = std::is_same<T, float>::value && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; }
+	tiled_ = mfma;
 	slab_stride_ = (long)RP_ * std::max(mpad_, npad_);
 	const long slab_elems = slab_stride_ * std::max(planH_.splits, planW_.splits);
 	const long panelW = (long)RP_ * mpad_, panelH = (long)RP_ * npad_, rr = (long)RP_ * RP_;
@@ -125,23 +126,47 @@ Status Engine<T>::allocate() {
 
 // ---- upload / download --------------------------------------------------------------------
 
+// Column-major staging image of V (ld = mpad_) -> the resident images and the tr(V^T V) terms.
+// MFMA path (fp32): V_ and Vt_ are x-TILED (kernels.hip, k_factor_product_f32); the staging image
+// is a temporary.  Generic path: V_ IS the column-major image and Vt_ its plain transpose.
 template <typename T>
-Status Engine<T>::upload_dense(const T* V, long ld) {
-	if (!V || ld < m_) return ST_INVALID;
-	HIPX(hipMemcpy2DAsync(V_, mpad_ * sizeof(T), V, ld * sizeof(T), m_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_));
-	HIPX(launch_transpose<T>(V_, mpad_, m_, n_, Vt_, npad_, stream_));
-	HIPX(launch_column_sumsq<T>(V_, mpad_, m_, n_, psN_, stream_));
+Status Engine<T>::finish_upload(T* Vcol) {
+	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_));
 	h_vtv_.resize(n_);
 	HIPX(hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_));
+	if (tiled_) {
+		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_));
+		HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_));
+		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, 128 * npad_, false, stream_));
+		HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, 128 * mpad_, stream_));
+	} else {
+		HIPX(launch_transpose<T>(Vcol, mpad_, m_, n_, Vt_, npad_, stream_));
+	}
 	HIPX(hipStreamSynchronize(stream_));
 	std::sort(h_vtv_.begin(), h_vtv_.end());
 	return ST_OK;
 }
 
 template <typename T>
+Status Engine<T>::upload_dense(const T* V, long ld) {
+	if (!V || ld < m_) return ST_INVALID;
+	T* Vcol = V_;
+	if (tiled_) {
+		HIPX(hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_)));
+		hipError_t e = hipMemsetAsync(Vcol, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_);
+		if (e != hipSuccess) { (void)hipFree(Vcol); return hip_fail(e, "hipMemsetAsync(staging)"); }
+	}
+	hipError_t e = hipMemcpy2DAsync(Vcol, mpad_ * sizeof(T), V, ld * sizeof(T), m_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_);
+	Status st = e == hipSuccess ? finish_upload(Vcol) : hip_fail(e, "hipMemcpy2DAsync(V)");
+	if (tiled_) (void)hipFree(Vcol);
+	return st;
+}
+
+template <typename T>
 Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const int* b, long nnz, int base) {
 	if (format < 1 || format > 3 || nnz < 0 || (nnz > 0 && (!values || !a || !b))) return ST_INVALID;
 	T* d_val = nullptr; int *d_a = nullptr, *d_b = nullptr;
+	T* Vcol = nullptr;
 	const int outer = format == 1 ? m_ : n_;
 	const long na = format == 3 ? nnz : (long)outer + 1;
 	Status st = ST_OK;
@@ -155,18 +180,16 @@ Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const
 			    (e = hipMemcpyAsync(d_b, b, sizeof(int) * nnz, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse)"); break; }
 		}
 		if (na > 0 && (e = hipMemcpyAsync(d_a, a, sizeof(int) * na, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse ptr)"); break; }
-		if ((e = hipMemsetAsync(V_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_)) != hipSuccess) { st = hip_fail(e, "hipMemsetAsync(V)"); break; }
+		if (tiled_ && (e = hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_))) != hipSuccess) { Vcol = nullptr; st = hip_fail(e, "hipMalloc(staging)"); break; }
+		if (!tiled_) Vcol = V_;
+		if ((e = hipMemsetAsync(Vcol, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_)) != hipSuccess) { st = hip_fail(e, "hipMemsetAsync(V)"); break; }
 		// CSR: ptr = a (rowPtr), idx = b (columns); CSC: ptr = a (columnPtr), idx = b (rows); COO: idx = a (rows), idx2 = b (columns)
-		if (format == 3) e = launch_densify<T>(3, d_val, nullptr, d_a, d_b, nnz, 0, base, V_, mpad_, m_, n_, stream_);
-		else e = launch_densify<T>(format, d_val, d_a, d_b, nullptr, nnz, outer, base, V_, mpad_, m_, n_, stream_);
+		if (format == 3) e = launch_densify<T>(3, d_val, nullptr, d_a, d_b, nnz, 0, base, Vcol, mpad_, m_, n_, stream_);
+		else e = launch_densify<T>(format, d_val, d_a, d_b, nullptr, nnz, outer, base, Vcol, mpad_, m_, n_, stream_);
 		if (e != hipSuccess) { st = hip_fail(e, "densify"); break; }
-		if ((e = launch_transpose<T>(V_, mpad_, m_, n_, Vt_, npad_, stream_)) != hipSuccess ||
-		    (e = launch_column_sumsq<T>(V_, mpad_, m_, n_, psN_, stream_)) != hipSuccess) { st = hip_fail(e, "transpose/sumsq"); break; }
-		h_vtv_.resize(n_);
-		if ((e = hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_)) != hipSuccess ||
-		    (e = hipStreamSynchronize(stream_)) != hipSuccess) { st = hip_fail(e, "sync(sparse upload)"); break; }
-		std::sort(h_vtv_.begin(), h_vtv_.end());
+		st = finish_upload(Vcol);
 	} while (0);
+	if (tiled_ && Vcol) (void)hipFree(Vcol);
 	if (d_val) (void)hipFree(d_val);
 	if (d_a) (void)hipFree(d_a);
 	if (d_b) (void)hipFree(d_b);
@@ -259,10 +282,10 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches) {
 template <typename T>
 Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 	if constexpr (std::is_same<T, float>::value) {
-		if (planH_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+		if (tiled_) {
 			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planH_, Vt_, npad_, F, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_f32(planH_, Vt_, 128 * mpad_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -276,10 +299,10 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 template <typename T>
 Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 	if constexpr (std::is_same<T, float>::value) {
-		if (planW_.splits > 1 || std::getenv("NMFAMD_FORCE_VALU") == nullptr) {
+		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planW_, V_, mpad_, F, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_f32(planW_, V_, 128 * npad_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -432,7 +455,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 template <typename T>
 bool Engine<T>::fused_capable() const {
 	return std::is_same<T, float>::value && RP_ == 64 && alg_ == ALG_MU &&
-	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
+	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;   // (evaluated before allocate(): no tiled_ here)
 }
 
 template <typename T>
@@ -568,8 +591,22 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 	case 3: src = HHt_; avail = (long)RP_ * RP_; break;
 	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
 	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
-	case 6: src = V_; avail = mpad_ * npad_; break;
-	case 7: src = Vt_; avail = mpad_ * npad_; break;
+	case 6: case 7: {
+		// V (ld mpad_) / Vt (ld npad_) as column-major images; the MFMA path keeps them x-tiled
+		const bool vt = which == 7;
+		const T* img = vt ? Vt_ : V_;
+		avail = mpad_ * npad_;
+		if (count > avail) return ST_INVALID;
+		if (!tiled_) { src = img; break; }
+		T* tmp = nullptr;
+		HIPX(hipMalloc((void**)&tmp, sizeof(T) * (size_t)avail));
+		hipError_t e = hipMemsetAsync(tmp, 0, sizeof(T) * (size_t)avail, stream_);
+		if (e == hipSuccess) e = vt ? launch_tile<T>(img, npad_, n_, m_, tmp, 128 * mpad_, true, stream_) : launch_tile<T>(img, mpad_, m_, n_, tmp, 128 * npad_, true, stream_);
+		if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(T) * count, hipMemcpyDeviceToHost, stream_);
+		if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+		(void)hipFree(tmp);
+		return e == hipSuccess ? ST_OK : hip_fail(e, "debug_read(V)");
+	}
 	default: return ST_INVALID;
 	}
 	if (count > avail) return ST_INVALID;

@@ -92,6 +92,7 @@ private:
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
 	Status materialize_w();                          // fold the pending column scale into Wt_
 	Status normal_inverse(T* A, T offdiag, T diag);  // A <- (A + regulariser)^-1
+	Status finish_upload(T* Vcol);
 	Status fetch_error_terms(int count_n);            // enqueue the copies, do not wait
 	void finalize_error(bool resolve);
 	void record_begin();
@@ -102,7 +103,7 @@ private:
 	long mpad_, npad_;
 	int num_cus_ = 256;
 	hipStream_t stream_ = nullptr;
-	bool own_everything_ = false;
+	bool tiled_ = false;                      // V_/Vt_ are x-tiled (fp32 MFMA path)
 	const char* last_error_ = "";
 
 	T *V_ = nullptr, *Vt_ = nullptr;

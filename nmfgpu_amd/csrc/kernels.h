@@ -29,9 +29,17 @@ struct GramReduceArgs {
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 
+// A is x-TILED: A(x, y) at A[(x/128) * tile_stride + y*128 + x%128] (launch_tile / launch_tile_transposed).
 // slabs: plan.splits partial results, slab s at slabs + s * slab_stride, panel layout [x][RP].
-hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
+
+// Column-major (ld) -> x-tiled copy of an X x Y matrix into a ZERO-FILLED destination (untile: the reverse),
+// and the x-tiled image of the TRANSPOSE of a column-major I x J matrix.
+template <typename T>
+hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, bool untile, hipStream_t stream);
+template <typename T>
+hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, hipStream_t stream);
 
 // Diagnostic build of the same kernel with in-kernel clock stamps (8 x uint64 per wave:
 // shader clock at entry / first MFMA / loop end / kernel end, 100 MHz real time at entry / end, steps, XCC id).

@@ -39,8 +39,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // streams its y piece two columns per v_mfma_f32_32x32x2_f32:
 //
 //   A operand (32 x 2): lane l holds A(x0 + 4*(l&31) + b, y + (l>>5)) for b = 0..3 -- ONE 16-byte
-//       load per lane (512 contiguous bytes per half wave); component b feeds M-block b, i.e.
-//       MFMA row i of block b is matrix row x0 + 4*i + b (the row order inside a tile is free).
+//       load per lane; component b feeds M-block b, i.e. MFMA row i of block b is matrix row
+//       x0 + 4*i + b (the row order inside a tile is free).  A is stored x-TILED in HBM
+//       (A(x, y) at A[(x/128)*tile_stride + y*128 + x%128]): the two columns of a K-step are 1 KiB
+//       contiguous and a wave's whole y piece is one sequential stream -- with plain column-major
+//       storage the same loads are 512-byte fragments 4*lda bytes apart and the main loop loses ~8 %
+//       to DRAM row misses (in-kernel stamps: 1127 vs 1031 cycles per step pair).
 //   B operand (2 x 32): lane l holds F(coff + NB*(l&31) + nb, y + (l>>5)) for nb = 0..NB-1 -- one
 //       4*NB-byte load; MFMA column j of N-block nb is factor row coff + NB*j + nb.
 //
@@ -128,7 +132,7 @@ __device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, floa
 
 template <int NB, int D, bool STAMP, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
-	const float* __restrict__ A, long lda,
+	const float* __restrict__ A, long tile_stride,
 	const float* __restrict__ F, int RP, int coff,
 	float* __restrict__ slabs, long slab_stride,
 	int steps_total, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
@@ -170,11 +174,13 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
 
 	if (steps > 0) {
-		const float* abase = A + (long)(2 * s0) * lda + (long)xt * FP_XT;   // uniform
-		const float* fbase = F + (long)(2 * s0) * RP + coff;                 // uniform
-		const unsigned aoff = (unsigned)(half * lda + 4 * l31);              // per lane, elements
+		// A is x-tiled: the 128 rows of a tile are contiguous per column and the columns of a tile follow
+		// each other, so a wave's whole y piece is ONE sequential stream (1 KiB per K-step)
+		const float* abase = A + (long)xt * tile_stride + (long)(2 * s0) * FP_XT;   // uniform
+		const float* fbase = F + (long)(2 * s0) * RP + coff;                         // uniform
+		const unsigned aoff = (unsigned)(half * FP_XT + 4 * l31);                    // per lane, elements
 		const unsigned foff = (unsigned)(half * RP + NB * l31);
-		const long astep = 2 * lda;
+		const long astep = 2 * FP_XT;
 		const long fstep = 2 * (long)RP;
 		const int last = steps - 1;
 
@@ -304,7 +310,7 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
 }
 
 template <int NB, int D, bool STAMP, int DIAG = 0>
-static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                               float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
 	const bool with_reduce = rg != nullptr && rg->partials != nullptr && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
@@ -320,7 +326,7 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long l
 	}
 	for (int ch = 0; ch < p.chunks; ++ch)
 		hipLaunchKernelGGL((k_factor_product_f32<NB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
-		                   A, lda, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
+		                   A, tile_stride, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
 
@@ -1025,5 +1031,52 @@ hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint
 }
 template hipError_t launch_fill_uniform<float>(float*, int, int, long, long, uint64_t, hipStream_t);
 template hipError_t launch_fill_uniform<double>(double*, int, int, long, long, uint64_t, hipStream_t);
+
+// ------------------------------------------------------------------------------------------
+// x-tiled storage of the streamed matrix (see k_factor_product_f32)
+// ------------------------------------------------------------------------------------------
+// dst(x, y) = src(x, y): column-major src (ld) -> tiled dst.  dst has been zero-filled.
+template <typename T>
+__global__ __launch_bounds__(256) void k_tile(const T* __restrict__ src, long ld, int X, int Y, T* __restrict__ dst, long tile_stride, int untile) {
+	const long x = (long)blockIdx.x * 256 + threadIdx.x;
+	const long y = blockIdx.y;
+	if (x >= X || y >= Y) return;
+	const long t = (x >> 7) * tile_stride + y * 128 + (x & 127);
+	if (untile) dst[y * ld + x] = src[t];   // (roles swapped: src tiled, dst column-major)
+	else dst[t] = src[y * ld + x];
+}
+
+// dst(j, i) = src(i, j): column-major src (rows = I, cols = J, ld) -> tiled dst of the transpose.
+template <typename T>
+__global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ src, long ld, int I, int J, T* __restrict__ dst, long tile_stride) {
+	__shared__ T tile[32][33];
+	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	for (int jj = ty; jj < 32; jj += 8) {
+		const int i = i0 + tx, j = j0 + jj;
+		tile[jj][tx] = (i < I && j < J) ? src[(long)j * ld + i] : T(0);
+	}
+	__syncthreads();
+	for (int ii = ty; ii < 32; ii += 8) {
+		const int i = i0 + ii, j = j0 + tx;
+		if (i < I && j < J) dst[(long)(j >> 7) * tile_stride + (long)i * 128 + (j & 127)] = tile[tx][ii];
+	}
+}
+
+template <typename T>
+hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, bool untile, hipStream_t stream) {
+	hipLaunchKernelGGL((k_tile<T>), dim3((X + 255) / 256, Y), dim3(256), 0, stream, src, ld, X, Y, dst, tile_stride, untile ? 1 : 0);
+	return hipGetLastError();
+}
+template hipError_t launch_tile<float>(const float*, long, int, int, float*, long, bool, hipStream_t);
+template hipError_t launch_tile<double>(const double*, long, int, int, double*, long, bool, hipStream_t);
+
+template <typename T>
+hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, hipStream_t stream) {
+	hipLaunchKernelGGL((k_tile_transposed<T>), dim3((I + 31) / 32, (J + 31) / 32), dim3(256), 0, stream, src, ld, I, J, dst, tile_stride);
+	return hipGetLastError();
+}
+template hipError_t launch_tile_transposed<float>(const float*, long, int, int, float*, long, hipStream_t);
+template hipError_t launch_tile_transposed<double>(const double*, long, int, int, double*, long, hipStream_t);
 
 } // namespace nmfamd

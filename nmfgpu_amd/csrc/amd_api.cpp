@@ -38,10 +38,10 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	const int RP = padded_rank(r);
-	const long Xp = pad128(X), Yp = pad128(Y);
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
-	FactorProductPlan plan = plan_factor_product((int)Xp, Y, RP, prop.multiProcessorCount);
+	FactorProductPlan plan = plan_factor_product(X, Y, RP, prop.multiProcessorCount);
+	const long Xp = pad128(std::max<long>(X, (long)plan.xtiles * plan.th)), Yp = pad128(Y);
 	const bool mfma = std::is_same<T, float>::value && !use_valu;
 	const int S = mfma ? plan.splits : 1;
 	DevBuf dA, dF, dS, dO;
@@ -55,8 +55,8 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 		if (mfma) {
 			DevBuf dT;   // x-tiled image of A for the MFMA kernel
 			if (dT.alloc(sizeof(T) * Xp * Yp) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
-			e = launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, 128 * Yp, false, nullptr);
-			if (e == hipSuccess) e = launch_factor_product_f32(plan, (const float*)dT.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+			e = launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, plan.th * Yp, plan.th, false, nullptr);
+			if (e == hipSuccess) e = launch_factor_product_f32(plan, (const float*)dT.p, plan.th * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
 			if (e == hipSuccess) e = hipDeviceSynchronize();
 		}
 		else e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
@@ -172,7 +172,7 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 	if (!e || !out) return NMFAMD_INVALID_ARGUMENT;
 	auto fill = [&](const auto& g) {
 		out->m = g.m(); out->n = g.n(); out->r = g.r(); out->padded_rank = g.rp();
-		out->padded_m = pad128(g.m()); out->padded_n = pad128(g.n());
+		out->padded_m = g.mpad(); out->padded_n = g.npad();
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
@@ -235,10 +235,10 @@ int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned 
 	if (X <= 0 || Y <= 0 || reps <= 0 || !avg_us) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	const int RP = 64;
-	const long Xp = pad128(X), Yp = pad128(Y);
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
-	FactorProductPlan plan = plan_factor_product((int)Xp, Y, RP, prop.multiProcessorCount);
+	FactorProductPlan plan = plan_factor_product(X, Y, RP, prop.multiProcessorCount);
+	const long Xp = pad128(std::max<long>(X, (long)plan.xtiles * plan.th)), Yp = pad128(Y);
 	DevBuf dA, dF, dS, dT;
 	const long slab_stride = (long)RP * Xp;
 	const long nwaves = (long)plan.xtiles * plan.splits * 8;
@@ -248,16 +248,16 @@ int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned 
 	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	hipEvent_t e0, e1;
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
-	for (int i = 0; i < 3; ++i) launch_factor_product_f32(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	for (int i = 0; i < 3; ++i) launch_factor_product_f32(plan, (const float*)dA.p, plan.th * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
 	(void)hipEventRecord(e0, nullptr);
-	for (int i = 0; i < reps; ++i) launch_factor_product_f32(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
+	for (int i = 0; i < reps; ++i) launch_factor_product_f32(plan, (const float*)dA.p, plan.th * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, nullptr);
 	(void)hipEventRecord(e1, nullptr);
 	if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
 	float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
 	*avg_us = ms * 1e3 / reps;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	if (stamps_out && stamps_capacity >= 8 * nwaves) {
-		if (launch_factor_product_f32_stamped(plan, (const float*)dA.p, 128 * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, (unsigned long long*)dT.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (launch_factor_product_f32_stamped(plan, (const float*)dA.p, plan.th * Yp, (const float*)dF.p, RP, (float*)dS.p, slab_stride, (unsigned long long*)dT.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 		if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 		if (stamps_count) *stamps_count = nwaves;
 	} else if (stamps_count) *stamps_count = 0;

@@ -75,11 +75,18 @@ Status Engine<T>::allocate() {
 	HIPX(hipGetDeviceProperties(&prop, dev));
 	num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-	planH_ = plan_factor_product((int)npad_, m_, RP_, num_cus_);
-	planW_ = plan_factor_product((int)mpad_, n_, RP_, num_cus_);
+	planH_ = plan_factor_product(n_, m_, RP_, num_cus_);
+	planW_ = plan_factor_product(m_, n_, RP_, num_cus_);
 	const bool mfma = std::is_same<T, float>::value && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
-	if (!mfma) { planH_.splits = 1; planW_.splits = 1; }
+	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
+	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
+	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
+	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
+	strideV_ = (long)planW_.th * npad_;
+	strideVt_ = (long)planH_.th * mpad_;
+	elemsV_ = tiled_ ? (long)planW_.xtiles * strideV_ : mpad_ * npad_;
+	elemsVt_ = tiled_ ? (long)planH_.xtiles * strideVt_ : mpad_ * npad_;
 	slab_stride_ = (long)RP_ * std::max(mpad_, npad_);
 	const long slab_elems = slab_stride_ * std::max(planH_.splits, planW_.splits);
 	const long panelW = (long)RP_ * mpad_, panelH = (long)RP_ * npad_, rr = (long)RP_ * RP_;
@@ -89,8 +96,8 @@ Status Engine<T>::allocate() {
 		if (e != hipSuccess) return e;
 		return hipMemsetAsync(*p, 0, (size_t)elems * sizeof(T), stream_);
 	};
-	HIPX(dalloc(&V_, mpad_ * npad_));
-	HIPX(dalloc(&Vt_, npad_ * mpad_));
+	HIPX(dalloc(&V_, elemsV_));
+	HIPX(dalloc(&Vt_, elemsVt_));
 	HIPX(dalloc(&Wt_, panelW));
 	HIPX(dalloc(&H_, panelH));
 	HIPX(dalloc(&slabs_, slab_elems));
@@ -135,10 +142,10 @@ Status Engine<T>::finish_upload(T* Vcol) {
 	h_vtv_.resize(n_);
 	HIPX(hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_));
 	if (tiled_) {
-		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_));
-		HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_));
-		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, 128 * npad_, false, stream_));
-		HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, 128 * mpad_, stream_));
+		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)elemsV_, stream_));
+		HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)elemsVt_, stream_));
+		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, strideV_, planW_.th, false, stream_));
+		HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, strideVt_, planH_.th, stream_));
 	} else {
 		HIPX(launch_transpose<T>(Vcol, mpad_, m_, n_, Vt_, npad_, stream_));
 	}
@@ -285,7 +292,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 		if (tiled_) {
 			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planH_, Vt_, 128 * mpad_, F, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_f32(planH_, Vt_, strideVt_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -302,7 +309,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planW_, V_, 128 * npad_, F, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -601,7 +608,7 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 		T* tmp = nullptr;
 		HIPX(hipMalloc((void**)&tmp, sizeof(T) * (size_t)avail));
 		hipError_t e = hipMemsetAsync(tmp, 0, sizeof(T) * (size_t)avail, stream_);
-		if (e == hipSuccess) e = vt ? launch_tile<T>(img, npad_, n_, m_, tmp, 128 * mpad_, true, stream_) : launch_tile<T>(img, mpad_, m_, n_, tmp, 128 * npad_, true, stream_);
+		if (e == hipSuccess) e = vt ? launch_tile<T>(img, npad_, n_, m_, tmp, strideVt_, planH_.th, true, stream_) : launch_tile<T>(img, mpad_, m_, n_, tmp, strideV_, planW_.th, true, stream_);
 		if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(T) * count, hipMemcpyDeviceToHost, stream_);
 		if (e == hipSuccess) e = hipStreamSynchronize(stream_);
 		(void)hipFree(tmp);

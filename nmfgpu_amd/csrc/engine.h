@@ -77,6 +77,8 @@ public:
 	int n() const { return n_; }
 	int r() const { return r_; }
 	int rp() const { return RP_; }
+	long mpad() const { return mpad_; }
+	long npad() const { return npad_; }
 	int slabs_h() const { return planH_.splits; }
 	int slabs_w() const { return planW_.splits; }
 	const char* last_error() const { return last_error_; }
@@ -101,6 +103,7 @@ private:
 	int m_, n_, r_, RP_, alg_;
 	AlgorithmParams prm_;
 	long mpad_, npad_;
+	long strideV_ = 0, strideVt_ = 0, elemsV_ = 0, elemsVt_ = 0;   // x-tiled images of V / Vt
 	int num_cus_ = 256;
 	hipStream_t stream_ = nullptr;
 	bool tiled_ = false;                      // V_/Vt_ are x-tiled (fp32 MFMA path)

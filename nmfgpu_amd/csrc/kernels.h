@@ -9,11 +9,12 @@ namespace nmfamd {
 
 // How one factor product OUT(c, x) = sum_y F(c, y) A(x, y) is cut into workgroups.
 struct FactorProductPlan {
-	int xtiles;       // 128-row tiles of the output index x
+	int th;           // x-tile height: 128 or 160 rows
+	int xtiles;       // tiles of the output index x
 	int steps_total;  // reduction length in MFMA K-steps (two y per step)
 	int splits;       // workgroup slices of the reduction range = number of output slabs
-	int nb;           // 32-wide N-blocks per wave tile (2 or 4)
-	int chunks;       // launches needed to cover RP = chunks * 32 * nb factor rows
+	int nb;           // 32-wide N-blocks per wave tile (2)
+	int chunks;       // launches needed to cover RP = chunks * 64 factor rows
 };
 
 FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);
@@ -29,7 +30,8 @@ struct GramReduceArgs {
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 
-// A is x-TILED: A(x, y) at A[(x/128) * tile_stride + y*128 + x%128] (launch_tile / launch_tile_transposed).
+// X: valid output length (the plan picks the tile height; panels must be allocated for xtiles * th rows).
+// A is x-TILED: A(x, y) at A[(x/th) * tile_stride + y*th + x%th] (launch_tile / launch_tile_transposed).
 // slabs: plan.splits partial results, slab s at slabs + s * slab_stride, panel layout [x][RP].
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
@@ -37,9 +39,9 @@ hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A,
 // Column-major (ld) -> x-tiled copy of an X x Y matrix into a ZERO-FILLED destination (untile: the reverse),
 // and the x-tiled image of the TRANSPOSE of a column-major I x J matrix.
 template <typename T>
-hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, bool untile, hipStream_t stream);
+hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, int th, bool untile, hipStream_t stream);
 template <typename T>
-hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, hipStream_t stream);
+hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, int th, hipStream_t stream);
 
 // Diagnostic build of the same kernel with in-kernel clock stamps (8 x uint64 per wave:
 // shader clock at entry / first MFMA / loop end / kernel end, 100 MHz real time at entry / end, steps, XCC id).

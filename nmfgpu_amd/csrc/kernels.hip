@@ -130,18 +130,22 @@ __device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, floa
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
-template <int NB, int D, bool STAMP, int DIAG = 0>
+template <int XB, int D, bool STAMP, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long tile_stride,
 	const float* __restrict__ F, int RP, int coff,
 	float* __restrict__ slabs, long slab_stride,
 	int steps_total, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
+	// XB = 32-row M-blocks per wave tile: 4 (128-row x-tiles) or 5 (160-row x-tiles; the fifth block
+	// is fed by an extra 4-byte load).  The plan picks the height that fills the 256 CUs best.
 	// STAMP: diagnostic build only (nmfamd_tune_factor_product): per-wave shader-clock and 100 MHz
 	// real-time stamps at kernel entry, first MFMA, end of the main loop and end of the epilogue,
 	// written to a buffer of their own; the production instantiation has STAMP = false.
+	constexpr int NB = 2;
+	constexpr int TH = 32 * XB;
 	unsigned long long t_entry = 0, r_entry = 0, t_loop0 = 0, t_loop1 = 0;
 	if (STAMP) { t_entry = __builtin_amdgcn_s_memtime(); r_entry = __builtin_amdgcn_s_memrealtime(); }
-	typedef typename FVec<NB>::type fvec;
+	typedef f32x2 fvec;
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 
 	if (blockIdx.y == (unsigned)splits) {   // the reduce row of the grid (only launched when rg.partials != nullptr)
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const int xt = blockIdx.x;
 	const int sp = blockIdx.y;
 	// wave-uniform values are forced into SGPRs so that the address arithmetic of the main loop
-	// runs on the scalar unit and the loads take the saddr + 32-bit voffset form
+	// runs on the scalar unit
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	const int half = lane >> 5;
@@ -165,31 +169,34 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const int s1 = (int)(((long)steps_total * (widx + 1)) / nw);
 	const int steps = s1 - s0;
 
-	f32x16 acc[4][NB];
+	f32x16 acc[XB][NB];
 #pragma unroll
-	for (int b = 0; b < 4; ++b)
+	for (int b = 0; b < XB; ++b)
 #pragma unroll
 		for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
 			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
 
 	if (steps > 0) {
-		// A is x-tiled: the 128 rows of a tile are contiguous per column and the columns of a tile follow
-		// each other, so a wave's whole y piece is ONE sequential stream (1 KiB per K-step)
-		const float* abase = A + (long)xt * tile_stride + (long)(2 * s0) * FP_XT;   // uniform
-		const float* fbase = F + (long)(2 * s0) * RP + coff;                         // uniform
-		const unsigned aoff = (unsigned)(half * FP_XT + 4 * l31);                    // per lane, elements
+		// A is x-tiled: the TH rows of a tile are contiguous per column and the columns of a tile follow
+		// each other, so a wave's whole y piece is ONE sequential stream (8 * TH bytes per K-step)
+		const float* abase = A + (long)xt * tile_stride + (long)(2 * s0) * TH;   // uniform
+		const float* fbase = F + (long)(2 * s0) * RP + coff;                      // uniform
+		const unsigned aoff = (unsigned)(half * TH + 4 * l31);                    // per lane, elements
+		const unsigned eoff = (unsigned)(half * TH + 128 + l31);                  // fifth block (XB == 5)
 		const unsigned foff = (unsigned)(half * RP + NB * l31);
-		const long astep = 2 * FP_XT;
+		const long astep = 2 * TH;
 		const long fstep = 2 * (long)RP;
 		const int last = steps - 1;
 
 		f32x4 va[D];
+		float ve[D];
 		fvec fb[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) {
 			const int st = d < last ? d : last;
 			va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+			if (XB == 5) ve[d] = abase[st * astep + eoff]; else ve[d] = 0.f;
 			fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
 		}
 		__builtin_amdgcn_sched_barrier(0);
@@ -199,19 +206,22 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 #pragma unroll
 			for (int d = 0; d < D; ++d) {
 #pragma unroll
-				for (int b = 0; b < 4; ++b)
+				for (int b = 0; b < XB; ++b)
 #pragma unroll
 					for (int nb = 0; nb < NB; ++nb)
-						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][b], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fb[d][nb], acc[b][nb], 0, 0, 0);
 				int st = t + D + d;
 				st = st < last ? st : last;
 				// DIAG (stamped diagnostic builds only): 1 = no refill at all (pure MFMA issue rate),
 				// 2 = refill A only, 3 = refill F only
-				if (DIAG == 0 || DIAG == 2) va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+				if (DIAG == 0 || DIAG == 2) {
+					va[d] = *reinterpret_cast<const f32x4*>(abase + st * astep + aoff);
+					if (XB == 5) ve[d] = abase[st * astep + eoff];
+				}
 				if (DIAG == 0 || DIAG == 3) fb[d] = *reinterpret_cast<const fvec*>(fbase + st * fstep + foff);
 				// keep the operand that was NOT reloaded opaque to the optimiser (never the reloaded one:
 				// an asm use would wait for the load right behind its issue)
-				if (DIAG == 1 || DIAG == 3) { asm volatile("" : "+v"(va[d])); }
+				if (DIAG == 1 || DIAG == 3) { asm volatile("" : "+v"(va[d]), "+v"(ve[d])); }
 				if (DIAG == 1 || DIAG == 2) { asm volatile("" : "+v"(fb[d])); }
 				// pin the order: the refill of ring slot d is issued right behind the MFMAs that
 				// consumed it, D-1 steps before its data is needed (hipcc otherwise sinks all loads
@@ -224,23 +234,20 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 		for (int d = 0; d < D; ++d) {
 			if (d < rem) {
 #pragma unroll
-				for (int b = 0; b < 4; ++b)
+				for (int b = 0; b < XB; ++b)
 #pragma unroll
 					for (int nb = 0; nb < NB; ++nb)
-						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][b], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fb[d][nb], acc[b][nb], 0, 0, 0);
 			}
 		}
 	}
 
 	if (STAMP) { __builtin_amdgcn_sched_barrier(0); t_loop1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 
-	// ---- sum the eight per-wave tiles through LDS, four accumulator tiles per round ----------
+	// ---- sum the eight per-wave tiles through LDS, two M-blocks (four accumulator tiles) per round ----
 	// LDS image of a round: [src wave 8][tile 4][q 4][lane 64] float4  (128 KiB)
 	// C/D map of the 32x32 MFMA: register g of lane l is row (g&3) + 8*(g>>2) + 4*(l>>5), column l&31.
-	constexpr int TILES = 4 * NB;
-	constexpr int ROUNDS = TILES / 4;
-	constexpr int BPR = 4 / NB;          // M-blocks per round
-	constexpr int ITEMS = BPR * 4;       // (b_local, q) pairs handed out to the waves
+	constexpr int ROUNDS = (XB + 1) / 2;
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
@@ -248,36 +255,40 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 		if (rd > 0) __syncthreads();
 #pragma unroll
 		for (int tl = 0; tl < 4; ++tl) {
-			const int tix = rd * 4 + tl;
-			const int b = tix / NB, nb = tix % NB;
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			if (b < XB) {
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				f32x4 v;
-				v[0] = acc[b][nb][4 * q + 0]; v[1] = acc[b][nb][4 * q + 1];
-				v[2] = acc[b][nb][4 * q + 2]; v[3] = acc[b][nb][4 * q + 3];
-				l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+				for (int q = 0; q < 4; ++q) {
+					f32x4 v;
+					v[0] = acc[b < XB ? b : 0][nb][4 * q + 0]; v[1] = acc[b < XB ? b : 0][nb][4 * q + 1];
+					v[2] = acc[b < XB ? b : 0][nb][4 * q + 2]; v[3] = acc[b < XB ? b : 0][nb][4 * q + 3];
+					l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+				}
 			}
 		}
 		__syncthreads();
-		for (int item = wave; item < ITEMS; item += FP_WAVES) {
-			const int bl = item >> 2, q = item & 3;
-			const int b = rd * BPR + bl;
-			f32x4 sum[NB];
+		{
+			// wave w owns (M-block 2*rd + (w >> 2), register quad q = w & 3), both N-blocks
+			const int bl = wave >> 2, q = wave & 3;
+			const int b = 2 * rd + bl;
+			if (b < XB) {
+				f32x4 sum[NB];
 #pragma unroll
-			for (int nb = 0; nb < NB; ++nb) {
-				const int tl = bl * NB + nb;
-				f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+				for (int nb = 0; nb < NB; ++nb) {
+					const int tl = bl * NB + nb;
+					f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
 #pragma unroll
-				for (int src = 1; src < FP_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
-				sum[nb] = s;
-			}
+					for (int src = 1; src < FP_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
+					sum[nb] = s;
+				}
 #pragma unroll
-			for (int gi = 0; gi < 4; ++gi) {
-				const int x = xt * FP_XT + 4 * (gi + 8 * q + 4 * half) + b;
-				fvec o;
-#pragma unroll
-				for (int nb = 0; nb < NB; ++nb) o[nb] = sum[nb][gi];
-				*reinterpret_cast<fvec*>(slab + (long)x * RP + coff + NB * l31) = o;
+				for (int gi = 0; gi < 4; ++gi) {
+					const int i = gi + 8 * q + 4 * half;   // MFMA row of this value
+					const int x = xt * TH + (b < 4 ? 4 * i + b : 128 + i);
+					fvec o;
+					o[0] = sum[0][gi]; o[1] = sum[1][gi];
+					*reinterpret_cast<fvec*>(slab + (long)x * RP + coff + NB * l31) = o;
+				}
 			}
 		}
 	}
@@ -293,23 +304,41 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	}
 }
 
+// X = valid output length.  x-tile height: 128 rows unless NMFAMD_FP_TILE=160 asks for the 160-row form.
+// Measured at 10 000 x 5 000 (round 1): 160-row tiles fill 252 / 256 of the CUs instead of 237 / 240 and
+// the product alone runs ~3-5 % faster, but the grid then leaves no CU for the passenger Gram
+// reduction (it serialises behind the product: 72 vs 64 us in the iteration) and the extra split-K
+// slab slows the update kernels; net 6 % slower per iteration, so 128 stays the default.
 FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
-	FactorProductPlan p;
-	p.xtiles = (X + FP_XT - 1) / FP_XT;
-	p.steps_total = (Y + 1) / 2;
-	int splits = num_cus / p.xtiles;
-	if (splits < 1) splits = 1;
+	FactorProductPlan best;
+	double best_score = -1.0;
+	const int steps_total = (Y + 1) / 2;
 	// keep at least 16 K-steps per wave, otherwise the prologue dominates
-	int max_splits = p.steps_total / (16 * FP_WAVES);
+	int max_splits = steps_total / (16 * FP_WAVES);
 	if (max_splits < 1) max_splits = 1;
-	if (splits > max_splits) splits = max_splits;
-	p.splits = splits;
-	p.nb = 2;                   // RP is a multiple of 64 (engine: padded_rank); the NB = 4 form needs 256 accumulator VGPRs and spills at two waves per SIMD
-	p.chunks = RP / (32 * p.nb);
-	return p;
+	const char* force = getenv("NMFAMD_FP_TILE");
+	const int forced = force ? atoi(force) : 128;
+	for (int th = 128; th <= 160; th += 32) {
+		if (forced != th) continue;
+		FactorProductPlan p;
+		p.th = th;
+		p.xtiles = (X + th - 1) / th;
+		p.steps_total = steps_total;
+		int splits = num_cus / p.xtiles;
+		if (splits < 1) splits = 1;
+		if (splits > max_splits) splits = max_splits;
+		p.splits = splits;
+		p.nb = 2;                    // RP is a multiple of 64 (engine: padded_rank); the NB = 4 form needs 256 accumulator VGPRs
+		p.chunks = RP / 64;
+		const int wgs = p.xtiles * p.splits;
+		const double fill = wgs >= num_cus ? 1.0 / ((wgs + num_cus - 1) / num_cus) * ((double)wgs / num_cus) : (double)wgs / num_cus;
+		const double score = fill * ((double)X / ((double)p.xtiles * th)) * (th == 160 ? 0.985 : 1.0);   // 160: one more epilogue round
+		if (score > best_score + 1e-9) { best_score = score; best = p; }
+	}
+	return best;
 }
 
-template <int NB, int D, bool STAMP, int DIAG = 0>
+template <int XB, int D, bool STAMP, int DIAG = 0>
 static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                               float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -319,14 +348,14 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
 	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<NB, D, STAMP, DIAG>),
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG>),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		if (e != hipSuccess) return e;
 		attr_done = true;
 	}
 	for (int ch = 0; ch < p.chunks; ++ch)
-		hipLaunchKernelGGL((k_factor_product_f32<NB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
-		                   A, tile_stride, F, RP, ch * 32 * NB, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
+		hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
+		                   A, tile_stride, F, RP, ch * 64, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
 
@@ -336,38 +365,38 @@ static int fp_depth() {
 	if (d < 0) {
 		const char* e = getenv("NMFAMD_FP_DEPTH");
 		d = e ? atoi(e) : 8;
-		if (d != 4 && d != 6 && d != 8 && d != 10 && d != 12) d = 8;
+		if (d != 4 && d != 6 && d != 8) d = 8;
 	}
 	return d;
 }
 
-template <int NB>
-static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+template <int XB>
+static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                             float* slabs, long slab_stride, const GramReduceArgs* rg, hipStream_t stream) {
 	switch (fp_depth()) {
-	case 4: return launch_fp_d<NB, 4, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
-	case 8: return launch_fp_d<NB, 8, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
-	case 10: return launch_fp_d<NB, 10, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
-	case 12: return launch_fp_d<NB, 12, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
-	default: return launch_fp_d<NB, 6, false>(p, A, lda, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	case 4: return launch_fp_d<XB, 4, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	case 6: return launch_fp_d<XB, 6, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	default: return launch_fp_d<XB, 8, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
 	}
 }
 
-hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                                              float* slabs, long slab_stride, unsigned long long* stamps, hipStream_t stream) {
 	static int diag = -1;
 	if (diag < 0) { const char* e = getenv("NMFAMD_FP_DIAG"); diag = e ? atoi(e) : 0; }
+	if (p.th == 160) return launch_fp_d<5, 8, true, 0>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 	switch (diag) {
-	case 1: return launch_fp_d<2, 8, true, 1>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
-	case 2: return launch_fp_d<2, 8, true, 2>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
-	case 3: return launch_fp_d<2, 8, true, 3>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
-	default: return launch_fp_d<2, 8, true, 0>(p, A, lda, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	case 1: return launch_fp_d<4, 8, true, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	case 2: return launch_fp_d<4, 8, true, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	case 3: return launch_fp_d<4, 8, true, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
+	default: return launch_fp_d<4, 8, true, 0>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 	}
 }
 
-hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long lda, const float* F, int RP,
+hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
-	return launch_fp<2>(p, A, lda, F, RP, slabs, slab_stride, rg, stream);
+	if (p.th == 160) return launch_fp<5>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, stream);
+	return launch_fp<4>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1033,22 +1062,23 @@ template hipError_t launch_fill_uniform<float>(float*, int, int, long, long, uin
 template hipError_t launch_fill_uniform<double>(double*, int, int, long, long, uint64_t, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
-// x-tiled storage of the streamed matrix (see k_factor_product_f32)
+// x-tiled storage of the streamed matrix (see k_factor_product_f32): A(x, y) at
+// A[(x / th) * tile_stride + y * th + x % th], th = tile height (128 or 160)
 // ------------------------------------------------------------------------------------------
 // dst(x, y) = src(x, y): column-major src (ld) -> tiled dst.  dst has been zero-filled.
 template <typename T>
-__global__ __launch_bounds__(256) void k_tile(const T* __restrict__ src, long ld, int X, int Y, T* __restrict__ dst, long tile_stride, int untile) {
-	const long x = (long)blockIdx.x * 256 + threadIdx.x;
-	const long y = blockIdx.y;
+__global__ __launch_bounds__(256) void k_tile(const T* __restrict__ src, long ld, int X, int Y, T* __restrict__ dst, long tile_stride, int th, int untile) {
+	const long x = (long)blockIdx.y * 256 + threadIdx.x;
+	const long y = blockIdx.x;
 	if (x >= X || y >= Y) return;
-	const long t = (x >> 7) * tile_stride + y * 128 + (x & 127);
+	const long t = (x / th) * tile_stride + y * th + (x % th);
 	if (untile) dst[y * ld + x] = src[t];   // (roles swapped: src tiled, dst column-major)
 	else dst[t] = src[y * ld + x];
 }
 
 // dst(j, i) = src(i, j): column-major src (rows = I, cols = J, ld) -> tiled dst of the transpose.
 template <typename T>
-__global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ src, long ld, int I, int J, T* __restrict__ dst, long tile_stride) {
+__global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ src, long ld, int I, int J, T* __restrict__ dst, long tile_stride, int th) {
 	__shared__ T tile[32][33];
 	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1059,24 +1089,24 @@ __global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ s
 	__syncthreads();
 	for (int ii = ty; ii < 32; ii += 8) {
 		const int i = i0 + ii, j = j0 + tx;
-		if (i < I && j < J) dst[(long)(j >> 7) * tile_stride + (long)i * 128 + (j & 127)] = tile[tx][ii];
+		if (i < I && j < J) dst[(long)(j / th) * tile_stride + (long)i * th + (j % th)] = tile[tx][ii];
 	}
 }
 
 template <typename T>
-hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, bool untile, hipStream_t stream) {
-	hipLaunchKernelGGL((k_tile<T>), dim3((X + 255) / 256, Y), dim3(256), 0, stream, src, ld, X, Y, dst, tile_stride, untile ? 1 : 0);
+hipError_t launch_tile(const T* src, long ld, int X, int Y, T* dst, long tile_stride, int th, bool untile, hipStream_t stream) {
+	hipLaunchKernelGGL((k_tile<T>), dim3(Y, (X + 255) / 256), dim3(256), 0, stream, src, ld, X, Y, dst, tile_stride, th, untile ? 1 : 0);
 	return hipGetLastError();
 }
-template hipError_t launch_tile<float>(const float*, long, int, int, float*, long, bool, hipStream_t);
-template hipError_t launch_tile<double>(const double*, long, int, int, double*, long, bool, hipStream_t);
+template hipError_t launch_tile<float>(const float*, long, int, int, float*, long, int, bool, hipStream_t);
+template hipError_t launch_tile<double>(const double*, long, int, int, double*, long, int, bool, hipStream_t);
 
 template <typename T>
-hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, hipStream_t stream) {
-	hipLaunchKernelGGL((k_tile_transposed<T>), dim3((I + 31) / 32, (J + 31) / 32), dim3(256), 0, stream, src, ld, I, J, dst, tile_stride);
+hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, int th, hipStream_t stream) {
+	hipLaunchKernelGGL((k_tile_transposed<T>), dim3((I + 31) / 32, (J + 31) / 32), dim3(256), 0, stream, src, ld, I, J, dst, tile_stride, th);
 	return hipGetLastError();
 }
-template hipError_t launch_tile_transposed<float>(const float*, long, int, int, float*, long, hipStream_t);
-template hipError_t launch_tile_transposed<double>(const double*, long, int, int, double*, long, hipStream_t);
+template hipError_t launch_tile_transposed<float>(const float*, long, int, int, float*, long, int, hipStream_t);
+template hipError_t launch_tile_transposed<double>(const double*, long, int, int, double*, long, int, hipStream_t);
 
 } // namespace nmfamd

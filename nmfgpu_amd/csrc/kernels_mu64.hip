@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup = 4 waves = 64 panel columns = one contiguous 16 KiB tile of the panel.
 // Global traffic is fully coalesced: every array tile (slabs, old panel values, result) moves as
-// 16 B per lane over consecutive lanes, up to six slabs in flight at once and summed in slab order,
+// 16 B per lane over consecutive lanes, up to eight slabs in flight at once and summed in slab order,
 // and the row-per-lane order the MFMA wants is produced by a pass through LDS (a row-per-lane
 // pattern straight from global memory is texture-addresser bound: 64 cache lines per instruction).
 // MFMA pass: wave w = (ct = w & 1: which 32 columns, mb = w >> 1: which 32 rows of the result);
@@ -57,34 +57,34 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 	// ---- linear pass: slab sum (slab order), pending scale, into LDS ---------------------------
 	f32x4 nl[4], ol[4];
 	{
-		f32x4 t[5][4];
+		f32x4 t[7][4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const long e = tile + 4 * (tid + 256 * j);
 			nl[j] = *reinterpret_cast<const f32x4*>(slabs + e);
 			ol[j] = *reinterpret_cast<const f32x4*>(P + e);
 #pragma unroll
-			for (int u = 0; u < 5; ++u) {
+			for (int u = 0; u < 7; ++u) {
 				const int k = 1 + u < S ? 1 + u : 0;   // clamped duplicate, discarded below
 				t[u][j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + e);
 			}
 		}
 #pragma unroll
-		for (int u = 0; u < 5; ++u)
+		for (int u = 0; u < 7; ++u)
 			if (1 + u < S) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) nl[j] += t[u][j];
 			}
-		for (int k0 = 6; k0 < S; k0 += 5) {      // more than six slabs: further batches of five
+		for (int k0 = 8; k0 < S; k0 += 7) {      // more than eight slabs: further batches of seven
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
 #pragma unroll
-				for (int u = 0; u < 5; ++u) {
+				for (int u = 0; u < 7; ++u) {
 					const int k = k0 + u < S ? k0 + u : 0;
 					t[u][j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + tile + 4 * (tid + 256 * j));
 				}
 #pragma unroll
-			for (int u = 0; u < 5; ++u)
+			for (int u = 0; u < 7; ++u)
 				if (k0 + u < S) {
 #pragma unroll
 					for (int j = 0; j < 4; ++j) nl[j] += t[u][j];

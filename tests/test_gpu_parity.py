@@ -409,3 +409,20 @@ def test_config5_full_size_algorithm_dispatch(alg, kw, tol):
     Wg, Hg = eng.get_factors()
     assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=10 * tol)
+
+
+def test_factor_product_160_row_tiles_bit_exact(monkeypatch):
+    """The 160-row x-tile form of the product kernel (NMFAMD_FP_TILE=160, off by default)."""
+    monkeypatch.setenv("NMFAMD_FP_TILE", "160")
+    rng = np.random.default_rng(160)
+    for X, Y, r in [(1000, 777, 64), (330, 2049, 33)]:
+        A = F(rng.random((X, Y)).astype(np.float32)); Fm = F(rng.random((r, Y)).astype(np.float32))
+        out, slabs = na.op_factor_product(A, Fm)
+        assert np.array_equal(out, oracle.emulate_factor_product(A, Fm, slabs))
+    V, W, H = problem(700, 450, 64, np.float32, seed=31)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    oracle.run("mu", V64, W64, H64, 10)
+    eng = na.Engine(700, 450, 64, "mu"); eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(10, last_iteration=10)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 1e-4 and rel(Hg, H64) < 1e-4

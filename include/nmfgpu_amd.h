@@ -50,6 +50,9 @@ typedef struct nmfamd_params {
 	double alphaW;   /* AHCLS "alphaW" */
 	double alphaH;   /* AHCLS "alphaH" */
 	double theta;    /* nsNMF "theta" */
+	/* extensions without a reference counterpart (nmfgpu::compute: Parameter names "divergence", "sparseCompute") */
+	double divergence;      /* 0 = Frobenius objective; 1 = generalised KL divergence (Multiplicative only; implies sparse_compute) */
+	double sparse_compute;  /* 1 = keep V as CSR + CSC in HBM and use SpMM / SDDMM kernels instead of densifying (Multiplicative only) */
 } nmfamd_params;
 
 typedef struct nmfamd_engine nmfamd_engine;  /* opaque; owns every device buffer of one factorisation */
@@ -94,6 +97,8 @@ NMFAMD_API int nmfamd_engine_synchronize(nmfamd_engine* e);
 /* Frobenius norm / RMSD of the most recent error iteration (IAlgorithm::frobeniusNorm / rmsd). */
 NMFAMD_API double nmfamd_engine_frobenius(nmfamd_engine* e);
 NMFAMD_API double nmfamd_engine_rmsd(nmfamd_engine* e);
+/* Generalised KL divergence D(V || W H) of the most recent error iteration (divergence = 1 only). */
+NMFAMD_API double nmfamd_engine_kl_divergence(nmfamd_engine* e);
 
 /* Dominant-kernel timing.  enable = k > 0: every launch of the factor-product kernel (the two
  * products against V, reference: gemm TN / NT at AlgorithmMultiplicativeFrobenius.h:187-188,240-241)

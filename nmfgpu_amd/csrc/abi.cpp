@@ -217,6 +217,22 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		log_error("[ERROR] Chosen algorithm is not implemented!");
 		return ResultType::ErrorInvalidArgument;
 	}
+	// extension switches ride on Parameter names the reference ignores (lookup is by name only,
+	// Interface.cpp:41-49): absent => reference behaviour
+	{
+		int idx = parameter_index(d.parameters, d.numParameters, "divergence");
+		if (idx >= 0) prm.divergence = d.parameters[idx].value;
+		idx = parameter_index(d.parameters, d.numParameters, "sparseCompute");
+		if (idx >= 0) prm.sparse_compute = d.parameters[idx].value;
+		if ((prm.divergence != 0 || prm.sparse_compute != 0) && d.algorithm != NmfAlgorithm::Multiplicative) {
+			log_error("[ERROR] 'divergence' / 'sparseCompute' are only available for the Multiplicative algorithm!");
+			return ResultType::ErrorInvalidArgument;
+		}
+		if (prm.divergence != 0 && d.useConstantBasisVectors) {
+			log_error("[ERROR] The KL-divergence update does not support constant basis vectors!");
+			return ResultType::ErrorInvalidArgument;
+		}
+	}
 	if (d.inputMatrix.rows == 0 || d.inputMatrix.columns == 0 || d.features == 0 ||
 	    d.outputMatrixW.format != StorageFormat::Dense || d.outputMatrixH.format != StorageFormat::Dense) {
 		log_error("[ERROR] Empty problem or non-dense output matrices!");

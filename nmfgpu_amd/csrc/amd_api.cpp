@@ -94,7 +94,7 @@ int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params
 	*out = nullptr;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	AlgorithmParams p;
-	if (params) { p.lambda = params->lambda; p.lambdaW = params->lambdaW; p.lambdaH = params->lambdaH; p.alphaW = params->alphaW; p.alphaH = params->alphaH; p.theta = params->theta; }
+	if (params) { p.lambda = params->lambda; p.lambdaW = params->lambdaW; p.lambdaH = params->lambdaH; p.alphaW = params->alphaW; p.alphaH = params->alphaH; p.theta = params->theta; p.divergence = params->divergence; p.sparse_compute = params->sparse_compute; }
 	nmfamd_engine* e = new (std::nothrow) nmfamd_engine();
 	if (!e) return NMFAMD_NO_HOST_MEMORY;
 	e->elem_bytes = elem_bytes;
@@ -155,6 +155,7 @@ int nmfamd_engine_synchronize(nmfamd_engine* e) {
 }
 
 double nmfamd_engine_frobenius(nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->frobenius() : e->d->frobenius()); }
+double nmfamd_engine_kl_divergence(nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->kl_divergence() : e->d->kl_divergence()); }
 double nmfamd_engine_rmsd(nmfamd_engine* e) { return !e ? 0.0 : (e->elem_bytes == 4 ? e->f->rmsd() : e->d->rmsd()); }
 
 int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable) {

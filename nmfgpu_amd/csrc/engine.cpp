@@ -57,6 +57,10 @@ Engine<T>::~Engine() {
 	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, psR_, stage_};
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
+	{
+		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
+		for (void* b : sp) if (b) (void)hipFree(b);
+	}
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -80,6 +84,13 @@ Status Engine<T>::allocate() {
 	const bool mfma = std::is_same<T, float>::value && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
+	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;
+	if (sparse_) {
+		if (alg_ != ALG_MU || RP_ > 256) return ST_INVALID;   // sparse compute: multiplicative update, padded rank 64 / 128 / 256
+		tiled_ = false;
+		planH_.splits = planW_.splits = 1; planH_.th = planW_.th = 128;
+		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
+	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
 	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
@@ -96,8 +107,16 @@ Status Engine<T>::allocate() {
 		if (e != hipSuccess) return e;
 		return hipMemsetAsync(*p, 0, (size_t)elems * sizeof(T), stream_);
 	};
-	HIPX(dalloc(&V_, elemsV_));
-	HIPX(dalloc(&Vt_, elemsVt_));
+	if (!sparse_) {
+		HIPX(dalloc(&V_, elemsV_));
+		HIPX(dalloc(&Vt_, elemsVt_));
+	} else {
+		HIPX(dalloc(&t_vwh_, mpad_));
+		HIPX(dalloc(&t_kl_, mpad_));
+		HIPX(dalloc(&rowsum_part_, (std::max(mpad_, npad_) / 128) * RP_));
+		HIPX(dalloc(&sW_, RP_));
+		HIPX(dalloc(&sH_, RP_));
+	}
 	HIPX(dalloc(&Wt_, panelW));
 	HIPX(dalloc(&H_, panelH));
 	HIPX(dalloc(&slabs_, slab_elems));
@@ -157,6 +176,16 @@ Status Engine<T>::finish_upload(T* Vcol) {
 template <typename T>
 Status Engine<T>::upload_dense(const T* V, long ld) {
 	if (!V || ld < m_) return ST_INVALID;
+	if (sparse_) {
+		// dense input on the sparse path: the non-zero entries become the stored entries
+		std::vector<int> rows, cols; std::vector<T> vals;
+		for (int j = 0; j < n_; ++j)
+			for (int i = 0; i < m_; ++i) {
+				const T v = V[(size_t)j * ld + i];
+				if (v != T(0)) { rows.push_back(i); cols.push_back(j); vals.push_back(v); }
+			}
+		return upload_triplets(rows, cols, vals);
+	}
 	T* Vcol = V_;
 	if (tiled_) {
 		HIPX(hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_)));
@@ -172,6 +201,17 @@ Status Engine<T>::upload_dense(const T* V, long ld) {
 template <typename T>
 Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const int* b, long nnz, int base) {
 	if (format < 1 || format > 3 || nnz < 0 || (nnz > 0 && (!values || !a || !b))) return ST_INVALID;
+	if (sparse_) {
+		// expand to 0-based (row, column, value) triplets with the caller's index base applied exactly
+		// (reference: cusparseSetMatIndexBase, Matrix.h:158-160,184-186,215-217); out-of-range entries are dropped
+		std::vector<int> rows, cols; std::vector<T> vals;
+		rows.reserve(nnz); cols.reserve(nnz); vals.reserve(nnz);
+		auto push = [&](long i, long j, T v) { if (i >= 0 && i < m_ && j >= 0 && j < n_) { rows.push_back((int)i); cols.push_back((int)j); vals.push_back(v); } };
+		if (format == 1) { for (int i = 0; i < m_; ++i) for (long p = (long)a[i] - base; p < (long)a[i + 1] - base && p < nnz; ++p) if (p >= 0) push(i, (long)b[p] - base, values[p]); }
+		else if (format == 2) { for (int j = 0; j < n_; ++j) for (long p = (long)a[j] - base; p < (long)a[j + 1] - base && p < nnz; ++p) if (p >= 0) push((long)b[p] - base, j, values[p]); }
+		else { for (long p = 0; p < nnz; ++p) push((long)a[p] - base, (long)b[p] - base, values[p]); }
+		return upload_triplets(rows, cols, vals);
+	}
 	T* d_val = nullptr; int *d_a = nullptr, *d_b = nullptr;
 	T* Vcol = nullptr;
 	const int outer = format == 1 ? m_ : n_;
@@ -288,6 +328,14 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches) {
 
 template <typename T>
 Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
+	if (sparse_) {
+		// W^T V as a row-gather SpMM over the CSC image: out(:, j) = sum_i V(i, j) F(:, i)
+		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
+		record_begin();
+		HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, csc_val_, F, RP_, slabs_, n_, (int)npad_, stream_));
+		record_end();
+		return ST_OK;
+	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (tiled_) {
 			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
@@ -305,6 +353,14 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 
 template <typename T>
 Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
+	if (sparse_) {
+		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
+		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
+		record_begin();
+		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, csr_val_, F, RP_, slabs_, m_, (int)mpad_, stream_));
+		record_end();
+		return ST_OK;
+	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
@@ -510,6 +566,7 @@ template <typename T>
 Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	const T eps = std::numeric_limits<T>::epsilon();
 	timing_now_ = timing_ && (timing_iter_++ % timing_stride_ == 0);
+	if (prm_.divergence != 0) return constant_w ? ST_INVALID : iterate_kl(compute_error);
 	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 	if (Status s = h_step(compute_error)) return s;
@@ -588,6 +645,115 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	return ST_OK;
 }
 
+// Sparse mode: 0-based triplets (any order) -> CSR and CSC images on the device, the permutation
+// between the two value orders, the sorted tr(V^T V) terms and sum(V).  Built on the host with stable
+// counting sorts, once per upload (outside the iteration loop).  Duplicate coordinates stay separate
+// entries (their contributions add; the dense path keeps the last one).
+template <typename T>
+Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals) {
+	const long nnz = (long)vals.size();
+	if (nnz >= (1l << 31)) return ST_INVALID;
+	std::vector<int> csr_ptr(m_ + 1, 0), csc_ptr(n_ + 1, 0), csr_idx(nnz), csc_idx(nnz), from_csr(nnz), order(nnz);
+	std::vector<T> csr_val(nnz), csc_val(nnz);
+	for (long p = 0; p < nnz; ++p) ++csr_ptr[rows[p] + 1];
+	for (int i = 0; i < m_; ++i) csr_ptr[i + 1] += csr_ptr[i];
+	{
+		std::vector<int> fill(csr_ptr.begin(), csr_ptr.end() - 1);
+		for (long p = 0; p < nnz; ++p) order[fill[rows[p]]++] = (int)p;       // stable by row
+	}
+	// inside a row: ascending column (stable), so that CSR / CSC / COO inputs of one matrix agree bit for bit
+	for (int i = 0; i < m_; ++i)
+		std::stable_sort(order.begin() + csr_ptr[i], order.begin() + csr_ptr[i + 1], [&](int x, int y) { return cols[x] < cols[y]; });
+	for (long q = 0; q < nnz; ++q) { csr_idx[q] = cols[order[q]]; csr_val[q] = vals[order[q]]; }
+	for (long q = 0; q < nnz; ++q) ++csc_ptr[csr_idx[q] + 1];
+	for (int j = 0; j < n_; ++j) csc_ptr[j + 1] += csc_ptr[j];
+	{
+		std::vector<int> fill(csc_ptr.begin(), csc_ptr.end() - 1);
+		int row = 0;
+		for (long q = 0; q < nnz; ++q) {
+			while (q >= csr_ptr[row + 1]) ++row;
+			const int dst = fill[csr_idx[q]]++;
+			csc_idx[dst] = row; csc_val[dst] = csr_val[q]; from_csr[dst] = (int)q;
+		}
+	}
+	// tr(V^T V) terms per column, accumulated in T like the trace kernel, and sum(V) for the KL divergence
+	h_vtv_.assign(n_, T(0));
+	sum_v_ = 0;
+	for (int j = 0; j < n_; ++j) {
+		T s = 0;
+		for (int p = csc_ptr[j]; p < csc_ptr[j + 1]; ++p) { s += csc_val[p] * csc_val[p]; sum_v_ += (double)csc_val[p]; }
+		h_vtv_[j] = s;
+	}
+	std::sort(h_vtv_.begin(), h_vtv_.end());
+
+	void** old[] = {(void**)&csr_ptr_, (void**)&csr_idx_, (void**)&csc_ptr_, (void**)&csc_idx_, (void**)&csc_from_csr_, (void**)&csr_val_, (void**)&csc_val_, (void**)&q_, (void**)&q2_};
+	for (void** b : old) { if (*b) (void)hipFree(*b); *b = nullptr; }
+	const size_t ni = sizeof(int) * (size_t)std::max<long>(nnz, 1), nv = sizeof(T) * (size_t)std::max<long>(nnz, 1);
+	HIPX(hipMalloc((void**)&csr_ptr_, sizeof(int) * (m_ + 1)));
+	HIPX(hipMalloc((void**)&csc_ptr_, sizeof(int) * (n_ + 1)));
+	HIPX(hipMalloc((void**)&csr_idx_, ni)); HIPX(hipMalloc((void**)&csc_idx_, ni)); HIPX(hipMalloc((void**)&csc_from_csr_, ni));
+	HIPX(hipMalloc((void**)&csr_val_, nv)); HIPX(hipMalloc((void**)&csc_val_, nv));
+	HIPX(hipMalloc((void**)&q_, nv)); HIPX(hipMalloc((void**)&q2_, nv));
+	HIPX(hipMemcpyAsync(csr_ptr_, csr_ptr.data(), sizeof(int) * (m_ + 1), hipMemcpyHostToDevice, stream_));
+	HIPX(hipMemcpyAsync(csc_ptr_, csc_ptr.data(), sizeof(int) * (n_ + 1), hipMemcpyHostToDevice, stream_));
+	if (nnz > 0) {
+		HIPX(hipMemcpyAsync(csr_idx_, csr_idx.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
+		HIPX(hipMemcpyAsync(csc_idx_, csc_idx.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
+		HIPX(hipMemcpyAsync(csc_from_csr_, from_csr.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
+		HIPX(hipMemcpyAsync(csr_val_, csr_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
+		HIPX(hipMemcpyAsync(csc_val_, csc_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
+	}
+	HIPX(hipStreamSynchronize(stream_));
+	nnz_ = nnz;
+	return ST_OK;
+}
+
+// KL-divergence multiplicative update (Lee & Seung, "Algorithms for Non-negative Matrix
+// Factorization", NIPS 2001 -- the paper the reference's README cites; the reference itself only has
+// the Frobenius form), in the skeleton of the reference's MU iteration: H step, W step, column
+// normalisation of W, error terms referring to (W_{k-1}, H_k):
+//   Q = V ./ (W H + eps) on the stored entries (SDDMM);  H .*= (W^T Q) ./ (colsum(W) + eps)
+//   Q = V ./ (W H + eps) again;                          W .*= (Q H^T) ./ (rowsum(H) + eps);  normalise
+template <typename T>
+Status Engine<T>::iterate_kl(bool compute_error) {
+	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	const int norm_parts = (int)(mpad_ / 128);
+	// H step
+	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, t_vwh_, t_kl_, m_, stream_));
+	HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
+	HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
+	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
+	HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
+	// W step (the quotient is re-evaluated with the new H)
+	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, t_vwh_, t_kl_, m_, stream_));
+	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sH_, stream_));
+	if (compute_error) {
+		// Frobenius error by the reference's trace formula with (W_{k-1}, H_k); KL divergence next to it
+		HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G_, stream_));
+		HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
+		HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_));
+		std::vector<T> vwh(m_), kl(m_), sW(RP_), sH(RP_), psr(r_);
+		HIPX(hipMemcpyAsync(vwh.data(), t_vwh_, sizeof(T) * m_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(kl.data(), t_kl_, sizeof(T) * m_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(sW.data(), sW_, sizeof(T) * RP_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(sH.data(), sH_, sizeof(T) * RP_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(psr.data(), psR_, sizeof(T) * r_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipStreamSynchronize(stream_));
+		finalize_error(false);
+		h_psN_ = vwh; h_psR_ = psr;
+		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
+		double d = -sum_v_;
+		for (int i = 0; i < m_; ++i) d += (double)kl[i];
+		for (int c = 0; c < r_; ++c) d += (double)sW[c] * (double)sH[c];
+		kl_ = d;
+	}
+	HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, q_, H_, RP_, slabs_, m_, (int)mpad_, stream_));
+	HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
+	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+	return ST_OK;
+}
+
 template <typename T>
 Status Engine<T>::debug_read(int which, T* out, long count) {
 	const T* src = nullptr; long avail = 0;
@@ -599,6 +765,7 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
 	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
 	case 6: case 7: {
+		if (sparse_) return ST_INVALID;   // no dense image in sparse mode
 		// V (ld mpad_) / Vt (ld npad_) as column-major images; the MFMA path keeps them x-tiled
 		const bool vt = which == 7;
 		const T* img = vt ? Vt_ : V_;

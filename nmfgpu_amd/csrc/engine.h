@@ -18,6 +18,9 @@ enum Algorithm { ALG_MU = 0, ALG_GDCLS = 1, ALG_ALS = 2, ALG_ACLS = 3, ALG_AHCLS
 
 struct AlgorithmParams {
 	double lambda = 0, lambdaW = 0, lambdaH = 0, alphaW = 0, alphaH = 0, theta = 0;
+	// extensions without a reference counterpart (selected by new Parameter names, see abi.cpp):
+	double divergence = 0;      // 0: Frobenius objective, 1: generalised KL divergence (multiplicative update only)
+	double sparse_compute = 0;  // 1: keep V as CSR + CSC in HBM and multiply by SpMM instead of densifying
 };
 
 // Status codes shared with nmfgpu_amd.h (NMFAMD_*).
@@ -64,6 +67,9 @@ public:
 	// Error of the most recent error iteration.  The n + r partial sums travel to the host
 	// asynchronously; the first reader waits for them and does the sorted summation, so a caller
 	// that does not look at the error every time (the benchmark loop) never stalls the stream.
+	double kl_divergence() { finalize_error(true); return kl_; }
+	bool sparse_mode() const { return sparse_; }
+	long nnz() const { return nnz_; }
 	double frobenius() { finalize_error(true); return frob_; }
 	double rmsd() { finalize_error(true); return rmsd_; }
 
@@ -95,6 +101,8 @@ private:
 	Status materialize_w();                          // fold the pending column scale into Wt_
 	Status normal_inverse(T* A, T offdiag, T diag);  // A <- (A + regulariser)^-1
 	Status finish_upload(T* Vcol);
+	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC
+	Status iterate_kl(bool compute_error);            // KL-divergence multiplicative update (sparse mode)
 	Status fetch_error_terms(int count_n);            // enqueue the copies, do not wait
 	void finalize_error(bool resolve);
 	void record_begin();
@@ -117,6 +125,13 @@ private:
 	T *Wold_ = nullptr;                       // LS family: W before the update
 	T *G_ = nullptr, *G2_ = nullptr, *HHt_ = nullptr, *Qinv_ = nullptr, *gram_part_ = nullptr;
 	T *sumsq_part_ = nullptr;
+	// sparse-V compute path (kernels_sparse.hip): CSR and CSC images of V, 0-based
+	bool sparse_ = false;
+	long nnz_ = 0;
+	int *csr_ptr_ = nullptr, *csr_idx_ = nullptr, *csc_ptr_ = nullptr, *csc_idx_ = nullptr, *csc_from_csr_ = nullptr;
+	T *csr_val_ = nullptr, *csc_val_ = nullptr, *q_ = nullptr, *q2_ = nullptr;
+	T *t_vwh_ = nullptr, *t_kl_ = nullptr, *rowsum_part_ = nullptr, *sW_ = nullptr, *sH_ = nullptr;
+	double sum_v_ = 0, kl_ = 0;
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
 	bool fused_ready_ = false, w_pending_ = false;

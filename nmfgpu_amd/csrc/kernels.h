@@ -126,4 +126,21 @@ hipError_t launch_densify(int format, const T* values, const int* ptr, const int
 template <typename T>
 hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
 
+// ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------
+// out(row, :) = sum_p val[p] P(idx[p], :) over the stored entries of `row`; rows in [rows, rows_pad) are zeroed.
+template <typename T>
+hipError_t launch_spmm_rows(const int* ptr, const int* idx, const T* val, const T* P, int RP, T* out, int rows, int rows_pad, hipStream_t stream);
+// q[p] = val[p] / (A(row,:).B(idx[p],:) + eps) and the per-row sums of val*wh and val*log(val/wh)
+template <typename T>
+hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
+                                 T* q, T* t_vwh, T* t_kl, int rows, hipStream_t stream);
+template <typename T>
+hipError_t launch_permute(const T* src, const int* perm, T* dst, long count, hipStream_t stream);
+// sums(c) = sum_y P(c, y); partial: (len_pad / 128) * RP elements of scratch
+template <typename T>
+hipError_t launch_panel_rowsum(const T* P, int RP, int len_pad, T* partial, T* sums, hipStream_t stream);
+// P(c, y) <- P(c, y) num(c, y) / (den(c) + eps); sumsq_part (optional): (len_pad / 128) * RP partial sums of squares
+template <typename T>
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream);
+
 } // namespace nmfamd

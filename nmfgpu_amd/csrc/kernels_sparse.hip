@@ -1,0 +1,223 @@
+// kernels_sparse.hip -- sparse-V compute path (extension; the reference densifies sparse input with
+// cuSPARSE and runs the dense algorithm, source/common/Matrix.h:145-232).
+//
+// V stays in HBM as CSR (rows of V) and CSC (= CSR of V^T), 0-based int32 indices, built once on
+// the host from the caller's CSR / CSC / COO arrays with the caller's index base applied exactly.
+// The two products against V become row-gather SpMMs over the factor panels (whose rows are
+// contiguous: panel layout [y][RP]):
+//     W^T V      out(:, j) = sum_{i in column j} V(i, j) Wt(:, i)      CSC + Wt panel
+//     (V H^T)^T  out(:, i) = sum_{j in row i}    V(i, j) H(:, j)       CSR + H panel
+// and the KL-divergence update adds an SDDMM (W H evaluated at the stored entries only).
+// One wave owns one output row ("wavefront-segmented" reduction: the 64 lanes hold the RP factor
+// rows of the running sum, the stored entries of the row are walked in index order), so every
+// sum has a fixed order and the result is deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// broadcast of lane `src` (wave-uniform index) through v_readlane: no LDS crossbar round trip
+__device__ inline int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ inline float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ inline double bcast(double v, int src) {
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// out(row, :) = sum_p val[p] * P(idx[p], :), p in [ptr[row], ptr[row+1]); rows >= `rows` are zeroed.
+// VEC = RP / 64 factor rows per lane (contiguous: one gathered panel row is one coalesced access).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_spmm_rows(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                                   const T* __restrict__ P, T* __restrict__ out, int rows, int rows_pad) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int row = blockIdx.x * 4 + wave;
+	if (row >= rows_pad) return;
+	constexpr int RP = 64 * VEC;
+	T acc[VEC];
+#pragma unroll
+	for (int v = 0; v < VEC; ++v) acc[v] = 0;
+	if (row < rows) {
+		const int p_begin = ptr[row], p_end = ptr[row + 1];
+		for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+			const int cnt = min(64, p_end - p0);
+			int my_idx = 0; T my_val = 0;
+			if (lane < cnt) { my_idx = idx[p0 + lane]; my_val = val[p0 + lane]; }
+			int u = 0;
+			for (; u + 4 <= cnt; u += 4) {
+				T g[4][VEC]; T v[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int i = bcast(my_idx, u + k);
+					v[k] = bcast(my_val, u + k);
+					const T* src = P + (long)i * RP + lane * VEC;
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) g[k][e] = src[e];
+				}
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) acc[e] += v[k] * g[k][e];
+			}
+			for (; u < cnt; ++u) {
+				const int i = bcast(my_idx, u);
+				const T v = bcast(my_val, u);
+				const T* src = P + (long)i * RP + lane * VEC;
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) acc[e] += v * src[e];
+			}
+		}
+	}
+	T* dst = out + (long)row * RP + lane * VEC;
+#pragma unroll
+	for (int e = 0; e < VEC; ++e) dst[e] = acc[e];
+}
+
+template <typename T>
+hipError_t launch_spmm_rows(const int* ptr, const int* idx, const T* val, const T* P, int RP, T* out, int rows, int rows_pad, hipStream_t stream) {
+	dim3 grid((rows_pad + 3) / 4), block(256);
+	switch (RP / 64) {
+	case 1: hipLaunchKernelGGL((k_spmm_rows<T, 1>), grid, block, 0, stream, ptr, idx, val, P, out, rows, rows_pad); break;
+	case 2: hipLaunchKernelGGL((k_spmm_rows<T, 2>), grid, block, 0, stream, ptr, idx, val, P, out, rows, rows_pad); break;
+	case 4: hipLaunchKernelGGL((k_spmm_rows<T, 4>), grid, block, 0, stream, ptr, idx, val, P, out, rows, rows_pad); break;
+	default: return hipErrorInvalidValue;   // padded ranks 64, 128, 256
+	}
+	return hipGetLastError();
+}
+template hipError_t launch_spmm_rows<float>(const int*, const int*, const float*, const float*, int, float*, int, int, hipStream_t);
+template hipError_t launch_spmm_rows<double>(const int*, const int*, const double*, const double*, int, double*, int, int, hipStream_t);
+
+// SDDMM + quotient for the KL update: for every stored entry p = (row, idx[p]):
+//     wh   = A(row, :) . B(idx[p], :)          (both panel rows, RP contiguous values)
+//     q[p] = val[p] / (wh + eps)
+// and per row the three partial sums the error evaluation needs:
+//     t_vwh(row) = sum_p val * wh              (terms of tr(H^T W^T V))
+//     t_kl(row)  = sum_p val * log(val / wh)   (first term of the generalised KL divergence)
+// One wave per row; the A row sits in registers, each lane covers VEC contiguous factor rows and the
+// dot product is finished with a butterfly sum (fixed order).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_sddmm_quotient(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                                        const T* __restrict__ A, const T* __restrict__ B, T eps,
+                                                        T* __restrict__ q, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int row = blockIdx.x * 4 + wave;
+	if (row >= rows) return;
+	constexpr int RP = 64 * VEC;
+	T a[VEC];
+#pragma unroll
+	for (int e = 0; e < VEC; ++e) a[e] = A[(long)row * RP + lane * VEC + e];
+	const int p_begin = ptr[row], p_end = ptr[row + 1];
+	T s_vwh = 0, s_kl = 0;
+	for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+		const int cnt = min(64, p_end - p0);
+		int my_idx = 0; T my_val = 0, my_q = 0;
+		if (lane < cnt) { my_idx = idx[p0 + lane]; my_val = val[p0 + lane]; }
+		for (int u = 0; u < cnt; u += 2) {
+			// two entries in flight
+			const int i0 = bcast(my_idx, u), i1 = bcast(my_idx, u + 1 < cnt ? u + 1 : u);
+			T d0 = 0, d1 = 0;
+			const T* b0 = B + (long)i0 * RP + lane * VEC;
+			const T* b1 = B + (long)i1 * RP + lane * VEC;
+#pragma unroll
+			for (int e = 0; e < VEC; ++e) { d0 += a[e] * b0[e]; d1 += a[e] * b1[e]; }
+			for (int w = 32; w > 0; w >>= 1) { d0 += __shfl_xor(d0, w); d1 += __shfl_xor(d1, w); }
+			if (lane == u) my_q = d0;
+			if (lane == u + 1) my_q = d1;
+		}
+		if (lane < cnt) {
+			const T wh = my_q;
+			q[p0 + lane] = my_val / (wh + eps);
+			s_vwh += my_val * wh;
+			if (my_val > T(0)) s_kl += my_val * (T)log((double)my_val / (double)(wh + eps));
+		}
+	}
+	for (int w = 32; w > 0; w >>= 1) { s_vwh += __shfl_xor(s_vwh, w); s_kl += __shfl_xor(s_kl, w); }
+	if (lane == 0) { t_vwh[row] = s_vwh; t_kl[row] = s_kl; }
+}
+
+template <typename T>
+hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
+                                 T* q, T* t_vwh, T* t_kl, int rows, hipStream_t stream) {
+	dim3 grid((rows + 3) / 4), block(256);
+	switch (RP / 64) {
+	case 1: hipLaunchKernelGGL((k_sddmm_quotient<T, 1>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
+	case 2: hipLaunchKernelGGL((k_sddmm_quotient<T, 2>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
+	case 4: hipLaunchKernelGGL((k_sddmm_quotient<T, 4>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+template hipError_t launch_sddmm_quotient<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, hipStream_t);
+template hipError_t launch_sddmm_quotient<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, hipStream_t);
+
+// dst[p] = src[perm[p]]: the quotients in the other storage order
+template <typename T>
+__global__ void k_permute(const T* __restrict__ src, const int* __restrict__ perm, T* __restrict__ dst, long count) {
+	const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p < count) dst[p] = src[perm[p]];
+}
+
+template <typename T>
+hipError_t launch_permute(const T* src, const int* perm, T* dst, long count, hipStream_t stream) {
+	if (count == 0) return hipSuccess;
+	hipLaunchKernelGGL((k_permute<T>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, src, perm, dst, count);
+	return hipGetLastError();
+}
+template hipError_t launch_permute<float>(const float*, const int*, float*, long, hipStream_t);
+template hipError_t launch_permute<double>(const double*, const int*, double*, long, hipStream_t);
+
+// partial(wg, c) = sum of P(c, y) over the workgroup's 128 panel columns (row sums of the factor
+// matrix: the KL denominators); reduced in order by launch_reduce_partials.
+template <typename T>
+__global__ __launch_bounds__(256) void k_panel_rowsum_partial(const T* __restrict__ P, int RP, T* __restrict__ partial) {
+	const long base = (long)blockIdx.x * 128 * RP;
+	for (int c = threadIdx.x; c < RP; c += 256) {
+		T s = 0;
+		for (int y = 0; y < 128; ++y) s += P[base + (long)y * RP + c];
+		partial[(long)blockIdx.x * RP + c] = s;
+	}
+}
+
+template <typename T>
+hipError_t launch_panel_rowsum(const T* P, int RP, int len_pad, T* partial, T* sums, hipStream_t stream) {
+	const int parts = len_pad / 128;
+	hipLaunchKernelGGL((k_panel_rowsum_partial<T>), dim3(parts), dim3(256), 0, stream, P, RP, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return launch_reduce_partials<T>(partial, parts, RP, sums, RP, stream);
+}
+template hipError_t launch_panel_rowsum<float>(const float*, int, int, float*, float*, hipStream_t);
+template hipError_t launch_panel_rowsum<double>(const double*, int, int, double*, double*, hipStream_t);
+
+// KL multiplicative update: P(c, y) <- P(c, y) * num(c, y) / (den(c) + eps), plus the per-workgroup
+// sums of squares of the result (for the column normalisation of W).  One workgroup = 128 panel columns.
+template <typename T>
+__global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* __restrict__ num, const T* __restrict__ den, int RP, T eps,
+                                                   T* __restrict__ sumsq_part) {
+	const long base = (long)blockIdx.x * 128 * RP;
+	for (int c = threadIdx.x; c < RP; c += 256) {
+		const T d = den[c] + eps;
+		T ss = 0;
+		for (int y = 0; y < 128; ++y) {
+			const long e = base + (long)y * RP + c;
+			const T v = P[e] * num[e] / d;
+			P[e] = v;
+			ss += v * v;
+		}
+		if (sumsq_part) sumsq_part[(long)blockIdx.x * RP + c] = ss;
+	}
+}
+
+template <typename T>
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream) {
+	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part);
+	return hipGetLastError();
+}
+template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t);
+template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t);
+
+} // namespace nmfamd

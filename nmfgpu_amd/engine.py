@@ -19,7 +19,7 @@ class EngineError(RuntimeError):
 
 
 class _Params(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("lam", "lambdaW", "lambdaH", "alphaW", "alphaH", "theta")]
+    _fields_ = [(n, C.c_double) for n in ("lam", "lambdaW", "lambdaH", "alphaW", "alphaH", "theta", "divergence", "sparse_compute")]
 
 
 class _Geometry(C.Structure):
@@ -48,13 +48,14 @@ class Engine:
     """One factorisation resident on the current HIP device (see include/nmfgpu_amd.h)."""
 
     def __init__(self, m: int, n: int, r: int, algorithm: str = "mu", dtype=np.float32, stream: int = 0,
-                 lam=0.0, lambda_w=0.0, lambda_h=0.0, alpha_w=0.0, alpha_h=0.0, theta=0.0):
+                 lam=0.0, lambda_w=0.0, lambda_h=0.0, alpha_w=0.0, alpha_h=0.0, theta=0.0, divergence: str = "frobenius",
+                 sparse_compute: bool = False):
         self._lib = library()
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("float32 or float64")
         self.m, self.n, self.r = m, n, r
-        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta)
+        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute))
         h = C.c_void_p()
         st = self._lib.nmfamd_engine_create(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), C.byref(h))
         if st != 0:
@@ -62,6 +63,7 @@ class Engine:
         self._h = h
         self._lib.nmfamd_engine_frobenius.restype = C.c_double
         self._lib.nmfamd_engine_rmsd.restype = C.c_double
+        self._lib.nmfamd_engine_kl_divergence.restype = C.c_double
         self._lib.nmfamd_engine_last_error.restype = C.c_char_p
         self._lib.nmfamd_engine_error_terms.restype = C.c_long
 
@@ -116,6 +118,10 @@ class Engine:
     @property
     def frobenius(self) -> float:
         return float(self._lib.nmfamd_engine_frobenius(self._h))
+
+    @property
+    def kl_divergence(self) -> float:
+        return float(self._lib.nmfamd_engine_kl_divergence(self._h))
 
     @property
     def rmsd(self) -> float:

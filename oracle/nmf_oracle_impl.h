@@ -524,6 +524,76 @@ int FN(oracle_run)(int algorithm, int m, int n, int r, const T* V, int ldv, T* W
 	return iteration;
 }
 
+/* ---- KL-divergence multiplicative update (EXTENSION: no reference counterpart) ----------- */
+/* The reference implements only the Frobenius form (NmfAlgorithm has no KL member, nmfgpu.h:107-114).
+ * This restates the update of Lee & Seung, "Algorithms for Non-negative Matrix Factorization" (NIPS 2001,
+ * cited by the reference's README), in the skeleton of the reference's MU iteration
+ * (AlgorithmMultiplicativeFrobenius.h:150-248): H step, W step with the new H, column normalisation of W,
+ * eps = machine epsilon added to every denominator, error terms referring to (W_{k-1}, H_k):
+ *     Q = V ./ (W H + eps);   H .*= (W^T Q) ./ (colsum(W) + eps)
+ *     Q = V ./ (W H + eps);   W .*= (Q H^T) ./ (rowsum(H) + eps);   normalise columns of W
+ * Zero entries of V contribute nothing (Q = 0), so a sparse evaluation over the stored entries is the
+ * same arithmetic.  Reported: the Frobenius error by the reference's trace formula (per-ROW terms of
+ * tr(H^T W^T V) here) and the generalised KL divergence
+ *     D = sum_{v>0} v log(v / (wh + eps)) - sum v + sum_c colsum(W)_c rowsum(H)_c.
+ * PARITY UNPINNED by the reference. */
+int FN(oracle_kl_run)(int m, int n, int r, const T* V, int ldv, T* W, int ldw, T* H, int ldh, int numIterations,
+                      double* out_frob, double* out_rmsd, double* out_kl) {
+	const T eps = EPS_T;
+	T* WH = (T*)malloc(sizeof(T) * (size_t)m * n);
+	T* Q = (T*)malloc(sizeof(T) * (size_t)m * n);
+	T* NH = (T*)malloc(sizeof(T) * (size_t)r * n);
+	T* NW = (T*)malloc(sizeof(T) * (size_t)m * r);
+	T* sW = (T*)malloc(sizeof(T) * (size_t)r);
+	T* sH = (T*)malloc(sizeof(T) * (size_t)r);
+	T* G = (T*)malloc(sizeof(T) * (size_t)r * r);
+	T* HHt = (T*)malloc(sizeof(T) * (size_t)r * r);
+	T* psRow = (T*)malloc(sizeof(T) * (size_t)m);
+	T* psR = (T*)malloc(sizeof(T) * (size_t)r);
+	T* vtv = (T*)malloc(sizeof(T) * (size_t)n);
+	FN(oracle_vtv_sorted)(m, n, V, ldv, vtv);
+	double frob = 0, rmsd = 0, kl = 0;
+	for (int it = 1; it <= numIterations; ++it) {
+		const int computeError = (it % 10 == 0) || it == numIterations;
+		/* H step */
+		FN(gemm_nn)(m, n, r, W, ldw, H, ldh, WH, m);
+		for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) Q[(size_t)j * m + i] = V[(size_t)j * ldv + i] / (WH[(size_t)j * m + i] + eps);
+		FN(gemm_tn)(m, r, n, W, ldw, Q, m, NH, r);
+		for (int c = 0; c < r; ++c) { T s = 0; for (int i = 0; i < m; ++i) s += W[(size_t)c * ldw + i]; sW[c] = s; }
+		for (int j = 0; j < n; ++j) for (int c = 0; c < r; ++c) H[(size_t)j * ldh + c] = H[(size_t)j * ldh + c] * NH[(size_t)j * r + c] / (sW[c] + eps);
+		/* W step */
+		FN(gemm_nn)(m, n, r, W, ldw, H, ldh, WH, m);
+		for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) Q[(size_t)j * m + i] = V[(size_t)j * ldv + i] / (WH[(size_t)j * m + i] + eps);
+		for (int c = 0; c < r; ++c) { T s = 0; for (int j = 0; j < n; ++j) s += H[(size_t)j * ldh + c]; sH[c] = s; }
+		if (computeError) {
+			double sumv = 0, d = 0;
+			for (int i = 0; i < m; ++i) {
+				T t = 0;
+				for (int j = 0; j < n; ++j) {
+					const T v = V[(size_t)j * ldv + i], wh = WH[(size_t)j * m + i];
+					t += v * wh;
+					sumv += (double)v;
+					if (v > 0) d += (double)v * log((double)v / (double)(wh + eps));
+				}
+				psRow[i] = t;
+			}
+			FN(gemm_tn)(m, r, r, W, ldw, W, ldw, G, r);
+			FN(gemm_nt)(r, n, r, H, ldh, H, ldh, HHt, r);
+			FN(trace_multiplication)(0, r, r, HHt, r, G, r, psR);
+			frob = FN(oracle_resolve_frobenius)(vtv, n, psRow, m, psR, r);
+			rmsd = frob / sqrt((double)((unsigned)m * (unsigned)n));
+			for (int c = 0; c < r; ++c) d += (double)sW[c] * (double)sH[c];
+			kl = d - sumv;
+		}
+		FN(gemm_nt)(m, n, r, Q, m, H, ldh, NW, m);
+		for (int c = 0; c < r; ++c) for (int i = 0; i < m; ++i) W[(size_t)c * ldw + i] = W[(size_t)c * ldw + i] * NW[(size_t)c * m + i] / (sH[c] + eps);
+		FN(normalize_columns)(m, r, W, ldw);
+	}
+	*out_frob = frob; *out_rmsd = rmsd; *out_kl = kl;
+	free(WH); free(Q); free(NH); free(NW); free(sW); free(sH); free(G); free(HHt); free(psRow); free(psR); free(vtv);
+	return numIterations;
+}
+
 /* Exposed single products / kernels so the parity tests can check each HIP kernel on its own. */
 void FN(oracle_gemm_tn)(int m, int ka, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) { FN(gemm_tn)(m, ka, kb, A, lda, B, ldb, C, ldc); }
 void FN(oracle_gemm_nt)(int m, int n, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) { FN(gemm_nt)(m, n, kb, A, lda, B, ldb, C, ldc); }

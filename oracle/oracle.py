@@ -240,3 +240,17 @@ def emulate_factor_product(A, F, splits: int):
     set_threads_for(float(X) * Y * r)
     lib().oracle_emulate_factor_product_f32(X, Y, r, _ptr(_f(A)), _ld(A), _ptr(_f(F)), _ld(F), splits, _ptr(out), _ld(out))
     return out
+
+
+def run_kl(V, W, H, num_iterations: int):
+    """KL-divergence multiplicative update (extension, literature formula; see oracle_kl_run).
+    W and H are updated in place.  Returns dict(frobenius, rmsd, kl)."""
+    s = _sfx(V.dtype)
+    m, n = V.shape
+    r = W.shape[1]
+    set_threads_for(float(m) * n * r)
+    fn = getattr(lib(), f"oracle_kl_run_{s}")
+    fn.restype = C.c_int
+    frob = C.c_double(0); rmsd = C.c_double(0); kl = C.c_double(0)
+    fn(m, n, r, _ptr(_f(V)), _ld(V), _ptr(_f(W)), _ld(W), _ptr(_f(H)), _ld(H), num_iterations, C.byref(frob), C.byref(rmsd), C.byref(kl))
+    return {"frobenius": frob.value, "rmsd": rmsd.value, "kl": kl.value}

@@ -426,3 +426,113 @@ def test_factor_product_160_row_tiles_bit_exact(monkeypatch):
     eng.iterate(10, last_iteration=10)
     Wg, Hg = eng.get_factors()
     assert rel(Wg, W64) < 1e-4 and rel(Hg, H64) < 1e-4
+
+
+# ------------------------------------------------------------------ sparse-V compute path (extension)
+
+def _sparse_problem(m, n, r, density, dtype, seed=17):
+    rng = np.random.default_rng(seed)
+    D = ((rng.random((m, n)) < density) * rng.integers(1, 6, size=(m, n))).astype(dtype)
+    W = F((1.0 - rng.random((m, r))).astype(dtype)); H = F((1.0 - rng.random((r, n))).astype(dtype))
+    return F(D), W, H
+
+
+@pytest.mark.parametrize("m,n,r,dtype,tol", [(300, 260, 8, np.float32, 2e-4), (280, 200, 100, np.float32, 2e-4), (150, 120, 6, np.float64, 1e-9)])
+def test_sparse_compute_frobenius_mu_equals_dense_oracle(m, n, r, dtype, tol):
+    """CSR SpMM path: same factorisation as the reference's densify-then-dense route (fp64 oracle on the dense matrix)."""
+    import scipy.sparse as sp
+    D, W, H = _sparse_problem(m, n, r, 0.15, dtype)
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W, H))
+    ref = oracle.run("mu", D64, W64, H64, 20)
+    s = sp.csr_matrix(D)
+    eng = na.Engine(m, n, r, "mu", dtype=dtype, sparse_compute=True)
+    eng.upload_sparse(1, s.data, s.indptr, s.indices, 0)
+    eng.set_factors(W, H)
+    eng.iterate(20, last_iteration=20)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-5))
+
+
+def test_sparse_compute_formats_and_index_bases_bit_identical():
+    """CSR / CSC / COO with base 0 and 1, and a dense upload of the same matrix: identical factors (bit-exact indexing)."""
+    import scipy.sparse as sp
+    m, n, r = 200, 150, 8
+    D, W, H = _sparse_problem(m, n, r, 0.1, np.float32)
+    results = []
+    for fmt in (1, 2, 3, 0):
+        for base in ((0, 1) if fmt else (0,)):
+            eng = na.Engine(m, n, r, "mu", sparse_compute=True)
+            if fmt == 1:
+                s = sp.csr_matrix(D); eng.upload_sparse(1, s.data, s.indptr + base, s.indices + base, base)
+            elif fmt == 2:
+                s = sp.csc_matrix(D); eng.upload_sparse(2, s.data, s.indptr + base, s.indices + base, base)
+            elif fmt == 3:
+                s = sp.coo_matrix(D)
+                perm = np.random.default_rng(1).permutation(s.nnz)   # unordered triplets
+                eng.upload_sparse(3, s.data[perm], (s.row + base)[perm], (s.col + base)[perm], base)
+            else:
+                eng.upload(D)
+            eng.set_factors(W, H)
+            eng.iterate(10, last_iteration=10)
+            results.append(eng.get_factors() + (eng.frobenius,))
+    for Wg, Hg, f in results[1:]:
+        assert np.array_equal(Wg, results[0][0]) and np.array_equal(Hg, results[0][1]) and f == results[0][2]
+
+
+@pytest.mark.parametrize("m,n,r,dtype,tol", [(220, 180, 8, np.float32, 5e-4), (160, 140, 70, np.float32, 5e-4), (120, 100, 5, np.float64, 1e-9)])
+def test_kl_divergence_mu_matches_literature_oracle(m, n, r, dtype, tol):
+    import scipy.sparse as sp
+    D, W, H = _sparse_problem(m, n, r, 0.2, dtype, seed=23)
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W, H))
+    ref = oracle.run_kl(D64, W64, H64, 20)
+    s = sp.csr_matrix(D)
+    eng = na.Engine(m, n, r, "mu", dtype=dtype, divergence="kl")
+    eng.upload_sparse(1, s.data, s.indptr, s.indices, 0)
+    eng.set_factors(W, H)
+    eng.iterate(20, last_iteration=20)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.kl_divergence == pytest.approx(ref["kl"], rel=max(20 * tol, 1e-6))
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6))
+    assert (Wg >= 0).all() and (Hg >= 0).all()
+
+
+def test_compute_accepts_extension_parameters():
+    import scipy.sparse as sp
+    m, n, r = 120, 90, 5
+    D, W, H = _sparse_problem(m, n, r, 0.2, np.float32, seed=29)
+    s = sp.csr_matrix(D)
+    idx = s.indices.astype(np.int32); ptr = s.indptr.astype(np.int32); val = s.data.astype(np.float32)
+    desc = na.api.sparse_description(na.StorageFormat.CSR, m, n, val, ptr, idx)
+    Wa, Ha = W.copy(order="F"), H.copy(order="F")
+    assert na.compute(desc, Wa, Ha, iterations=10, parameters={"sparseCompute": 1.0}) == na.ResultType.Success
+    Wb, Hb = W.copy(order="F"), H.copy(order="F")
+    assert na.compute(desc, Wb, Hb, iterations=10) == na.ResultType.Success      # reference route: densify
+    assert rel(Wa, Wb) < 1e-5 and rel(Ha, Hb) < 1e-5
+    Wk, Hk = W.copy(order="F"), H.copy(order="F")
+    sm = na.Summary()
+    assert na.compute(desc, Wk, Hk, iterations=10, parameters={"divergence": 1.0}, summary=sm) == na.ResultType.Success
+    assert np.isfinite(sm.record(0).frobenius) and not np.allclose(Wk, Wa)
+    assert na.compute(desc, Wk, Hk, algorithm=na.NmfAlgorithm.ALS, iterations=2, parameters={"sparseCompute": 1.0}) == na.ResultType.ErrorInvalidArgument
+
+
+def test_sparse_kl_medium_size_properties():
+    """20 000 x 5 000 at 1 % density, r = 128 (BASELINE config 3 scaled by 1/20): the divergence does not increase,
+    factors stay non-negative, W keeps unit columns."""
+    import scipy.sparse as sp
+    m, n, r = 20000, 5000, 128
+    rng = np.random.default_rng(3)
+    s = sp.random(m, n, density=0.01, format="csr", random_state=3, data_rvs=lambda k: rng.integers(1, 6, size=k).astype(np.float32)).astype(np.float32)
+    W = F((1.0 - rng.random((m, r))).astype(np.float32)); H = F((1.0 - rng.random((r, n))).astype(np.float32))
+    eng = na.Engine(m, n, r, "mu", divergence="kl")
+    eng.upload_sparse(1, s.data, s.indptr, s.indices, 0)
+    eng.set_factors(W, H)
+    kls = []
+    for k in range(4):
+        eng.iterate(10, first_iteration=10 * k + 1, error_every=10)
+        kls.append(eng.kl_divergence)
+    assert all(np.isfinite(kls)) and all(b <= a * (1 + 1e-5) for a, b in zip(kls, kls[1:])), kls
+    Wg, Hg = eng.get_factors()
+    assert (Wg >= 0).all() and (Hg >= 0).all()
+    np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-4)

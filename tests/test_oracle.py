@@ -250,3 +250,31 @@ def test_ls_first_h_solve_is_the_normal_equations():
     oracle.run("als", V, W, H, 1, const_w=True)
     want = np.maximum(np.linalg.solve(W0.T @ W0, W0.T @ Vc), 0.0)
     np.testing.assert_allclose(H, want, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------- KL extension (literature formula)
+
+def test_kl_update_decreases_the_divergence_and_keeps_invariants():
+    rng = np.random.default_rng(6)
+    m, n, r = 50, 35, 4
+    V = F(rng.random((m, n)) * (rng.random((m, n)) < 0.4))
+    W = F(1.0 - rng.random((m, r))); H = F(1.0 - rng.random((r, n)))
+    kls = []
+    for iters in (10, 20, 40, 80):
+        Wc, Hc = W.copy(order="F"), H.copy(order="F")
+        res = oracle.run_kl(V, Wc, Hc, iters)
+        kls.append(res["kl"])
+        assert (Wc >= 0).all() and (Hc >= 0).all()
+        np.testing.assert_allclose(np.linalg.norm(Wc, axis=0), 1.0, rtol=1e-12)
+    assert all(b <= a + 1e-9 for a, b in zip(kls, kls[1:]))
+    # the reported divergence is D(V || W_{k-1} H_k) evaluated directly
+    Wp, Hp = W.copy(order="F"), H.copy(order="F")
+    oracle.run_kl(V, Wp, Hp, 9)
+    Wc, Hc = W.copy(order="F"), H.copy(order="F")
+    res = oracle.run_kl(V, Wc, Hc, 10)
+    WH = Wp @ Hc
+    eps = np.finfo(np.float64).eps
+    mask = V > 0
+    direct = (V[mask] * np.log(V[mask] / (WH[mask] + eps))).sum() - V.sum() + WH.sum()
+    assert res["kl"] == pytest.approx(direct, rel=1e-9)
+    assert res["frobenius"] == pytest.approx(np.linalg.norm(V - WH), rel=1e-8)

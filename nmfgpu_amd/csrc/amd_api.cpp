@@ -293,8 +293,7 @@ int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float 
 	DevBuf dA, dI, dW;
 	if (dA.alloc(sizeof(float) * RP * RP) != hipSuccess || dI.alloc(sizeof(float) * RP * RP) != hipSuccess || dW.alloc(sizeof(double) * 2 * (size_t)r * r) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
 	if (hipMemcpy2D(dA.p, RP * sizeof(float), A, lda * sizeof(float), r * sizeof(float), r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_fill_small<float>((float*)dA.p, RP, r, 1, offdiag, diag, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_inverse_small<float>((const float*)dA.p, RP, r, (float*)dI.p, (double*)dW.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_inverse_small<float>((float*)dA.p, RP, r, (float*)dI.p, (double*)dW.p, offdiag, diag, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(Ainv, ldi * sizeof(float), dI.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }

@@ -378,8 +378,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 
 template <typename T>
 Status Engine<T>::normal_inverse(T* A, T offdiag, T diag) {
-	HIPX(launch_fill_small<T>(A, RP_, r_, 1, offdiag, diag, stream_));
-	HIPX(launch_inverse_small<T>(A, RP_, r_, Qinv_, inv_work_, stream_));
+	HIPX(launch_inverse_small<T>(A, RP_, r_, Qinv_, inv_work_, offdiag, diag, stream_));
 	return ST_OK;
 }
 

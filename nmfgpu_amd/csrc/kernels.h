@@ -107,9 +107,10 @@ hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps
 template <typename T>
 hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, hipStream_t stream);
 
-// work: 2 * r * r doubles
+// Ainv = (A + regulariser)^-1, regulariser = offdiag everywhere, diag on the diagonal.  work: 2 * r * r doubles
+// (r > 64 only; that route also adds the regulariser to A in place).
 template <typename T>
-hipError_t launch_inverse_small(const T* A, int RP, int r, T* Ainv, double* work, hipStream_t stream);
+hipError_t launch_inverse_small(T* A, int RP, int r, T* Ainv, double* work, T offdiag, T diag, hipStream_t stream);
 
 template <typename T>
 hipError_t launch_transpose(const T* src, long lds, int rows, int cols, T* dst, long ldd, hipStream_t stream);

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void k_inverse_small(const T* __restrict__ A, 
 // Same result as the QR route (cusolver geqrf + ormqr + trsm, Matrix.h:565-618) up to rounding for
 // the non-singular normal matrices the LS algorithms produce.
 template <typename T>
-__global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv) {
+__global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, T offdiag, T diag) {
 	__shared__ double s_col[2][64];
 	__shared__ double s_row[2][128];
 	__shared__ int s_inv[64];
@@ -867,7 +867,8 @@ __global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, i
 		for (int cc = 0; cc < 8; ++cc) {
 			const int i = 4 * ti + rr, j = 8 * tj + cc;
 			double v;
-			if (j < 64) v = (i < r && j < r) ? (double)A[(long)j * RP + i] : (i == j ? 1.0 : 0.0);
+			// the regulariser (kernel::addConstantToMatrix, KernelFillMatrix.cu:29-45) is added in T on the way in
+			if (j < 64) v = (i < r && j < r) ? (double)(T)(A[(long)j * RP + i] + (i == j ? diag : offdiag)) : (i == j ? 1.0 : 0.0);
 			else v = (j - 64 == i) ? 1.0 : 0.0;
 			M[rr][cc] = v;
 		}
@@ -936,16 +937,20 @@ __global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, i
 }
 
 template <typename T>
-hipError_t launch_inverse_small(const T* A, int RP, int r, T* Ainv, double* work, hipStream_t stream) {
+hipError_t launch_inverse_small(T* A, int RP, int r, T* Ainv, double* work, T offdiag, T diag, hipStream_t stream) {
 	if (r <= 64) {
-		hipLaunchKernelGGL((k_inverse_gj64<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv);
+		hipLaunchKernelGGL((k_inverse_gj64<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv, offdiag, diag);
 		return hipGetLastError();
+	}
+	if (offdiag != T(0) || diag != T(0)) {
+		hipError_t e = launch_fill_small<T>(A, RP, r, 1, offdiag, diag, stream);
+		if (e != hipSuccess) return e;
 	}
 	hipLaunchKernelGGL((k_inverse_small<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv, work);
 	return hipGetLastError();
 }
-template hipError_t launch_inverse_small<float>(const float*, int, int, float*, double*, hipStream_t);
-template hipError_t launch_inverse_small<double>(const double*, int, int, double*, double*, hipStream_t);
+template hipError_t launch_inverse_small<float>(float*, int, int, float*, double*, float, float, hipStream_t);
+template hipError_t launch_inverse_small<double>(double*, int, int, double*, double*, double, double, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // one-time data movement kernels (outside the iteration loop)

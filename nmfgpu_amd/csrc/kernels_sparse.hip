@@ -94,11 +94,13 @@ template hipError_t launch_spmm_rows<double>(const int*, const int*, const doubl
 // SDDMM + quotient for the KL update: for every stored entry p = (row, idx[p]):
 //     wh   = A(row, :) . B(idx[p], :)          (both panel rows, RP contiguous values)
 //     q[p] = val[p] / (wh + eps)
-// and per row the three partial sums the error evaluation needs:
+// and per row the partial sums the error evaluation needs:
 //     t_vwh(row) = sum_p val * wh              (terms of tr(H^T W^T V))
 //     t_kl(row)  = sum_p val * log(val / wh)   (first term of the generalised KL divergence)
-// One wave per row; the A row sits in registers, each lane covers VEC contiguous factor rows and the
-// dot product is finished with a butterfly sum (fixed order).
+// One wave per row, FOUR stored entries per step: a group of 16 lanes owns one entry, each lane
+// covers RP/16 contiguous factor rows of the dot product (one gathered panel row = one coalesced
+// access of the group) and the dot is finished with four butterfly steps inside the group.
+// Fixed summation order: lane segments, then the butterfly, then groups 0..3.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_sddmm_quotient(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                                         const T* __restrict__ A, const T* __restrict__ B, T eps,
@@ -106,37 +108,44 @@ __global__ __launch_bounds__(256) void k_sddmm_quotient(const int* __restrict__ 
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int row = blockIdx.x * 4 + wave;
 	if (row >= rows) return;
-	constexpr int RP = 64 * VEC;
-	T a[VEC];
+	constexpr int RP = 64 * VEC, SEG = 4 * VEC;
+	const int g = lane >> 4, sl = lane & 15;
+	T a[SEG];
 #pragma unroll
-	for (int e = 0; e < VEC; ++e) a[e] = A[(long)row * RP + lane * VEC + e];
+	for (int e = 0; e < SEG; ++e) a[e] = A[(long)row * RP + sl * SEG + e];
 	const int p_begin = ptr[row], p_end = ptr[row + 1];
 	T s_vwh = 0, s_kl = 0;
-	for (int p0 = p_begin; p0 < p_end; p0 += 64) {
-		const int cnt = min(64, p_end - p0);
-		int my_idx = 0; T my_val = 0, my_q = 0;
-		if (lane < cnt) { my_idx = idx[p0 + lane]; my_val = val[p0 + lane]; }
-		for (int u = 0; u < cnt; u += 2) {
-			// two entries in flight
-			const int i0 = bcast(my_idx, u), i1 = bcast(my_idx, u + 1 < cnt ? u + 1 : u);
-			T d0 = 0, d1 = 0;
-			const T* b0 = B + (long)i0 * RP + lane * VEC;
-			const T* b1 = B + (long)i1 * RP + lane * VEC;
+	for (int p0 = p_begin; p0 < p_end; p0 += 8) {
+		// two entries per group in flight
+		const int pa = p0 + g, pb = p0 + 4 + g;
+		const bool va = pa < p_end, vb = pb < p_end;
+		const int ja = idx[va ? pa : p_begin], jb = idx[vb ? pb : p_begin];
+		const T* ba = B + (long)ja * RP + sl * SEG;
+		const T* bb = B + (long)jb * RP + sl * SEG;
+		T da = 0, db = 0;
 #pragma unroll
-			for (int e = 0; e < VEC; ++e) { d0 += a[e] * b0[e]; d1 += a[e] * b1[e]; }
-			for (int w = 32; w > 0; w >>= 1) { d0 += __shfl_xor(d0, w); d1 += __shfl_xor(d1, w); }
-			if (lane == u) my_q = d0;
-			if (lane == u + 1) my_q = d1;
-		}
-		if (lane < cnt) {
-			const T wh = my_q;
-			q[p0 + lane] = my_val / (wh + eps);
-			s_vwh += my_val * wh;
-			if (my_val > T(0)) s_kl += my_val * (T)log((double)my_val / (double)(wh + eps));
+		for (int e = 0; e < SEG; ++e) { da += a[e] * ba[e]; db += a[e] * bb[e]; }
+#pragma unroll
+		for (int w = 8; w > 0; w >>= 1) { da += __shfl_xor(da, w, 16); db += __shfl_xor(db, w, 16); }
+		if (sl == 0) {
+			if (va) {
+				const T v = val[pa];
+				q[pa] = v / (da + eps);
+				s_vwh += v * da;
+				if (v > T(0)) s_kl += v * (T)log((double)v / (double)(da + eps));
+			}
+			if (vb) {
+				const T v = val[pb];
+				q[pb] = v / (db + eps);
+				s_vwh += v * db;
+				if (v > T(0)) s_kl += v * (T)log((double)v / (double)(db + eps));
+			}
 		}
 	}
-	for (int w = 32; w > 0; w >>= 1) { s_vwh += __shfl_xor(s_vwh, w); s_kl += __shfl_xor(s_kl, w); }
-	if (lane == 0) { t_vwh[row] = s_vwh; t_kl[row] = s_kl; }
+	// group partials sit in lanes 0, 16, 32, 48
+	const T v0 = __shfl(s_vwh, 0), v1 = __shfl(s_vwh, 16), v2 = __shfl(s_vwh, 32), v3 = __shfl(s_vwh, 48);
+	const T k0 = __shfl(s_kl, 0), k1 = __shfl(s_kl, 16), k2 = __shfl(s_kl, 32), k3 = __shfl(s_kl, 48);
+	if (lane == 0) { t_vwh[row] = ((v0 + v1) + v2) + v3; t_kl[row] = ((k0 + k1) + k2) + k3; }
 }
 
 template <typename T>

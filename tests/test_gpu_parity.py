@@ -536,3 +536,39 @@ def test_sparse_kl_medium_size_properties():
     Wg, Hg = eng.get_factors()
     assert (Wg >= 0).all() and (Hg >= 0).all()
     np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ ragged / edge shapes
+
+@pytest.mark.parametrize("m,n,r", [(1, 1, 1), (2, 3, 1), (5, 64, 3), (64, 5, 4), (129, 127, 64), (127, 129, 63), (300, 65, 65),
+                                   (1025, 33, 2), (33, 1025, 7), (640, 641, 32), (257, 2051, 16), (2051, 257, 128)])
+def test_mu_edge_shapes_match_oracle(m, n, r):
+    """Sizes that are not multiples of any tile (and the smallest possible ones): padding rows/columns stay inert."""
+    V, W, H = problem(m, n, r, np.float32, seed=m * 7 + n)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, 12)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(12, first_iteration=1, error_every=10, last_iteration=12)
+    Wg, Hg = eng.get_factors()
+    assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
+    assert rel(Wg, W64) < 3e-4 and rel(Hg, H64) < 3e-4
+    if np.isfinite(ref["frobenius"]) and ref["frobenius"] > 1e-3:
+        assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+
+
+def test_zero_columns_and_rows_stay_zero():
+    """A zero row of V drives the matching row of W to zero; a zero column of W must stay zero (sum > 0 guard, no NaN)."""
+    m, n, r = 200, 150, 6
+    V, W, H = problem(m, n, r, np.float32, seed=77)
+    V[17, :] = 0.0
+    W[:, 2] = 0.0
+    V, W = F(V), F(W)
+    eng = na.Engine(m, n, r, "mu"); eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(15, last_iteration=15)
+    Wg, Hg = eng.get_factors()
+    assert np.isfinite(Wg).all() and np.isfinite(Hg).all() and np.isfinite(eng.frobenius)
+    assert (Wg[:, 2] == 0).all() and (Wg[17, :] == 0).all()
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    oracle.run("mu", V64, W64, H64, 15)
+    assert rel(Wg, W64) < 3e-4 and rel(Hg, H64) < 3e-4

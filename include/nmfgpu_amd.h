@@ -53,6 +53,7 @@ typedef struct nmfamd_params {
 	/* extensions without a reference counterpart (nmfgpu::compute: Parameter names "divergence", "sparseCompute") */
 	double divergence;      /* 0 = Frobenius objective; 1 = generalised KL divergence (Multiplicative only; implies sparse_compute) */
 	double sparse_compute;  /* 1 = keep V as CSR + CSC in HBM and use SpMM / SDDMM kernels instead of densifying (Multiplicative only) */
+	double precision;       /* 0 = native; 1 = bf16 MFMA operands in the two big products (float, Multiplicative, rank <= 64; Parameter "precision") */
 } nmfamd_params;
 
 typedef struct nmfamd_engine nmfamd_engine;  /* opaque; owns every device buffer of one factorisation */
@@ -153,6 +154,8 @@ NMFAMD_API int nmfamd_op_factor_product_f64(const double* A, long lda, int X, in
  * records 8 uint64 per wave: shader clock at entry / first MFMA / loop end / kernel end, 100 MHz
  * real-time counter at entry / end, K-steps, XCC id. */
 NMFAMD_API int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned long long* stamps_out, long stamps_capacity, long* stamps_count);
+/* The same product with bf16-rounded operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation), r <= 64. */
+NMFAMD_API int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo);
 /* G (r x r) = P P^T for a host r x len matrix P. */
 NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg);
 /* Ainv = (A + regulariser)^-1 for a host r x r matrix (offdiag / diag added as KernelFillMatrix.cu:29-45). */

@@ -94,7 +94,7 @@ int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params
 	*out = nullptr;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	AlgorithmParams p;
-	if (params) { p.lambda = params->lambda; p.lambdaW = params->lambdaW; p.lambdaH = params->lambdaH; p.alphaW = params->alphaW; p.alphaH = params->alphaH; p.theta = params->theta; p.divergence = params->divergence; p.sparse_compute = params->sparse_compute; }
+	if (params) { p.lambda = params->lambda; p.lambdaW = params->lambdaW; p.lambdaH = params->lambdaH; p.alphaW = params->alphaW; p.alphaH = params->alphaH; p.theta = params->theta; p.divergence = params->divergence; p.sparse_compute = params->sparse_compute; p.precision = params->precision; }
 	nmfamd_engine* e = new (std::nothrow) nmfamd_engine();
 	if (!e) return NMFAMD_NO_HOST_MEMORY;
 	e->elem_bytes = elem_bytes;
@@ -267,6 +267,30 @@ int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned 
 
 int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int use_valu, int* out_slabs) {
 	return op_factor_product<float>(A, lda, X, Y, F, ldf, r, OUT, ldo, use_valu != 0, out_slabs);
+}
+
+int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo) {
+	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || r > 64 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	int dev = 0; hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const long Xp = pad128(X), Yp = pad128(Y);
+	const int KS = (Y + 15) / 16;
+	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;
+	plan.splits = std::max(1, std::min(prop.multiProcessorCount / plan.xtiles, KS / 16));
+	DevBuf dA, dF, dAb, dFb, dS, dO;
+	const long slab_stride = 64 * Xp;
+	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * 64 * Yp) != hipSuccess ||
+	    dAb.alloc(16 * (size_t)plan.xtiles * KS * 256) != hipSuccess || dFb.alloc(16 * (size_t)KS * 128) != hipSuccess ||
+	    dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess || dO.alloc(sizeof(float) * slab_stride) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dA.p, Xp * sizeof(float), A, lda * sizeof(float), X * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dF.p, 64 * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_stream_bf16((const float*)dA.p, Xp, X, Y, false, dAb.p, plan.xtiles, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_bf16((const float*)dF.p, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_factor_product_bf16(plan, dAb.p, KS, dFb.p, (float*)dS.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, 64 * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
 int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r, double* OUT, long ldo) {

@@ -61,6 +61,7 @@ Engine<T>::~Engine() {
 		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
+	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -91,6 +92,18 @@ Status Engine<T>::allocate() {
 		planH_.splits = planW_.splits = 1; planH_.th = planW_.th = 128;
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
 	}
+	if (prm_.precision != 0) {
+		// bf16 operands: multiplicative update at padded rank 64 on dense (resident) V only
+		if (!std::is_same<T, float>::value || alg_ != ALG_MU || RP_ != 64 || sparse_ || !mfma) return ST_INVALID;
+		bf16_ = true;
+		tiled_ = false;
+		planH_.th = planW_.th = 128;
+		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
+		planH_.splits = std::max(1, num_cus_ / planH_.xtiles); planW_.splits = std::max(1, num_cus_ / planW_.xtiles);
+		ksW_ = (n_ + 15) / 16; ksH_ = (m_ + 15) / 16;
+		planH_.splits = std::max(1, std::min(planH_.splits, ksH_ / 16)); planW_.splits = std::max(1, std::min(planW_.splits, ksW_ / 16));
+		planHb_ = planH_; planWb_ = planW_;
+	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
 	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
@@ -107,7 +120,12 @@ Status Engine<T>::allocate() {
 		if (e != hipSuccess) return e;
 		return hipMemsetAsync(*p, 0, (size_t)elems * sizeof(T), stream_);
 	};
-	if (!sparse_) {
+	if (bf16_) {
+		HIPX(hipMalloc(&Vb_, 16 * (size_t)planW_.xtiles * ksW_ * 256));
+		HIPX(hipMalloc(&Vtb_, 16 * (size_t)planH_.xtiles * ksH_ * 256));
+		HIPX(hipMalloc(&Wtb_, 16 * (size_t)ksH_ * 128));
+		HIPX(hipMalloc(&Hb_, 16 * (size_t)ksW_ * 128));
+	} else if (!sparse_) {
 		HIPX(dalloc(&V_, elemsV_));
 		HIPX(dalloc(&Vt_, elemsVt_));
 	} else {
@@ -160,7 +178,12 @@ Status Engine<T>::finish_upload(T* Vcol) {
 	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_));
 	h_vtv_.resize(n_);
 	HIPX(hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_));
-	if (tiled_) {
+	if (bf16_) {
+		if constexpr (std::is_same<T, float>::value) {
+			HIPX(launch_pack_stream_bf16(Vcol, mpad_, m_, n_, false, Vb_, planW_.xtiles, ksW_, stream_));
+			HIPX(launch_pack_stream_bf16(Vcol, mpad_, n_, m_, true, Vtb_, planH_.xtiles, ksH_, stream_));
+		}
+	} else if (tiled_) {
 		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)elemsV_, stream_));
 		HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)elemsVt_, stream_));
 		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, strideV_, planW_.th, false, stream_));
@@ -187,14 +210,15 @@ Status Engine<T>::upload_dense(const T* V, long ld) {
 		return upload_triplets(rows, cols, vals);
 	}
 	T* Vcol = V_;
-	if (tiled_) {
+	const bool staged = tiled_ || bf16_;
+	if (staged) {
 		HIPX(hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_)));
 		hipError_t e = hipMemsetAsync(Vcol, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_);
 		if (e != hipSuccess) { (void)hipFree(Vcol); return hip_fail(e, "hipMemsetAsync(staging)"); }
 	}
 	hipError_t e = hipMemcpy2DAsync(Vcol, mpad_ * sizeof(T), V, ld * sizeof(T), m_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_);
 	Status st = e == hipSuccess ? finish_upload(Vcol) : hip_fail(e, "hipMemcpy2DAsync(V)");
-	if (tiled_) (void)hipFree(Vcol);
+	if (staged) (void)hipFree(Vcol);
 	return st;
 }
 
@@ -227,8 +251,8 @@ Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const
 			    (e = hipMemcpyAsync(d_b, b, sizeof(int) * nnz, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse)"); break; }
 		}
 		if (na > 0 && (e = hipMemcpyAsync(d_a, a, sizeof(int) * na, hipMemcpyHostToDevice, stream_)) != hipSuccess) { st = hip_fail(e, "hipMemcpyAsync(sparse ptr)"); break; }
-		if (tiled_ && (e = hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_))) != hipSuccess) { Vcol = nullptr; st = hip_fail(e, "hipMalloc(staging)"); break; }
-		if (!tiled_) Vcol = V_;
+		if ((tiled_ || bf16_) && (e = hipMalloc((void**)&Vcol, sizeof(T) * (size_t)(mpad_ * npad_))) != hipSuccess) { Vcol = nullptr; st = hip_fail(e, "hipMalloc(staging)"); break; }
+		if (!(tiled_ || bf16_)) Vcol = V_;
 		if ((e = hipMemsetAsync(Vcol, 0, sizeof(T) * (size_t)(mpad_ * npad_), stream_)) != hipSuccess) { st = hip_fail(e, "hipMemsetAsync(V)"); break; }
 		// CSR: ptr = a (rowPtr), idx = b (columns); CSC: ptr = a (columnPtr), idx = b (rows); COO: idx = a (rows), idx2 = b (columns)
 		if (format == 3) e = launch_densify<T>(3, d_val, nullptr, d_a, d_b, nnz, 0, base, Vcol, mpad_, m_, n_, stream_);
@@ -236,7 +260,7 @@ Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const
 		if (e != hipSuccess) { st = hip_fail(e, "densify"); break; }
 		st = finish_upload(Vcol);
 	} while (0);
-	if (tiled_ && Vcol) (void)hipFree(Vcol);
+	if ((tiled_ || bf16_) && Vcol) (void)hipFree(Vcol);
 	if (d_val) (void)hipFree(d_val);
 	if (d_a) (void)hipFree(d_a);
 	if (d_b) (void)hipFree(d_b);
@@ -337,6 +361,15 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 		return ST_OK;
 	}
 	if constexpr (std::is_same<T, float>::value) {
+		if (bf16_) {
+			// bf16 operands: the factor panel is re-rounded and re-ordered for every product
+			HIPX(launch_pack_panel_bf16(F, m_, Wtb_, ksH_, stream_));
+			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			record_begin();
+			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, slabs_, slab_stride_, stream_, rg));
+			record_end();
+			return ST_OK;
+		}
 		if (tiled_) {
 			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
@@ -362,6 +395,14 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 		return ST_OK;
 	}
 	if constexpr (std::is_same<T, float>::value) {
+		if (bf16_) {
+			HIPX(launch_pack_panel_bf16(F, n_, Hb_, ksW_, stream_));
+			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			record_begin();
+			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, slabs_, slab_stride_, stream_, rg));
+			record_end();
+			return ST_OK;
+		}
 		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
@@ -764,7 +805,7 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
 	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
 	case 6: case 7: {
-		if (sparse_) return ST_INVALID;   // no dense image in sparse mode
+		if (sparse_ || bf16_) return ST_INVALID;   // no fp32 dense image in sparse / bf16 mode
 		// V (ld mpad_) / Vt (ld npad_) as column-major images; the MFMA path keeps them x-tiled
 		const bool vt = which == 7;
 		const T* img = vt ? Vt_ : V_;

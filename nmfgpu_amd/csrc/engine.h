@@ -21,6 +21,7 @@ struct AlgorithmParams {
 	// extensions without a reference counterpart (selected by new Parameter names, see abi.cpp):
 	double divergence = 0;      // 0: Frobenius objective, 1: generalised KL divergence (multiplicative update only)
 	double sparse_compute = 0;  // 1: keep V as CSR + CSC in HBM and multiply by SpMM instead of densifying
+	double precision = 0;       // 1: bf16 MFMA operands (V, W, H rounded to bf16 inside the two big products), fp32 everywhere else
 };
 
 // Status codes shared with nmfgpu_amd.h (NMFAMD_*).
@@ -125,6 +126,11 @@ private:
 	T *Wold_ = nullptr;                       // LS family: W before the update
 	T *G_ = nullptr, *G2_ = nullptr, *HHt_ = nullptr, *Qinv_ = nullptr, *gram_part_ = nullptr;
 	T *sumsq_part_ = nullptr;
+	// bf16-operand products (kernels_bf16.hip): fragment-ordered bf16 images of V, Vt and of the two factor panels
+	bool bf16_ = false;
+	void *Vb_ = nullptr, *Vtb_ = nullptr, *Wtb_ = nullptr, *Hb_ = nullptr;
+	int ksW_ = 0, ksH_ = 0;
+	FactorProductPlan planHb_, planWb_;
 	// sparse-V compute path (kernels_sparse.hip): CSR and CSC images of V, 0-based
 	bool sparse_ = false;
 	long nnz_ = 0;

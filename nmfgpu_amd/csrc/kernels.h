@@ -127,6 +127,13 @@ hipError_t launch_densify(int format, const T* values, const int* ptr, const int
 template <typename T>
 hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
 
+// ---- bf16-operand factor product (kernels_bf16.hip) ------------------------------------------
+// Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and 64-row factor panel.
+hipError_t launch_pack_stream_bf16(const float* src, long ld, int X, int Y, bool transposed, void* dst, int xtiles, int KS, hipStream_t stream);
+hipError_t launch_pack_panel_bf16(const float* P, int len, void* dst, int KS, hipStream_t stream);
+hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F,
+                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
+
 // ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------
 // out(row, :) = sum_p val[p] P(idx[p], :) over the stored entries of `row`; rows in [rows, rows_pad) are zeroed.
 template <typename T>

@@ -19,7 +19,7 @@ class EngineError(RuntimeError):
 
 
 class _Params(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("lam", "lambdaW", "lambdaH", "alphaW", "alphaH", "theta", "divergence", "sparse_compute")]
+    _fields_ = [(n, C.c_double) for n in ("lam", "lambdaW", "lambdaH", "alphaW", "alphaH", "theta", "divergence", "sparse_compute", "precision")]
 
 
 class _Geometry(C.Structure):
@@ -49,13 +49,14 @@ class Engine:
 
     def __init__(self, m: int, n: int, r: int, algorithm: str = "mu", dtype=np.float32, stream: int = 0,
                  lam=0.0, lambda_w=0.0, lambda_h=0.0, alpha_w=0.0, alpha_h=0.0, theta=0.0, divergence: str = "frobenius",
-                 sparse_compute: bool = False):
+                 sparse_compute: bool = False, precision: str = "native"):
         self._lib = library()
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("float32 or float64")
         self.m, self.n, self.r = m, n, r
-        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute))
+        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute),
+                    {"native": 0.0, "bf16": 1.0}[precision])
         h = C.c_void_p()
         st = self._lib.nmfamd_engine_create(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), C.byref(h))
         if st != 0:
@@ -195,6 +196,19 @@ def op_factor_product(A: np.ndarray, F: np.ndarray, use_valu: bool = False):
     if st != 0:
         raise EngineError(st, "nmfamd_op_factor_product_f64")
     return out, 1
+
+
+def op_factor_product_bf16(A: np.ndarray, F: np.ndarray) -> np.ndarray:
+    """OUT (r x X) = F A^T with both operands rounded to bf16 and fp32 accumulation (r <= 64)."""
+    A = _f(A); F = _f(F)
+    X, Y = A.shape
+    r = F.shape[0]
+    out = np.zeros((r, X), dtype=np.float32, order="F")
+    st = library().nmfamd_op_factor_product_bf16(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), X, Y, C.c_void_p(F.ctypes.data), C.c_long(_ld(F)), r,
+                                                 C.c_void_p(out.ctypes.data), C.c_long(r))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_factor_product_bf16")
+    return out
 
 
 def op_gram(P: np.ndarray) -> np.ndarray:

@@ -572,3 +572,48 @@ def test_zero_columns_and_rows_stay_zero():
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
     oracle.run("mu", V64, W64, H64, 15)
     assert rel(Wg, W64) < 3e-4 and rel(Hg, H64) < 3e-4
+
+
+# ------------------------------------------------------------------ bf16 operand mode (extension)
+
+def _round_bf16(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64)])
+def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
+    """Fragment order, lane maps and the K-step bookkeeping: the result must be the fp32-accumulated
+    product of the bf16-ROUNDED operands (products of bf16 values are exact in fp32)."""
+    rng = np.random.default_rng(X * 3 + Y)
+    A = F(rng.random((X, Y)).astype(np.float32)); Fm = F((rng.random((r, Y)) - 0.3).astype(np.float32))
+    out = na.op_factor_product_bf16(A, Fm)
+    Ab, Fb = _round_bf16(A).astype(np.float64), _round_bf16(Fm).astype(np.float64)
+    want = Fb @ Ab.T
+    bound = 4e-7 * (np.abs(Fb) @ np.abs(Ab).T) + 1e-30
+    assert (np.abs(out - want) <= bound).all()
+    # and it is NOT the fp32 product: the rounding of the operands is visible
+    exact = Fm.astype(np.float64) @ A.astype(np.float64).T
+    assert np.abs(out - exact).max() > 10 * np.abs(out - want).max()
+
+
+def test_bf16_operand_mode_tracks_fp32_within_stated_tolerance():
+    """precision = bf16: operands of the two big products carry 8 significant bits; factors after 20 iterations
+    agree with the fp64 oracle to 2e-2 relative (fp32 mode: 2e-4), the reported error to 1e-3."""
+    m, n, r = 900, 700, 64
+    V, W, H = problem(m, n, r, np.float32, seed=41)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, 20)
+    eng = na.Engine(m, n, r, "mu", precision="bf16")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(20, last_iteration=20)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-2 and rel(Hg, H64) < 2e-2
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-3)
+    assert (Wg >= 0).all() and (Hg >= 0).all()
+    np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+    with pytest.raises(na.EngineError):
+        na.Engine(m, n, 100, "mu", precision="bf16")        # padded rank 64 only
+    with pytest.raises(na.EngineError):
+        na.Engine(m, n, r, "als", precision="bf16")         # multiplicative update only

@@ -226,8 +226,8 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		if (idx >= 0) prm.sparse_compute = d.parameters[idx].value;
 		idx = parameter_index(d.parameters, d.numParameters, "precision");
 		if (idx >= 0 && std::is_same<T, float>::value) prm.precision = d.parameters[idx].value;
-		if ((prm.divergence != 0 || prm.sparse_compute != 0 || prm.precision != 0) && d.algorithm != NmfAlgorithm::Multiplicative) {
-			log_error("[ERROR] 'divergence' / 'sparseCompute' / 'precision' are only available for the Multiplicative algorithm!");
+		if ((prm.divergence != 0 || prm.sparse_compute != 0) && d.algorithm != NmfAlgorithm::Multiplicative) {
+			log_error("[ERROR] 'divergence' / 'sparseCompute' are only available for the Multiplicative algorithm!");
 			return ResultType::ErrorInvalidArgument;
 		}
 		if (prm.divergence != 0 && d.useConstantBasisVectors) {

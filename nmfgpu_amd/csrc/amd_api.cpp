@@ -270,26 +270,27 @@ int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const f
 }
 
 int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo) {
-	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || r > 64 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
+	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const int RP = padded_rank(r);
 	const long Xp = pad128(X), Yp = pad128(Y);
 	const int KS = (Y + 15) / 16;
 	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;
-	plan.splits = std::max(1, std::min(prop.multiProcessorCount / plan.xtiles, KS / 16));
+	plan.splits = plan_splits_bf16(plan.xtiles, KS, RP, prop.multiProcessorCount);
 	DevBuf dA, dF, dAb, dFb, dS, dO;
-	const long slab_stride = 64 * Xp;
-	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * 64 * Yp) != hipSuccess ||
-	    dAb.alloc(16 * (size_t)plan.xtiles * KS * 256) != hipSuccess || dFb.alloc(16 * (size_t)KS * 128) != hipSuccess ||
+	const long slab_stride = (long)RP * Xp;
+	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * RP * Yp) != hipSuccess ||
+	    dAb.alloc(16 * (size_t)plan.xtiles * KS * 256) != hipSuccess || dFb.alloc(16 * (size_t)KS * (RP / 32) * 64) != hipSuccess ||
 	    dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess || dO.alloc(sizeof(float) * slab_stride) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
 	if (hipMemcpy2D(dA.p, Xp * sizeof(float), A, lda * sizeof(float), X * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (hipMemcpy2D(dF.p, 64 * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dF.p, RP * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_pack_stream_bf16((const float*)dA.p, Xp, X, Y, false, dAb.p, plan.xtiles, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_pack_panel_bf16((const float*)dF.p, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_factor_product_bf16(plan, dAb.p, KS, dFb.p, (float*)dS.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_bf16((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_factor_product_bf16(plan, dAb.p, KS, dFb.p, RP, (float*)dS.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, 64 * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 

@@ -93,15 +93,15 @@ Status Engine<T>::allocate() {
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
 	}
 	if (prm_.precision != 0) {
-		// bf16 operands: multiplicative update at padded rank 64 on dense (resident) V only
-		if (!std::is_same<T, float>::value || alg_ != ALG_MU || RP_ != 64 || sparse_ || !mfma) return ST_INVALID;
+		// bf16 operands for the two big products, dense (resident) V only; every algorithm, padded rank 64 or k * 128
+		if (!std::is_same<T, float>::value || sparse_ || !mfma) return ST_INVALID;
 		bf16_ = true;
 		tiled_ = false;
 		planH_.th = planW_.th = 128;
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
-		planH_.splits = std::max(1, num_cus_ / planH_.xtiles); planW_.splits = std::max(1, num_cus_ / planW_.xtiles);
 		ksW_ = (n_ + 15) / 16; ksH_ = (m_ + 15) / 16;
-		planH_.splits = std::max(1, std::min(planH_.splits, ksH_ / 16)); planW_.splits = std::max(1, std::min(planW_.splits, ksW_ / 16));
+		planH_.splits = plan_splits_bf16(planH_.xtiles, ksH_, RP_, num_cus_);
+		planW_.splits = plan_splits_bf16(planW_.xtiles, ksW_, RP_, num_cus_);
 		planHb_ = planH_; planWb_ = planW_;
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
@@ -123,8 +123,8 @@ Status Engine<T>::allocate() {
 	if (bf16_) {
 		HIPX(hipMalloc(&Vb_, 16 * (size_t)planW_.xtiles * ksW_ * 256));
 		HIPX(hipMalloc(&Vtb_, 16 * (size_t)planH_.xtiles * ksH_ * 256));
-		HIPX(hipMalloc(&Wtb_, 16 * (size_t)ksH_ * 128));
-		HIPX(hipMalloc(&Hb_, 16 * (size_t)ksW_ * 128));
+		HIPX(hipMalloc(&Wtb_, 16 * (size_t)ksH_ * (RP_ / 32) * 64));
+		HIPX(hipMalloc(&Hb_, 16 * (size_t)ksW_ * (RP_ / 32) * 64));
 	} else if (!sparse_) {
 		HIPX(dalloc(&V_, elemsV_));
 		HIPX(dalloc(&Vt_, elemsVt_));
@@ -363,10 +363,10 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
 			// bf16 operands: the factor panel is re-rounded and re-ordered for every product
-			HIPX(launch_pack_panel_bf16(F, m_, Wtb_, ksH_, stream_));
+			HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
 			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -396,10 +396,10 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
-			HIPX(launch_pack_panel_bf16(F, n_, Hb_, ksW_, stream_));
+			HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
 			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}

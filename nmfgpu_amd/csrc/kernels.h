@@ -128,11 +128,14 @@ template <typename T>
 hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
 
 // ---- bf16-operand factor product (kernels_bf16.hip) ------------------------------------------
-// Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and 64-row factor panel.
+// Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and the factor
+// panel [y][RP] (RP = 64 or a multiple of 128; 16 * KS * RP / 32 * 64 bytes).
 hipError_t launch_pack_stream_bf16(const float* src, long ld, int X, int Y, bool transposed, void* dst, int xtiles, int KS, hipStream_t stream);
-hipError_t launch_pack_panel_bf16(const float* P, int len, void* dst, int KS, hipStream_t stream);
-hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F,
+hipError_t launch_pack_panel_bf16(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream);
+hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
+// K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP
+int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
 
 // ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------
 // out(row, :) = sum_p val[p] P(idx[p], :) over the stored entries of `row`; rows in [rows, rows_pad) are zeroed.

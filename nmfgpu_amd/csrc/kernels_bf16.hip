@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace nmfamd {
@@ -53,24 +55,27 @@ hipError_t launch_pack_stream_bf16(const float* src, long ld, int X, int Y, bool
 	return hipGetLastError();
 }
 
-// P: fp32 panel [y][64]; len = valid panel columns.
-__global__ __launch_bounds__(256) void k_pack_panel_bf16(const float* __restrict__ P, int len, bf16x8* __restrict__ dst, long frags) {
+// P: fp32 panel [y][RP]; len = valid panel rows (y); NBT = RP / 32 column blocks.
+__global__ __launch_bounds__(256) void k_pack_panel_bf16(const float* __restrict__ P, int RP, int NBT, int len, bf16x8* __restrict__ dst, long frags) {
 	const long f = (long)blockIdx.x * 256 + threadIdx.x;
 	if (f >= frags) return;
-	const int r = (int)(f & 31), h = (int)((f >> 5) & 1), nb = (int)((f >> 6) & 1);
-	const long ks = f >> 7;
+	const int r = (int)(f & 31), h = (int)((f >> 5) & 1);
+	const long t = f >> 6;
+	const int nb = (int)(t % NBT);
+	const long ks = t / NBT;
 	bf16x8 o;
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		const long y = 16 * ks + 8 * h + j;
-		o[j] = (__bf16)(y < len ? P[y * 64 + 32 * nb + r] : 0.f);
+		o[j] = (__bf16)(y < len ? P[y * RP + 32 * nb + r] : 0.f);
 	}
 	dst[f] = o;
 }
 
-hipError_t launch_pack_panel_bf16(const float* P, int len, void* dst, int KS, hipStream_t stream) {
-	const long frags = (long)KS * 128;
-	hipLaunchKernelGGL(k_pack_panel_bf16, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, stream, P, len, reinterpret_cast<bf16x8*>(dst), frags);
+hipError_t launch_pack_panel_bf16(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream) {
+	const int NBT = RP / 32;
+	const long frags = (long)KS * NBT * 64;
+	hipLaunchKernelGGL(k_pack_panel_bf16, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, stream, P, RP, NBT, len, reinterpret_cast<bf16x8*>(dst), frags);
 	return hipGetLastError();
 }
 
@@ -123,29 +128,36 @@ __device__ inline void gram_reduce_block_bf(const GramReduceArgs& rg, int blk, f
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
-// Same decomposition as the fp32 kernel: workgroup = 8 waves = one 128-row x-tile times one slice of
-// the reduction range (K-steps of 16 y), the slice cut into 8 wave pieces; 8 accumulator tiles per
-// wave; D-deep register ring; in-workgroup sum through LDS in wave order; one fp32 slab per slice.
-template <int D>
+// Workgroup = 8 waves = one 128-row x-tile times one slice of the reduction range (K-steps of 16 y)
+// times CH chunks of 64 panel columns; the slice is cut into KP = 8 / CH wave pieces.  A wave keeps a
+// 128 x 64 accumulator block (8 tiles), streams its piece through a D-deep register ring, and the KP
+// pieces of a chunk are summed through LDS in piece order; one fp32 slab per slice.
+//   CH = 1: padded rank 64 (all eight waves cut K);  CH = 2 / 4: 128 / 256 panel columns per pass over
+//   A -- the CH waves that share a K piece read the same A fragments (one HBM fetch, L1/L2 hits).
+template <int D, int CH>
 __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 	const bf16x8* __restrict__ A, long tile_frags,      // 16-byte fragments per x-tile = KS * 256
-	const bf16x8* __restrict__ F,
-	float* __restrict__ slabs, long slab_stride,
+	const bf16x8* __restrict__ F, int NBT,              // factor fragments, NBT = RP / 32 column blocks per K-step
+	float* __restrict__ slabs, long slab_stride, int RP,
 	int steps_total, int splits, GramReduceArgs rg) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
+	constexpr int KP = BF_WAVES / CH;
 	if (blockIdx.y == (unsigned)splits) {
 		if (blockIdx.x < GRAM_REDUCE_BLOCKS) gram_reduce_block_bf(rg, blockIdx.x, lds);
 		return;
 	}
-	const int xt = blockIdx.x, sp = blockIdx.y;
+	const int xt = blockIdx.x, sp = blockIdx.y, grp = blockIdx.z;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	const int half = lane >> 5, l31 = lane & 31;
-	const int nw = splits * BF_WAVES, widx = sp * BF_WAVES + wave;
-	const int s0 = (int)(((long)steps_total * widx) / nw);
-	const int s1 = (int)(((long)steps_total * (widx + 1)) / nw);
+	const int chunk = wave % CH, kp = wave / CH;
+	const int cg = grp * CH + chunk;                    // 64-column chunk of the panel
+	const int b0 = (int)(((long)steps_total * sp) / splits);
+	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
+	const int s0 = b0 + (int)(((long)(b1 - b0) * kp) / KP);
+	const int s1 = b0 + (int)(((long)(b1 - b0) * (kp + 1)) / KP);
 	const int steps = s1 - s0;
-
+	const long fstep = (long)NBT * 64;                  // factor fragments per K-step
 	f32x16 acc[4][2];
 #pragma unroll
 	for (int b = 0; b < 4; ++b)
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 
 	if (steps > 0) {
 		const bf16x8* ap = A + (long)xt * tile_frags + (long)s0 * 256 + lane;   // + b*64 per M-block, + 256 per K-step
-		const bf16x8* fp = F + (long)s0 * 128 + lane;                           // + nb*64 per N-block, + 128 per K-step
+		const bf16x8* fp = F + (long)s0 * fstep + (long)cg * 128 + lane;        // + nb*64 per N-block, + fstep per K-step
 		const int last = steps - 1;
 		bf16x8 va[D][4], fb[D][2];
 #pragma unroll
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 #pragma unroll
 			for (int b = 0; b < 4; ++b) va[d][b] = ap[(long)st * 256 + b * 64];
 #pragma unroll
-			for (int nb = 0; nb < 2; ++nb) fb[d][nb] = fp[(long)st * 128 + nb * 64];
+			for (int nb = 0; nb < 2; ++nb) fb[d][nb] = fp[(long)st * fstep + nb * 64];
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		int t = 0;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 #pragma unroll
 				for (int b = 0; b < 4; ++b) va[d][b] = ap[(long)st * 256 + b * 64];
 #pragma unroll
-				for (int nb = 0; nb < 2; ++nb) fb[d][nb] = fp[(long)st * 128 + nb * 64];
+				for (int nb = 0; nb < 2; ++nb) fb[d][nb] = fp[(long)st * fstep + nb * 64];
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
@@ -200,7 +212,8 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 	}
 
 	// in-workgroup sum through LDS, two M-blocks (four tiles) per round; C/D map: register g of lane l
-	// is row (g&3) + 8*(g>>2) + 4*(l>>5), column l&31
+	// is row (g&3) + 8*(g>>2) + 4*(l>>5), column l&31.  A round leaves CH * 16 (chunk, tile, q) slices
+	// of 64 x 16 B, each the sum of KP pieces in piece order; every wave sums 2 * CH of them.
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
@@ -218,41 +231,61 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 			}
 		}
 		__syncthreads();
-		const int bl = wave >> 2, q = wave & 3;
-		const int b = 2 * rd + bl;
 #pragma unroll
-		for (int nb = 0; nb < 2; ++nb) {
-			const int tl = bl * 2 + nb;
-			f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+		for (int i = 0; i < 2 * CH; ++i) {
+			const int sl = wave * 2 * CH + i;           // slice = (chunk, tile, q)
+			const int q = sl & 3, tl = (sl >> 2) & 3, ch = sl >> 4;
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			f32x4 s = l4[((ch * 4 + tl) * 4 + q) * 64 + lane];
 #pragma unroll
-			for (int src = 1; src < BF_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
+			for (int p = 1; p < KP; ++p) s += l4[(((p * CH + ch) * 4 + tl) * 4 + q) * 64 + lane];
+			const int c = 64 * (grp * CH + ch) + 32 * nb + l31;
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) {
 				const int x = xt * 128 + 32 * b + gi + 8 * q + 4 * half;
-				slab[(long)x * 64 + 32 * nb + l31] = s[gi];
+				slab[(long)x * RP + c] = s[gi];
 			}
 		}
 	}
 }
 
-hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F,
-                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
-	constexpr int D = 4;
+template <int D, int CH>
+static hipError_t launch_fp_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
+                                 float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
 	const bool with_reduce = rg != nullptr && rg->partials != nullptr && p.xtiles >= GRAM_REDUCE_BLOCKS;
-	if (rg != nullptr && rg->partials != nullptr && !with_reduce) return hipErrorInvalidValue;
-	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0)), block(512);
+	if (rg != nullptr && rg->partials != nullptr && (!with_reduce || CH != 1)) return hipErrorInvalidValue;
+	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), RP / (64 * CH)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
 	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_bf16<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_bf16<D, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		if (e != hipSuccess) return e;
 		attr_done = true;
 	}
-	hipLaunchKernelGGL((k_factor_product_bf16<D>), grid, block, lds_bytes, stream,
-	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F),
-	                   slabs, slab_stride, KS, p.splits, with_reduce ? *rg : none);
+	hipLaunchKernelGGL((k_factor_product_bf16<D, CH>), grid, block, lds_bytes, stream,
+	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
+	                   slabs, slab_stride, RP, KS, p.splits, with_reduce ? *rg : none);
 	return hipGetLastError();
+}
+
+// Every wave piece gets at least 8 K-steps (the ring is 4 deep); as many slices as fill the chip.
+int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus) {
+	const int KP = RP == 64 ? 8 : (RP % 256 == 0 ? 2 : 4);
+	const int by_fill = std::max(1, num_cus / std::max(1, xtiles));
+	const int by_depth = std::max(1, KS / (8 * KP));
+	return std::max(1, std::min(by_fill, by_depth));
+}
+
+// RP: padded rank of the panel (64, or a multiple of 128).  256 columns per pass over A when RP is a
+// multiple of 256, else 128 (64 for RP = 64); wider panels take RP / 256 (RP / 128) passes (grid.z).
+hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
+                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
+	constexpr int D = 4;
+	if (RP == 64) return launch_fp_bf16<D, 1>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
+	if (RP % 256 == 0) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
+	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
+	return hipErrorInvalidValue;
 }
 
 } // namespace nmfamd

@@ -199,7 +199,7 @@ def op_factor_product(A: np.ndarray, F: np.ndarray, use_valu: bool = False):
 
 
 def op_factor_product_bf16(A: np.ndarray, F: np.ndarray) -> np.ndarray:
-    """OUT (r x X) = F A^T with both operands rounded to bf16 and fp32 accumulation (r <= 64)."""
+    """OUT (r x X) = F A^T with both operands rounded to bf16 and fp32 accumulation (any r)."""
     A = _f(A); F = _f(F)
     X, Y = A.shape
     r = F.shape[0]

@@ -582,7 +582,8 @@ def _round_bf16(a):
     return r.astype(np.uint32).view(np.float32).reshape(a.shape)
 
 
-@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64)])
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64),
+                                   (300, 500, 100), (1000, 3000, 128), (257, 1111, 256), (40000, 700, 256), (640, 4100, 300)])
 def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
     """Fragment order, lane maps and the K-step bookkeeping: the result must be the fp32-accumulated
     product of the bf16-ROUNDED operands (products of bf16 values are exact in fp32)."""
@@ -614,6 +615,23 @@ def test_bf16_operand_mode_tracks_fp32_within_stated_tolerance():
     assert (Wg >= 0).all() and (Hg >= 0).all()
     np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
     with pytest.raises(na.EngineError):
-        na.Engine(m, n, 100, "mu", precision="bf16")        # padded rank 64 only
+        na.Engine(m, n, r, "mu", precision="bf16", sparse_compute=True)   # dense resident V only
     with pytest.raises(na.EngineError):
-        na.Engine(m, n, r, "als", precision="bf16")         # multiplicative update only
+        na.Engine(m, n, r, "mu", precision="bf16", dtype=np.float64)      # fp32 engine only
+
+
+@pytest.mark.parametrize("alg,r,kw", [("mu", 100, {}), ("nsnmf", 256, dict(theta=0.5)), ("nsnmf", 40, dict(theta=0.3)),
+                                      ("gdcls", 64, dict(lam=0.01)), ("acls", 130, dict(lambda_w=0.01, lambda_h=0.01))])
+def test_bf16_operand_mode_every_algorithm_and_wide_panels(alg, r, kw):
+    """bf16 operands are a property of the two big products, so every algorithm and every padded rank
+    (64, k * 128) takes them; same tolerance statement as above (2e-2 on the factors after 10 iterations)."""
+    m, n = 1100, 800
+    V, W, H = problem(m, n, r, np.float32, seed=43)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, 10, **kw)
+    eng = na.Engine(m, n, r, alg, precision="bf16", **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(10, last_iteration=10)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-2 and rel(Hg, H64) < 2e-2
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=2e-3)

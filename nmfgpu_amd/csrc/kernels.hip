@@ -621,8 +621,11 @@ int panel_update_rows(int RP, size_t elem) {
 	return yb;
 }
 
+static bool use_wide_update(int RP) { return panel_update_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr; }
+
 int panel_update_parts(int RP, size_t elem, int len_pad) {
 	if (elem == 4 && RP == 64) return len_pad / 128;       // k_panel_update64_f32
+	if (elem == 4 && use_wide_update(RP)) return len_pad / 32;   // k_panel_update_wide_f32
 	return len_pad / panel_update_rows(RP, elem);
 }
 
@@ -632,6 +635,8 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 	if constexpr (std::is_same<T, float>::value) {
 		if (RP == 64 && mode != MODE_SET)
 			return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+		if (use_wide_update(RP) && mode != MODE_SET)
+			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 	}
 	const int yb = panel_update_rows(RP, sizeof(T));
 	dim3 grid(len_pad / yb), block(256);

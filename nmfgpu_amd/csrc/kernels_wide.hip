@@ -1,0 +1,167 @@
+// kernels_wide.hip -- fp32 MFMA forms of the r x r x (m + n) sized work at padded ranks 128 ... 512.
+//
+// At rank 256 (BASELINE config 4) the products `RR * H` / `W * RR` and the Gram matrices are
+// 2 * r^2 * (m + n) FLOP each -- as much as a product against V costs in bf16 -- so they cannot stay
+// on the generic VALU kernels of kernels.hip.  Same arithmetic as k_panel_update / k_gram_partial
+// (reference: symm/gemm + kernel::multiplyDivide, AlgorithmMultiplicativeFrobenius.h:181-191,235-244;
+// syrk, :168-178,208-209) up to fp32 summation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WIDE_YB = 32;       // panel rows (y) per workgroup
+constexpr int WIDE_MAX_RP = 512;
+
+// ------------------------------------------------------------------------------------------
+// panel update, wide panels: slab reduction + r x r product on the MFMA pipe + element-wise update
+// + error / norm partial sums.  Semantics of k_panel_update (kernels.hip), MODE_MU and MODE_LS.
+// ------------------------------------------------------------------------------------------
+// Workgroup = 4 waves = 32 panel rows y.  The reduced numerator and the old panel values sit in LDS
+// as [32][RP + 4] images (coalesced global traffic both ways).  D(c, y) = sum_k Q(k, c) vec(y, k):
+//   wave w owns the column blocks cb = w, w + 4, ... (32 columns c each), all 32 y;
+//   B operand: lane (y = l & 31, h = l >> 5) reads vec(y, 8u + 4h .. + 3) as one ds_read_b128 and feeds
+//              the four values to four MFMAs -- the K order is k = 8u + 4h + gi;
+//   A operand: lane (c = l & 31, h) holds Q(8u + 4h + gi, 32 cb + c): 128 B per half-wave from L2.
+// The MFMA C/D map gives lane (y, h) the rows c = 32 cb + 8q + 4h + gi -- four consecutive c per q, so
+// the element-wise step reads old / num and writes new as b128 LDS accesses.
+template <int MODE, int NCB>      // NCB = column blocks per wave = RP / 128
+__global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
+	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
+	const float* __restrict__ Q, int RP, float eps, float* __restrict__ ps, int len_valid,
+	float* __restrict__ sumsq_part, float* __restrict__ num_out) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	const int LD = RP + 4;
+	float* s_num = lds;                       // [32][LD]
+	float* s_old = lds + WIDE_YB * LD;        // [32][LD]   old values, then the new ones
+	float* s_ps = s_old + WIDE_YB * LD;       // [4][32]
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const long base = (long)blockIdx.x * WIDE_YB * RP;
+	const int q4 = RP / 4;                    // float4 per panel row
+
+	// 1. numerator = sum of the split-K slabs (slab order), old panel values
+	for (int e = tid; e < WIDE_YB * q4; e += 256) {
+		const int y = e / q4, c4 = e - y * q4;
+		f32x4 s = *reinterpret_cast<const f32x4*>(slabs + base + 4l * e);
+		for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * e);
+		*reinterpret_cast<f32x4*>(s_num + y * LD + 4 * c4) = s;
+		if (num_out) *reinterpret_cast<f32x4*>(num_out + base + 4l * e) = s;
+		if (MODE == PANEL_MU) *reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = *reinterpret_cast<const f32x4*>(P + base + 4l * e);
+	}
+	__syncthreads();
+
+	// 2. the r x r product
+	const float* vec = (MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 4 * half;
+	f32x16 acc[NCB];
+#pragma unroll
+	for (int i = 0; i < NCB; ++i)
+#pragma unroll
+		for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
+	const float* qp = Q + (long)(4 * half) * RP + 32 * wave + l31;
+	const int groups = RP / 8;
+#pragma unroll 2
+	for (int u = 0; u < groups; ++u) {
+		const f32x4 b = *reinterpret_cast<const f32x4*>(vec + 8 * u);
+		float a[NCB][4];
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) a[i][gi] = qp[(long)(8 * u + gi) * RP + 128 * i];
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+			for (int i = 0; i < NCB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][gi], b[gi], acc[i], 0, 0, 0);
+	}
+
+	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave
+	//    has finished reading them as B operands
+	f32x4 nv[NCB][4];
+	float psum = 0.f;
+#pragma unroll
+	for (int i = 0; i < NCB; ++i)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int c = 32 * (wave + 4 * i) + 8 * q + 4 * half;
+			const f32x4 num = *reinterpret_cast<const f32x4*>(s_num + l31 * LD + c);
+			f32x4 o;
+			if (MODE == PANEL_MU) {
+				const f32x4 old = *reinterpret_cast<const f32x4*>(s_old + l31 * LD + c);
+#pragma unroll
+				for (int gi = 0; gi < 4; ++gi) o[gi] = old[gi] * num[gi] / (acc[i][4 * q + gi] + eps);
+			} else {
+#pragma unroll
+				for (int gi = 0; gi < 4; ++gi) { const float d = acc[i][4 * q + gi]; o[gi] = d > 0.f ? d : 0.f; }
+			}
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) psum += o[gi] * num[gi];
+			nv[i][q] = o;
+		}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < NCB; ++i)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(s_old + l31 * LD + 32 * (wave + 4 * i) + 8 * q + 4 * half) = nv[i][q];
+	psum += __shfl_xor(psum, 32);
+	if (half == 0) s_ps[wave * 32 + l31] = psum;
+	__syncthreads();
+
+	// 4. coalesced write-out, per-row error terms, per-column sums of squares
+	for (int e = tid; e < WIDE_YB * q4; e += 256) {
+		const int y = e / q4, c4 = e - y * q4;
+		*reinterpret_cast<f32x4*>(P + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_old + y * LD + 4 * c4);
+	}
+	if (ps != nullptr && tid < WIDE_YB) {
+		const int y = blockIdx.x * WIDE_YB + tid;
+		if (y < len_valid) ps[y] = ((s_ps[tid] + s_ps[32 + tid]) + s_ps[64 + tid]) + s_ps[96 + tid];
+	}
+	if (sumsq_part != nullptr) {
+		for (int c = tid; c < RP; c += 256) {
+			float s = 0.f;
+#pragma unroll 8
+			for (int y = 0; y < WIDE_YB; ++y) { const float v = s_old[y * LD + c]; s += v * v; }
+			sumsq_part[(long)blockIdx.x * RP + c] = s;
+		}
+	}
+}
+
+bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }
+
+template <int MODE, int NCB>
+static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
+                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 128);
+	static bool attr_done = false;
+	if (!attr_done) {
+		const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+		if (e != hipSuccess) return e;
+		attr_done = true;
+	}
+	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);
+	return hipGetLastError();
+}
+
+hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
+                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+	if (!panel_update_wide_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % WIDE_YB != 0) return hipErrorInvalidValue;
+#define NMFAMD_WIDE(NCB)                                                                                                                   \
+	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream) \
+	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream)
+	switch (RP / 128) {
+	case 1: NMFAMD_WIDE(1);
+	case 2: NMFAMD_WIDE(2);
+	case 3: NMFAMD_WIDE(3);
+	default: NMFAMD_WIDE(4);
+	}
+#undef NMFAMD_WIDE
+}
+
+} // namespace nmfamd

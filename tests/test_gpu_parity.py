@@ -142,6 +142,24 @@ def test_mu_large_rank_uses_chunked_product():
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
 
 
+@pytest.mark.parametrize("alg,r,kw", [("mu", 128, {}), ("mu", 200, {}), ("nsnmf", 256, dict(theta=0.5)), ("mu", 300, {}), ("mu", 500, {}), ("acls", 400, dict(lambda_w=1.0, lambda_h=1.0)),
+                                      ("acls", 129, dict(lambda_w=0.01, lambda_h=0.01)), ("gdcls", 256, dict(lam=0.01))])
+def test_wide_panels_take_the_mfma_update(alg, r, kw):
+    """Padded ranks 128 ... 512: k_panel_update_wide_f32 (r x r product on the MFMA pipe, LDS-staged panel rows),
+    multiplicative and least-squares forms, with error terms and the column-norm partial sums."""
+    m, n, iters = 700, 610, 10
+    V, W, H = problem(m, n, r, np.float32, seed=23)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)
+    eng = na.Engine(m, n, r, alg, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    tol = 2e-4 if alg in ("mu", "nsnmf") else 2e-3
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+
+
 def test_mu_fused_path_interleaved_with_downloads():
     """get_factors() in the middle of a run folds the pending column scale into W and the run continues."""
     m, n, r = 640, 2300, 64   # 18 x-tiles on the H side: the Gram reduction rides in the product launch

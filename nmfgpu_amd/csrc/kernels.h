@@ -89,15 +89,16 @@ hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, 
 template <typename T>
 hipError_t launch_reduce_partials(const T* partial, int parts, long stride, T* out, long count, hipStream_t stream);
 template <typename T>
-hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream);
+hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream);
 
 // See k_panel_update.  sumsq_part needs (len_pad / panel_update_rows) * RP elements.
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
                                T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream);
 
+// sumsq_part: parts * RP partial sums followed by 16 * RP elements of scratch
 template <typename T>
-hipError_t launch_normalize_panel(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream);
+hipError_t launch_normalize_panel(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream);
 
 template <typename T>
 hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream);

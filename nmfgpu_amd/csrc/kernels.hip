@@ -673,11 +673,11 @@ __global__ __launch_bounds__(256) void k_normalize_panel(T* __restrict__ P, int 
 }
 
 template <typename T>
-hipError_t launch_normalize_panel(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream) {
+hipError_t launch_normalize_panel(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream) {
 	return launch_normalize_panel_v2<T>(P, RP, len_pad, sumsq_part, parts, stream);
 }
-template hipError_t launch_normalize_panel<float>(float*, int, int, const float*, int, hipStream_t);
-template hipError_t launch_normalize_panel<double>(double*, int, int, const double*, int, hipStream_t);
+template hipError_t launch_normalize_panel<float>(float*, int, int, float*, int, hipStream_t);
+template hipError_t launch_normalize_panel<double>(double*, int, int, double*, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // nsNMF smoothing of a panel: out(:, y) = S P(:, y), S = (1-theta) I + (theta/r) 1 1^T

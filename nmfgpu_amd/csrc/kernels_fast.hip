@@ -315,12 +315,45 @@ __global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, i
 	}
 }
 
+// Many partials (short workgroup tiles on a long panel): sum them into NORM_GROUPS groups first, so that
+// the scaling workgroups re-derive the norms from NORM_GROUPS rows instead of `parts` rows each.
+constexpr int NORM_GROUPS = 16;
 template <typename T>
-hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, const T* sumsq_part, int parts, hipStream_t stream) {
-	hipLaunchKernelGGL((k_normalize_panel_v2<T>), dim3(len_pad / 128), dim3(256), 5 * RP * sizeof(T), stream, P, RP, sumsq_part, parts);
+__global__ __launch_bounds__(256) void k_compact_partials(const T* __restrict__ partial, int parts, int RP, T* __restrict__ out) {
+	__shared__ T red[4][64];
+	const int tx = threadIdx.x & 63, sub = threadIdx.x >> 6;
+	const int c = blockIdx.x * 64 + tx, g = blockIdx.y;
+	const int g0 = (int)(((long)parts * g) / NORM_GROUPS), g1 = (int)(((long)parts * (g + 1)) / NORM_GROUPS);
+	const int p0 = g0 + ((g1 - g0) * sub) / 4, p1 = g0 + ((g1 - g0) * (sub + 1)) / 4;
+	T s = 0;
+	int p = p0;
+	for (; p + 8 <= p1; p += 8) {
+		T v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = partial[(long)(p + u) * RP + c];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s += v[u];
+	}
+	for (; p < p1; ++p) s += partial[(long)p * RP + c];
+	red[sub][tx] = s;
+	__syncthreads();
+	if (sub == 0) out[(long)g * RP + c] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+}
+
+// sumsq_part: parts * RP partial sums followed by NORM_GROUPS * RP elements of scratch.
+template <typename T>
+hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream) {
+	const T* src = sumsq_part;
+	if (parts > 4 * NORM_GROUPS) {
+		T* compact = sumsq_part + (long)parts * RP;
+		hipLaunchKernelGGL((k_compact_partials<T>), dim3(RP / 64, NORM_GROUPS), dim3(256), 0, stream, sumsq_part, parts, RP, compact);
+		src = compact;
+		parts = NORM_GROUPS;
+	}
+	hipLaunchKernelGGL((k_normalize_panel_v2<T>), dim3(len_pad / 128), dim3(256), 5 * RP * sizeof(T), stream, P, RP, src, parts);
 	return hipGetLastError();
 }
-template hipError_t launch_normalize_panel_v2<float>(float*, int, int, const float*, int, hipStream_t);
-template hipError_t launch_normalize_panel_v2<double>(double*, int, int, const double*, int, hipStream_t);
+template hipError_t launch_normalize_panel_v2<float>(float*, int, int, float*, int, hipStream_t);
+template hipError_t launch_normalize_panel_v2<double>(double*, int, int, double*, int, hipStream_t);
 
 } // namespace nmfamd

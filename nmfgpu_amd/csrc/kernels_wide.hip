@@ -65,19 +65,37 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 #pragma unroll
 		for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
 	const float* qp = Q + (long)(4 * half) * RP + 32 * wave + l31;
-	const int groups = RP / 8;
-#pragma unroll 2
-	for (int u = 0; u < groups; ++u) {
-		const f32x4 b = *reinterpret_cast<const f32x4*>(vec + 8 * u);
-		float a[NCB][4];
+	const int groups = RP / 8;                // multiple of 16
+	// The A operands come from L2 (Q is RP x RP, shared by every workgroup): a D-deep register ring keeps
+	// D groups of loads in flight so that the L2 latency is paid once, not once per group.
+	constexpr int D = NCB <= 2 ? 8 : 4;
+	float a[D][NCB][4];
+	f32x4 b[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		b[d] = *reinterpret_cast<const f32x4*>(vec + 8 * d);
 #pragma unroll
 		for (int i = 0; i < NCB; ++i)
 #pragma unroll
-			for (int gi = 0; gi < 4; ++gi) a[i][gi] = qp[(long)(8 * u + gi) * RP + 128 * i];
+			for (int gi = 0; gi < 4; ++gi) a[d][i][gi] = qp[(long)(8 * d + gi) * RP + 128 * i];
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	for (int u = 0; u < groups; u += D) {
 #pragma unroll
-		for (int gi = 0; gi < 4; ++gi)
+		for (int d = 0; d < D; ++d) {
 #pragma unroll
-			for (int i = 0; i < NCB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][gi], b[gi], acc[i], 0, 0, 0);
+			for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+				for (int i = 0; i < NCB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][i][gi], b[d][gi], acc[i], 0, 0, 0);
+			int nu = u + D + d;
+			nu = nu < groups ? nu : groups - 1;       // tail: harmless re-load of the last group
+			b[d] = *reinterpret_cast<const f32x4*>(vec + 8 * nu);
+#pragma unroll
+			for (int i = 0; i < NCB; ++i)
+#pragma unroll
+				for (int gi = 0; gi < 4; ++gi) a[d][i][gi] = qp[(long)(8 * nu + gi) * RP + 128 * i];
+			__builtin_amdgcn_sched_barrier(0);
+		}
 	}
 
 	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave

@@ -512,7 +512,7 @@ Status Engine<T>::h_step(bool compute_error) {
 
 template <typename T>
 Status Engine<T>::w_products(T* exchange) {
-	if (alg_ != ALG_MU) return ST_INVALID;
+	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
 	T* ex_hht = exchange + (long)RP_ * mpad_;
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
@@ -524,15 +524,23 @@ Status Engine<T>::w_products(T* exchange) {
 			return ST_OK;
 		}
 	}
-	HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, ex_hht, stream_));
-	if (Status s = product_w(H_)) return s;
+	const T* Fh = H_;
+	if (alg_ == ALG_NSNMF) {
+		// the smoothed local columns S H_g enter both sums (AlgorithmNonSmoothNMF.h:194-197,213)
+		const T off = (T)prm_.theta / (T)(unsigned)r_;
+		const T diag = (T)((1.0 - (T)prm_.theta) + off);
+		HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, diag, stream_));
+		Fh = Hs_;
+	}
+	HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, ex_hht, stream_));
+	if (Status s = product_w(Fh)) return s;
 	HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 	return ST_OK;
 }
 
 template <typename T>
 Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
-	if (alg_ != ALG_MU) return ST_INVALID;
+	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
 	const T eps = std::numeric_limits<T>::epsilon();
 	const T* ex_hht = exchange + (long)RP_ * mpad_;
 	if constexpr (std::is_same<T, float>::value) {
@@ -547,7 +555,12 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		}
 	}
 	if (compute_error) {
-		HIPX(launch_trace_small<T>(ex_hht, G_, RP_, r_, psR_, stream_));
+		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
+			HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
+			wtw = G2_;
+		}
+		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_));

@@ -26,7 +26,7 @@ def _free_port():
 class OracleShard:
     """Test-only backend: the sharded MU steps restated with oracle primitives (float64)."""
 
-    def __init__(self, V_local, W, H_local):
+    def __init__(self, V_local, W, H_local, theta=None):
         import torch
         from oracle import oracle
         self.o = oracle
@@ -40,11 +40,14 @@ class OracleShard:
         self.vtv = oracle.vtv_sorted(self.V)
         self.psN = None
         self.psR = None
+        # nsNMF: S = (1 - theta) I + (theta / r) 1 1^T  (AlgorithmNonSmoothNMF.h:131-134); None = plain MU
+        self.S = None if theta is None else np.asfortranarray((1.0 - theta) * np.eye(r) + (theta / r) * np.ones((r, r)))
 
     def h_step(self, compute_error):
         o = self.o
-        self.G = o.gemm_tn(self.W, self.W)
-        RN = o.gemm_tn(self.W, self.V)
+        Ws = self.W if self.S is None else o.gemm_nn(self.W, self.S)
+        self.G = o.gemm_tn(Ws, Ws)
+        RN = o.gemm_tn(Ws, self.V)
         RN2 = o.gemm_nn(self.G, self.H)
         o.multiply_divide(self.H, RN, RN2)
         if compute_error:
@@ -52,8 +55,9 @@ class OracleShard:
 
     def w_products(self):
         o = self.o
-        MR = o.gemm_nt(self.V, self.H)            # m x r
-        HHt = o.gemm_nt(self.H, self.H)           # r x r
+        Hs = self.H if self.S is None else o.gemm_nn(self.S, self.H)
+        MR = o.gemm_nt(self.V, Hs)                # m x r
+        HHt = o.gemm_nt(Hs, Hs)                   # r x r
         ex = self.exchange.numpy()
         ex[: self.r * self.m] = np.ascontiguousarray(MR).ravel()     # panel layout [x][c]
         ex[self.r * self.m:] = HHt.ravel(order="F")
@@ -64,7 +68,8 @@ class OracleShard:
         MR = np.asfortranarray(ex[: self.r * self.m].reshape(self.m, self.r))
         HHt = np.asfortranarray(ex[self.r * self.m:].reshape(self.r, self.r, order="F"))
         if compute_error:
-            self.psR = o.trace_multiplication(False, HHt, self.G)
+            wtw = self.G if self.S is None else o.gemm_tn(self.W, self.W)     # nsNMF: unsmoothed W^T W (:201-202)
+            self.psR = o.trace_multiplication(False, HHt, wtw)
         MR2 = o.gemm_nn(self.W, HHt)
         o.multiply_divide(self.W, MR, MR2)
         o.normalize_columns(self.W)
@@ -76,10 +81,10 @@ class OracleShard:
         return self.o.resolve_frobenius(np.ascontiguousarray(vtv_sorted), htwtv, hhtwtw)
 
     def factors(self):
-        return self.W, self.H
+        return (self.W if self.S is None else self.o.gemm_nn(self.W, self.S)), self.H
 
 
-def _worker(rank, world, port, m, n, r, iters, out_dir):
+def _worker(rank, world, port, m, n, r, iters, out_dir, theta):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from nmfgpu_amd.distributed import ShardedMU
@@ -90,7 +95,7 @@ def _worker(rank, world, port, m, n, r, iters, out_dir):
     V = rng.random((m, n)); W = 1.0 - rng.random((m, r)); H = 1.0 - rng.random((r, n))
     per = n // world
     cols = slice(rank * per, (rank + 1) * per)
-    backend = OracleShard(V[:, cols], W, H[:, cols])
+    backend = OracleShard(V[:, cols], W, H[:, cols], theta)
     drv = ShardedMU(backend, total_columns=n, rows=m)
     drv.run(iters, first_iteration=1, error_every=10, last_iteration=iters)
     Wg, Hg = backend.factors()
@@ -98,15 +103,16 @@ def _worker(rank, world, port, m, n, r, iters, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_mu_two_ranks_equals_single_process(tmp_path):
+@pytest.mark.parametrize("theta", [None, 0.5], ids=["mu", "nsnmf"])
+def test_sharded_mu_two_ranks_equals_single_process(tmp_path, theta):
     import torch.multiprocessing as mp
     from oracle import oracle
     m, n, r, iters, world = 60, 48, 5, 25, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, n, r, iters, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, m, n, r, iters, str(tmp_path), theta), nprocs=world, join=True)
     rng = np.random.default_rng(5)
     V = np.asfortranarray(rng.random((m, n))); W = np.asfortranarray(1.0 - rng.random((m, r))); H = np.asfortranarray(1.0 - rng.random((r, n)))
-    ref = oracle.run("mu", V, W, H, iters)
+    ref = oracle.run("mu", V, W, H, iters) if theta is None else oracle.run("nsnmf", V, W, H, iters, theta=theta)
     outs = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     per = n // world
     for k, o in enumerate(outs):

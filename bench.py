@@ -24,13 +24,20 @@ sys.path.insert(0, ROOT)
 
 M, N_COLS, R = 10000, 5000, 64
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS spec"
+PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s spec (6.29 TB/s measured copy rate)
+
+# --workload c4 (NOT the default and not the BASELINE metric line): one column shard of BASELINE config 4 per GPU
+C4 = {"rows": 50000, "columns_per_gpu": 6250, "features": 256, "theta": 0.5}
 
 
-def make_problem(shard: int):
+def make_problem(shard: int, m: int = M, n: int = N_COLS, r: int = R):
     """V = U[0,1) fp32 from mt19937(1 + shard); W0, H0 = U(0,1] from seeds 2, 3."""
-    V = np.asfortranarray(np.random.RandomState(1 + shard).random_sample((N_COLS, M)).astype(np.float32).T)
-    W = np.asfortranarray((1.0 - np.random.RandomState(2).random_sample((R, M))).astype(np.float32).T)
-    H = np.asfortranarray((1.0 - np.random.RandomState(3 + 1000 * shard).random_sample((N_COLS, R))).astype(np.float32).T)
+    rs = np.random.RandomState(1 + shard)
+    V = np.empty((m, n), dtype=np.float32, order="F")
+    for j0 in range(0, n, 1000):       # column blocks: the same stream as one (n, m) draw, without the fp64 temporary
+        V[:, j0:j0 + 1000] = rs.random_sample((min(1000, n - j0), m)).astype(np.float32).T
+    W = np.asfortranarray((1.0 - np.random.RandomState(2).random_sample((r, m))).astype(np.float32).T)
+    H = np.asfortranarray((1.0 - np.random.RandomState(3 + 1000 * shard).random_sample((n, r))).astype(np.float32).T)
     return V, W, H
 
 
@@ -59,7 +66,11 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 (default) = BASELINE configs[1], the metric line; c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands)")
     args = ap.parse_args()
+    if args.workload == "c4":
+        return main_c4(args)
 
     import torch
     import nmfgpu_amd as na
@@ -163,6 +174,74 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, W, H)
         print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def main_c4(args):
+    """BASELINE configs[3] per GPU: 50000 x 6250 column shard of a 50000 x (6250 N) matrix, nsNMF theta = 0.5, r = 256,
+    bf16 MFMA operands, W replicated, all-reduce of 51.2 MB + 256 KB per iteration.  Same timing contract as the default."""
+    import torch
+    import nmfgpu_amd as na
+    from nmfgpu_amd.distributed import EngineShard, ShardedMU
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    m, n, r, theta = C4["rows"], C4["columns_per_gpu"], C4["features"], C4["theta"]
+    V, W, H = make_problem(rank, m, n, r)
+    K, Wm = args.steps, args.warmup
+    shard = EngineShard(V, W, H, algorithm="nsnmf", theta=theta, precision="bf16")
+    drv = ShardedMU(shard, total_columns=n * world, rows=m)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    drv.run(Wm, first_iteration=1, error_every=10)
+    shard.synchronize()
+    if not args.no_kernel_events:
+        shard.engine.kernel_timing(args.event_stride)
+    barrier()
+    t0 = time.perf_counter()
+    drv.run(K, first_iteration=Wm + 1, error_every=10)
+    shard.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches = (0.0, 0) if args.no_kernel_events else shard.engine.kernel_timing_read()
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        bytes_per_launch = 2.0 * m * n                       # one pass over the bf16 image of the shard
+        roofline = None
+        if kernel_launches > 0:
+            avg_s = kernel_ms / 1e3 / kernel_launches
+            roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_factor_product_bf16",
+                        "avg_launch_us": avg_s * 1e6, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
+        iter_flops = 4.0 * m * n * r + 6.0 * r * r * (m + n)
+        print(json.dumps({
+            "metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256",
+            "value": world * K / elapsed, "unit": "shard-iterations/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "configs[3] per GPU: dense random V 50000x6250 column shard, r=256, nsNMF theta=0.5, bf16 MFMA operands",
+                       "rows": m, "columns_per_gpu": n, "features": r, "error_every": 10,
+                       "parallelism": f"column shards x{world}, W replicated, all-reduce of (V (SH)^T | (SH)(SH)^T) per iteration"},
+            "frobenius_last": drv.frobenius, "iter_flops": iter_flops,
+            "achieved_tflops_whole_iteration": iter_flops * (K / elapsed) / 1e12, "roofline": roofline}), flush=True)
     if distributed:
         dist.destroy_process_group()
 

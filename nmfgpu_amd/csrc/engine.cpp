@@ -461,8 +461,14 @@ void Engine<T>::resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, s
 
 template <typename T>
 Status Engine<T>::h_step(bool compute_error) {
+	// first call of an iteration in the sharded form: decides whether this iteration's products are timed
+	timing_now_ = timing_ && (timing_iter_++ % timing_stride_ == 0);
+	return h_step_impl(compute_error);
+}
+
+template <typename T>
+Status Engine<T>::h_step_impl(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
-	if (timing_ && timing_stride_ == 1) timing_now_ = true;
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
 			// sharded form of the four-launch iteration (kernels_mu64.hip): K_H + U_H here
@@ -622,7 +628,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	if (prm_.divergence != 0) return constant_w ? ST_INVALID : iterate_kl(compute_error);
 	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
-	if (Status s = h_step(compute_error)) return s;
+	if (Status s = h_step_impl(compute_error)) return s;
 
 	const bool ls_family = alg_ == ALG_ALS || alg_ == ALG_ACLS || alg_ == ALG_AHCLS;
 	int error_terms_n = n_;   // length of the tr(H^T W^T V) term vector

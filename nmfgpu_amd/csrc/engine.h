@@ -95,6 +95,7 @@ public:
 
 private:
 	Status hip_fail(hipError_t e, const char* what);
+	Status h_step_impl(bool compute_error);
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of F V   (r x n)
 	Status product_w(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU

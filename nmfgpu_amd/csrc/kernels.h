@@ -84,6 +84,9 @@ hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int
                                      float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
 // fp32 / padded rank 128 ... 512 (kernels_wide.hip)
 bool panel_update_wide_available(int RP);
+bool gram_wide_available(int RP);
+// len: valid panel rows (the padding rows behind them are zero); partial: parts * RP * RP elements
+hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream);
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
 template <typename T>

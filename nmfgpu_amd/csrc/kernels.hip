@@ -525,6 +525,7 @@ template <typename T>
 hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G, hipStream_t stream) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (RP == 64) return launch_gram64_f32(P, len, parts, partial, G, stream);
+		if (gram_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return launch_gram_wide_f32(P, RP, len, parts, partial, G, stream);
 	}
 	int blocks = RP / 64; // RP is a multiple of 64
 	hipLaunchKernelGGL((k_gram_partial<T>), dim3(parts, blocks, blocks), dim3(256), 0, stream, P, RP, len, parts, partial);

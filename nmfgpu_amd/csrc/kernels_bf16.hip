@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -249,6 +250,204 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16(
 	}
 }
 
+// ---- 256 panel columns per pass: A through LDS --------------------------------------------------
+// With CH = 4 the four waves that share a K piece request the SAME A fragments: the bytes they keep in
+// flight are counted four times against the registers that hold them, and the kernel above stalls at
+// ~3.5 TB/s (Little's law: 32 KiB of distinct A in flight per CU).  Here every wave loads DISTINCT A
+// blocks (register staged, SETS - 1 stages in flight), parks them in a two-buffer LDS image in fragment
+// order (three buffers), and all waves of a piece read their operands from there (ds_read_b128, lane-linear, conflict
+// free).  F fragments are private to a wave and stay on the direct global -> register ring.
+//   stage = G = 2 K-steps of both pieces = 16 blocks of 1 KiB; wave w loads blocks 2w, 2w + 1:
+//   block ((pk * G + g) * 4 + b) = fragments of piece pk, K-step g of the stage, M-block b.
+//   stage q: loads issued in iteration q - SETS - 1, written to LDS buffer q % 3 in iteration q - 2 (after the
+//   barrier that retires the reads of stage q - 3), visible after the barrier of iteration q - 1, so that the
+//   operand reads of a K-step can be issued one K-step ahead of its MFMAs, across the stage boundary.
+template <int SETS>
+__global__ __launch_bounds__(512, 2) void k_factor_product_bf16_staged(
+	const bf16x8* __restrict__ A, long tile_frags, const bf16x8* __restrict__ F, int NBT,
+	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	constexpr int CH = 4, KP = 2, G = 2;
+	const int xt = blockIdx.x, sp = blockIdx.y, grp = blockIdx.z;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int chunk = wave % CH, kp = wave / CH;
+	const int cg = grp * CH + chunk;
+	const int b0 = (int)(((long)steps_total * sp) / splits);
+	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
+	const int mid = b0 + (b1 - b0) / 2;
+	const int s0 = kp == 0 ? b0 : mid, steps = kp == 0 ? mid - b0 : b1 - mid;      // this wave's piece
+	const int nst = ((b1 - mid) + G - 1) / G;                                       // stage count (piece 1 is the longer one)
+	const long fstep = (long)NBT * 64;
+
+	// loader role: blocks 2w, 2w + 1 of every stage
+	const int lpk = wave >> 2, lg = (wave >> 1) & 1, lb = 2 * (wave & 1);
+	const int ls0 = lpk == 0 ? b0 : mid, lsteps = lpk == 0 ? mid - b0 : b1 - mid;
+	const int llast = lsteps > 0 ? lsteps - 1 : 0;
+	const bf16x8* lap = A + (long)xt * tile_frags + (long)ls0 * 256 + lb * 64 + lane;
+	bf16x8* l8 = reinterpret_cast<bf16x8*>(lds);
+	const int lblk = ((lpk * G + lg) * 4 + lb) * 64 + lane;      // + 1024 per buffer, + 64 for the second block
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int b = 0; b < 4; ++b)
+#pragma unroll
+		for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
+
+	// The loop body is branch-free (hipcc then counts vmcnt exactly instead of draining the queue): K-steps past
+	// the end of a piece are ZERO blocks in LDS (the loader writes zeros), and the stage count is padded to a
+	// multiple of SETS.
+	const int nst_pad = ((nst + SETS - 1) / SETS) * SETS;
+	const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+	// prologue: stages 0 .. SETS - 1 requested, stages 0 and 1 parked in LDS, stage SETS requested
+	bf16x8 st[SETS][2];
+#pragma unroll
+	for (int q = 0; q < SETS; ++q) {
+		int k = q * G + lg;
+		k = k < llast ? k : llast;
+		st[q][0] = lap[(long)k * 256];
+		st[q][1] = lap[(long)k * 256 + 64];
+	}
+	const bf16x8* fp = F + (long)s0 * fstep + (long)cg * 128 + lane;
+	const int flast = steps > 0 ? steps - 1 : 0;
+	bf16x8 fb[2][G][2];
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+#pragma unroll
+		for (int g = 0; g < G; ++g) {
+			int k = q * G + g;
+			k = k < flast ? k : flast;
+			fb[q][g][0] = fp[(long)k * fstep];
+			fb[q][g][1] = fp[(long)k * fstep + 64];
+		}
+	{
+		const bool v0 = lg < lsteps, v1 = G + lg < lsteps;
+		l8[lblk] = v0 ? st[0][0] : zero;
+		l8[lblk + 64] = v0 ? st[0][1] : zero;
+		l8[1024 + lblk] = v1 ? st[1][0] : zero;
+		l8[1024 + lblk + 64] = v1 ? st[1][1] : zero;
+		int k = SETS * G + lg;
+		k = k < llast ? k : llast;
+		st[0][0] = lap[(long)k * 256];
+		st[0][1] = lap[(long)k * 256 + 64];
+	}
+	__syncthreads();
+	const bf16x8* rbase = l8 + (kp * G) * 256 + lane;      // this wave's piece inside a buffer
+	// operands of K-step j live in va[j & 1]; the reads of K-step j + 1 are issued ahead of the MFMAs of K-step j
+	bf16x8 va[2][4];
+#pragma unroll
+	for (int b = 0; b < 4; ++b) va[0][b] = rbase[b * 64];
+	__builtin_amdgcn_sched_barrier(0);
+
+	int buf = 0;      // LDS buffer of stage t (three buffers)
+	for (int t0 = 0; t0 < nst_pad; t0 += SETS) {
+#pragma unroll
+		for (int u = 0; u < SETS; ++u) {
+			const int t = t0 + u;
+			const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+			__syncthreads();      // stage t + 1 visible; buffer of stage t + 2 (= stage t - 1) free
+			// stage t + 2 (set (u + 2) % SETS) -> LDS
+			{
+				const bool valid = (t + 2) * G + lg < lsteps;
+				bf16x8* dst = l8 + buf2 * 1024 + lblk;
+				dst[0] = valid ? st[(u + 2) % SETS][0] : zero;
+				dst[64] = valid ? st[(u + 2) % SETS][1] : zero;
+			}
+			// loads of stage t + SETS + 1 -> set (u + 1) % SETS (stage t + 1 left it for LDS one iteration ago)
+			{
+				int k = (t + SETS + 1) * G + lg;
+				k = k < llast ? k : llast;
+				st[(u + 1) % SETS][0] = lap[(long)k * 256];
+				st[(u + 1) % SETS][1] = lap[(long)k * 256 + 64];
+			}
+			// K-step 2t: read 2t + 1 (same stage), multiply 2t
+#pragma unroll
+			for (int b = 0; b < 4; ++b) va[1][b] = rbase[buf * 1024 + (4 + b) * 64];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb)
+					acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0][b], fb[u & 1][0][nb], acc[b][nb], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			// K-step 2t + 1: read 2t + 2 (first K-step of stage t + 1), multiply 2t + 1
+#pragma unroll
+			for (int b = 0; b < 4; ++b) va[0][b] = rbase[buf1 * 1024 + b * 64];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb)
+					acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1][b], fb[u & 1][1][nb], acc[b][nb], 0, 0, 0);
+			// F of stage t + 2 -> the ring slot just consumed
+#pragma unroll
+			for (int g = 0; g < G; ++g) {
+				int k = (t + 2) * G + g;
+				k = k < flast ? k : flast;
+				fb[u & 1][g][0] = fp[(long)k * fstep];
+				fb[u & 1][g][1] = fp[(long)k * fstep + 64];
+			}
+			buf = buf1;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	__syncthreads();      // the staging buffers become the epilogue's exchange area
+
+	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+	float* slab = slabs + (long)sp * slab_stride;
+#pragma unroll
+	for (int rd = 0; rd < 2; ++rd) {
+		if (rd > 0) __syncthreads();
+#pragma unroll
+		for (int tl = 0; tl < 4; ++tl) {
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				f32x4 v;
+				v[0] = acc[b][nb][4 * q + 0]; v[1] = acc[b][nb][4 * q + 1];
+				v[2] = acc[b][nb][4 * q + 2]; v[3] = acc[b][nb][4 * q + 3];
+				l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 2 * CH; ++i) {
+			const int sl = wave * 2 * CH + i;
+			const int q = sl & 3, tl = (sl >> 2) & 3, ch = sl >> 4;
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			f32x4 s = l4[((ch * 4 + tl) * 4 + q) * 64 + lane];
+#pragma unroll
+			for (int p = 1; p < KP; ++p) s += l4[(((p * CH + ch) * 4 + tl) * 4 + q) * 64 + lane];
+			const int c = 64 * (grp * CH + ch) + 32 * nb + l31;
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const int x = xt * 128 + 32 * b + gi + 8 * q + 4 * half;
+				slab[(long)x * RP + c] = s[gi];
+			}
+		}
+	}
+}
+
+template <int SETS>
+static hipError_t launch_fp_bf16_staged(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
+                                        float* slabs, long slab_stride, hipStream_t stream) {
+	dim3 grid(p.xtiles, p.splits, RP / 256), block(512);
+	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
+	static bool attr_done = false;
+	if (!attr_done) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_bf16_staged<SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		if (e != hipSuccess) return e;
+		attr_done = true;
+	}
+	hipLaunchKernelGGL((k_factor_product_bf16_staged<SETS>), grid, block, lds_bytes, stream,
+	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
+	                   slabs, slab_stride, RP, KS, p.splits);
+	return hipGetLastError();
+}
+
 template <int D, int CH>
 static hipError_t launch_fp_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                  float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
@@ -283,7 +482,12 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
 	constexpr int D = 4;
 	if (RP == 64) return launch_fp_bf16<D, 1>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
-	if (RP % 256 == 0) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
+	if (RP % 256 == 0) {
+		static const bool unstaged = std::getenv("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
+		if (unstaged) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
+		if (rg != nullptr && rg->partials != nullptr) return hipErrorInvalidValue;
+		return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
+	}
 	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	return hipErrorInvalidValue;
 }

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace nmfamd {
@@ -147,6 +149,109 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			sumsq_part[(long)blockIdx.x * RP + c] = s;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------
+// Gram matrix G = P P^T of a wide panel on the MFMA pipe (reference: syrk / gemm for W^T W and H H^T,
+// AlgorithmMultiplicativeFrobenius.h:168-178,208-209; AlgorithmNonSmoothNMF.h:176,196,201)
+// ------------------------------------------------------------------------------------------
+// Workgroup = 4 waves = one 128 x 128 super-block (I <= J) of G over one slice of y; wave (wi, wj) owns the
+// 64 x 64 quarter as 2 x 2 MFMA tiles.  K-step = 2 panel rows y (lane half h takes y = 2t + h): an operand is
+// one coalesced 128-B read of P(y, 32 block + (l & 31)) per half-wave, and A and B operands have the same lane
+// map, so a diagonal quarter needs two loads per K-step instead of four.  D-deep register ring.
+// Every workgroup writes its 128 x 128 partial (and its transpose for I < J); partials are summed in slice
+// order by k_reduce_partials.
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_gram_wide_f32(const float* __restrict__ P, int RP, int len, int parts, float* __restrict__ partial) {
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	// blockIdx.y enumerates the super-blocks of the upper triangle row by row
+	const int nb = RP / 128;
+	int I = 0, rem = blockIdx.y;
+	while (rem >= nb - I) { rem -= nb - I; ++I; }
+	const int J = I + rem;
+	const int wi = wave >> 1, wj = wave & 1;
+	const int ca = 128 * I + 64 * wi, cb = 128 * J + 64 * wj;      // first row / column of the quarter
+	const int steps_total = (len + 1) / 2;
+	const int s0 = (int)(((long)steps_total * blockIdx.x) / parts);
+	const int s1 = (int)(((long)steps_total * (blockIdx.x + 1)) / parts);
+	const int steps = s1 - s0;
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int b = 0; b < 2; ++b)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+	if (steps > 0) {
+		// rows past len read as zero: clamp the row and scale by 0 (len may be odd; panel rows past len are zero anyway
+		// up to the padded length, which is even)
+		const float* pa = P + ((long)2 * s0 + half) * RP + ca + l31;
+		const float* pb = P + ((long)2 * s0 + half) * RP + cb + l31;
+		const int last = steps - 1;
+		float va[D][2], vb[D][2];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int t = d < last ? d : last;
+			va[d][0] = pa[(long)2 * t * RP]; va[d][1] = pa[(long)2 * t * RP + 32];
+			vb[d][0] = pb[(long)2 * t * RP]; vb[d][1] = pb[(long)2 * t * RP + 32];
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		int t = 0;
+		for (; t + D <= steps; t += D) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+#pragma unroll
+				for (int a = 0; a < 2; ++a)
+#pragma unroll
+					for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+				int tn = t + D + d;
+				tn = tn < last ? tn : last;
+				va[d][0] = pa[(long)2 * tn * RP]; va[d][1] = pa[(long)2 * tn * RP + 32];
+				vb[d][0] = pb[(long)2 * tn * RP]; vb[d][1] = pb[(long)2 * tn * RP + 32];
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		const int remn = steps - t;
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			if (d < remn) {
+#pragma unroll
+				for (int a = 0; a < 2; ++a)
+#pragma unroll
+					for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+			}
+		}
+	}
+	// C/D map: register g of lane l is row (g&3) + 8*(g>>2) + 4*(l>>5) (A index), column l&31 (B index)
+	float* out = partial + (long)blockIdx.x * RP * RP;
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int b = 0; b < 2; ++b)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const int r = ca + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * half;
+				const int c = cb + 32 * b + l31;
+				out[(long)r * RP + c] = acc[a][b][g];
+				if (I != J) out[(long)c * RP + r] = acc[a][b][g];
+			}
+}
+
+bool gram_wide_available(int RP) { return RP >= 128 && RP % 128 == 0; }
+
+// len: valid panel rows (an odd len reads one zero row of the padding); partial: parts * RP * RP elements of scratch
+hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream) {
+	if (!gram_wide_available(RP)) return hipErrorInvalidValue;
+	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
+	// two workgroups per CU are enough; fewer, longer slices keep the partial traffic down
+	parts = std::max(1, std::min(parts, std::max(16, 512 / nsuper)));
+	hipLaunchKernelGGL((k_gram_wide_f32<8>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return launch_reduce_partials<float>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
 }
 
 bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }

@@ -76,7 +76,7 @@ def test_factor_product_valu_and_fp64_paths():
     np.testing.assert_allclose(out64, F64 @ A64.T, rtol=1e-12)
 
 
-@pytest.mark.parametrize("r,length", [(8, 500), (64, 1000), (100, 333)])
+@pytest.mark.parametrize("r,length", [(8, 500), (64, 1000), (100, 333), (128, 777), (200, 1001), (256, 5000), (300, 640), (500, 333)])
 def test_gram(r, length):
     rng = np.random.default_rng(r)
     P = F(rng.random((r, length)).astype(np.float32))

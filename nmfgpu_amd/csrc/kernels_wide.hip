@@ -48,14 +48,36 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	const long base = (long)blockIdx.x * WIDE_YB * RP;
 	const int q4 = RP / 4;                    // float4 per panel row
 
-	// 1. numerator = sum of the split-K slabs (slab order), old panel values
-	for (int e = tid; e < WIDE_YB * q4; e += 256) {
-		const int y = e / q4, c4 = e - y * q4;
-		f32x4 s = *reinterpret_cast<const f32x4*>(slabs + base + 4l * e);
-		for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * e);
-		*reinterpret_cast<f32x4*>(s_num + y * LD + 4 * c4) = s;
-		if (num_out) *reinterpret_cast<f32x4*>(num_out + base + 4l * e) = s;
-		if (MODE == PANEL_MU) *reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = *reinterpret_cast<const f32x4*>(P + base + 4l * e);
+	// 1. numerator = sum of the split-K slabs (slab order), old panel values.  All of a thread's loads of one
+	//    slab are issued together (NE independent 16-byte loads): one memory latency per slab, not per element.
+	constexpr int NE = WIDE_YB * 32 * NCB / 256;      // float4 per thread
+	{
+		f32x4 num[NE];
+#pragma unroll
+		for (int i = 0; i < NE; ++i) num[i] = *reinterpret_cast<const f32x4*>(slabs + base + 4l * (tid + 256 * i));
+		if (MODE == PANEL_MU) {
+			f32x4 old[NE];
+#pragma unroll
+			for (int i = 0; i < NE; ++i) old[i] = *reinterpret_cast<const f32x4*>(P + base + 4l * (tid + 256 * i));
+#pragma unroll
+			for (int i = 0; i < NE; ++i) {
+				const int e = tid + 256 * i, y = e / q4, c4 = e - y * q4;
+				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = old[i];
+			}
+		}
+		for (int k = 1; k < S; ++k) {
+			f32x4 t[NE];
+#pragma unroll
+			for (int i = 0; i < NE; ++i) t[i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));
+#pragma unroll
+			for (int i = 0; i < NE; ++i) num[i] += t[i];
+		}
+#pragma unroll
+		for (int i = 0; i < NE; ++i) {
+			const int e = tid + 256 * i, y = e / q4, c4 = e - y * q4;
+			*reinterpret_cast<f32x4*>(s_num + y * LD + 4 * c4) = num[i];
+			if (num_out) *reinterpret_cast<f32x4*>(num_out + base + 4l * e) = num[i];
+		}
 	}
 	__syncthreads();
 

@@ -128,7 +128,7 @@ def main():
         drv.run(Wm, first_iteration=1, error_every=10)
         shard.synchronize()
         if not args.no_kernel_events:
-            shard.engine.kernel_timing(1)
+            shard.engine.kernel_timing(args.event_stride)
         barrier()
         t0 = time.perf_counter()
         drv.run(K, first_iteration=Wm + 1, error_every=10)

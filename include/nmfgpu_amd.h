@@ -136,6 +136,10 @@ NMFAMD_API int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, in
 /* which: 0 = sorted tr(V^T V) terms (n), 1 = tr(H^T W^T V) terms (n), 2 = tr(H H^T W^T W) terms (r).
  * Returns the number of elements copied (<= capacity), negative on error. */
 NMFAMD_API long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capacity);
+/* Stream-ordered form for callers that must not stall the stream on error iterations: copies the n_local
+ * tr(H^T W^T V) terms followed by the r tr(H H^T W^T W) terms of the last error iteration into the DEVICE buffer
+ * `dst` (device-to-device, asynchronous on the engine's stream).  Returns n_local + r, negative on error. */
+NMFAMD_API long nmfamd_engine_error_terms_to_device(nmfamd_engine* e, void* dst_device, long capacity);
 /* The host half of the error evaluation (source/nmf/FrobeniusResolver.cpp:29-51) on caller-supplied
  * term vectors (the two latter ones are sorted in place). */
 NMFAMD_API double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw);

@@ -208,6 +208,11 @@ long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capa
 	return e->elem_bytes == 4 ? copy(*e->f) : copy(*e->d);
 }
 
+long nmfamd_engine_error_terms_to_device(nmfamd_engine* e, void* dst_device, long capacity) {
+	if (!e || !dst_device) return -1;
+	return e->elem_bytes == 4 ? e->f->error_terms_to_device((float*)dst_device, capacity) : e->d->error_terms_to_device((double*)dst_device, capacity);
+}
+
 double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw) {
 	std::vector<float> a(vtv_sorted, vtv_sorted + n_vtv), b(htwtv, htwtv + n_htwtv), c(hhtwtw, hhtwtw + n_hhtwtw);
 	double f = resolve_frobenius<float>(a, b, c);

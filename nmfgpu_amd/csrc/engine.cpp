@@ -437,6 +437,15 @@ Status Engine<T>::fetch_error_terms(int count_n) {
 }
 
 template <typename T>
+long Engine<T>::error_terms_to_device(T* dst, long capacity) {
+	const long cnt = (long)err_count_ + r_;
+	if (err_count_ <= 0 || capacity < cnt) return -1;
+	if (hipMemcpyAsync(dst, psN_, sizeof(T) * (size_t)err_count_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return -1;
+	if (hipMemcpyAsync(dst + err_count_, psR_, sizeof(T) * (size_t)r_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return -1;
+	return cnt;
+}
+
+template <typename T>
 void Engine<T>::finalize_error(bool resolve) {
 	if (err_pending_) {
 		(void)hipEventSynchronize(err_event_);

@@ -63,6 +63,7 @@ public:
 	const std::vector<T>& terms_htwtv() { finalize_error(false); return h_psN_; }
 	const std::vector<T>& terms_hhtwtw() { finalize_error(false); return h_psR_; }
 	const std::vector<T>& terms_vtv_sorted() const { return h_vtv_; }
+	long error_terms_to_device(T* dst, long capacity);   // [psN (last count) | psR (r)], D2D on the stream
 	void resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);
 
 	// Error of the most recent error iteration.  The n + r partial sums travel to the host

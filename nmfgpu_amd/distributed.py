@@ -63,6 +63,15 @@ class EngineShard:
     def error_terms(self, which: int) -> np.ndarray:
         return self.engine.error_terms(which)
 
+    def error_terms_async(self):
+        """Device tensor [n_local tr(H^T W^T V) terms | r tr(H H^T W^T W) terms] of the last error iteration,
+        filled by a device-to-device copy ordered on the engine's (= torch's current) stream: no host wait."""
+        torch = self.torch
+        n_local, r = self.engine.n, self.engine.r
+        t = torch.empty(n_local + r, dtype=self.exchange.dtype, device=self.device)
+        self.engine.error_terms_to_device(t.data_ptr(), n_local + r)
+        return t, n_local, r
+
     def resolve(self, vtv_sorted, htwtv, hhtwtw) -> float:
         from .engine import resolve_frobenius
         return resolve_frobenius(vtv_sorted, htwtv, hhtwtw)
@@ -85,9 +94,50 @@ class ShardedMU:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.total_elements = int(np.uint32(rows) * np.uint32(total_columns))  # the reference multiplies unsigned ints
-        self.frobenius = 0.0
-        self.rmsd = 0.0
+        self._frobenius = 0.0
+        self._rmsd = 0.0
         self._vtv_all = None
+        self._pending = None      # (event, pinned host tensor, n_local, r) of an error iteration not yet resolved
+
+    # The error of the most recent error iteration.  With a backend that offers error_terms_async the terms
+    # travel (all-gather, device-to-host copy) stream-ordered behind the iteration that produced them and are
+    # summed on the host only when somebody looks -- the iteration loop never waits for the GPU.
+    @property
+    def frobenius(self) -> float:
+        self._resolve_pending()
+        return self._frobenius
+
+    @property
+    def rmsd(self) -> float:
+        self._resolve_pending()
+        return self._rmsd
+
+    def _resolve_pending(self):
+        if self._pending is None:
+            return
+        ev, pinned, n_local, r = self._pending
+        self._pending = None
+        ev.synchronize()
+        arr = pinned.numpy()
+        per = n_local + r
+        htwtv = np.concatenate([arr[k * per:k * per + n_local] for k in range(self.world)])
+        hhtwtw = arr[n_local:per].copy()          # identical on every rank (reduced H H^T, replicated W^T W)
+        self._frobenius = self.backend.resolve(self._vtv_all, htwtv, hhtwtw)
+        self._rmsd = self._frobenius / np.sqrt(float(self.total_elements))
+
+    def _launch_error_gather(self):
+        torch, dist, b = self.torch, self.dist, self.backend
+        loc, n_local, r = b.error_terms_async()
+        if self.world > 1:
+            out = torch.empty(self.world * loc.numel(), dtype=loc.dtype, device=loc.device)
+            dist.all_gather(list(out.chunk(self.world)), loc, group=self.group)
+        else:
+            out = loc
+        pinned = torch.empty(out.numel(), dtype=out.dtype, pin_memory=True)
+        pinned.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (ev, pinned, n_local, r)
 
     def _all_gather_host(self, local: np.ndarray) -> np.ndarray:
         """Gathers equally sized host vectors of every rank (error iterations only)."""
@@ -110,12 +160,16 @@ class ShardedMU:
             self.dist.all_reduce(b.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
         b.w_finish(compute_error)
         if compute_error:
-            if self._vtv_all is None:
+            if self._vtv_all is None:      # once per factorisation (V does not change)
                 self._vtv_all = np.sort(self._all_gather_host(b.error_terms(0)))
-            htwtv = self._all_gather_host(b.error_terms(1))
-            hhtwtw = b.error_terms(2)
-            self.frobenius = b.resolve(self._vtv_all, htwtv, hhtwtw)
-            self.rmsd = self.frobenius / np.sqrt(float(self.total_elements))
+            if hasattr(b, "error_terms_async"):
+                self._resolve_pending()    # the previous error iteration's terms arrived long ago
+                self._launch_error_gather()
+            else:
+                htwtv = self._all_gather_host(b.error_terms(1))
+                hhtwtw = b.error_terms(2)
+                self._frobenius = b.resolve(self._vtv_all, htwtv, hhtwtw)
+                self._rmsd = self._frobenius / np.sqrt(float(self.total_elements))
 
     def run(self, count: int, first_iteration: int = 1, error_every: int = 10, last_iteration: int = 0):
         for k in range(count):

@@ -160,6 +160,15 @@ class Engine:
             raise EngineError(1, "error_terms")
         return out[:cnt]
 
+    def error_terms_to_device(self, dst_ptr: int, capacity: int) -> int:
+        """[n_local tr(H^T W^T V) terms | r tr(H H^T W^T W) terms] of the last error iteration -> device buffer (async)."""
+        fn = self._lib.nmfamd_engine_error_terms_to_device
+        fn.restype = C.c_long
+        cnt = fn(self._h, C.c_void_p(dst_ptr), C.c_long(capacity))
+        if cnt < 0:
+            raise EngineError(1, "error_terms_to_device")
+        return int(cnt)
+
     def debug_read(self, which: int, count: int) -> np.ndarray:
         out = np.zeros(count, dtype=self.dtype)
         self._check(self._lib.nmfamd_engine_debug_read(self._h, which, C.c_void_p(out.ctypes.data), C.c_long(count)), "debug_read")

@@ -133,7 +133,12 @@ class ShardedMU:
             dist.all_gather(list(out.chunk(self.world)), loc, group=self.group)
         else:
             out = loc
-        pinned = torch.empty(out.numel(), dtype=out.dtype, pin_memory=True)
+        # two pinned landing buffers, allocated once (pinning memory is slow and synchronises the device)
+        if getattr(self, "_pinned", None) is None or self._pinned[0].numel() != out.numel():
+            self._pinned = [torch.empty(out.numel(), dtype=out.dtype, pin_memory=True) for _ in range(2)]
+            self._pin_turn = 0
+        pinned = self._pinned[self._pin_turn]
+        self._pin_turn ^= 1
         pinned.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

@@ -385,12 +385,13 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 }
 
 template <typename T>
-Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
+Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out) {
+	T* dest = (single_slab_out != nullptr && planW_.splits == 1) ? single_slab_out : slabs_;
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
 		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
 		record_begin();
-		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, csr_val_, F, RP_, slabs_, m_, (int)mpad_, stream_));
+		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, csr_val_, F, RP_, dest, m_, (int)mpad_, stream_));
 		record_end();
 		return ST_OK;
 	}
@@ -399,20 +400,20 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg) {
 			HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
 			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
 		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, slabs_, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
 	}
 	record_begin();
-	HIPX(launch_factor_product_valu<T>(V_, mpad_, (int)mpad_, n_, F, RP_, slabs_, stream_));
+	HIPX(launch_factor_product_valu<T>(V_, mpad_, (int)mpad_, n_, F, RP_, dest, stream_));
 	record_end();
 	return ST_OK;
 }
@@ -548,8 +549,9 @@ Status Engine<T>::w_products(T* exchange) {
 		Fh = Hs_;
 	}
 	HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, ex_hht, stream_));
-	if (Status s = product_w(Fh)) return s;
-	HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
+	// a single K slice writes the exchange panel itself; several are summed into it
+	if (Status s = product_w(Fh, nullptr, exchange)) return s;
+	if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 	return ST_OK;
 }
 

@@ -98,7 +98,7 @@ private:
 	Status hip_fail(hipError_t e, const char* what);
 	Status h_step_impl(bool compute_error);
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of F V   (r x n)
-	Status product_w(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of (V F^T)^T (r x m)
+	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
 	Status materialize_w();                          // fold the pending column scale into Wt_

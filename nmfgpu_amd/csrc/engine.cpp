@@ -66,6 +66,9 @@ Engine<T>::~Engine() {
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
 	if (err_event_) (void)hipEventDestroy(err_event_);
+	if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+	if (ev_join_) (void)hipEventDestroy(ev_join_);
+	if (aux_) (void)hipStreamDestroy(aux_);
 	if (pin_psN_) (void)hipHostFree(pin_psN_);
 	if (pin_psR_) (void)hipHostFree(pin_psR_);
 	for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
@@ -155,6 +158,12 @@ Status Engine<T>::allocate() {
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
+		if (std::getenv("NMFAMD_NO_OVERLAP") == nullptr) {
+			HIPX(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
+			HIPX(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+			HIPX(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+			overlap_inverse_ = true;
+		}
 	}
 	if (fused_capable()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
@@ -424,6 +433,26 @@ Status Engine<T>::normal_inverse(T* A, T offdiag, T diag) {
 	return ST_OK;
 }
 
+// Fork: everything enqueued on the main stream so far (the Gram matrix, its saved copy) precedes the inverse;
+// join: the main stream waits for the inverse before the update kernel reads Qinv_.  Between the two the main
+// stream must not touch A, Qinv_ or inv_work_.
+template <typename T>
+Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
+	if (!overlap_inverse_) return normal_inverse(A, offdiag, diag);
+	HIPX(hipEventRecord(ev_fork_, stream_));
+	HIPX(hipStreamWaitEvent(aux_, ev_fork_, 0));
+	HIPX(launch_inverse_small<T>(A, RP_, r_, Qinv_, inv_work_, offdiag, diag, aux_));
+	HIPX(hipEventRecord(ev_join_, aux_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::normal_inverse_join() {
+	if (!overlap_inverse_) return ST_OK;
+	HIPX(hipStreamWaitEvent(stream_, ev_join_, 0));
+	return ST_OK;
+}
+
 // ---- error terms ----------------------------------------------------------------------------
 
 template <typename T>
@@ -503,9 +532,9 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		F = Ws_;
 	}
 	HIPX(launch_gram<T>(F, RP_, m_, gram_parts_, gram_part_, G_, stream_));
-	if (Status s = product_h(F)) return s;
 	const int S = planH_.splits;
 	if (alg_ == ALG_MU || alg_ == ALG_NSNMF) {
+		if (Status s = product_h(F)) return s;
 		HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, S, slab_stride_, G_, RP_, (int)npad_, eps,
 		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_));
 	} else {
@@ -519,7 +548,10 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			off = -lam; diag = lam * beta - lam;
 		}
 		if (compute_error) HIPX(hipMemcpyAsync(G2_, G_, sizeof(T) * (size_t)RP_ * RP_, hipMemcpyDeviceToDevice, stream_));
-		if (Status s = normal_inverse(G_, off, diag)) return s;
+		// the inverse of the normal matrix (one workgroup) runs beside the product against V
+		if (Status s = normal_inverse_fork(G_, off, diag)) return s;
+		if (Status s = product_h(F)) return s;
+		if (Status s = normal_inverse_join()) return s;
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
 		                            nullptr, n_, nullptr, nullptr, stream_));
 	}
@@ -662,8 +694,20 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_));
 		}
 		if (!constant_w) {
-			if (Status s = product_w(Fh)) return s;
 			const int S = planW_.splits;
+			T offW = 0, diagW = 0;
+			if (ls_family) {
+				if (alg_ == ALG_ACLS) diagW = (T)prm_.lambdaW;
+				else if (alg_ == ALG_AHCLS) {
+					const T lam = (T)prm_.lambdaW, alpha = (T)prm_.alphaW;
+					T beta = (T)((1 - alpha) * std::sqrt((double)(unsigned)r_) + alpha);
+					beta *= beta;
+					offW = -lam; diagW = lam * beta - lam;
+				}
+				// (the trace kernel above has read H H^T; the inverse destroys it) -- beside the product against V
+				if (Status s = normal_inverse_fork(HHt_, offW, diagW)) return s;
+			}
+			if (Status s = product_w(Fh)) return s;
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
@@ -675,15 +719,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					error_terms_n = r_;
 				}
 			} else {
-				T off = 0, diag = 0;
-				if (alg_ == ALG_ACLS) diag = (T)prm_.lambdaW;
-				else if (alg_ == ALG_AHCLS) {
-					const T lam = (T)prm_.lambdaW, alpha = (T)prm_.alphaW;
-					T beta = (T)((1 - alpha) * std::sqrt((double)(unsigned)r_) + alpha);
-					beta *= beta;
-					off = -lam; diag = lam * beta - lam;
-				}
-				if (Status s = normal_inverse(HHt_, off, diag)) return s;
+				if (Status s = normal_inverse_join()) return s;
 				if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
 				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_));

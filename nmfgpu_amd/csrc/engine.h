@@ -102,7 +102,9 @@ private:
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
 	Status materialize_w();                          // fold the pending column scale into Wt_
-	Status normal_inverse(T* A, T offdiag, T diag);  // A <- (A + regulariser)^-1
+	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
+	Status normal_inverse_fork(T* A, T offdiag, T diag);   // the same on the side stream; normal_inverse_join() before Qinv_ is read
+	Status normal_inverse_join();
 	Status finish_upload(T* Vcol);
 	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC
 	Status iterate_kl(bool compute_error);            // KL-divergence multiplicative update (sparse mode)
@@ -117,6 +119,11 @@ private:
 	long strideV_ = 0, strideVt_ = 0, elemsV_ = 0, elemsVt_ = 0;   // x-tiled images of V / Vt
 	int num_cus_ = 256;
 	hipStream_t stream_ = nullptr;
+	// side stream for the r x r inverse of the least-squares algorithms: one workgroup, independent of the product
+	// against V that follows the Gram matrix, so the two run side by side (the product leaves CUs idle)
+	hipStream_t aux_ = nullptr;
+	hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+	bool overlap_inverse_ = false;
 	bool tiled_ = false;                      // V_/Vt_ are x-tiled (fp32 MFMA path)
 	const char* last_error_ = "";
 

@@ -859,6 +859,19 @@ __global__ __launch_bounds__(256) void k_inverse_small(const T* __restrict__ A, 
 // The step loop is unrolled by 8 so that every register index is static.
 // Same result as the QR route (cusolver geqrf + ormqr + trsm, Matrix.h:565-618) up to rounding for
 // the non-singular normal matrices the LS algorithms produce.
+// maximum of a 32-bit key over the 64 lanes of a wave with DPP row shifts / row broadcasts (seven VALU ops and
+// one readlane) instead of six ds_bpermute round trips
+__device__ inline unsigned wave_max_u32(unsigned v) {
+	unsigned t;
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:4
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:8
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15 -> rows 1, 3
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31 -> rows 2, 3
+	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, T offdiag, T diag) {
 	__shared__ double s_col[2][64];
@@ -898,9 +911,14 @@ __global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, i
 		// by 63 - lane -- so the wave reduction is six single shuffles (the first of equal maxima wins).
 		unsigned key = 0u;
 		if (!((used >> lane) & 1ull)) key = (__float_as_uint((float)fabs(s_col[b][lane])) & ~63u) | (unsigned)(63 - lane);
-		for (int w = 32; w > 0; w >>= 1) { const unsigned o = __shfl_xor(key, w); key = o > key ? o : key; }
+		key = wave_max_u32(key);
 		const int p = 63 - (int)(key & 63u);
-		const double pivinv = 1.0 / s_col[b][p];
+		// reciprocal of the pivot: hardware estimate + two Newton steps (the matrix carries fp32 data; the
+		// full IEEE division sequence was a quarter of the step's dependent chain)
+		const double piv = s_col[b][p];
+		double pivinv = __builtin_amdgcn_rcp(piv);
+		pivinv = pivinv * (2.0 - piv * pivinv);
+		pivinv = pivinv * (2.0 - piv * pivinv);
 		if (ti == (p >> 2)) {
 #pragma unroll
 			for (int rr = 0; rr < 4; ++rr)

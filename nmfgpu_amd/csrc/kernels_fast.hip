@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_compact_partials(const T* __restrict__ 
 template <typename T>
 hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream) {
 	const T* src = sumsq_part;
-	if (parts > 4 * NORM_GROUPS) {
+	if (parts > 16 * NORM_GROUPS) {
 		T* compact = sumsq_part + (long)parts * RP;
 		hipLaunchKernelGGL((k_compact_partials<T>), dim3(RP / 64, NORM_GROUPS), dim3(256), 0, stream, sumsq_part, parts, RP, compact);
 		src = compact;

@@ -446,6 +446,13 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 	return ST_OK;
 }
 
+// fp32 MFMA product at padded rank 64 with a passenger row in its grid
+template <typename T>
+bool Engine<T>::inverse_rides(const FactorProductPlan& plan) const {
+	return std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
+	       std::getenv("NMFAMD_NO_OVERLAP") == nullptr && std::getenv("NMFAMD_INVERSE_SIDE_STREAM") == nullptr;
+}
+
 template <typename T>
 Status Engine<T>::normal_inverse_join() {
 	if (!overlap_inverse_) return ST_OK;
@@ -548,10 +555,19 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			off = -lam; diag = lam * beta - lam;
 		}
 		if (compute_error) HIPX(hipMemcpyAsync(G2_, G_, sizeof(T) * (size_t)RP_ * RP_, hipMemcpyDeviceToDevice, stream_));
-		// the inverse of the normal matrix (one workgroup) runs beside the product against V
-		if (Status s = normal_inverse_fork(G_, off, diag)) return s;
-		if (Status s = product_h(F)) return s;
-		if (Status s = normal_inverse_join()) return s;
+		// the inverse of the normal matrix (one workgroup) runs beside the product against V: as a passenger
+		// workgroup of the product launch where that exists (fp32 MFMA product, r <= 64), else on the side stream
+		if (inverse_rides(planH_)) {
+			if constexpr (std::is_same<T, float>::value) {
+				GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
+				rg.inv_a = G_; rg.inv_out = Qinv_; rg.inv_offdiag = off; rg.inv_diag = diag; rg.inv_r = r_;
+				if (Status s = product_h(F, &rg)) return s;
+			}
+		} else {
+			if (Status s = normal_inverse_fork(G_, off, diag)) return s;
+			if (Status s = product_h(F)) return s;
+			if (Status s = normal_inverse_join()) return s;
+		}
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
 		                            nullptr, n_, nullptr, nullptr, stream_));
 	}
@@ -705,9 +721,17 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					offW = -lam; diagW = lam * beta - lam;
 				}
 				// (the trace kernel above has read H H^T; the inverse destroys it) -- beside the product against V
-				if (Status s = normal_inverse_fork(HHt_, offW, diagW)) return s;
+				if (!inverse_rides(planW_)) { if (Status s = normal_inverse_fork(HHt_, offW, diagW)) return s; }
 			}
-			if (Status s = product_w(Fh)) return s;
+			if (ls_family && inverse_rides(planW_)) {
+				if constexpr (std::is_same<T, float>::value) {
+					GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
+					rg.inv_a = HHt_; rg.inv_out = Qinv_; rg.inv_offdiag = offW; rg.inv_diag = diagW; rg.inv_r = r_;
+					if (Status s = product_w(Fh, &rg)) return s;
+				}
+			} else {
+				if (Status s = product_w(Fh)) return s;
+			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
@@ -719,7 +743,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					error_terms_n = r_;
 				}
 			} else {
-				if (Status s = normal_inverse_join()) return s;
+				if (!inverse_rides(planW_)) { if (Status s = normal_inverse_join()) return s; }
 				if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
 				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_));

@@ -105,6 +105,7 @@ private:
 	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
 	Status normal_inverse_fork(T* A, T offdiag, T diag);   // the same on the side stream; normal_inverse_join() before Qinv_ is read
 	Status normal_inverse_join();
+	bool inverse_rides(const FactorProductPlan& plan) const;   // the inverse can be a passenger workgroup of the product launch
 	Status finish_upload(T* Vcol);
 	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC
 	Status iterate_kl(bool compute_error);            // KL-divergence multiplicative update (sparse mode)

@@ -27,6 +27,12 @@ struct GramReduceArgs {
 	float* G;               // [4096]
 	float* scale;           // [64] or nullptr
 	int normalize;          // 1: scale = 1/sqrt(diag), G scaled on both sides; 0: scale = 1
+	// the other kind of passenger (least-squares algorithms; fp32 kernel only, not together with the reduction):
+	// inv_out <- (inv_a + regulariser)^-1, 64 x 64, one workgroup running k_inverse_gj64's body
+	const float* inv_a = nullptr;
+	float* inv_out = nullptr;
+	float inv_offdiag = 0.f, inv_diag = 0.f;
+	int inv_r = 0;
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 

@@ -130,6 +130,116 @@ __device__ inline void gram_reduce_block(const GramReduceArgs& rg, int blk, floa
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
+// Fast form for r <= 64: Gauss-Jordan elimination with partial pivoting, double precision, register resident,
+// no row swaps (the pivot row stays where it is and the permutation is undone when the result is written).
+// Same result as the QR route (cusolver geqrf + ormqr + trsm, Matrix.h:565-618) up to rounding for
+// the non-singular normal matrices the LS algorithms produce.
+// maximum of a 32-bit key over the 64 lanes of a wave with DPP row shifts / row broadcasts (seven VALU ops and
+// one readlane) instead of six ds_bpermute round trips
+__device__ inline unsigned wave_max_u32(unsigned v) {
+	unsigned t;
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:4
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:8
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15 -> rows 1, 3
+	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31 -> rows 2, 3
+	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ inline double readlane_f64(double v, int lane_uniform) {
+	const long long bits = __double_as_longlong(v);
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane_uniform);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), lane_uniform);
+	return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// Pivot search of one Gauss-Jordan step, wave-local: lane = row, v = the pivot column.  The (near-)largest |v|
+// among the rows not used yet wins -- one 32-bit key per lane, the float bits of |v| with the low six bits
+// replaced by 63 - lane (the first of equal maxima wins).  Publishes the multipliers f / piv, the pivot row,
+// 1 / piv (hardware estimate + two Newton steps: the matrix carries fp32 data) and the bookkeeping.
+__device__ inline void gj_search(double v, unsigned long long used, int lane, int k, int b,
+                                 double (*s_f)[64], double* s_pivinv, int* s_p, int* s_rowof, int* s_pivrow) {
+	unsigned key = 0u;
+	if (!((used >> lane) & 1ull)) key = (__float_as_uint((float)fabs(v)) & ~63u) | (unsigned)(63 - lane);
+	key = wave_max_u32(key);
+	const int p = 63 - (int)(key & 63u);
+	const double piv = readlane_f64(v, p);
+	double pivinv = __builtin_amdgcn_rcp(piv);
+	pivinv = pivinv * (2.0 - piv * pivinv);
+	pivinv = pivinv * (2.0 - piv * pivinv);
+	s_f[b][lane] = v * pivinv;
+	if (lane == 0) { s_p[b] = p; s_pivinv[b] = pivinv; s_rowof[p] = k; s_pivrow[k] = p; }
+}
+
+// In-place Gauss-Jordan with partial pivoting in fp64, r <= 64, one workgroup of 8 waves: wave w owns columns
+// 8w .. 8w+7 of the (identity-padded) 64 x 64 matrix, lane = row, so
+//   * the pivot search of step k is local to wave k / 8 (register k % 8: static index, no LDS),
+//   * one barrier per step carries the multipliers, the pivot row index and 1 / piv to the other waves,
+//   * every wave fetches its eight pivot-row values with v_readlane (same-address ds_read_b128 is serialised)
+//     and updates eight columns: rows i != p: M_i -= (f_i / piv) row_p; row p: row_p / piv = row_p - (1 - 1/piv) row_p,
+//   * the search of step k + 1 is issued as soon as its column is final, ahead of the next barrier.
+// Physical column k ends up as the column of the inverse that belongs to pivot row p_k; physical row p_k as row k.
+// (Measured: 26 us against 55 us for the two-barrier, LDS-broadcast form this replaces: tools/probe/gj_probe.hip.)
+template <typename T>
+__device__ inline void inverse_gj64_body(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, T offdiag, T diag) {
+	__shared__ double s_f[2][64];
+	__shared__ double s_pivinv[2];
+	__shared__ int s_p[2];
+	__shared__ int s_rowof[64], s_pivrow[64];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	double M[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const int i = lane, j = 8 * wave + q;
+		// the regulariser (kernel::addConstantToMatrix, KernelFillMatrix.cu:29-45) is added in T on the way in
+		M[q] = (i < r && j < r) ? (double)(T)(A[(long)j * RP + i] + (i == j ? diag : offdiag)) : (i == j ? 1.0 : 0.0);
+	}
+	unsigned long long used = 0ull;
+	if (wave == 0) gj_search(M[0], used, lane, 0, 0, s_f, s_pivinv, s_p, s_rowof, s_pivrow);
+#pragma unroll 1
+	for (int kg = 0; kg < 8; ++kg) {
+#pragma unroll
+		for (int kc = 0; kc < 8; ++kc) {
+			const int b = kc & 1;
+			__syncthreads();
+			const double fm = s_f[b][lane];                  // f / piv
+			const int p = __builtin_amdgcn_readfirstlane(s_p[b]);
+			const double pivinv = s_pivinv[b];
+			used |= 1ull << p;
+			double prow[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) prow[q] = readlane_f64(M[q], p);
+			const double fadj = (lane == p) ? 1.0 - pivinv : fm;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) M[q] = M[q] - fadj * prow[q];
+			if (wave == kg) M[kc] = (lane == p) ? pivinv : -fm;      // the eliminated column becomes a column of the inverse
+			if (kc < 7) { if (wave == kg) gj_search(M[kc + 1], used, lane, 8 * kg + kc + 1, b ^ 1, s_f, s_pivinv, s_p, s_rowof, s_pivrow); }
+			else if (kg < 7) { if (wave == kg + 1) gj_search(M[0], used, lane, 8 * kg + 8, b ^ 1, s_f, s_pivinv, s_p, s_rowof, s_pivrow); }
+		}
+	}
+	__syncthreads();
+	{
+		const int kk = s_rowof[lane];                            // this physical row is row kk of the inverse
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int j = s_pivrow[8 * wave + q];
+			if (kk < r && j < r) Ainv[(long)j * RP + kk] = (T)M[q];
+		}
+	}
+	// zero padding of the RP x RP output outside the r x r block
+	for (int e = tid; e < RP * RP; e += 512) {
+		const int i = e % RP, j = e / RP;
+		if (i >= r || j >= r) Ainv[e] = T(0);
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, T offdiag, T diag) {
+	inverse_gj64_body<T>(A, RP, r, Ainv, offdiag, diag);
+}
+
 template <int XB, int D, bool STAMP, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long tile_stride,
@@ -148,8 +258,13 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	typedef f32x2 fvec;
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 
-	if (blockIdx.y == (unsigned)splits) {   // the reduce row of the grid (only launched when rg.partials != nullptr)
-		if (blockIdx.x < GRAM_REDUCE_BLOCKS) gram_reduce_block(rg, blockIdx.x, lds);
+	if (blockIdx.y == (unsigned)splits) {   // the passenger row of the grid (only launched when there is a passenger)
+		// the 64 x 64 inverse of the least-squares algorithms rides as the FIRST block of the row: the workgroup
+		// distributor hands blocks to the shader engines in turn and does not look for a free CU elsewhere, so the
+		// block right behind the product's last one is the one that lands on a CU the product left idle
+		if (rg.inv_a != nullptr) {
+			if (blockIdx.x == 0) inverse_gj64_body<float>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
+		} else if (blockIdx.x < GRAM_REDUCE_BLOCKS) gram_reduce_block(rg, blockIdx.x, lds);
 		return;
 	}
 
@@ -342,8 +457,10 @@ template <int XB, int D, bool STAMP, int DIAG = 0>
 static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                               float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	const bool with_reduce = rg != nullptr && rg->partials != nullptr && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
-	if (rg != nullptr && rg->partials != nullptr && !with_reduce) return hipErrorInvalidValue;
+	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr);
+	if (wanted && rg->partials != nullptr && rg->inv_a != nullptr) return hipErrorInvalidValue;      // one kind of passenger per launch
+	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
+	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static bool attr_done = false;
@@ -849,121 +966,10 @@ __global__ __launch_bounds__(256) void k_inverse_small(const T* __restrict__ A, 
 	}
 }
 
-// Fast form for r <= 64: Gauss-Jordan elimination with partial pivoting on the augmented matrix
-// [A | I] (A embedded in a 64 x 64 block-diagonal with an identity tail), double precision,
-// REGISTER resident: 256 threads as a 16 x 16 grid, thread (ti, tj) owns rows 4ti..4ti+3 and
-// columns 8tj..8tj+7 (32 doubles).  Per elimination step only the pivot column and the scaled pivot
-// row travel through (double-buffered) LDS: two barriers per step, no row swaps -- the pivot row
-// stays where it is and the row permutation is undone when the result is written
-// (left half ends as a permutation matrix P = E A, right half E, so A^-1 row k = E row p_k).
-// The step loop is unrolled by 8 so that every register index is static.
-// Same result as the QR route (cusolver geqrf + ormqr + trsm, Matrix.h:565-618) up to rounding for
-// the non-singular normal matrices the LS algorithms produce.
-// maximum of a 32-bit key over the 64 lanes of a wave with DPP row shifts / row broadcasts (seven VALU ops and
-// one readlane) instead of six ds_bpermute round trips
-__device__ inline unsigned wave_max_u32(unsigned v) {
-	unsigned t;
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:4
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:8
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15 -> rows 1, 3
-	t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31 -> rows 2, 3
-	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_inverse_gj64(const T* __restrict__ A, int RP, int r, T* __restrict__ Ainv, T offdiag, T diag) {
-	__shared__ double s_col[2][64];
-	__shared__ double s_row[2][128];
-	__shared__ int s_inv[64];
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int ti = tid >> 4, tj = tid & 15;
-	double M[4][8];
-#pragma unroll
-	for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-		for (int cc = 0; cc < 8; ++cc) {
-			const int i = 4 * ti + rr, j = 8 * tj + cc;
-			double v;
-			// the regulariser (kernel::addConstantToMatrix, KernelFillMatrix.cu:29-45) is added in T on the way in
-			if (j < 64) v = (i < r && j < r) ? (double)(T)(A[(long)j * RP + i] + (i == j ? diag : offdiag)) : (i == j ? 1.0 : 0.0);
-			else v = (j - 64 == i) ? 1.0 : 0.0;
-			M[rr][cc] = v;
-		}
-	unsigned long long used = 0ull;
-	// 8 (rolled) x 8 (unrolled) steps: the register index of pivot column k inside its owner's
-	// block (k % 8) is static, while the code stays small enough for the instruction cache
-	// (all 64 steps unrolled run ~7x slower on instruction fetch).
-#pragma unroll 1
-	for (int kg = 0; kg < 8; ++kg)
-#pragma unroll
-	for (int kc = 0; kc < 8; ++kc) {
-		const int k = 8 * kg + kc;
-		const int b = kc & 1;
-		if (tj == kg) {
-#pragma unroll
-			for (int rr = 0; rr < 4; ++rr) s_col[b][4 * ti + rr] = M[rr][kc];
-		}
-		__syncthreads();
-		// pivot: (near-)largest |column k| among the rows not used yet; every wave computes the same
-		// answer.  One 32-bit key per lane -- the float bits of |value| with the low six bits replaced
-		// by 63 - lane -- so the wave reduction is six single shuffles (the first of equal maxima wins).
-		unsigned key = 0u;
-		if (!((used >> lane) & 1ull)) key = (__float_as_uint((float)fabs(s_col[b][lane])) & ~63u) | (unsigned)(63 - lane);
-		key = wave_max_u32(key);
-		const int p = 63 - (int)(key & 63u);
-		// reciprocal of the pivot: hardware estimate + two Newton steps (the matrix carries fp32 data; the
-		// full IEEE division sequence was a quarter of the step's dependent chain)
-		const double piv = s_col[b][p];
-		double pivinv = __builtin_amdgcn_rcp(piv);
-		pivinv = pivinv * (2.0 - piv * pivinv);
-		pivinv = pivinv * (2.0 - piv * pivinv);
-		if (ti == (p >> 2)) {
-#pragma unroll
-			for (int rr = 0; rr < 4; ++rr)
-				if (rr == (p & 3)) {
-#pragma unroll
-					for (int cc = 0; cc < 8; ++cc) s_row[b][8 * tj + cc] = M[rr][cc] * pivinv;
-				}
-		}
-		if (tid == 0) s_inv[p] = k;
-		used |= 1ull << p;
-		__syncthreads();
-		double prow[8];
-#pragma unroll
-		for (int cc = 0; cc < 8; ++cc) prow[cc] = s_row[b][8 * tj + cc];
-#pragma unroll
-		for (int rr = 0; rr < 4; ++rr) {
-			const int i = 4 * ti + rr;
-			const double f = s_col[b][i];
-#pragma unroll
-			for (int cc = 0; cc < 8; ++cc) M[rr][cc] = (i == p) ? prow[cc] : M[rr][cc] - f * prow[cc];
-		}
-	}
-	__syncthreads();
-	if (tj >= 8) {
-#pragma unroll
-		for (int rr = 0; rr < 4; ++rr) {
-			const int kk = s_inv[4 * ti + rr];
-#pragma unroll
-			for (int cc = 0; cc < 8; ++cc) {
-				const int j = 8 * tj + cc - 64;
-				if (kk < r && j < r) Ainv[(long)j * RP + kk] = (T)M[rr][cc];
-			}
-		}
-	}
-	// zero padding of the RP x RP output outside the r x r block
-	for (int e = tid; e < RP * RP; e += 256) {
-		const int i = e % RP, j = e / RP;
-		if (i >= r || j >= r) Ainv[e] = T(0);
-	}
-}
-
 template <typename T>
 hipError_t launch_inverse_small(T* A, int RP, int r, T* Ainv, double* work, T offdiag, T diag, hipStream_t stream) {
 	if (r <= 64) {
-		hipLaunchKernelGGL((k_inverse_gj64<T>), dim3(1), dim3(256), 0, stream, A, RP, r, Ainv, offdiag, diag);
+		hipLaunchKernelGGL((k_inverse_gj64<T>), dim3(1), dim3(512), 0, stream, A, RP, r, Ainv, offdiag, diag);
 		return hipGetLastError();
 	}
 	if (offdiag != T(0) || diag != T(0)) {

@@ -21,6 +21,18 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);
 
 // Optional passenger of a factor-product launch (rank-64 MU fast path, kernels_mu64.hip): reduce
 // `parts` partial 64 x 64 Gram matrices into G, optionally turning its diagonal into column scales.
+// Raises a kernel's dynamic LDS limit once per DEVICE (the attribute is per device; a process may switch
+// devices through nmfgpu::chooseGpu).  `done` is the caller's static bit mask, one bit per device ordinal.
+inline hipError_t allow_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+	e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+	if (e == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+	return e;
+}
+
 struct GramReduceArgs {
 	const float* partials;  // [parts][4096]
 	int parts;

@@ -463,13 +463,8 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static bool attr_done = false;
-	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG>),
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if (e != hipSuccess) return e;
-		attr_done = true;
-	}
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	for (int ch = 0; ch < p.chunks; ++ch)
 		hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
 		                   A, tile_stride, F, RP, ch * 64, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);

@@ -436,12 +436,8 @@ static hipError_t launch_fp_bf16_staged(const FactorProductPlan& p, const void* 
                                         float* slabs, long slab_stride, hipStream_t stream) {
 	dim3 grid(p.xtiles, p.splits, RP / 256), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static bool attr_done = false;
-	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_bf16_staged<SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if (e != hipSuccess) return e;
-		attr_done = true;
-	}
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_bf16_staged<SETS>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_bf16_staged<SETS>), grid, block, lds_bytes, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
 	                   slabs, slab_stride, RP, KS, p.splits);
@@ -456,12 +452,8 @@ static hipError_t launch_fp_bf16(const FactorProductPlan& p, const void* A, int 
 	if (rg != nullptr && rg->partials != nullptr && (!with_reduce || CH != 1)) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), RP / (64 * CH)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static bool attr_done = false;
-	if (!attr_done) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_product_bf16<D, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if (e != hipSuccess) return e;
-		attr_done = true;
-	}
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_bf16<D, CH>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_bf16<D, CH>), grid, block, lds_bytes, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
 	                   slabs, slab_stride, RP, KS, p.splits, with_reduce ? *rg : none);

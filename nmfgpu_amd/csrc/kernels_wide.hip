@@ -282,13 +282,9 @@ template <int MODE, int NCB>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                               float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
 	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 128);
-	static bool attr_done = false;
-	if (!attr_done) {
-		const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
-		if (e != hipSuccess) return e;
-		attr_done = true;
-	}
+	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
 	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);
 	return hipGetLastError();

@@ -109,6 +109,8 @@ NMFAMD_API double nmfamd_engine_kl_divergence(nmfamd_engine* e);
  * read, and resets the counters. */
 NMFAMD_API int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable);
 NMFAMD_API int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches);
+/* The same, plus what an EMPTY event pair reports on the idle stream (ms): the share of each sample that is not kernel time. */
+NMFAMD_API int nmfamd_engine_kernel_timing_read2(nmfamd_engine* e, double* total_ms, long* launches, double* pair_overhead_ms);
 
 /* Geometry the harness needs for its roofline arithmetic. */
 typedef struct nmfamd_geometry {

@@ -169,6 +169,12 @@ int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* l
 	                   [&](Engine<double>& g) { g.dominant_stats(total_ms, launches); return ST_OK; });
 }
 
+int nmfamd_engine_kernel_timing_read2(nmfamd_engine* e, double* total_ms, long* launches, double* pair_overhead_ms) {
+	if (!e) return NMFAMD_INVALID_ARGUMENT;
+	if (e->elem_bytes == 4) e->f->dominant_stats(total_ms, launches, pair_overhead_ms); else e->d->dominant_stats(total_ms, launches, pair_overhead_ms);
+	return NMFAMD_OK;
+}
+
 int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 	if (!e || !out) return NMFAMD_INVALID_ARGUMENT;
 	auto fill = [&](const auto& g) {

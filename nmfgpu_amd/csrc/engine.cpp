@@ -347,7 +347,7 @@ void Engine<T>::record_end() {
 }
 
 template <typename T>
-void Engine<T>::dominant_stats(double* total_ms, long* launches) {
+void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms) {
 	double tot = 0; long cnt = 0;
 	(void)hipStreamSynchronize(stream_);
 	for (size_t i = 0; i + 1 < ev_used_; i += 2) {
@@ -357,6 +357,21 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches) {
 	ev_used_ = 0;
 	if (total_ms) *total_ms = tot;
 	if (launches) *launches = cnt;
+	if (pair_overhead_ms) {
+		// what an event pair reports with NOTHING between the two records (idle stream, smallest of eight):
+		// the part of every sample above that is not kernel time
+		double best = -1;
+		if (ev_.size() >= 2) {
+			for (int i = 0; i < 8; ++i) {
+				(void)hipEventRecord(ev_[0], stream_);
+				(void)hipEventRecord(ev_[1], stream_);
+				(void)hipEventSynchronize(ev_[1]);
+				float ms = 0;
+				if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess && (best < 0 || ms < best)) best = ms;
+			}
+		}
+		*pair_overhead_ms = best < 0 ? 0.0 : best;
+	}
 }
 
 template <typename T>

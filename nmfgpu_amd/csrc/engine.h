@@ -79,7 +79,7 @@ public:
 	// by HIP events on the engine's stream; dominant_stats reads them back (host sync).
 	// stride: time the launches of every stride-th iteration only (1 = all)
 	void enable_kernel_timing(bool on, int stride = 1) { timing_ = on; timing_stride_ = stride > 0 ? stride : 1; timing_iter_ = 0; }
-	void dominant_stats(double* total_ms, long* launches);
+	void dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms = nullptr);
 
 	int m() const { return m_; }
 	int n() const { return n_; }

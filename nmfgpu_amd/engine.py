@@ -137,6 +137,12 @@ class Engine:
         self._check(self._lib.nmfamd_engine_kernel_timing_read(self._h, C.byref(ms), C.byref(cnt)), "kernel_timing_read")
         return ms.value, cnt.value
 
+    def kernel_timing_read2(self):
+        """(total ms, launches, ms an empty event pair reports on the idle stream)."""
+        ms = C.c_double(0); cnt = C.c_long(0); ov = C.c_double(0)
+        self._check(self._lib.nmfamd_engine_kernel_timing_read2(self._h, C.byref(ms), C.byref(cnt), C.byref(ov)), "kernel_timing_read2")
+        return ms.value, cnt.value, ov.value
+
     def geometry(self) -> dict:
         g = _Geometry()
         self._check(self._lib.nmfamd_engine_geometry(self._h, C.byref(g)), "geometry")

@@ -688,3 +688,43 @@ def test_config4_shard_size_nsnmf_bf16_properties():
     a, b = 1.0 - theta, theta / r
     Wn = (WS.astype(np.float64) - (b / (a + b * r)) * WS.astype(np.float64).sum(axis=1, keepdims=True)) / a
     np.testing.assert_allclose(np.linalg.norm(Wn, axis=0), 1.0, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ constant basis vectors (semi-supervised projection)
+
+@pytest.mark.parametrize("alg,r,kw", [("mu", 8, {}), ("mu", 64, {}), ("mu", 100, {}), ("nsnmf", 8, dict(theta=0.4)), ("gdcls", 8, dict(lam=0.01)),
+                                      ("als", 8, {}), ("acls", 8, dict(lambda_w=0.01, lambda_h=0.01)),
+                                      ("ahcls", 8, dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01))])
+def test_constant_basis_vectors_fit_h_only(alg, r, kw):
+    """useConstantBasisVectors (ref AlgorithmMultiplicativeFrobenius.h:144-146,218-228 and the siblings): W is never
+    written, H is fitted to it -- the mode the R binding uses to project new data onto a trained basis."""
+    m, n, iters = 300, 180, 20
+    V, W, H = problem(m, n, r, np.float32, seed=31)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    W0 = W64.copy()
+    ref = oracle.run(alg, V64, W64, H64, iters, const_w=True, **kw)
+    eng = na.Engine(m, n, r, alg, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters, constant_w=True)
+    Wg, Hg = eng.get_factors()
+    tol = 2e-3 if alg in ("als", "acls", "ahcls", "gdcls") else 2e-4
+    assert rel(Hg, H64) < tol
+    if alg == "nsnmf":
+        assert rel(Wg, W64) < tol                      # both sides return W S
+    else:
+        np.testing.assert_array_equal(W64, W0)         # the oracle left W alone ...
+        np.testing.assert_allclose(Wg, W, rtol=1e-6)   # ... and so did the engine (panel round trip only)
+    if alg in ("mu", "nsnmf"):
+        assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+
+
+def test_compute_with_constant_basis_vectors_through_the_boundary():
+    V, W, H = problem(240, 150, 6, np.float32, seed=33)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    W_before = W.copy()
+    ref = oracle.run("mu", V64, W64, H64, 50, const_w=True)
+    s = na.Summary()
+    assert na.compute(V, W, H, iterations=50, constant_basis_vectors=True, summary=s) == na.ResultType.Success
+    np.testing.assert_allclose(W, W_before, rtol=1e-6)
+    assert rel(H, H64) < 2e-4
+    assert s.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-4)

@@ -728,3 +728,22 @@ def test_compute_with_constant_basis_vectors_through_the_boundary():
     np.testing.assert_allclose(W, W_before, rtol=1e-6)
     assert rel(H, H64) < 2e-4
     assert s.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+
+
+# ------------------------------------------------------------------ device introspection
+
+def test_device_introspection_and_selection():
+    """getNumberOfGpu / getInformationForGpuIndex / chooseGpu (ref Interface.cpp:152-202)."""
+    count = na.get_number_of_gpu()
+    assert count >= 1 and count == na.device_count()
+    res, info = na.get_information_for_gpu_index(0)
+    assert res == na.ResultType.Success
+    assert len(info.name) > 0
+    assert 0 < info.freeMemory <= info.totalMemory and info.totalMemory > (100 << 30)      # an MI355X carries 288 GB
+    res, _ = na.get_information_for_gpu_index(count)                                         # one past the end
+    assert res == na.ResultType.ErrorDeviceSelection
+    assert na.choose_gpu(0) == na.ResultType.Success                                          # fixture has initialised the library
+    assert na.choose_gpu(count) == na.ResultType.ErrorDeviceSelection
+    # the library still computes on the selected device afterwards
+    V, W, H = problem(64, 40, 4, np.float32, seed=3)
+    assert na.compute(V, W, H, iterations=5) == na.ResultType.Success

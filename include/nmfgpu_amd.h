@@ -150,11 +150,11 @@ NMFAMD_API double nmfamd_resolve_frobenius_f64(const double* vtv_sorted, long n_
 /* ---- single operations on host data (parity tests of the individual kernels) -----------------
  * OUT (r x X) = F (r x Y) * A^T, A is X x Y: the factor product both big GEMMs are instances of.
  * out_slabs (optional) receives the number of split-K slabs the MFMA kernel used.
- * use_valu != 0 selects the generic VALU kernel (the fp64 path) instead of the fp32 MFMA kernel. */
+ * use_valu != 0 selects the generic VALU kernel (the cross-check) instead of the fp32 / fp64 MFMA kernel. */
 NMFAMD_API int nmfamd_op_factor_product_f32(const float* A, long lda, int X, int Y, const float* F, long ldf, int r,
                                             float* OUT, long ldo, int use_valu, int* out_slabs);
 NMFAMD_API int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r,
-                                            double* OUT, long ldo);
+                                            double* OUT, long ldo, int use_valu, int* out_slabs);
 /* Tuning / diagnosis of the factor-product kernel (rank 64) on synthetic device data: average of
  * `reps` back-to-back launches; optionally (stamps_out != NULL) one launch of the diagnostic build that
  * records 8 uint64 per wave: shader clock at entry / first MFMA / loop end / kernel end, 100 MHz

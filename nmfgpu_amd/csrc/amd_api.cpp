@@ -40,9 +40,10 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 	const int RP = padded_rank(r);
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
-	FactorProductPlan plan = plan_factor_product(X, Y, RP, prop.multiProcessorCount);
+	FactorProductPlan plan = std::is_same<T, double>::value ? plan_factor_product_f64(X, Y, RP, prop.multiProcessorCount)
+	                                                         : plan_factor_product(X, Y, RP, prop.multiProcessorCount);
 	const long Xp = pad128(std::max<long>(X, (long)plan.xtiles * plan.th)), Yp = pad128(Y);
-	const bool mfma = std::is_same<T, float>::value && !use_valu;
+	const bool mfma = !use_valu;
 	const int S = mfma ? plan.splits : 1;
 	DevBuf dA, dF, dS, dO;
 	const long slab_stride = (long)RP * Xp;
@@ -61,7 +62,15 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 		}
 		else e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
 	} else {
-		e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
+		if (mfma) {
+			DevBuf dT;   // x-tiled image of A for the fp64 MFMA kernel
+			if (dT.alloc(sizeof(T) * Xp * Yp) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+			e = hipMemset(dT.p, 0, sizeof(T) * Xp * Yp);
+			if (e == hipSuccess) e = launch_tile<double>((const double*)dA.p, Xp, X, Y, (double*)dT.p, plan.th * Yp, plan.th, false, nullptr);
+			if (e == hipSuccess) e = launch_factor_product_f64(plan, (const double*)dT.p, plan.th * Yp, (const double*)dF.p, RP, (double*)dS.p, slab_stride, nullptr);
+			if (e == hipSuccess) e = hipDeviceSynchronize();
+		}
+		else e = launch_factor_product_valu<T>((const T*)dA.p, Xp, (int)Xp, Y, (const T*)dF.p, RP, (T*)dS.p, nullptr);
 	}
 	if (e != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_reduce_slabs<T>((const T*)dS.p, S, slab_stride, (T*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
@@ -305,8 +314,8 @@ int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const 
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
-int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r, double* OUT, long ldo) {
-	return op_factor_product<double>(A, lda, X, Y, F, ldf, r, OUT, ldo, true, nullptr);
+int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r, double* OUT, long ldo, int use_valu, int* out_slabs) {
+	return op_factor_product<double>(A, lda, X, Y, F, ldf, r, OUT, ldo, use_valu != 0, out_slabs);
 }
 
 int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg) {

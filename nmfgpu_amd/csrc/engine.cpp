@@ -83,9 +83,11 @@ Status Engine<T>::allocate() {
 	HIPX(hipGetDeviceProperties(&prop, dev));
 	num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-	planH_ = plan_factor_product(n_, m_, RP_, num_cus_);
-	planW_ = plan_factor_product(m_, n_, RP_, num_cus_);
-	const bool mfma = std::is_same<T, float>::value && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
+	// both products run on the MFMA pipe: fp32 (kernels.hip) or fp64 (kernels_f64.hip), each with its own cut
+	const bool f64 = std::is_same<T, double>::value;
+	planH_ = f64 ? plan_factor_product_f64(n_, m_, RP_, num_cus_) : plan_factor_product(n_, m_, RP_, num_cus_);
+	planW_ = f64 ? plan_factor_product_f64(m_, n_, RP_, num_cus_) : plan_factor_product(m_, n_, RP_, num_cus_);
+	const bool mfma = std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
 	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;
@@ -402,6 +404,14 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 			return ST_OK;
 		}
 	}
+	if constexpr (std::is_same<T, double>::value) {
+		if (tiled_) {
+			record_begin();
+			HIPX(launch_factor_product_f64(planH_, Vt_, strideVt_, F, RP_, slabs_, slab_stride_, stream_));
+			record_end();
+			return ST_OK;
+		}
+	}
 	record_begin();
 	HIPX(launch_factor_product_valu<T>(Vt_, npad_, (int)npad_, m_, F, RP_, slabs_, stream_));
 	record_end();
@@ -432,6 +442,14 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_, rg));
+			record_end();
+			return ST_OK;
+		}
+	}
+	if constexpr (std::is_same<T, double>::value) {
+		if (tiled_) {
+			record_begin();
+			HIPX(launch_factor_product_f64(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_));
 			record_end();
 			return ST_OK;
 		}

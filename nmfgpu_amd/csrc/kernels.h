@@ -153,6 +153,11 @@ hipError_t launch_densify(int format, const T* values, const int* ptr, const int
 template <typename T>
 hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
 
+// ---- fp64 MFMA factor product (kernels_f64.hip): same x-tiled image of A (tile height 128), K-steps of four y ----
+FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus);
+hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
+                                     double* slabs, long slab_stride, hipStream_t stream);
+
 // ---- bf16-operand factor product (kernels_bf16.hip) ------------------------------------------
 // Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and the factor
 // panel [y][RP] (RP = 64 or a multiple of 128; 16 * KS * RP / 32 * 64 bytes).

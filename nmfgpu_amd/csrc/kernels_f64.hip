@@ -1,0 +1,172 @@
+// kernels_f64.hip -- the factor product OUT(c, x) = sum_y F(c, y) A(x, y) in double precision on the fp64 MFMA pipe.
+//
+// The reference instantiates every algorithm for double as well (include/nmfgpu.h:298-299; the R binding works in
+// double); its products are cublasDgemm / Dsyrk / Dsymm (source/common/Matrix.h:314-442).  Same decomposition and the
+// same x-tiled image of A as the fp32 kernel (kernels.hip, k_factor_product_f32), with
+//   * v_mfma_f64_16x16x4_f64 (64 cycles, 2048 FLOP: the fp64 matrix peak of gfx950 equals its vector peak, 78.6 TFLOP/s,
+//     but one MFMA replaces 16 VALU FMAs per lane and needs no LDS / cross-lane traffic for the operands),
+//   * workgroup = 8 waves = one 128-row x-tile times one slice of the reduction range; the waves form 2 row halves of
+//     64 rows times 4 pieces of the slice; a wave keeps a 64 x 64 block of the output = 4 x 4 MFMA tiles = 128 VGPRs,
+//   * K-step = 4 y.  Operand lane maps (A: lane l holds row l & 15, k = l >> 4; B: column l & 15, k = l >> 4); the rows /
+//     columns of the four tiles are interleaved (row 4 i + b, column 4 j + nb), so a lane's four A values and its four
+//     F values are 32 contiguous bytes each,
+//   * the four pieces of a row half are summed through LDS in piece order; one fp64 slab per slice.
+// At 8 bytes per element the product is as close to the HBM roof (400 MB per pass at config 2: 67 us at 6 TB/s) as to
+// the MFMA roof (6.4 GFLOP: 81 us at peak).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace nmfamd {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int F64_TH = 128;
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void k_factor_product_f64(
+	const double* __restrict__ A, long tile_stride,
+	const double* __restrict__ F, int RP, int coff,
+	double* __restrict__ slabs, long slab_stride,
+	int steps_total, int splits) {
+	extern __shared__ __attribute__((aligned(16))) double lds64[];
+	const int xt = blockIdx.x, sp = blockIdx.y;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int l15 = lane & 15, kq = lane >> 4;
+	const int rh = wave & 1, kp = wave >> 1;      // row half, piece of the slice
+
+	const int np = splits * 4, pidx = sp * 4 + kp;
+	const int s0 = (int)(((long)steps_total * pidx) / np);
+	const int s1 = (int)(((long)steps_total * (pidx + 1)) / np);
+	const int steps = s1 - s0;
+
+	f64x4 acc[4][4];
+#pragma unroll
+	for (int b = 0; b < 4; ++b)
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) acc[b][nb][g] = 0.0;
+
+	if (steps > 0) {
+		// lane (i, k): rows 64 rh + 4 i .. + 3 of the tile at y = 4 t + k; columns coff + 4 j .. + 3 of the panel
+		const double* ap = A + (long)xt * tile_stride + (long)(4 * s0 + kq) * F64_TH + 64 * rh + 4 * l15;
+		const double* fp = F + (long)(4 * s0 + kq) * RP + coff + 4 * l15;
+		const long astep = 4 * F64_TH, fstep = 4 * (long)RP;
+		const int last = steps - 1;
+		f64x4 va[D], fb[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int st = d < last ? d : last;
+			va[d] = *reinterpret_cast<const f64x4*>(ap + st * astep);
+			fb[d] = *reinterpret_cast<const f64x4*>(fp + st * fstep);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		int t = 0;
+		for (; t + D <= steps; t += D) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+#pragma unroll
+					for (int nb = 0; nb < 4; ++nb)
+						acc[b][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][b], fb[d][nb], acc[b][nb], 0, 0, 0);
+				int st = t + D + d;
+				st = st < last ? st : last;
+				va[d] = *reinterpret_cast<const f64x4*>(ap + st * astep);
+				fb[d] = *reinterpret_cast<const f64x4*>(fp + st * fstep);
+				__builtin_amdgcn_sched_barrier(0);      // refill right behind the MFMAs that consumed the slot
+			}
+		}
+		const int rem = steps - t;
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			if (d < rem) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+#pragma unroll
+					for (int nb = 0; nb < 4; ++nb)
+						acc[b][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][b], fb[d][nb], acc[b][nb], 0, 0, 0);
+			}
+		}
+	}
+
+	// ---- sum the four pieces of each row half through LDS, two row blocks (eight tiles) per round -------------
+	// LDS image of a round: [wave 8][tile 8 = (b in round 2) x (nb 4)][pair 2][lane 64] f64x2   (128 KiB)
+	// C/D map of the 16x16 fp64 MFMA (measured: tests/test_gpu_parity.py identity-layout check): register g of lane l is
+	// row (l >> 4) + 4 g, column l & 15.
+	f64x2* l2 = reinterpret_cast<f64x2*>(lds64);
+	double* slab = slabs + (long)sp * slab_stride;
+#pragma unroll
+	for (int rd = 0; rd < 2; ++rd) {
+		if (rd > 0) __syncthreads();
+#pragma unroll
+		for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+			for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+				for (int pr = 0; pr < 2; ++pr) {
+					f64x2 v;
+					v[0] = acc[2 * rd + bl][nb][2 * pr]; v[1] = acc[2 * rd + bl][nb][2 * pr + 1];
+					l2[(((wave * 8) + bl * 4 + nb) * 2 + pr) * 64 + lane] = v;
+				}
+		__syncthreads();
+		{
+			// wave w sums (row half w & 1, row block 2 rd + ((w >> 1) & 1), register pair w >> 2) for all four column blocks
+			const int orh = wave & 1, obl = (wave >> 1) & 1, opr = wave >> 2;
+			f64x2 sum[4];
+#pragma unroll
+			for (int nb = 0; nb < 4; ++nb) {
+				f64x2 s = l2[((((0 * 2 + orh) * 8) + obl * 4 + nb) * 2 + opr) * 64 + lane];
+#pragma unroll
+				for (int p = 1; p < 4; ++p) s += l2[((((p * 2 + orh) * 8) + obl * 4 + nb) * 2 + opr) * 64 + lane];
+				sum[nb] = s;
+			}
+			const int b = 2 * rd + obl;
+#pragma unroll
+			for (int gg = 0; gg < 2; ++gg) {
+				const int i = kq + 4 * (2 * opr + gg);                  // MFMA row of this value
+				const int x = xt * F64_TH + 64 * orh + 4 * i + b;
+				f64x4 o;
+				o[0] = sum[0][gg]; o[1] = sum[1][gg]; o[2] = sum[2][gg]; o[3] = sum[3][gg];
+				*reinterpret_cast<f64x4*>(slab + (long)x * RP + coff + 4 * l15) = o;
+			}
+		}
+	}
+}
+
+// Reduction length in K-steps of four y; as many slices as fill the CUs, at least 16 K-steps per wave piece.
+FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus) {
+	FactorProductPlan p;
+	p.th = F64_TH;
+	p.xtiles = (X + F64_TH - 1) / F64_TH;
+	p.steps_total = (Y + 3) / 4;
+	int max_splits = p.steps_total / (16 * 4);
+	if (max_splits < 1) max_splits = 1;
+	p.splits = std::max(1, std::min(num_cus / std::max(1, p.xtiles), max_splits));
+	p.nb = 4;
+	p.chunks = RP / 64;
+	return p;
+}
+
+// A: x-tiled image (launch_tile<double>, tile height 128, the reduction length padded to a multiple of 4 with zeros);
+// F: panel [y][RP]; slabs: plan.splits partial results, panel layout [x][RP].
+hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
+                                     double* slabs, long slab_stride, hipStream_t stream) {
+	constexpr int D = 6;
+	if (p.th != F64_TH || RP % 64 != 0) return hipErrorInvalidValue;
+	const size_t lds_bytes = 8 * 8 * 2 * 64 * sizeof(f64x2);
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	dim3 grid(p.xtiles, p.splits), block(512);
+	for (int ch = 0; ch < p.chunks; ++ch)
+		hipLaunchKernelGGL((k_factor_product_f64<D>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, ch * 64, slabs, slab_stride, p.steps_total, p.splits);
+	return hipGetLastError();
+}
+
+} // namespace nmfamd

@@ -206,11 +206,12 @@ def op_factor_product(A: np.ndarray, F: np.ndarray, use_valu: bool = False):
         if st != 0:
             raise EngineError(st, "nmfamd_op_factor_product_f32")
         return out, slabs.value
+    slabs = C.c_int(0)
     st = lib.nmfamd_op_factor_product_f64(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), X, Y, C.c_void_p(F.ctypes.data), C.c_long(_ld(F)), r,
-                                          C.c_void_p(out.ctypes.data), C.c_long(r))
+                                          C.c_void_p(out.ctypes.data), C.c_long(r), int(use_valu), C.byref(slabs))
     if st != 0:
         raise EngineError(st, "nmfamd_op_factor_product_f64")
-    return out, 1
+    return out, slabs.value
 
 
 def op_factor_product_bf16(A: np.ndarray, F: np.ndarray) -> np.ndarray:

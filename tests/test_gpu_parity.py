@@ -76,6 +76,35 @@ def test_factor_product_valu_and_fp64_paths():
     np.testing.assert_allclose(out64, F64 @ A64.T, rtol=1e-12)
 
 
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64), (300, 501, 100), (10000, 1203, 64)])
+def test_factor_product_fp64_mfma(X, Y, r):
+    """k_factor_product_f64 (v_mfma_f64_16x16x4_f64): operand lane maps, the interleaved row / column order of the four
+    tiles, K-steps of four y with ragged ends, the in-workgroup piece sum and the split-K slabs -- against numpy in
+    double (1e-13 relative to the absolute-value product: summation order only) and against the VALU kernel."""
+    rng = np.random.default_rng(X * 7 + Y)
+    A = F(rng.random((X, Y)) - 0.25); Fm = F(rng.random((r, Y)) - 0.4)
+    out, slabs = na.op_factor_product(A, Fm)
+    want = Fm @ A.T
+    bound = 1e-13 * (np.abs(Fm) @ np.abs(A).T) + 1e-300
+    assert (np.abs(out - want) <= bound).all()
+    assert slabs >= 1
+    ref, one = na.op_factor_product(A, Fm, use_valu=True)
+    assert one == 1
+    assert (np.abs(out - ref) <= 2 * bound).all()
+
+
+def test_factor_product_fp64_identity_layout_check():
+    """F = shifted identity picks single entries of A: any row / column permutation inside a tile shows up exactly."""
+    X, Y, r = 384, 256, 64
+    A = F(np.arange(X * Y, dtype=np.float64).reshape(X, Y) / 7.0)
+    Fm = F(np.zeros((r, Y)))
+    for c in range(r):
+        Fm[c, (5 * c + 3) % Y] = 1.0
+    out, _ = na.op_factor_product(A, Fm)
+    want = np.stack([A[:, (5 * c + 3) % Y] for c in range(r)])
+    assert np.array_equal(out, want)
+
+
 @pytest.mark.parametrize("r,length", [(8, 500), (64, 1000), (100, 333), (128, 777), (200, 1001), (256, 5000), (300, 640), (500, 333)])
 def test_gram(r, length):
     rng = np.random.default_rng(r)

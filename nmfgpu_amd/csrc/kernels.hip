@@ -751,6 +751,11 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 		if (use_wide_update(RP) && mode != MODE_SET)
 			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 	}
+	if constexpr (std::is_same<T, double>::value) {
+		// same 32 rows per workgroup as the generic kernel at this rank: the norm-partial count does not change
+		if (RP == 64 && mode != MODE_SET && std::getenv("NMFAMD_FORCE_VALU") == nullptr)
+			return launch_panel_update64_f64(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+	}
 	const int yb = panel_update_rows(RP, sizeof(T));
 	dim3 grid(len_pad / yb), block(256);
 	size_t smem = 2 * (size_t)yb * RP * sizeof(T);

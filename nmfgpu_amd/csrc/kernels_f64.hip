@@ -169,4 +169,128 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 	return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// panel update at padded rank 64 in double precision: slab reduction + r x r product on the fp64 MFMA pipe +
+// element-wise update + error / norm partial sums (semantics of k_panel_update, kernels.hip, MODE_MU / MODE_LS;
+// reference: symm/gemm + kernel::multiplyDivide, AlgorithmMultiplicativeFrobenius.h:181-191,235-244)
+// ------------------------------------------------------------------------------------------
+// Workgroup = 4 waves = 32 panel rows y, staged in LDS as [32][68] (coalesced global traffic both ways).
+// D(c, y) = sum_k Q(k, c) vec(y, k): wave w owns the 16 columns c = 16 w + i and both 16-row y tiles;
+//   A operand: lane (i = l & 15, kq = l >> 4) holds Q(4 t + kq, 16 w + i)  -- 128 contiguous bytes per kq, from L2;
+//   B operand: lane (j = l & 15, kq) holds vec(16 yt + j, 4 t + kq)        -- LDS;
+//   C/D: register g of lane (j, kq) is column c = 16 w + kq + 4 g of row y = 16 yt + j.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
+	double* __restrict__ P, const double* __restrict__ slabs, int S, long slab_stride,
+	const double* __restrict__ Q, double eps, double* __restrict__ ps, int len_valid,
+	double* __restrict__ sumsq_part, double* __restrict__ num_out) {
+	constexpr int YB = 32, LD = 68;
+	__shared__ __attribute__((aligned(16))) double s_num[YB * LD];
+	__shared__ __attribute__((aligned(16))) double s_old[YB * LD];      // old values, then the new ones
+	__shared__ double s_ps[4][YB];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int l15 = lane & 15, kq = lane >> 4;
+	const long base = (long)blockIdx.x * YB * 64;
+
+	// A operands of the whole product, requested next to the panel loads: one L2 latency
+	double qa[16];
+#pragma unroll
+	for (int t = 0; t < 16; ++t) qa[t] = Q[(long)(4 * t + kq) * 64 + 16 * wave + l15];
+
+	// numerator = sum of the split-K slabs (slab order), old panel values: four 16-byte pieces per thread and array
+	{
+		f64x2 num[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) num[i] = *reinterpret_cast<const f64x2*>(slabs + base + 2l * (tid + 256 * i));
+		if (MODE == PANEL_MU) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int e = tid + 256 * i, y = e >> 5, c2 = e & 31;
+				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+			}
+		}
+		for (int k = 1; k < S; ++k) {
+			f64x2 t[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f64x2*>(slabs + (long)k * slab_stride + base + 2l * (tid + 256 * i));
+#pragma unroll
+			for (int i = 0; i < 4; ++i) num[i] += t[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int e = tid + 256 * i, y = e >> 5, c2 = e & 31;
+			*reinterpret_cast<f64x2*>(s_num + y * LD + 2 * c2) = num[i];
+			if (num_out) *reinterpret_cast<f64x2*>(num_out + base + 2l * e) = num[i];
+		}
+	}
+	__syncthreads();
+
+	const double* vec = (MODE == PANEL_MU ? s_old : s_num) + l15 * LD + kq;
+	f64x4 acc[2];
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) acc[yt][g] = 0.0;
+#pragma unroll
+	for (int t = 0; t < 16; ++t) {
+		acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], vec[4 * t], acc[0], 0, 0, 0);
+		acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], vec[16 * LD + 4 * t], acc[1], 0, 0, 0);
+	}
+
+	double nv[2][4];
+	double psum[2] = {0.0, 0.0};
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const int off = (16 * yt + l15) * LD + 16 * wave + kq + 4 * g;
+			const double num = s_num[off];
+			double o;
+			if (MODE == PANEL_MU) o = s_old[off] * num / (acc[yt][g] + eps);
+			else o = acc[yt][g] > 0.0 ? acc[yt][g] : 0.0;
+			psum[yt] += o * num;
+			nv[yt][g] = o;
+		}
+	__syncthreads();      // every wave has finished reading the old values as B operands
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) s_old[(16 * yt + l15) * LD + 16 * wave + kq + 4 * g] = nv[yt][g];
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt) {
+		double v = psum[yt];
+		v += __shfl_xor(v, 16);
+		v += __shfl_xor(v, 32);
+		if (kq == 0) s_ps[wave][16 * yt + l15] = v;
+	}
+	__syncthreads();
+
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int e = tid + 256 * i, y = e >> 5, c2 = e & 31;
+		*reinterpret_cast<f64x2*>(P + base + 2l * e) = *reinterpret_cast<const f64x2*>(s_old + y * LD + 2 * c2);
+	}
+	if (ps != nullptr && tid < YB) {
+		const int y = blockIdx.x * YB + tid;
+		if (y < len_valid) ps[y] = ((s_ps[0][tid] + s_ps[1][tid]) + s_ps[2][tid]) + s_ps[3][tid];
+	}
+	if (sumsq_part != nullptr && tid < 64) {
+		double s = 0.0;
+#pragma unroll 8
+		for (int y = 0; y < YB; ++y) { const double v = s_old[y * LD + tid]; s += v * v; }
+		sumsq_part[(long)blockIdx.x * 64 + tid] = s;
+	}
+}
+
+hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
+                                     double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
+	if ((mode != PANEL_MU && mode != PANEL_LS) || len_pad % 32 != 0) return hipErrorInvalidValue;
+	dim3 grid(len_pad / 32), block(256);
+	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	else hipLaunchKernelGGL((k_panel_update64_f64<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	return hipGetLastError();
+}
+
 } // namespace nmfamd

@@ -149,7 +149,7 @@ Status Engine<T>::allocate() {
 	HIPX(dalloc(&HHt_, rr));
 	HIPX(dalloc(&Qinv_, rr));
 	HIPX(dalloc(&gram_part_, rr * gram_parts_));
-	HIPX(dalloc(&sumsq_part_, (mpad_ / panel_update_rows(RP_, sizeof(T)) + 16) * RP_));
+	HIPX(dalloc(&sumsq_part_, ((long)std::max(panel_update_parts(RP_, sizeof(T), (int)mpad_), (int)(mpad_ / panel_update_rows(RP_, sizeof(T)))) + 16) * RP_));
 	HIPX(dalloc(&psN_, std::max<long>(npad_, RP_)));
 	HIPX(dalloc(&psR_, RP_));
 	HIPX(dalloc(&stage_, std::max(mpad_, npad_) * RP_));

@@ -162,6 +162,11 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
                                      double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream);
 
+// fp64 / padded rank 128 ... 512: 16 panel rows per workgroup
+bool panel_update_wide_f64_available(int RP);
+hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
+                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream);
+
 // ---- bf16-operand factor product (kernels_bf16.hip) ------------------------------------------
 // Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and the factor
 // panel [y][RP] (RP = 64 or a multiple of 128; 16 * KS * RP / 32 * 64 bytes).

@@ -243,9 +243,10 @@ __global__ __launch_bounds__(512) void k_inverse_gj64(const T* __restrict__ A, i
 template <int XB, int D, bool STAMP, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long tile_stride,
-	const float* __restrict__ F, int RP, int coff,
+	const float* __restrict__ F, int RP,
 	float* __restrict__ slabs, long slab_stride,
 	int steps_total, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
+	const int coff = 64 * blockIdx.z;   // 64-column chunk of the panel (grid.z = RP / 64)
 	// XB = 32-row M-blocks per wave tile: 4 (128-row x-tiles) or 5 (160-row x-tiles; the fifth block
 	// is fed by an extra 4-byte load).  The plan picks the height that fills the 256 CUs best.
 	// STAMP: diagnostic build only (nmfamd_tune_factor_product): per-wave shader-clock and 100 MHz
@@ -461,13 +462,12 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 	if (wanted && rg->partials != nullptr && rg->inv_a != nullptr) return hipErrorInvalidValue;      // one kind of passenger per launch
 	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
-	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0)), block(512);
+	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), p.chunks), block(512);      // passengers only ever with one chunk (RP == 64)
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static unsigned long long lds_done = 0ull;
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	for (int ch = 0; ch < p.chunks; ++ch)
-		hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
-		                   A, tile_stride, F, RP, ch * 64, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
+	hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
+	                   A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
 
@@ -739,6 +739,7 @@ static bool use_wide_update(int RP) { return panel_update_wide_available(RP) && 
 int panel_update_parts(int RP, size_t elem, int len_pad) {
 	if (elem == 4 && RP == 64) return len_pad / 128;       // k_panel_update64_f32
 	if (elem == 4 && use_wide_update(RP)) return len_pad / 32;   // k_panel_update_wide_f32
+	if (elem == 8 && panel_update_wide_f64_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return len_pad / 16;   // k_panel_update_wide_f64
 	return len_pad / panel_update_rows(RP, elem);
 }
 
@@ -755,6 +756,8 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 		// same 32 rows per workgroup as the generic kernel at this rank: the norm-partial count does not change
 		if (RP == 64 && mode != MODE_SET && std::getenv("NMFAMD_FORCE_VALU") == nullptr)
 			return launch_panel_update64_f64(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+		if (panel_update_wide_f64_available(RP) && mode != MODE_SET && std::getenv("NMFAMD_FORCE_VALU") == nullptr)
+			return launch_panel_update_wide_f64(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 	}
 	const int yb = panel_update_rows(RP, sizeof(T));
 	dim3 grid(len_pad / yb), block(256);

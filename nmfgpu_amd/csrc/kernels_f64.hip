@@ -30,11 +30,12 @@ constexpr int F64_TH = 128;
 template <int D>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const double* __restrict__ A, long tile_stride,
-	const double* __restrict__ F, int RP, int coff,
+	const double* __restrict__ F, int RP,
 	double* __restrict__ slabs, long slab_stride,
 	int steps_total, int splits) {
 	extern __shared__ __attribute__((aligned(16))) double lds64[];
 	const int xt = blockIdx.x, sp = blockIdx.y;
+	const int coff = 64 * blockIdx.z;             // 64-column chunk of the panel (grid.z = RP / 64)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	const int l15 = lane & 15, kq = lane >> 4;
@@ -163,9 +164,8 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 	const size_t lds_bytes = 8 * 8 * 2 * 64 * sizeof(f64x2);
 	static unsigned long long lds_done = 0ull;
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	dim3 grid(p.xtiles, p.splits), block(512);
-	for (int ch = 0; ch < p.chunks; ++ch)
-		hipLaunchKernelGGL((k_factor_product_f64<D>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, ch * 64, slabs, slab_stride, p.steps_total, p.splits);
+	dim3 grid(p.xtiles, p.splits, p.chunks), block(512);
+	hipLaunchKernelGGL((k_factor_product_f64<D>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
 	return hipGetLastError();
 }
 
@@ -282,6 +282,159 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 		for (int y = 0; y < YB; ++y) { const double v = s_old[y * LD + tid]; s += v * v; }
 		sumsq_part[(long)blockIdx.x * 64 + tid] = s;
 	}
+}
+
+// The same at padded ranks 128 ... 512 (the reference's example program runs r = 158 in double): 16 panel rows per
+// workgroup as [16][RP + 4] LDS images, wave w owns the 16-column tiles ct = w, w + 4, ... (NCT of them); the A operand
+// (Q, RP x RP, L2-resident) comes through a register ring, the B operand is one LDS read per K-step shared by the
+// wave's NCT tiles.
+template <int MODE, int NCT>
+__global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
+	double* __restrict__ P, const double* __restrict__ slabs, int S, long slab_stride,
+	const double* __restrict__ Q, int RP, double eps, double* __restrict__ ps, int len_valid,
+	double* __restrict__ sumsq_part, double* __restrict__ num_out) {
+	extern __shared__ __attribute__((aligned(16))) double ldsw[];
+	constexpr int YB = 16;
+	const int LD = RP + 4;
+	double* s_num = ldsw;                  // [16][LD]
+	double* s_old = ldsw + YB * LD;        // [16][LD]
+	double* s_ps = s_old + YB * LD;        // [4][16]
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int l15 = lane & 15, kq = lane >> 4;
+	const long base = (long)blockIdx.x * YB * RP;
+	const int h2 = RP / 2;                 // 16-byte pieces per panel row
+	constexpr int NE = YB * 32 * NCT / 256;   // pieces per thread: 16 rows * (64 NCT / 2) / 256 threads = 2 NCT
+
+	{
+		f64x2 num[NE];
+#pragma unroll
+		for (int i = 0; i < NE; ++i) num[i] = *reinterpret_cast<const f64x2*>(slabs + base + 2l * (tid + 256 * i));
+		if (MODE == PANEL_MU) {
+#pragma unroll
+			for (int i = 0; i < NE; ++i) {
+				const int e = tid + 256 * i, y = e / h2, c2 = e - y * h2;
+				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+			}
+		}
+		for (int k = 1; k < S; ++k) {
+			f64x2 t[NE];
+#pragma unroll
+			for (int i = 0; i < NE; ++i) t[i] = *reinterpret_cast<const f64x2*>(slabs + (long)k * slab_stride + base + 2l * (tid + 256 * i));
+#pragma unroll
+			for (int i = 0; i < NE; ++i) num[i] += t[i];
+		}
+#pragma unroll
+		for (int i = 0; i < NE; ++i) {
+			const int e = tid + 256 * i, y = e / h2, c2 = e - y * h2;
+			*reinterpret_cast<f64x2*>(s_num + y * LD + 2 * c2) = num[i];
+			if (num_out) *reinterpret_cast<f64x2*>(num_out + base + 2l * e) = num[i];
+		}
+	}
+	__syncthreads();
+
+	const double* vec = (MODE == PANEL_MU ? s_old : s_num) + l15 * LD + kq;
+	f64x4 acc[NCT];
+#pragma unroll
+	for (int i = 0; i < NCT; ++i)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) acc[i][g] = 0.0;
+	const double* qp = Q + (long)kq * RP + 16 * wave + l15;      // + 4 t RP per K-step, + 64 i per tile
+	const int steps = RP / 4;                                     // multiple of 32
+	constexpr int D = 8;
+	double a[D][NCT], b[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		b[d] = vec[4 * d];
+#pragma unroll
+		for (int i = 0; i < NCT; ++i) a[d][i] = qp[(long)(4 * d) * RP + 64 * i];
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	for (int t = 0; t < steps; t += D) {
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+#pragma unroll
+			for (int i = 0; i < NCT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][i], b[d], acc[i], 0, 0, 0);
+			int tn = t + D + d;
+			tn = tn < steps ? tn : steps - 1;
+			b[d] = vec[4 * tn];
+#pragma unroll
+			for (int i = 0; i < NCT; ++i) a[d][i] = qp[(long)(4 * tn) * RP + 64 * i];
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+
+	double nv[NCT][4];
+	double psum = 0.0;
+#pragma unroll
+	for (int i = 0; i < NCT; ++i)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const int off = l15 * LD + 16 * (wave + 4 * i) + kq + 4 * g;
+			const double num = s_num[off];
+			double o;
+			if (MODE == PANEL_MU) o = s_old[off] * num / (acc[i][g] + eps);
+			else o = acc[i][g] > 0.0 ? acc[i][g] : 0.0;
+			psum += o * num;
+			nv[i][g] = o;
+		}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < NCT; ++i)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) s_old[l15 * LD + 16 * (wave + 4 * i) + kq + 4 * g] = nv[i][g];
+	psum += __shfl_xor(psum, 16);
+	psum += __shfl_xor(psum, 32);
+	if (kq == 0) s_ps[wave * YB + l15] = psum;
+	__syncthreads();
+
+#pragma unroll
+	for (int i = 0; i < NE; ++i) {
+		const int e = tid + 256 * i, y = e / h2, c2 = e - y * h2;
+		*reinterpret_cast<f64x2*>(P + base + 2l * e) = *reinterpret_cast<const f64x2*>(s_old + y * LD + 2 * c2);
+	}
+	if (ps != nullptr && tid < YB) {
+		const int y = blockIdx.x * YB + tid;
+		if (y < len_valid) ps[y] = ((s_ps[tid] + s_ps[YB + tid]) + s_ps[2 * YB + tid]) + s_ps[3 * YB + tid];
+	}
+	if (sumsq_part != nullptr) {
+		for (int c = tid; c < RP; c += 256) {
+			double s = 0.0;
+#pragma unroll
+			for (int y = 0; y < YB; ++y) { const double v = s_old[y * LD + c]; s += v * v; }
+			sumsq_part[(long)blockIdx.x * RP + c] = s;
+		}
+	}
+}
+
+bool panel_update_wide_f64_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= 512; }
+
+template <int MODE, int NCT>
+static hipError_t launch_wide_f64(double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
+                                  double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
+	const size_t lds_bytes = sizeof(double) * (2 * 16 * (size_t)(RP + 4) + 64);
+	const size_t max_bytes = sizeof(double) * (2 * 16 * (size_t)(64 * NCT + 4) + 64);
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f64<MODE, NCT>), (int)max_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT>), dim3(len_pad / 16), dim3(256), lds_bytes, stream,
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);
+	return hipGetLastError();
+}
+
+// 16 panel rows per workgroup: len_pad / 16 norm partials (panel_update_parts, kernels.hip, knows)
+hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
+                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
+	if (!panel_update_wide_f64_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % 16 != 0) return hipErrorInvalidValue;
+#define NMFAMD_WIDE64(NCT)                                                                                                                       \
+	return mode == PANEL_MU ? launch_wide_f64<PANEL_MU, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream) \
+	                        : launch_wide_f64<PANEL_LS, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream)
+	switch (RP / 128) {
+	case 1: NMFAMD_WIDE64(2);
+	case 2: NMFAMD_WIDE64(4);
+	case 3: NMFAMD_WIDE64(6);
+	default: NMFAMD_WIDE64(8);
+	}
+#undef NMFAMD_WIDE64
 }
 
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,

@@ -776,3 +776,21 @@ def test_device_introspection_and_selection():
     # the library still computes on the selected device afterwards
     V, W, H = problem(64, 40, 4, np.float32, seed=3)
     assert na.compute(V, W, H, iterations=5) == na.ResultType.Success
+
+
+@pytest.mark.parametrize("alg,r,kw", [("mu", 100, {}), ("nsnmf", 158, dict(theta=0.5)), ("mu", 300, {}), ("acls", 400, dict(lambda_w=1.0, lambda_h=1.0)),
+                                      ("gdcls", 130, dict(lam=0.05))])
+def test_double_precision_wide_panels(alg, r, kw):
+    """fp64 at padded ranks 128 ... 512: chunked fp64 MFMA product (one launch, grid.z = chunks) and k_panel_update_wide_f64.
+    nsNMF at r = 158 in double is the configuration of the reference's example program (ref example/main.cpp:30-32,130)."""
+    m, n, iters = 700, 610, 10
+    V, W, H = problem(m, n, r, np.float64, seed=29)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    ref = oracle.run(alg, V, Wo, Ho, iters, **kw)
+    eng = na.Engine(m, n, r, alg, dtype=np.float64, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    tol = 1e-9 if alg in ("mu", "nsnmf") else 1e-6
+    assert rel(Wg, Wo) < tol and rel(Hg, Ho) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=tol)

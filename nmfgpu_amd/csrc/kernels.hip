@@ -640,6 +640,7 @@ hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G,
 		if (gram_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return launch_gram_wide_f32(P, RP, len, parts, partial, G, stream);
 	}
 	int blocks = RP / 64; // RP is a multiple of 64
+	parts = std::max(1, std::min(parts, std::max(1, len / 64)));      // short panels: fewer, longer slices (less partial traffic)
 	hipLaunchKernelGGL((k_gram_partial<T>), dim3(parts, blocks, blocks), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;

@@ -258,7 +258,7 @@ hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int
 // columns; every workgroup re-derives the RP norms from the partial sums (fixed order).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, int RP, const T* __restrict__ sumsq_part, int parts) {
+__global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, int RP, const T* __restrict__ sumsq_part, int parts, int rows) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	T* s_norm = reinterpret_cast<T*>(smem_raw);        // [RP]
 	T* s_grp = s_norm + RP;                            // [4][RP]
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, i
 		s_norm[c] = s > T(0) ? (T)sqrt(s) : T(0);
 	}
 	__syncthreads();
-	// 128 panel columns x RP rows, four elements per thread and step, eight steps in flight
-	const long base = (long)blockIdx.x * 128 * RP;
-	const int quads = 128 * RP / 4;
+	// `rows` panel rows x RP values, four elements per thread and step, eight steps in flight
+	const long base = (long)blockIdx.x * rows * RP;
+	const int quads = rows * RP / 4;
 	for (int e0 = threadIdx.x; e0 < quads; e0 += 256 * 8) {
 		T v[8][4];
 #pragma unroll
@@ -340,13 +340,15 @@ __global__ __launch_bounds__(256) void k_compact_partials(const T* __restrict__ 
 template <typename T>
 hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, int parts, hipStream_t stream) {
 	const T* src = sumsq_part;
-	if (parts > 16 * NORM_GROUPS) {
+	if (parts > 8 * NORM_GROUPS) {
 		T* compact = sumsq_part + (long)parts * RP;
 		hipLaunchKernelGGL((k_compact_partials<T>), dim3(RP / 64, NORM_GROUPS), dim3(256), 0, stream, sumsq_part, parts, RP, compact);
 		src = compact;
 		parts = NORM_GROUPS;
 	}
-	hipLaunchKernelGGL((k_normalize_panel_v2<T>), dim3(len_pad / 128), dim3(256), 5 * RP * sizeof(T), stream, P, RP, src, parts);
+	// short panels: 32 rows per workgroup so that the pass is spread over more than a handful of CUs
+	const int rows = len_pad / 128 >= 256 ? 128 : 32;
+	hipLaunchKernelGGL((k_normalize_panel_v2<T>), dim3(len_pad / rows), dim3(256), 5 * RP * sizeof(T), stream, P, RP, src, parts, rows);
 	return hipGetLastError();
 }
 template hipError_t launch_normalize_panel_v2<float>(float*, int, int, float*, int, hipStream_t);

@@ -101,7 +101,9 @@ template hipError_t launch_spmm_rows<double>(const int*, const int*, const doubl
 // covers RP/16 contiguous factor rows of the dot product (one gathered panel row = one coalesced
 // access of the group) and the dot is finished with four butterfly steps inside the group.
 // Fixed summation order: lane segments, then the butterfly, then groups 0..3.
-template <typename T, int VEC>
+// TERMS = false: quotients only (every iteration needs those; the double-precision logarithm of the divergence term
+// on one lane in sixteen was half of the kernel's time).
+template <typename T, int VEC, bool TERMS>
 __global__ __launch_bounds__(256) void k_sddmm_quotient(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                                         const T* __restrict__ A, const T* __restrict__ B, T eps,
                                                         T* __restrict__ q, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows) {
@@ -131,33 +133,45 @@ __global__ __launch_bounds__(256) void k_sddmm_quotient(const int* __restrict__ 
 			if (va) {
 				const T v = val[pa];
 				q[pa] = v / (da + eps);
-				s_vwh += v * da;
-				if (v > T(0)) s_kl += v * (T)log((double)v / (double)(da + eps));
+				if (TERMS) {
+					s_vwh += v * da;
+					if (v > T(0)) s_kl += v * (T)log((double)v / (double)(da + eps));
+				}
 			}
 			if (vb) {
 				const T v = val[pb];
 				q[pb] = v / (db + eps);
-				s_vwh += v * db;
-				if (v > T(0)) s_kl += v * (T)log((double)v / (double)(db + eps));
+				if (TERMS) {
+					s_vwh += v * db;
+					if (v > T(0)) s_kl += v * (T)log((double)v / (double)(db + eps));
+				}
 			}
 		}
 	}
+	if (!TERMS) return;
 	// group partials sit in lanes 0, 16, 32, 48
 	const T v0 = __shfl(s_vwh, 0), v1 = __shfl(s_vwh, 16), v2 = __shfl(s_vwh, 32), v3 = __shfl(s_vwh, 48);
 	const T k0 = __shfl(s_kl, 0), k1 = __shfl(s_kl, 16), k2 = __shfl(s_kl, 32), k3 = __shfl(s_kl, 48);
 	if (lane == 0) { t_vwh[row] = ((v0 + v1) + v2) + v3; t_kl[row] = ((k0 + k1) + k2) + k3; }
 }
 
+// t_vwh == nullptr: no per-row error terms (quotients only)
 template <typename T>
 hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
                                  T* q, T* t_vwh, T* t_kl, int rows, hipStream_t stream) {
 	dim3 grid((rows + 3) / 4), block(256);
+	const bool terms = t_vwh != nullptr && t_kl != nullptr;
+#define NMFAMD_SDDMM(VEC)                                                                                                                  \
+	if (terms) hipLaunchKernelGGL((k_sddmm_quotient<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); \
+	else hipLaunchKernelGGL((k_sddmm_quotient<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows);      \
+	break
 	switch (RP / 64) {
-	case 1: hipLaunchKernelGGL((k_sddmm_quotient<T, 1>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
-	case 2: hipLaunchKernelGGL((k_sddmm_quotient<T, 2>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
-	case 4: hipLaunchKernelGGL((k_sddmm_quotient<T, 4>), grid, block, 0, stream, ptr, idx, val, A, B, eps, q, t_vwh, t_kl, rows); break;
+	case 1: NMFAMD_SDDMM(1);
+	case 2: NMFAMD_SDDMM(2);
+	case 4: NMFAMD_SDDMM(4);
 	default: return hipErrorInvalidValue;
 	}
+#undef NMFAMD_SDDMM
 	return hipGetLastError();
 }
 template hipError_t launch_sddmm_quotient<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, hipStream_t);

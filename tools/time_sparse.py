@@ -7,12 +7,12 @@ import scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nmfgpu_amd as na
 
-m, n, r = 100000, 20000, 128
+m, n, r = 100000, int(os.environ.get("SPARSE_N", 20000)), 128
 rng = np.random.default_rng(1)
 t0 = time.perf_counter()
 # fast generator: every row gets k = 1 % of n distinct columns (an arithmetic progression modulo n with a stride
 # coprime to n and a random start), values uniform in {1..5} (ratings-like)
-k = n // 100
+k = int(os.environ.get("SPARSE_K", n // 100))
 start = rng.integers(0, n, size=m)
 cols = np.sort((start[:, None] + 7919 * np.arange(k)[None, :]) % n, axis=1).astype(np.int32)
 vals = rng.integers(1, 6, size=m * k).astype(np.float32)

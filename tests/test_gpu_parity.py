@@ -76,7 +76,8 @@ def test_factor_product_valu_and_fp64_paths():
     np.testing.assert_allclose(out64, F64 @ A64.T, rtol=1e-12)
 
 
-@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64), (300, 501, 100), (10000, 1203, 64)])
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64), (300, 501, 100), (10000, 1203, 64),
+                                   (129, 1, 64), (5, 7, 3), (300, 20, 256), (64, 3, 130)])
 def test_factor_product_fp64_mfma(X, Y, r):
     """k_factor_product_f64 (v_mfma_f64_16x16x4_f64): operand lane maps, the interleaved row / column order of the four
     tiles, K-steps of four y with ragged ends, the in-workgroup piece sum and the split-K slabs -- against numpy in
@@ -630,7 +631,8 @@ def _round_bf16(a):
 
 
 @pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64),
-                                   (300, 500, 100), (1000, 3000, 128), (257, 1111, 256), (40000, 700, 256), (640, 4100, 300)])
+                                   (300, 500, 100), (1000, 3000, 128), (257, 1111, 256), (40000, 700, 256), (640, 4100, 300),
+                                   (300, 20, 256), (130, 5, 200), (129, 1, 256), (64, 33, 128), (5, 7, 3)])
 def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
     """Fragment order, lane maps and the K-step bookkeeping: the result must be the fp32-accumulated
     product of the bf16-ROUNDED operands (products of bf16 values are exact in fp32)."""

@@ -164,6 +164,7 @@ NMFAMD_API int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us
 NMFAMD_API int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo);
 /* G (r x r) = P P^T for a host r x len matrix P. */
 NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg);
+NMFAMD_API int nmfamd_op_gram_f64(const double* P, long ldp, int r, int len, double* G, long ldg);
 /* Ainv = (A + regulariser)^-1 for a host r x r matrix (offdiag / diag added as KernelFillMatrix.cu:29-45). */
 NMFAMD_API int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float diag, float* Ainv, long ldi);
 /* Test access to an engine's device intermediates in panel layout: which = 0 Wt, 1 H, 2 W^T W,

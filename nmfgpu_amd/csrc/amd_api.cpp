@@ -331,6 +331,19 @@ int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long 
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
+int nmfamd_op_gram_f64(const double* P, long ldp, int r, int len, double* G, long ldg) {
+	if (!P || !G || r <= 0 || len <= 0 || ldp < r || ldg < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r), parts = 128;
+	const long lp = pad128(len);
+	DevBuf dP, dPart, dG;
+	if (dP.alloc(sizeof(double) * RP * lp) != hipSuccess || dPart.alloc(sizeof(double) * (size_t)RP * RP * parts) != hipSuccess || dG.alloc(sizeof(double) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dP.p, RP * sizeof(double), P, ldp * sizeof(double), r * sizeof(double), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_gram<double>((const double*)dP.p, RP, len, parts, (double*)dPart.p, (double*)dG.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(G, ldg * sizeof(double), dG.p, RP * sizeof(double), r * sizeof(double), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
 int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float diag, float* Ainv, long ldi) {
 	if (!A || !Ainv || r <= 0 || lda < r || ldi < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;

@@ -162,6 +162,8 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
                                      double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream);
 
+// fp64 Gram matrix on the MFMA pipe (padded rank 64 or k * 128)
+hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* partial, double* G, hipStream_t stream);
 // fp64 / padded rank 128 ... 512: 16 panel rows per workgroup
 bool panel_update_wide_f64_available(int RP);
 hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,

@@ -446,4 +446,103 @@ hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, i
 	return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Gram matrix G = P P^T of a panel in double precision on the fp64 MFMA pipe (any padded rank: 64, k * 128)
+// (reference: Dsyrk / Dgemm for W^T W and H H^T, AlgorithmMultiplicativeFrobenius.h:168-178,208-209)
+// ------------------------------------------------------------------------------------------
+// Workgroup = 4 waves = one 128 x 128 super-block (I <= J; 64 x 64 when RP = 64) over one slice of y; a wave owns a
+// 64 x 64 (32 x 32) quarter as 4 x 4 (2 x 2) tiles of 16 x 16.  K-step = 4 panel rows; rows / columns of the tiles are
+// interleaved (c = base + NT i + a), so a lane's operands are NT contiguous doubles.  Mirrored writes for I < J,
+// slices summed in order by k_reduce_partials.
+template <int NT, int D>      // NT = tiles per wave and direction: 4 (RP >= 128) or 2 (RP = 64)
+__global__ __launch_bounds__(256, 2) void k_gram_f64(const double* __restrict__ P, int RP, int len, int parts, double* __restrict__ partial) {
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int l15 = lane & 15, kq = lane >> 4;
+	constexpr int Q = 16 * NT;          // quarter edge: 64 or 32
+	const int nb = RP / (2 * Q);
+	int I = 0, rem = blockIdx.y;
+	while (rem >= nb - I) { rem -= nb - I; ++I; }
+	const int J = I + rem;
+	const int ca = 2 * Q * I + Q * (wave >> 1), cb = 2 * Q * J + Q * (wave & 1);
+	const int steps_total = (len + 3) / 4;
+	const int s0 = (int)(((long)steps_total * blockIdx.x) / parts);
+	const int s1 = (int)(((long)steps_total * (blockIdx.x + 1)) / parts);
+	const int steps = s1 - s0;
+	typedef double vecn __attribute__((ext_vector_type(NT)));
+
+	f64x4 acc[NT][NT];
+#pragma unroll
+	for (int a = 0; a < NT; ++a)
+#pragma unroll
+		for (int b = 0; b < NT; ++b)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) acc[a][b][g] = 0.0;
+
+	if (steps > 0) {
+		const double* pa = P + ((long)4 * s0 + kq) * RP + ca + NT * l15;
+		const double* pb = P + ((long)4 * s0 + kq) * RP + cb + NT * l15;
+		const long step = 4 * (long)RP;
+		const int last = steps - 1;
+		vecn va[D], vb[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int t = d < last ? d : last;
+			va[d] = *reinterpret_cast<const vecn*>(pa + t * step);
+			vb[d] = *reinterpret_cast<const vecn*>(pb + t * step);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		int t = 0;
+		for (; t + D <= steps; t += D) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+#pragma unroll
+				for (int a = 0; a < NT; ++a)
+#pragma unroll
+					for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+				int tn = t + D + d;
+				tn = tn < last ? tn : last;
+				va[d] = *reinterpret_cast<const vecn*>(pa + tn * step);
+				vb[d] = *reinterpret_cast<const vecn*>(pb + tn * step);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		const int remn = steps - t;
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			if (d < remn) {
+#pragma unroll
+				for (int a = 0; a < NT; ++a)
+#pragma unroll
+					for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+			}
+		}
+	}
+	// C/D map: register g of lane (j = l & 15, kq) is tile row i = kq + 4 g, tile column j
+	double* out = partial + (long)blockIdx.x * RP * RP;
+#pragma unroll
+	for (int a = 0; a < NT; ++a)
+#pragma unroll
+		for (int b = 0; b < NT; ++b)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const int r = ca + NT * (kq + 4 * g) + a;
+				const int c = cb + NT * l15 + b;
+				out[(long)r * RP + c] = acc[a][b][g];
+				if (I != J) out[(long)c * RP + r] = acc[a][b][g];
+			}
+}
+
+// len: valid panel rows (rows behind them up to the padded length are zero); partial: parts * RP * RP elements of scratch
+hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* partial, double* G, hipStream_t stream) {
+	if (RP != 64 && RP % 128 != 0) return hipErrorInvalidValue;
+	const int nb = RP == 64 ? 1 : RP / 128, nsuper = nb * (nb + 1) / 2;
+	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
+	if (RP == 64) hipLaunchKernelGGL((k_gram_f64<2, 8>), dim3(parts, 1), dim3(256), 0, stream, P, RP, len, parts, partial);
+	else hipLaunchKernelGGL((k_gram_f64<4, 6>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return launch_reduce_partials<double>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
+}
+
 } // namespace nmfamd

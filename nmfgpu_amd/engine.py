@@ -230,10 +230,11 @@ def op_factor_product_bf16(A: np.ndarray, F: np.ndarray) -> np.ndarray:
 def op_gram(P: np.ndarray) -> np.ndarray:
     P = _f(P)
     r, length = P.shape
-    G = np.zeros((r, r), dtype=np.float32, order="F")
-    st = library().nmfamd_op_gram_f32(C.c_void_p(P.ctypes.data), C.c_long(_ld(P)), r, length, C.c_void_p(G.ctypes.data), C.c_long(r))
+    G = np.zeros((r, r), dtype=P.dtype, order="F")
+    fn = library().nmfamd_op_gram_f32 if P.dtype == np.float32 else library().nmfamd_op_gram_f64
+    st = fn(C.c_void_p(P.ctypes.data), C.c_long(_ld(P)), r, length, C.c_void_p(G.ctypes.data), C.c_long(r))
     if st != 0:
-        raise EngineError(st, "nmfamd_op_gram_f32")
+        raise EngineError(st, "nmfamd_op_gram")
     return G
 
 

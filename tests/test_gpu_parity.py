@@ -115,6 +115,16 @@ def test_gram(r, length):
     assert np.array_equal(G, G.T)
 
 
+@pytest.mark.parametrize("r,length", [(8, 500), (64, 1000), (64, 3), (100, 333), (158, 4096), (256, 5000), (300, 641), (500, 333)])
+def test_gram_fp64_mfma(r, length):
+    rng = np.random.default_rng(r + 1)
+    P = F(rng.random((r, length)) - 0.3)
+    G = na.op_gram(P)
+    want = P @ P.T
+    assert (np.abs(G - want) <= 1e-13 * (np.abs(P) @ np.abs(P).T) + 1e-300).all()
+    assert np.array_equal(G, G.T)
+
+
 @pytest.mark.parametrize("r", [3, 8, 64])
 def test_inverse_small(r):
     rng = np.random.default_rng(r)

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
+    ap.add_argument("--rccl1", action="store_true", help="with --sharded at N = 1: one-rank RCCL group, the all-reduce / all-gather are issued for real (identities): "
+                                                         "the fixed cost of the collective calls on one GPU")
     ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands)")
     args = ap.parse_args()
@@ -92,6 +94,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=args.backend)
+    elif args.sharded and args.rccl1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", device_index))
 
     V, W, H = make_problem(rank)
     K, Wm = args.steps, args.warmup
@@ -124,7 +130,14 @@ def main():
     else:
         from nmfgpu_amd.distributed import EngineShard, ShardedMU
         shard = EngineShard(V, W, H)
-        drv = ShardedMU(shard, total_columns=N_COLS * world, rows=M)
+        drv = ShardedMU(shard, total_columns=N_COLS * world, rows=M, force_collectives=args.rccl1)
+        # set-up, not steps: the first collectives of a process group, the pinned landing buffers of the error terms and
+        # the first launches of every kernel are one-time costs, and with a collective in the loop the iteration time keeps
+        # falling for the first ~150 iterations (tools/time_sharded_profile.py: 223, 171, 165, 160, ... 152 us per block of
+        # 20); run through that before the factors are (re)set to W0, H0.  Same count on every rank.
+        drv.run(240 if (distributed or args.rccl1) else 30, first_iteration=1, error_every=10)
+        shard.synchronize()
+        shard.engine.set_factors(W, H)
         drv.run(Wm, first_iteration=1, error_every=10)
         shard.synchronize()
         if not args.no_kernel_events:
@@ -161,6 +174,8 @@ def main():
                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                         "kernel": "k_factor_product_f32", "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
                         "flops_per_launch": flops_per_launch}
+        if args.rccl1 and not distributed:
+            parallelism += " (one-rank RCCL group: collectives issued, identities)"
         out = {
             "metric": "NMF MU iterations/sec, dense 10kx5k r=64",
             "value": world * K / elapsed,
@@ -177,7 +192,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, W, H)
         print(json.dumps(out), flush=True)
-    if distributed:
+    if distributed or (args.sharded and args.rccl1):
         dist.destroy_process_group()
 
 
@@ -205,6 +220,9 @@ def main_c4(args):
     K, Wm = args.steps, args.warmup
     shard = EngineShard(V, W, H, algorithm="nsnmf", theta=theta, precision="bf16")
     drv = ShardedMU(shard, total_columns=n * world, rows=m)
+    drv.run(12, first_iteration=1, error_every=10)      # set-up (one-time costs), then back to W0, H0
+    shard.synchronize()
+    shard.engine.set_factors(W, H)
 
     def barrier():
         if distributed:

@@ -86,13 +86,16 @@ class EngineShard:
 class ShardedMU:
     """Drives one backend per rank through the sharded iteration; `dist` is torch.distributed."""
 
-    def __init__(self, backend, total_columns: int, rows: int, group=None):
+    def __init__(self, backend, total_columns: int, rows: int, group=None, force_collectives: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.backend = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: issue the all-reduce / all-gather even in a one-rank group (they are identities there);
+        # lets a single-GPU box exercise the RCCL calls, their stream ordering against the engine's kernels included
+        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
         self.total_elements = int(np.uint32(rows) * np.uint32(total_columns))  # the reference multiplies unsigned ints
         self._frobenius = 0.0
         self._rmsd = 0.0
@@ -128,7 +131,7 @@ class ShardedMU:
     def _launch_error_gather(self):
         torch, dist, b = self.torch, self.dist, self.backend
         loc, n_local, r = b.error_terms_async()
-        if self.world > 1:
+        if self.collectives:
             out = torch.empty(self.world * loc.numel(), dtype=loc.dtype, device=loc.device)
             dist.all_gather(list(out.chunk(self.world)), loc, group=self.group)
         else:
@@ -146,7 +149,7 @@ class ShardedMU:
 
     def _all_gather_host(self, local: np.ndarray) -> np.ndarray:
         """Gathers equally sized host vectors of every rank (error iterations only)."""
-        if self.world == 1:
+        if not self.collectives:
             return local
         torch, dist = self.torch, self.dist
         t = torch.from_numpy(np.ascontiguousarray(local))
@@ -161,7 +164,7 @@ class ShardedMU:
         b = self.backend
         b.h_step(compute_error)
         b.w_products()
-        if self.world > 1:
+        if self.collectives:
             self.dist.all_reduce(b.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
         b.w_finish(compute_error)
         if compute_error:

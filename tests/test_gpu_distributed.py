@@ -93,3 +93,44 @@ def test_sharded_engine_two_ranks_on_one_gpu(tmp_path, alg, r, theta, precision,
         assert _rel(o["H"], H64[:, k * per:(k + 1) * per]) < tol
         assert float(o["frob"]) == pytest.approx(ref["frobenius"], rel=1e-5 if precision == "native" else 2e-3)
     assert np.array_equal(outs[0]["W"], outs[1]["W"])   # replicas bit-identical
+
+
+def _rccl_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from nmfgpu_amd.distributed import EngineShard, ShardedMU
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    for alg, r, theta, precision in (("mu", 64, 0.0, "native"), ("nsnmf", 200, 0.4, "native"), ("nsnmf", 256, 0.5, "bf16")):
+        V, W, H = _problem(640, 512, r)
+        shard = EngineShard(V, W, H, algorithm=alg, theta=theta, precision=precision)
+        drv = ShardedMU(shard, total_columns=512, rows=640, force_collectives=True)
+        drv.run(20, first_iteration=1, error_every=10, last_iteration=20)
+        Wg, Hg = shard.factors()
+        res[f"{alg}{r}{precision}"] = (Wg, Hg, drv.frobenius)
+    dist.barrier()
+    np.savez(os.path.join(out_dir, "rccl.npz"), **{k + "_W": v[0] for k, v in res.items()}, **{k + "_H": v[1] for k, v in res.items()},
+             **{k + "_f": np.array(v[2]) for k, v in res.items()})
+    dist.destroy_process_group()
+
+
+def test_sharded_engine_through_rccl_single_rank(tmp_path):
+    """backend "nccl" (= RCCL) with a one-rank group on the box's GPU: the all-reduce of the exchange buffer and the
+    all-gather of the error terms are issued for real (identities at world size 1), stream-ordered against the engine's
+    kernels exactly as in a multi-GPU run.  What a 1-GPU box can prove about the RCCL path."""
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = np.load(tmp_path / "rccl.npz")
+    for alg, r, theta, precision, tol in (("mu", 64, 0.0, "native", 2e-4), ("nsnmf", 200, 0.4, "native", 2e-4), ("nsnmf", 256, 0.5, "bf16", 2e-2)):
+        V, W, H = _problem(640, 512, r)
+        V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+        ref = oracle.run(alg, V64, W64, H64, 20, theta=theta)
+        key = f"{alg}{r}{precision}"
+        assert _rel(out[key + "_W"], W64) < tol and _rel(out[key + "_H"], H64) < tol
+        assert float(out[key + "_f"]) == pytest.approx(ref["frobenius"], rel=1e-5 if precision == "native" else 2e-3)

@@ -104,7 +104,15 @@ def _rccl_worker(rank, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:      # an environment that cannot bring up RCCL at all is a skip, not a failure of the code under test
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        probe = torch.ones(8, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as exc:      # noqa: BLE001
+        with open(os.path.join(out_dir, "skip.txt"), "w") as f:
+            f.write(repr(exc))
+        return
     res = {}
     for alg, r, theta, precision in (("mu", 64, 0.0, "native"), ("nsnmf", 200, 0.4, "native"), ("nsnmf", 256, 0.5, "bf16")):
         V, W, H = _problem(640, 512, r)
@@ -126,6 +134,8 @@ def test_sharded_engine_through_rccl_single_rank(tmp_path):
     import torch.multiprocessing as mp
     from oracle import oracle
     mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    if (tmp_path / "skip.txt").exists():
+        pytest.skip("RCCL process group could not be created here: " + (tmp_path / "skip.txt").read_text())
     out = np.load(tmp_path / "rccl.npz")
     for alg, r, theta, precision, tol in (("mu", 64, 0.0, "native", 2e-4), ("nsnmf", 200, 0.4, "native", 2e-4), ("nsnmf", 256, 0.5, "bf16", 2e-2)):
         V, W, H = _problem(640, 512, r)

@@ -806,3 +806,73 @@ def test_double_precision_wide_panels(alg, r, kw):
     tol = 1e-9 if alg in ("mu", "nsnmf") else 1e-6
     assert rel(Wg, Wo) < tol and rel(Hg, Ho) < tol
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=tol)
+
+
+# ------------------------------------------------------------------ seeded sweep over shapes / algorithms / number types
+
+def _sweep_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    alg = ["mu", "mu", "nsnmf", "gdcls", "acls", "ahcls"][seed % 6]
+    dtype = np.float64 if seed % 3 == 0 else np.float32
+    m = int(rng.integers(1, 700)); n = int(rng.integers(1, 700))
+    r = int(rng.integers(1, 150 if alg in ("mu", "nsnmf") else 24))
+    kw = {"mu": {}, "nsnmf": dict(theta=float(rng.uniform(0.1, 0.9))), "gdcls": dict(lam=0.3), "acls": dict(lambda_w=0.5, lambda_h=0.5),
+          "ahcls": dict(lambda_w=0.5, lambda_h=0.5, alpha_w=0.3, alpha_h=0.3)}[alg]
+    precision = "bf16" if (dtype == np.float32 and seed % 5 == 4 and alg in ("mu", "nsnmf")) else "native"
+    return alg, dtype, m, n, r, kw, precision
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_seeded_sweep_matches_oracle(seed):
+    """Ragged shapes (down to a single row / column), ranks on both sides of every padding boundary, all number types:
+    five iterations against the oracle.  Catches indexing slips the hand-picked shapes do not."""
+    alg, dtype, m, n, r, kw, precision = _sweep_case(seed)
+    V, W, H = problem(m, n, r, dtype, seed=seed)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, 5, **kw)
+    eng = na.Engine(m, n, r, alg, dtype=dtype, precision=precision, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(5, first_iteration=1, error_every=10, last_iteration=5)
+    Wg, Hg = eng.get_factors()
+    if precision == "bf16":
+        tol = 2e-2
+    elif dtype == np.float64:
+        tol = 1e-9 if alg in ("mu", "nsnmf") else 1e-6
+    else:
+        tol = 2e-4 if alg in ("mu", "nsnmf") else 3e-3
+    assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol, (alg, dtype, m, n, r, precision)
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6), abs=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_seeded_sweep_sparse_paths(seed):
+    """Sparse compute (CSR + CSC images, SpMM / SDDMM) over ragged shapes, densities, the three sparse formats, both index
+    bases, both objectives and both number types: against the oracle on the dense equivalent (Frobenius) / the literature
+    formula (KL)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(500 + seed)
+    dtype = np.float64 if seed % 4 == 0 else np.float32
+    m = int(rng.integers(2, 500)); n = int(rng.integers(2, 500)); r = int(rng.integers(1, 200))
+    density = float(rng.uniform(0.02, 0.4))
+    kl = seed % 2 == 1
+    D, W, H = _sparse_problem(m, n, r, density, dtype, seed=seed)
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W, H))
+    ref = oracle.run_kl(D64, W64, H64, 6) if kl else oracle.run("mu", D64, W64, H64, 6)
+    fmt, base = 1 + seed % 3, (seed // 3) % 2
+    if fmt == 1:
+        s = sp.csr_matrix(D); vals, a, b = s.data, s.indptr + base, s.indices + base
+    elif fmt == 2:
+        s = sp.csc_matrix(D); vals, a, b = s.data, s.indptr + base, s.indices + base
+    else:
+        s = sp.coo_matrix(D); vals, a, b = s.data, s.row + base, s.col + base
+    eng = na.Engine(m, n, r, "mu", dtype=dtype, divergence="kl" if kl else "frobenius", sparse_compute=True)
+    eng.upload_sparse(fmt, vals, a, b, base)
+    eng.set_factors(W, H)
+    eng.iterate(6, last_iteration=6)
+    Wg, Hg = eng.get_factors()
+    tol = 1e-9 if dtype == np.float64 else 3e-4
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol, (m, n, r, density, fmt, base, kl)
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6), abs=1e-9)
+    if kl:
+        assert eng.kl_divergence == pytest.approx(ref["kl"], rel=max(30 * tol, 1e-6), abs=1e-6)

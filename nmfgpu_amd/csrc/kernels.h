@@ -100,6 +100,9 @@ int panel_update_parts(int RP, size_t elem, int len_pad);
 hipError_t launch_gram64_f32(const float* P, int len, int parts, float* partial, float* G, hipStream_t stream);
 hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
                                      float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
+// fp32 / padded rank 64, LDS-staged (kernels_wide.hip): 64 panel rows per workgroup
+hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
+                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
 // fp32 / padded rank 128 ... 512 (kernels_wide.hip)
 bool panel_update_wide_available(int RP);
 bool gram_wide_available(int RP);

@@ -741,7 +741,7 @@ int panel_update_rows(int RP, size_t elem) {
 static bool use_wide_update(int RP) { return panel_update_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr; }
 
 int panel_update_parts(int RP, size_t elem, int len_pad) {
-	if (elem == 4 && RP == 64) return len_pad / 128;       // k_panel_update64_f32
+	if (elem == 4 && RP == 64) return std::getenv("NMFAMD_UPDATE64_OLD") ? len_pad / 128 : len_pad / 64;   // k_panel_update64_lds_f32 (old: k_panel_update64_f32)
 	if (elem == 4 && use_wide_update(RP)) return len_pad / 32;   // k_panel_update_wide_f32
 	if (elem == 8 && panel_update_wide_f64_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return len_pad / 16;   // k_panel_update_wide_f64
 	return len_pad / panel_update_rows(RP, elem);
@@ -751,8 +751,10 @@ template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
                                T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream) {
 	if constexpr (std::is_same<T, float>::value) {
-		if (RP == 64 && mode != MODE_SET)
-			return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+		if (RP == 64 && mode != MODE_SET) {
+			if (std::getenv("NMFAMD_UPDATE64_OLD")) return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+			return launch_panel_update64_lds_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+		}
 		if (use_wide_update(RP) && mode != MODE_SET)
 			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 	}

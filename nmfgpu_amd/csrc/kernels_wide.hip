@@ -276,6 +276,125 @@ hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, floa
 	return launch_reduce_partials<float>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same at padded rank 64 (nsNMF, GDCLS and the least-squares family at r <= 64; the multiplicative update has
+// its own fused kernel, kernels_mu64.hip): 64 panel rows per workgroup staged in LDS, wave (cb, yh) owns the 32
+// columns 32 cb + i of the 32 rows 32 yh + j; all eight K groups of the A operand are requested up front.
+// Replaces k_panel_update64_f32 (kernels_fast.hip), whose row-per-lane global loads were texture-addresser bound.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
+	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
+	const float* __restrict__ Q, float eps, float* __restrict__ ps, int len_valid,
+	float* __restrict__ sumsq_part, float* __restrict__ num_out) {
+	constexpr int YB = 64, LD = 68;
+	__shared__ __attribute__((aligned(16))) float s_num[YB * LD];
+	__shared__ __attribute__((aligned(16))) float s_old[YB * LD];
+	__shared__ float s_ps[2][YB];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int cb = wave & 1, yh = wave >> 1;
+	const long base = (long)blockIdx.x * YB * 64;
+
+	float qa[8][4];
+#pragma unroll
+	for (int u = 0; u < 8; ++u)
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi) qa[u][gi] = Q[(long)(8 * u + 4 * half + gi) * 64 + 32 * cb + l31];
+
+	{
+		f32x4 num[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) num[i] = *reinterpret_cast<const f32x4*>(slabs + base + 4l * (tid + 256 * i));
+		if (MODE == PANEL_MU) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int e = tid + 256 * i, y = e >> 4, c4 = e & 15;
+				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = *reinterpret_cast<const f32x4*>(P + base + 4l * e);
+			}
+		}
+		for (int k = 1; k < S; ++k) {
+			f32x4 t[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));
+#pragma unroll
+			for (int i = 0; i < 4; ++i) num[i] += t[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int e = tid + 256 * i, y = e >> 4, c4 = e & 15;
+			*reinterpret_cast<f32x4*>(s_num + y * LD + 4 * c4) = num[i];
+			if (num_out) *reinterpret_cast<f32x4*>(num_out + base + 4l * e) = num[i];
+		}
+	}
+	__syncthreads();
+
+	const float* vec = (MODE == PANEL_MU ? s_old : s_num) + (32 * yh + l31) * LD + 4 * half;
+	f32x16 acc;
+#pragma unroll
+	for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		const f32x4 b = *reinterpret_cast<const f32x4*>(vec + 8 * u);
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u][gi], b[gi], acc, 0, 0, 0);
+	}
+
+	f32x4 nv[4];
+	float psum = 0.f;
+	const int yrow = 32 * yh + l31;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const int c = 32 * cb + 8 * q + 4 * half;
+		const f32x4 num = *reinterpret_cast<const f32x4*>(s_num + yrow * LD + c);
+		f32x4 o;
+		if (MODE == PANEL_MU) {
+			const f32x4 old = *reinterpret_cast<const f32x4*>(s_old + yrow * LD + c);
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) o[gi] = old[gi] * num[gi] / (acc[4 * q + gi] + eps);
+		} else {
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) { const float d = acc[4 * q + gi]; o[gi] = d > 0.f ? d : 0.f; }
+		}
+#pragma unroll
+		for (int gi = 0; gi < 4; ++gi) psum += o[gi] * num[gi];
+		nv[q] = o;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(s_old + yrow * LD + 32 * cb + 8 * q + 4 * half) = nv[q];
+	psum += __shfl_xor(psum, 32);
+	if (half == 0) s_ps[cb][yrow] = psum;
+	__syncthreads();
+
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int e = tid + 256 * i, y = e >> 4, c4 = e & 15;
+		*reinterpret_cast<f32x4*>(P + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_old + y * LD + 4 * c4);
+	}
+	if (ps != nullptr && tid < YB) {
+		const int y = blockIdx.x * YB + tid;
+		if (y < len_valid) ps[y] = s_ps[0][tid] + s_ps[1][tid];
+	}
+	if (sumsq_part != nullptr && tid < 64) {
+		float s = 0.f;
+#pragma unroll 8
+		for (int y = 0; y < YB; ++y) { const float v = s_old[y * LD + tid]; s += v * v; }
+		sumsq_part[(long)blockIdx.x * 64 + tid] = s;
+	}
+}
+
+// 64 panel rows per workgroup: len_pad / 64 norm partials
+hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
+                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+	if ((mode != PANEL_MU && mode != PANEL_LS) || len_pad % 64 != 0) return hipErrorInvalidValue;
+	dim3 grid(len_pad / 64), block(256);
+	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	else hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	return hipGetLastError();
+}
+
 bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }
 
 template <int MODE, int NCB>

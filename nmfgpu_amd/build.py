@@ -64,7 +64,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    # -z defs: an undefined symbol fails the link here, not at the first call inside a running process
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB + ".tmp", *objs]
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -167,7 +167,7 @@ Status Engine<T>::allocate() {
 			overlap_inverse_ = true;
 		}
 	}
-	if (fused_capable()) {
+	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
@@ -282,7 +282,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false;
+		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -290,6 +290,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	}
 	if (H) {
 		if (ldh < r_) return ST_INVALID;
+		gram_h_partials_ = false;
 		HIPX(hipMemsetAsync(H_, 0, sizeof(T) * (size_t)RP_ * npad_, stream_));
 		HIPX(hipMemcpy2DAsync(H_, RP_ * sizeof(T), H, ldh * sizeof(T), r_ * sizeof(T), n_, hipMemcpyHostToDevice, stream_));
 	}
@@ -324,7 +325,8 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; }
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; }
+	if (h) gram_h_partials_ = false;
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_));
 	return ST_OK;
@@ -571,7 +573,8 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		HIPX(launch_smooth_panel<T>(Wt_, Ws_, RP_, r_, mpad_, off, diag, stream_));
 		F = Ws_;
 	}
-	HIPX(launch_gram<T>(F, RP_, m_, gram_parts_, gram_part_, G_, stream_));
+	if (!(gram_w_ready_ && F == Wt_)) HIPX(launch_gram<T>(F, RP_, m_, gram_parts_, gram_part_, G_, stream_));
+	gram_w_ready_ = false;      // consumed (the inverse passenger / update below read G_; W changes in the W step)
 	const int S = planH_.splits;
 	if (alg_ == ALG_MU || alg_ == ALG_NSNMF) {
 		if (Status s = product_h(F)) return s;
@@ -601,8 +604,11 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			if (Status s = product_h(F)) return s;
 			if (Status s = normal_inverse_join()) return s;
 		}
+		T* hpart = nullptr;
+		if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) hpart = gramH_part_; }
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
-		                            nullptr, n_, nullptr, nullptr, stream_));
+		                            nullptr, n_, nullptr, nullptr, stream_, hpart));
+		gram_h_partials_ = hpart != nullptr;
 	}
 	return ST_OK;
 }
@@ -672,6 +678,33 @@ bool Engine<T>::fused_capable() const {
 	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;   // (evaluated before allocate(): no tiled_ here)
 }
 
+// GDCLS and the ALS family never smooth their factors, so the Gram matrix the next half-step needs is the Gram matrix of
+// exactly what the update kernel has just written: at fp32 / padded rank 64 that kernel emits it as partial matrices
+// (64 panel rows each) and the 16-block reduction of the fused MU path replaces a pass over the panel.
+template <typename T>
+bool Engine<T>::gram_from_update() const {
+	return std::is_same<T, float>::value && alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS && panel_update_delivers_gram(RP_, sizeof(T)) &&
+	       std::getenv("NMFAMD_NO_GRAM_FROM_UPDATE") == nullptr;
+}
+
+// Column normalisation of W after its update (kernel::normalizeColumns).  With partial Gram matrices of the unnormalised W
+// at hand: their reduction yields the column scales 1 / ||W(:, c)|| and W^T W of the NORMALISED W in one 16-block launch,
+// W is scaled in place, and the next H step finds its Gram matrix ready.  Otherwise: norms from the sum-of-squares partials.
+template <typename T>
+Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (from_gram_partials) {
+			HIPX(launch_gram64_from_partials(gramW_part_, (int)(mpad_ / 64), G_, scale_, stream_));
+			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
+			gram_w_ready_ = true;
+			return ST_OK;
+		}
+	}
+	gram_w_ready_ = false;
+	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+	return ST_OK;
+}
+
 template <typename T>
 Status Engine<T>::materialize_w() {
 	if constexpr (std::is_same<T, float>::value) {
@@ -733,7 +766,15 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, diag, stream_));
 			Fh = Hs_;
 		}
-		HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
+		bool hht_done = false;
+		if constexpr (std::is_same<T, float>::value) {
+			if (gram_h_partials_ && Fh == H_) {
+				// H H^T from the partial Gram matrices the H update left behind
+				HIPX(launch_gram64_from_partials(gramH_part_, (int)(npad_ / 64), HHt_, nullptr, stream_));
+				hht_done = true;
+			}
+		}
+		if (!hht_done) HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
 		if (compute_error) {
 			const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
@@ -767,9 +808,11 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
+				T* wpart = nullptr;
+				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
-				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_));
-				HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart));
+				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
 				if (gd_err) {
 					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
 					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
@@ -778,14 +821,16 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			} else {
 				if (!inverse_rides(planW_)) { if (Status s = normal_inverse_join()) return s; }
 				if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
+				T* wpart = nullptr;
+				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
-				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_));
+				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_, wpart));
 				if (compute_error) {
 					// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
 					HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));
 					error_terms_n = r_;
 				}
-				HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
 			}
 		} else if (compute_error && alg_ != ALG_MU && alg_ != ALG_NSNMF) {
 			// constant basis vectors, LS algorithms: the reference's trace reads W against itself

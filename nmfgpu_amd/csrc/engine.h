@@ -100,8 +100,10 @@ private:
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of F V   (r x n)
 	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
+	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
 	Status materialize_w();                          // fold the pending column scale into Wt_
+	Status normalize_w(bool from_gram_partials, int norm_parts);   // column normalisation of W after its update
 	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
 	Status normal_inverse_fork(T* A, T offdiag, T diag);   // the same on the side stream; normal_inverse_join() before Qinv_ is read
 	Status normal_inverse_join();
@@ -151,6 +153,9 @@ private:
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
 	bool fused_ready_ = false, w_pending_ = false;
+	// generic rank-64 fp32 path: the update kernel leaves partial Gram matrices of what it wrote (gram_from_update())
+	bool gram_w_ready_ = false;      // G_ holds W^T W of the current (normalised) W
+	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;
 	double* inv_work_ = nullptr;

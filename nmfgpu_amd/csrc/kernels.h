@@ -79,6 +79,9 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
                               int compute_error, hipStream_t stream);
 // P(c, y) *= scale(c)
 hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream);
+// G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and
+// G <- diag(scale) G diag(scale): the stand-alone (not passenger) form of the Gram reduction
+hipError_t launch_gram64_from_partials(const float* partials, int parts, float* G, float* scale, hipStream_t stream);
 
 // Generic (VALU) form, writes the finished panel (no slabs).  Xpad multiple of 64, RP multiple of 32.
 template <typename T>
@@ -101,8 +104,12 @@ hipError_t launch_gram64_f32(const float* P, int len, int parts, float* partial,
 hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
                                      float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
 // fp32 / padded rank 64, LDS-staged (kernels_wide.hip): 64 panel rows per workgroup
+// gram_partial (optional): len_pad / 64 partial 64 x 64 Gram matrices of the new rows (layout of k_mu64_update)
 hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
-                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
+                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
+                                         float* gram_partial = nullptr);
+// true when launch_panel_update<float> at padded rank 64 can deliver those partial Gram matrices
+bool panel_update_delivers_gram(int RP, size_t elem);
 // fp32 / padded rank 128 ... 512 (kernels_wide.hip)
 bool panel_update_wide_available(int RP);
 bool gram_wide_available(int RP);
@@ -118,7 +125,7 @@ hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, i
 // See k_panel_update.  sumsq_part needs (len_pad / panel_update_rows) * RP elements.
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
-                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream);
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial = nullptr);
 
 // sumsq_part: parts * RP partial sums followed by 16 * RP elements of scratch
 template <typename T>

@@ -747,13 +747,18 @@ int panel_update_parts(int RP, size_t elem, int len_pad) {
 	return len_pad / panel_update_rows(RP, elem);
 }
 
+bool panel_update_delivers_gram(int RP, size_t elem) {
+	return elem == 4 && RP == 64 && std::getenv("NMFAMD_UPDATE64_OLD") == nullptr && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
+}
+
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
-                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream) {
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial) {
+	if (gram_partial != nullptr && !(panel_update_delivers_gram(RP, sizeof(T)) && mode != MODE_SET)) return hipErrorInvalidValue;
 	if constexpr (std::is_same<T, float>::value) {
 		if (RP == 64 && mode != MODE_SET) {
 			if (std::getenv("NMFAMD_UPDATE64_OLD")) return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
-			return launch_panel_update64_lds_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+			return launch_panel_update64_lds_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, gram_partial);
 		}
 		if (use_wide_update(RP) && mode != MODE_SET)
 			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
@@ -775,8 +780,8 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 	}
 	return hipGetLastError();
 }
-template hipError_t launch_panel_update<float>(int, float*, const float*, int, long, const float*, int, int, float, float*, int, float*, float*, hipStream_t);
-template hipError_t launch_panel_update<double>(int, double*, const double*, int, long, const double*, int, int, double, double*, int, double*, double*, hipStream_t);
+template hipError_t launch_panel_update<float>(int, float*, const float*, int, long, const float*, int, int, float, float*, int, float*, float*, hipStream_t, float*);
+template hipError_t launch_panel_update<double>(int, double*, const double*, int, long, const double*, int, int, double, double*, int, double*, double*, hipStream_t, double*);
 
 // ------------------------------------------------------------------------------------------
 // column normalisation of W (rows of the Wt panel): second half of kernel::normalizeColumns

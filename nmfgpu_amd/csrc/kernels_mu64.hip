@@ -266,6 +266,29 @@ hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream)
 	return hipGetLastError();
 }
 
+// Stand-alone form of the reduction for callers that cannot hide it behind a product launch: the wide
+// k_reduce_partials (64 workgroups, 4 us) sums the partial matrices; this one-workgroup kernel then turns the diagonal
+// into the column scales and scales G on both sides -- the passenger form takes 31 us when nothing runs beside it.
+__global__ __launch_bounds__(256) void k_scale_gram64(float* __restrict__ G, float* __restrict__ scale) {
+	__shared__ float s_scale[64];
+	const int tid = threadIdx.x;
+	if (tid < 64) {
+		const float d = G[tid * 65];
+		const float sc = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+		s_scale[tid] = sc;
+		scale[tid] = sc;
+	}
+	__syncthreads();
+	for (int e = tid; e < 4096; e += 256) G[e] = (G[e] * s_scale[e & 63]) * s_scale[e >> 6];
+}
+
+hipError_t launch_gram64_from_partials(const float* partials, int parts, float* G, float* scale, hipStream_t stream) {
+	hipError_t e = launch_reduce_partials<float>(partials, parts, 4096, G, 4096, stream);
+	if (e != hipSuccess || scale == nullptr) return e;
+	hipLaunchKernelGGL(k_scale_gram64, dim3(1), dim3(256), 0, stream, G, scale);
+	return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_mu64_apply_scale(float* __restrict__ P, long count4, const float* __restrict__ scale) {
 	const long e = (long)blockIdx.x * 256 + threadIdx.x;
 	if (e >= count4) return;

@@ -286,7 +286,7 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, float* __restrict__ num_out) {
+	float* __restrict__ sumsq_part, float* __restrict__ num_out, float* __restrict__ gram_partial) {
 	constexpr int YB = 64, LD = 68;
 	__shared__ __attribute__((aligned(16))) float s_num[YB * LD];
 	__shared__ __attribute__((aligned(16))) float s_old[YB * LD];
@@ -383,15 +383,34 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 		for (int y = 0; y < YB; ++y) { const float v = s_old[y * LD + tid]; s += v * v; }
 		sumsq_part[(long)blockIdx.x * 64 + tid] = s;
 	}
+	if (gram_partial != nullptr) {
+		// partial Gram matrix of the 64 new rows (layout of k_mu64_update: one 64 x 64 matrix per workgroup), so that the
+		// caller can reduce W^T W / H H^T with the 16-block reduction instead of a pass over the panel
+		const int ab = wave >> 1, bb = wave & 1;
+		f32x16 g;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) g[i] = 0.f;
+#pragma unroll 8
+		for (int x = 0; x < YB; x += 2) {
+			const float a = s_old[(x + half) * LD + ab * 32 + l31];
+			const float b = s_old[(x + half) * LD + bb * 32 + l31];
+			g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, g, 0, 0, 0);
+		}
+		float* out = gram_partial + (long)blockIdx.x * 4096;
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) out[(long)(ab * 32 + gi + 8 * q + 4 * half) * 64 + bb * 32 + l31] = g[4 * q + gi];
+	}
 }
 
 // 64 panel rows per workgroup: len_pad / 64 norm partials
 hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
-                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, float* gram_partial) {
 	if ((mode != PANEL_MU && mode != PANEL_LS) || len_pad % 64 != 0) return hipErrorInvalidValue;
 	dim3 grid(len_pad / 64), block(256);
-	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
-	else hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial);
+	else hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial);
 	return hipGetLastError();
 }
 

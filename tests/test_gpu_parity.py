@@ -876,3 +876,19 @@ def test_seeded_sweep_sparse_paths(seed):
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6), abs=1e-9)
     if kl:
         assert eng.kl_divergence == pytest.approx(ref["kl"], rel=max(30 * tol, 1e-6), abs=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 3e-4), (np.float64, 1e-9)])
+def test_rank_beyond_the_mfma_update_kernels(dtype, tol):
+    """r = 600 -> padded rank 640: past the 512-column limit of the MFMA update kernels, the generic update runs
+    (chunked MFMA products, generic panel update / Gram)."""
+    m, n, r, iters = 700, 660, 600, 4
+    V, W, H = problem(m, n, r, dtype, seed=37)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    eng = na.Engine(m, n, r, "mu", dtype=dtype)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6))

@@ -21,28 +21,44 @@
  * `W.transposed() * W` and `W.transposed() * V`
  * (AlgorithmMultiplicativeFrobenius.h:168-169,176-178,187-188 via Matrix.h:361-376). */
 static void FN(gemm_tn)(int m, int ka, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) {
+	/* Blocked for the cache hierarchy: a thread owns a pair of columns of B; the reduction range is walked in chunks of
+	 * IC rows (the chunk of A -- ka columns x IC rows -- stays in L2 while all column blocks of A pass over it), and a
+	 * 4 x 2 block of C is accumulated per pass with simd reductions (vector-wide partial sums; without the pragma a float
+	 * reduction stays scalar).  Before this the product streamed all of A once per column of B: 26 GFLOP/s on 8 threads. */
+	enum { IC = 2048, AB = 4 };
 #pragma omp parallel for schedule(static)
-	for (int j = 0; j < kb; ++j) {
-		const T* b = B + (size_t)j * ldb;
-		int a = 0;
-		for (; a + 4 <= ka; a += 4) {
-			const T* a0 = A + (size_t)(a + 0) * lda;
-			const T* a1 = A + (size_t)(a + 1) * lda;
-			const T* a2 = A + (size_t)(a + 2) * lda;
-			const T* a3 = A + (size_t)(a + 3) * lda;
-			T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-			for (int i = 0; i < m; ++i) {
-				T bv = b[i];
-				s0 += a0[i] * bv; s1 += a1[i] * bv; s2 += a2[i] * bv; s3 += a3[i] * bv;
+	for (int j0 = 0; j0 < kb; j0 += 2) {
+		const int jl = j0 + 2 <= kb ? 2 : 1;
+		const T* b0 = B + (size_t)j0 * ldb;
+		const T* b1 = B + (size_t)(j0 + jl - 1) * ldb;      /* = b0 when the last column stands alone */
+		for (int a = 0; a < ka; ++a) { C[(size_t)j0 * ldc + a] = 0; if (jl == 2) C[(size_t)(j0 + 1) * ldc + a] = 0; }
+		for (int i0 = 0; i0 < m; i0 += IC) {
+			const int i1 = i0 + IC < m ? i0 + IC : m;
+			int a = 0;
+			for (; a + AB <= ka; a += AB) {
+				const T* a0 = A + (size_t)(a + 0) * lda;
+				const T* a1 = A + (size_t)(a + 1) * lda;
+				const T* a2 = A + (size_t)(a + 2) * lda;
+				const T* a3 = A + (size_t)(a + 3) * lda;
+				T s00 = 0, s10 = 0, s20 = 0, s30 = 0, s01 = 0, s11 = 0, s21 = 0, s31 = 0;
+#pragma omp simd reduction(+ : s00, s10, s20, s30, s01, s11, s21, s31)
+				for (int i = i0; i < i1; ++i) {
+					const T v0 = b0[i], v1 = b1[i];
+					s00 += a0[i] * v0; s10 += a1[i] * v0; s20 += a2[i] * v0; s30 += a3[i] * v0;
+					s01 += a0[i] * v1; s11 += a1[i] * v1; s21 += a2[i] * v1; s31 += a3[i] * v1;
+				}
+				T* c0 = C + (size_t)j0 * ldc + a;
+				c0[0] += s00; c0[1] += s10; c0[2] += s20; c0[3] += s30;
+				if (jl == 2) { T* c1 = C + (size_t)(j0 + 1) * ldc + a; c1[0] += s01; c1[1] += s11; c1[2] += s21; c1[3] += s31; }
 			}
-			C[(size_t)j * ldc + a + 0] = s0; C[(size_t)j * ldc + a + 1] = s1;
-			C[(size_t)j * ldc + a + 2] = s2; C[(size_t)j * ldc + a + 3] = s3;
-		}
-		for (; a < ka; ++a) {
-			const T* a0 = A + (size_t)a * lda;
-			T s0 = 0;
-			for (int i = 0; i < m; ++i) s0 += a0[i] * b[i];
-			C[(size_t)j * ldc + a] = s0;
+			for (; a < ka; ++a) {
+				const T* a0 = A + (size_t)a * lda;
+				T s0 = 0, s1 = 0;
+#pragma omp simd reduction(+ : s0, s1)
+				for (int i = i0; i < i1; ++i) { s0 += a0[i] * b0[i]; s1 += a0[i] * b1[i]; }
+				C[(size_t)j0 * ldc + a] += s0;
+				if (jl == 2) C[(size_t)(j0 + 1) * ldc + a] += s1;
+			}
 		}
 	}
 }

@@ -892,3 +892,34 @@ def test_rank_beyond_the_mfma_update_kernels(dtype, tol):
     Wg, Hg = eng.get_factors()
     assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(10 * tol, 1e-6))
+
+
+def test_two_threads_compute_concurrently():
+    """The library context is per thread (ref Interface.cpp:51: thread_local): two threads, each with its own
+    initialize() / compute() / finalize(), factorise different problems at the same time on the one GPU."""
+    import threading
+    results = {}
+
+    def worker(tag, m, n, r, alg, seed):
+        try:
+            V, W, H = problem(m, n, r, np.float32, seed=seed)
+            V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+            ref = oracle.run("mu" if alg == na.NmfAlgorithm.Multiplicative else "als", V64, W64, H64, 60)
+            assert na.initialize() == na.ResultType.Success          # a fresh thread has no context yet
+            s = na.Summary()
+            res = na.compute(V, W, H, algorithm=alg, iterations=60, summary=s)
+            na.finalize()
+            tol = 2e-4 if alg == na.NmfAlgorithm.Multiplicative else 3e-3
+            results[tag] = (res == na.ResultType.Success and rel(W, W64) < tol and rel(H, H64) < tol
+                            and abs(s.record(0).frobenius - ref["frobenius"]) <= 10 * tol * ref["frobenius"])
+        except Exception as exc:      # noqa: BLE001
+            results[tag] = repr(exc)
+
+    threads = [threading.Thread(target=worker, args=("a", 900, 700, 64, na.NmfAlgorithm.Multiplicative, 51)),
+               threading.Thread(target=worker, args=("b", 640, 500, 12, na.NmfAlgorithm.ALS, 52)),
+               threading.Thread(target=worker, args=("c", 300, 1100, 100, na.NmfAlgorithm.Multiplicative, 53))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == {"a": True, "b": True, "c": True}, results

@@ -923,3 +923,36 @@ def test_two_threads_compute_concurrently():
     for t in threads:
         t.join()
     assert results == {"a": True, "b": True, "c": True}, results
+
+
+def test_engines_release_their_device_memory():
+    """Create / run / destroy engines of every flavour repeatedly: the free device memory comes back."""
+    import gc
+    def free_bytes():
+        res, info = na.get_information_for_gpu_index(0)
+        assert res == na.ResultType.Success
+        return info.freeMemory
+    V, W, H = problem(1500, 1100, 40, np.float32, seed=61)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    import scipy.sparse as sp
+    s = sp.csr_matrix(V * (V > 0.8))
+    def cycle():
+        for kw in (dict(algorithm="mu"), dict(algorithm="ahcls", lambda_w=0.1, lambda_h=0.1, alpha_w=0.1, alpha_h=0.1), dict(algorithm="nsnmf", theta=0.5),
+                   dict(algorithm="mu", precision="bf16"), dict(algorithm="mu", dtype=np.float64)):
+            dt = kw.get("dtype", np.float32)
+            eng = na.Engine(1500, 1100, 40, **kw)
+            eng.upload(V64 if dt == np.float64 else V); eng.set_factors(W64 if dt == np.float64 else W, H64 if dt == np.float64 else H)
+            eng.iterate(3, last_iteration=3)
+            assert np.isfinite(eng.frobenius)
+            eng.close()
+        eng = na.Engine(1500, 1100, 40, "mu", divergence="kl")
+        eng.upload_sparse(1, s.data.astype(np.float32), s.indptr, s.indices, 0); eng.set_factors(W, H)
+        eng.iterate(3, last_iteration=3)
+        eng.close()
+    cycle(); gc.collect()
+    before = free_bytes()
+    for _ in range(5):
+        cycle()
+    gc.collect()
+    after = free_bytes()
+    assert before - after < (64 << 20), (before, after)      # allocator granularity, not a leak of 100-MB images

@@ -278,3 +278,27 @@ def test_kl_update_decreases_the_divergence_and_keeps_invariants():
     direct = (V[mask] * np.log(V[mask] / (WH[mask] + eps))).sum() - V.sum() + WH.sum()
     assert res["kl"] == pytest.approx(direct, rel=1e-9)
     assert res["frobenius"] == pytest.approx(np.linalg.norm(V - WH), rel=1e-8)
+
+
+# ------------------------------------------------------------------ frozen trajectories of the oracle itself
+
+def test_oracle_reproduces_its_frozen_trajectories():
+    """tests/golden/oracle_trajectories.json freezes the oracle's own double-precision behaviour (generator committed next
+    to it): a change to its blocking / threading / summation order may move results by rounding, not more."""
+    import importlib.util
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_trajectories.json")))
+    spec = importlib.util.spec_from_file_location("make_oracle_trajectories", os.path.join(os.path.dirname(__file__), "golden", "make_oracle_trajectories.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    for case in gold["cases"]:
+        V, W, H = gen.problem(case["seed"])
+        res = oracle.run(case["algorithm"], V, W, H, gold["iterations"], **case["parameters"])
+        # LS algorithms: explicit solves amplify a changed summation order by cond(W^T W); the multiplicative ones do not
+        tol = 1e-11 if case["algorithm"] in ("mu", "nsnmf") else 1e-7
+        np.testing.assert_allclose(np.array(res["history"]), np.array(case["history"]), rtol=tol)
+        assert W.sum() == pytest.approx(case["w_sum"], rel=tol) and H.sum() == pytest.approx(case["h_sum"], rel=tol)
+        assert (W * W).sum() == pytest.approx(case["w_sq"], rel=tol) and (H * H).sum() == pytest.approx(case["h_sq"], rel=tol)
+    V, W, H = gen.problem(gold["kl"]["seed"])
+    V = np.asfortranarray(np.floor(V * 6.0) * (V > 0.6))
+    res = oracle.run_kl(V, W, H, gold["iterations"])
+    assert res["kl"] == pytest.approx(gold["kl"]["kl"], rel=1e-11) and res["frobenius"] == pytest.approx(gold["kl"]["frobenius"], rel=1e-11)
+    assert W.sum() == pytest.approx(gold["kl"]["w_sum"], rel=1e-11)

@@ -13,7 +13,7 @@ struct FactorProductPlan {
 	int xtiles;       // tiles of the output index x
 	int steps_total;  // reduction length in MFMA K-steps (two y per step)
 	int splits;       // workgroup slices of the reduction range = number of output slabs
-	int nb;           // 32-wide N-blocks per wave tile (2)
+	int nb;           // 32-wide N-blocks per wave tile: 2, or 1 when only the first 32 panel columns are needed (rank <= 32)
 	int chunks;       // launches needed to cover RP = chunks * 64 factor rows
 };
 

@@ -60,13 +60,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FP_WAVES = 8;
 constexpr int FP_XT = 128;
 
+// F operand of one K-step: NB column blocks of 32 per wave tile -- NB = 2 (64 panel columns, interleaved c = 2 j + nb, one
+// 8-byte load) or NB = 1 (ranks <= 32: only the first 32 panel columns exist, c = j, one 4-byte load, half the MFMAs)
 template <int NB> struct FVec;
+template <> struct FVec<1> { typedef float type; };
 template <> struct FVec<2> { typedef f32x2 type; };
-template <> struct FVec<4> { typedef f32x4 type; };
 
 template <int NB> __device__ inline float fcomp(const typename FVec<NB>::type& v, int i);
+template <> __device__ inline float fcomp<1>(const float& v, int) { return v; }
 template <> __device__ inline float fcomp<2>(const f32x2& v, int i) { return v[i]; }
-template <> __device__ inline float fcomp<4>(const f32x4& v, int i) { return v[i]; }
 
 // Extra workgroups of the factor-product launch (blockIdx.y == splits) reduce the partial Gram
 // matrices the previous update kernel left behind -- work that has no dependence on the product
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512) void k_inverse_gj64(const T* __restrict__ A, i
 	inverse_gj64_body<T>(A, RP, r, Ainv, offdiag, diag);
 }
 
-template <int XB, int D, bool STAMP, int DIAG = 0>
+template <int XB, int D, bool STAMP, int DIAG = 0, int NB = 2>
 __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	const float* __restrict__ A, long tile_stride,
 	const float* __restrict__ F, int RP,
@@ -252,11 +254,10 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	// STAMP: diagnostic build only (nmfamd_tune_factor_product): per-wave shader-clock and 100 MHz
 	// real-time stamps at kernel entry, first MFMA, end of the main loop and end of the epilogue,
 	// written to a buffer of their own; the production instantiation has STAMP = false.
-	constexpr int NB = 2;
 	constexpr int TH = 32 * XB;
 	unsigned long long t_entry = 0, r_entry = 0, t_loop0 = 0, t_loop1 = 0;
 	if (STAMP) { t_entry = __builtin_amdgcn_s_memtime(); r_entry = __builtin_amdgcn_s_memrealtime(); }
-	typedef f32x2 fvec;
+	typedef typename FVec<NB>::type fvec;
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 
 	if (blockIdx.y == (unsigned)splits) {   // the passenger row of the grid (only launched when there is a passenger)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 				for (int b = 0; b < XB; ++b)
 #pragma unroll
 					for (int nb = 0; nb < NB; ++nb)
-						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fb[d][nb], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
 				int st = t + D + d;
 				st = st < last ? st : last;
 				// DIAG (stamped diagnostic builds only): 1 = no refill at all (pure MFMA issue rate),
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 				for (int b = 0; b < XB; ++b)
 #pragma unroll
 					for (int nb = 0; nb < NB; ++nb)
-						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fb[d][nb], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b < 4 ? va[d][b & 3] : ve[d], fcomp<NB>(fb[d], nb), acc[b][nb], 0, 0, 0);
 			}
 		}
 	}
@@ -363,7 +364,9 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 	// ---- sum the eight per-wave tiles through LDS, two M-blocks (four accumulator tiles) per round ----
 	// LDS image of a round: [src wave 8][tile 4][q 4][lane 64] float4  (128 KiB)
 	// C/D map of the 32x32 MFMA: register g of lane l is row (g&3) + 8*(g>>2) + 4*(l>>5), column l&31.
-	constexpr int ROUNDS = (XB + 1) / 2;
+	// A round carries four accumulator tiles per wave: 2 M-blocks x 2 N-blocks (NB = 2) or 4 M-blocks (NB = 1).
+	constexpr int MPR = 4 / NB;                        // M-blocks per round
+	constexpr int ROUNDS = (XB + MPR - 1) / MPR;
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 		if (rd > 0) __syncthreads();
 #pragma unroll
 		for (int tl = 0; tl < 4; ++tl) {
-			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			const int b = MPR * rd + tl / NB, nb = tl % NB;
 			if (b < XB) {
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
@@ -384,26 +387,41 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f32(
 		}
 		__syncthreads();
 		{
-			// wave w owns (M-block 2*rd + (w >> 2), register quad q = w & 3), both N-blocks
-			const int bl = wave >> 2, q = wave & 3;
-			const int b = 2 * rd + bl;
-			if (b < XB) {
-				f32x4 sum[NB];
+			// 16 (tile, register quad) slices per round, two per wave: wave w owns quad q = w & 3 of the tiles
+			// NB * (w >> 2) + k, k = 0 .. NB-1 of M-block (w >> 2)   [NB = 2]
+			// (w >> 2) and (w >> 2) + 2, i.e. M-blocks (w >> 2) and (w >> 2) + 2   [NB = 1]
+			const int q = wave & 3;
+			f32x4 sum[2];
+			int bk[2];
 #pragma unroll
-				for (int nb = 0; nb < NB; ++nb) {
-					const int tl = bl * NB + nb;
-					f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+			for (int k = 0; k < 2; ++k) {
+				const int tl = NB == 2 ? 2 * (wave >> 2) + k : (wave >> 2) + 2 * k;
+				bk[k] = MPR * rd + tl / NB;
+				f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
 #pragma unroll
-					for (int src = 1; src < FP_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
-					sum[nb] = s;
-				}
+				for (int src = 1; src < FP_WAVES; ++src) s += l4[((src * 4 + tl) * 4 + q) * 64 + lane];
+				sum[k] = s;
+			}
 #pragma unroll
-				for (int gi = 0; gi < 4; ++gi) {
-					const int i = gi + 8 * q + 4 * half;   // MFMA row of this value
-					const int x = xt * TH + (b < 4 ? 4 * i + b : 128 + i);
-					fvec o;
-					o[0] = sum[0][gi]; o[1] = sum[1][gi];
-					*reinterpret_cast<fvec*>(slab + (long)x * RP + coff + NB * l31) = o;
+			for (int gi = 0; gi < 4; ++gi) {
+				const int i = gi + 8 * q + 4 * half;   // MFMA row of this value
+				if (NB == 2) {
+					// both N-blocks of one M-block: columns 2 j and 2 j + 1 are one 8-byte store
+					const int b = bk[0];
+					if (b < XB) {
+						const int x = xt * TH + (b < 4 ? 4 * i + b : 128 + i);
+						f32x2 o; o[0] = sum[0][gi]; o[1] = sum[1][gi];
+						*reinterpret_cast<f32x2*>(slab + (long)x * RP + coff + 2 * l31) = o;
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < 2; ++k) {
+						const int b = bk[k];
+						if (b < XB) {
+							const int x = xt * TH + (b < 4 ? 4 * i + b : 128 + i);
+							slab[(long)x * RP + coff + l31] = sum[k][gi];
+						}
+					}
 				}
 			}
 		}
@@ -454,7 +472,7 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus) {
 	return best;
 }
 
-template <int XB, int D, bool STAMP, int DIAG = 0>
+template <int XB, int D, bool STAMP, int DIAG = 0, int NB = 2>
 static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                               float* slabs, long slab_stride, const GramReduceArgs* rg, unsigned long long* stamps, hipStream_t stream) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -465,8 +483,8 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), p.chunks), block(512);      // passengers only ever with one chunk (RP == 64)
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
 	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG, NB>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG, NB>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
@@ -485,6 +503,9 @@ static int fp_depth() {
 template <int XB>
 static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                             float* slabs, long slab_stride, const GramReduceArgs* rg, hipStream_t stream) {
+	// ranks <= 32 (plan.nb == 1, padded rank 64): only the first 32 panel columns are computed and written; the other
+	// 32 columns of every slab stay at the zeros they were allocated with
+	if (p.nb == 1 && RP == 64 && XB == 4) return launch_fp_d<4, 8, false, 0, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
 	switch (fp_depth()) {
 	case 4: return launch_fp_d<XB, 4, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
 	case 6: return launch_fp_d<XB, 6, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);

@@ -42,7 +42,7 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
 	FactorProductPlan plan = std::is_same<T, double>::value ? plan_factor_product_f64(X, Y, RP, prop.multiProcessorCount)
 	                                                         : plan_factor_product(X, Y, RP, prop.multiProcessorCount);
-	if (std::is_same<T, float>::value && RP == 64 && r <= 32) plan.nb = 1;      // as the engine does: 32 panel columns for small ranks
+	if (RP == 64 && r <= 32) plan.nb = std::is_same<T, float>::value ? 1 : 2;      // as the engine does: 32 panel columns for small ranks (fp64 counts 16-column tiles)
 	const long Xp = pad128(std::max<long>(X, (long)plan.xtiles * plan.th)), Yp = pad128(Y);
 	const bool mfma = !use_valu;
 	const int S = mfma ? plan.splits : 1;

@@ -89,7 +89,7 @@ Status Engine<T>::allocate() {
 	planW_ = f64 ? plan_factor_product_f64(m_, n_, RP_, num_cus_) : plan_factor_product(m_, n_, RP_, num_cus_);
 	const bool mfma = std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 	// ranks <= 32: the fp32 product computes 32 panel columns instead of 64 (half the MFMA work; the kernel turns HBM-bound)
-	if (!f64 && RP_ == 64 && r_ <= 32 && std::getenv("NMFAMD_FP_FULL_WIDTH") == nullptr) { planH_.nb = 1; planW_.nb = 1; }
+	if (RP_ == 64 && r_ <= 32 && std::getenv("NMFAMD_FP_FULL_WIDTH") == nullptr) { planH_.nb = f64 ? 2 : 1; planW_.nb = planH_.nb; }      // (fp64 counts 16-column tiles)
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
 	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;

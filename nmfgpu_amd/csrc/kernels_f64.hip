@@ -27,7 +27,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F64_TH = 128;
 
-template <int D>
+template <int D, int NC>      // NC = 16-column tiles per wave: 4 (64 panel columns) or 2 (ranks <= 32: the first 32 columns only)
 __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const double* __restrict__ A, long tile_stride,
 	const double* __restrict__ F, int RP,
@@ -46,26 +46,28 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const int s1 = (int)(((long)steps_total * (pidx + 1)) / np);
 	const int steps = s1 - s0;
 
-	f64x4 acc[4][4];
+	typedef double fvec __attribute__((ext_vector_type(NC)));
+	f64x4 acc[4][NC];
 #pragma unroll
 	for (int b = 0; b < 4; ++b)
 #pragma unroll
-		for (int nb = 0; nb < 4; ++nb)
+		for (int nb = 0; nb < NC; ++nb)
 #pragma unroll
 			for (int g = 0; g < 4; ++g) acc[b][nb][g] = 0.0;
 
 	if (steps > 0) {
-		// lane (i, k): rows 64 rh + 4 i .. + 3 of the tile at y = 4 t + k; columns coff + 4 j .. + 3 of the panel
+		// lane (i, k): rows 64 rh + 4 i .. + 3 of the tile at y = 4 t + k; columns coff + NC j .. + NC - 1 of the panel
 		const double* ap = A + (long)xt * tile_stride + (long)(4 * s0 + kq) * F64_TH + 64 * rh + 4 * l15;
-		const double* fp = F + (long)(4 * s0 + kq) * RP + coff + 4 * l15;
+		const double* fp = F + (long)(4 * s0 + kq) * RP + coff + NC * l15;
 		const long astep = 4 * F64_TH, fstep = 4 * (long)RP;
 		const int last = steps - 1;
-		f64x4 va[D], fb[D];
+		f64x4 va[D];
+		fvec fb[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) {
 			const int st = d < last ? d : last;
 			va[d] = *reinterpret_cast<const f64x4*>(ap + st * astep);
-			fb[d] = *reinterpret_cast<const f64x4*>(fp + st * fstep);
+			fb[d] = *reinterpret_cast<const fvec*>(fp + st * fstep);
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		int t = 0;
@@ -75,12 +77,12 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 #pragma unroll
 				for (int b = 0; b < 4; ++b)
 #pragma unroll
-					for (int nb = 0; nb < 4; ++nb)
+					for (int nb = 0; nb < NC; ++nb)
 						acc[b][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][b], fb[d][nb], acc[b][nb], 0, 0, 0);
 				int st = t + D + d;
 				st = st < last ? st : last;
 				va[d] = *reinterpret_cast<const f64x4*>(ap + st * astep);
-				fb[d] = *reinterpret_cast<const f64x4*>(fp + st * fstep);
+				fb[d] = *reinterpret_cast<const fvec*>(fp + st * fstep);
 				__builtin_amdgcn_sched_barrier(0);      // refill right behind the MFMAs that consumed the slot
 			}
 		}
@@ -91,51 +93,61 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 #pragma unroll
 				for (int b = 0; b < 4; ++b)
 #pragma unroll
-					for (int nb = 0; nb < 4; ++nb)
+					for (int nb = 0; nb < NC; ++nb)
 						acc[b][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][b], fb[d][nb], acc[b][nb], 0, 0, 0);
 			}
 		}
 	}
 
-	// ---- sum the four pieces of each row half through LDS, two row blocks (eight tiles) per round -------------
-	// LDS image of a round: [wave 8][tile 8 = (b in round 2) x (nb 4)][pair 2][lane 64] f64x2   (128 KiB)
+	// ---- sum the four pieces of each row half through LDS, eight tiles per round ------------------------------
+	// A round carries BPR = 8 / NC row blocks x NC column tiles of every wave.
+	// LDS image of a round: [wave 8][tile 8][pair 2][lane 64] f64x2   (128 KiB)
 	// C/D map of the 16x16 fp64 MFMA (measured: tests/test_gpu_parity.py identity-layout check): register g of lane l is
 	// row (l >> 4) + 4 g, column l & 15.
+	constexpr int BPR = 8 / NC, ROUNDS = 4 / BPR;
 	f64x2* l2 = reinterpret_cast<f64x2*>(lds64);
 	double* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
-	for (int rd = 0; rd < 2; ++rd) {
+	for (int rd = 0; rd < ROUNDS; ++rd) {
 		if (rd > 0) __syncthreads();
 #pragma unroll
-		for (int bl = 0; bl < 2; ++bl)
+		for (int t8 = 0; t8 < 8; ++t8)
 #pragma unroll
-			for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-				for (int pr = 0; pr < 2; ++pr) {
-					f64x2 v;
-					v[0] = acc[2 * rd + bl][nb][2 * pr]; v[1] = acc[2 * rd + bl][nb][2 * pr + 1];
-					l2[(((wave * 8) + bl * 4 + nb) * 2 + pr) * 64 + lane] = v;
-				}
+			for (int pr = 0; pr < 2; ++pr) {
+				const int b = BPR * rd + t8 / NC, nb = t8 % NC;
+				f64x2 v;
+				v[0] = acc[b][nb][2 * pr]; v[1] = acc[b][nb][2 * pr + 1];
+				l2[(((wave * 8) + t8) * 2 + pr) * 64 + lane] = v;
+			}
 		__syncthreads();
 		{
-			// wave w sums (row half w & 1, row block 2 rd + ((w >> 1) & 1), register pair w >> 2) for all four column blocks
-			const int orh = wave & 1, obl = (wave >> 1) & 1, opr = wave >> 2;
-			f64x2 sum[4];
+			// 32 (row half, tile, register pair) slices per round, four per wave: all NC column tiles of
+			//   NC = 4: (row half w & 1, row block (w >> 1) & 1 of the round, pair w >> 2)
+			//   NC = 2: (row half w & 1, pair (w >> 1) & 1, row blocks 2 (w >> 2) and 2 (w >> 2) + 1 of the round)
+			const int orh = wave & 1;
+			const int opr = NC == 4 ? wave >> 2 : (wave >> 1) & 1;
 #pragma unroll
-			for (int nb = 0; nb < 4; ++nb) {
-				f64x2 s = l2[((((0 * 2 + orh) * 8) + obl * 4 + nb) * 2 + opr) * 64 + lane];
+			for (int k = 0; k < 4 / NC; ++k) {
+				const int obl = NC == 4 ? (wave >> 1) & 1 : 2 * (wave >> 2) + k;      // row block inside the round
+				f64x2 sum[NC];
 #pragma unroll
-				for (int p = 1; p < 4; ++p) s += l2[((((p * 2 + orh) * 8) + obl * 4 + nb) * 2 + opr) * 64 + lane];
-				sum[nb] = s;
-			}
-			const int b = 2 * rd + obl;
+				for (int nb = 0; nb < NC; ++nb) {
+					const int t8 = obl * NC + nb;
+					f64x2 s = l2[((((0 * 2 + orh) * 8) + t8) * 2 + opr) * 64 + lane];
 #pragma unroll
-			for (int gg = 0; gg < 2; ++gg) {
-				const int i = kq + 4 * (2 * opr + gg);                  // MFMA row of this value
-				const int x = xt * F64_TH + 64 * orh + 4 * i + b;
-				f64x4 o;
-				o[0] = sum[0][gg]; o[1] = sum[1][gg]; o[2] = sum[2][gg]; o[3] = sum[3][gg];
-				*reinterpret_cast<f64x4*>(slab + (long)x * RP + coff + 4 * l15) = o;
+					for (int p = 1; p < 4; ++p) s += l2[((((p * 2 + orh) * 8) + t8) * 2 + opr) * 64 + lane];
+					sum[nb] = s;
+				}
+				const int b = BPR * rd + obl;
+#pragma unroll
+				for (int gg = 0; gg < 2; ++gg) {
+					const int i = kq + 4 * (2 * opr + gg);                  // MFMA row of this value
+					const int x = xt * F64_TH + 64 * orh + 4 * i + b;
+					fvec o;
+#pragma unroll
+					for (int nb = 0; nb < NC; ++nb) o[nb] = sum[nb][gg];
+					*reinterpret_cast<fvec*>(slab + (long)x * RP + coff + NC * l15) = o;
+				}
 			}
 		}
 	}
@@ -162,10 +174,17 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 	constexpr int D = 6;
 	if (p.th != F64_TH || RP % 64 != 0) return hipErrorInvalidValue;
 	const size_t lds_bytes = 8 * 8 * 2 * 64 * sizeof(f64x2);
-	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	dim3 grid(p.xtiles, p.splits, p.chunks), block(512);
-	hipLaunchKernelGGL((k_factor_product_f64<D>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
+	if (p.nb == 2 && RP == 64) {
+		// ranks <= 32: the first 32 panel columns only (the rest of every slab stays at its initial zeros)
+		static unsigned long long lds_done2 = 0ull;
+		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 2>), (int)lds_bytes, lds_done2); e != hipSuccess) return e;
+		hipLaunchKernelGGL((k_factor_product_f64<D, 2>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
+		return hipGetLastError();
+	}
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 4>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_f64<D, 4>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
 	return hipGetLastError();
 }
 

@@ -147,6 +147,19 @@ NMFAMD_API long nmfamd_engine_error_terms_to_device(nmfamd_engine* e, void* dst_
 NMFAMD_API double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw);
 NMFAMD_API double nmfamd_resolve_frobenius_f64(const double* vtv_sorted, long n_vtv, double* htwtv, long n_htwtv, double* hhtwtw, long n_hhtwtw);
 
+/* The host-side initialisers (run once per run, before the iteration loop; host memory only, no device or
+ * context needed).  k-means: Lloyd with a Forgy start (source/kmeans/kMeans.cu:126-278); data is m x n with
+ * leading dimension ld, clusters m x k (ldc), membership n entries; *iterations receives the passes done.
+ * host_init: method is the NmfInitializationMethod value (include/nmfgpu.h:87-96) for MeanColumns,
+ * KMeans* and EInNMF (source/init/KMeansStrategy.cpp:31-65, EInNMF.cu:44-119); W is m x r (ld m), H r x n
+ * (ld r) or NULL.  Return 0, or 1 (invalid argument) for arguments the reference rejects. */
+NMFAMD_API int nmfamd_host_kmeans_f32(const float* data, long ld, int m, int n, float* clusters, long ldc, int k,
+                                      unsigned* membership, unsigned seed, unsigned maxiter, double threshold, unsigned* iterations);
+NMFAMD_API int nmfamd_host_kmeans_f64(const double* data, long ld, int m, int n, double* clusters, long ldc, int k,
+                                      unsigned* membership, unsigned seed, unsigned maxiter, double threshold, unsigned* iterations);
+NMFAMD_API int nmfamd_host_init_f32(const float* V, long ldv, int m, int n, int r, int method, unsigned seed, float* W, float* H);
+NMFAMD_API int nmfamd_host_init_f64(const double* V, long ldv, int m, int n, int r, int method, unsigned seed, double* W, double* H);
+
 /* ---- single operations on host data (parity tests of the individual kernels) -----------------
  * OUT (r x X) = F (r x Y) * A^T, A is X x Y: the factor product both big GEMMs are instances of.
  * out_slabs (optional) receives the number of split-K slabs the MFMA kernel used.

@@ -21,6 +21,10 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
 SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "engine.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
 ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
+# translation units without device code or HIP runtime calls: plain C++ (function multiversioning
+# is rejected by the device pass of a -x hip compile); no implicit contraction: where the reference's
+# nvcc build fuses a multiply-add the source says std::fma)
+HOST_ONLY = {"host_init.cpp"}
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",
          "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -50,7 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        cmd = [cc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src in HOST_ONLY:
+            cmd = [cc, *[f for f in FLAGS if not f.startswith("--offload-arch")], "-x", "c++", "-pthread", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
+        else:
+            cmd = [cc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

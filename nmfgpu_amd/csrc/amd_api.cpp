@@ -9,6 +9,7 @@
 
 #include "../../include/nmfgpu_amd.h"
 #include "engine.h"
+#include "host_init.h"
 
 using namespace nmfamd;
 
@@ -81,6 +82,35 @@ int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, 
 	return NMFAMD_OK;
 }
 }
+
+namespace {
+template <typename T>
+int host_kmeans(const T* data, long ld, int m, int n, T* clusters, long ldc, int k, unsigned* membership, unsigned seed,
+                unsigned maxiter, double threshold, unsigned* iterations) {
+	if (!data || !clusters || m <= 0 || n <= 0 || k <= 0 || ld < m || ldc < m) return nmfamd::ST_INVALID;
+	nmfgpu::KMeansDescription<T> d{};
+	d.inputMatrix.rows = (unsigned)m; d.inputMatrix.columns = (unsigned)n; d.inputMatrix.format = nmfgpu::StorageFormat::Dense;
+	d.inputMatrix.dense.values = const_cast<T*>(data); d.inputMatrix.dense.leadingDimension = (unsigned)ld;
+	d.outputMatrixClusters.rows = (unsigned)m; d.outputMatrixClusters.columns = (unsigned)k; d.outputMatrixClusters.format = nmfgpu::StorageFormat::Dense;
+	d.outputMatrixClusters.dense.values = clusters; d.outputMatrixClusters.dense.leadingDimension = (unsigned)ldc;
+	d.outputMemberships = membership; d.numClusters = (unsigned)k; d.numIterations = maxiter; d.seed = seed; d.thresholdValue = threshold;
+	nmfgpu::KMeansSummary s{};
+	if (nmfgpu::hostinit::compute_kmeans<T>(d, &s) != nmfgpu::ResultType::Success) return nmfamd::ST_INVALID;
+	if (iterations) *iterations = s.iterations;
+	return nmfamd::ST_OK;
+}
+
+template <typename T>
+int host_init(const T* V, long ldv, int m, int n, int r, int method, unsigned seed, T* W, T* H) {
+	if (!V || !W || m <= 0 || n <= 0 || r <= 0 || ldv < m) return nmfamd::ST_INVALID;
+	nmfgpu::NmfDescription<T> d{};
+	d.inputMatrix.rows = (unsigned)m; d.inputMatrix.columns = (unsigned)n; d.inputMatrix.format = nmfgpu::StorageFormat::Dense;
+	d.inputMatrix.dense.values = const_cast<T*>(V); d.inputMatrix.dense.leadingDimension = (unsigned)ldv;
+	d.features = (unsigned)r; d.seed = seed; d.initMethod = (nmfgpu::NmfInitializationMethod)method;
+	if ((d.initMethod != nmfgpu::NmfInitializationMethod::MeanColumns) && r >= n) return nmfamd::ST_INVALID;
+	return nmfgpu::hostinit::initialize<T>(d, W, H) ? nmfamd::ST_OK : nmfamd::ST_INVALID;
+}
+} // namespace
 
 extern "C" {
 
@@ -227,6 +257,21 @@ long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capa
 long nmfamd_engine_error_terms_to_device(nmfamd_engine* e, void* dst_device, long capacity) {
 	if (!e || !dst_device) return -1;
 	return e->elem_bytes == 4 ? e->f->error_terms_to_device((float*)dst_device, capacity) : e->d->error_terms_to_device((double*)dst_device, capacity);
+}
+
+int nmfamd_host_kmeans_f32(const float* data, long ld, int m, int n, float* clusters, long ldc, int k, unsigned* membership, unsigned seed,
+                           unsigned maxiter, double threshold, unsigned* iterations) {
+	return host_kmeans<float>(data, ld, m, n, clusters, ldc, k, membership, seed, maxiter, threshold, iterations);
+}
+int nmfamd_host_kmeans_f64(const double* data, long ld, int m, int n, double* clusters, long ldc, int k, unsigned* membership, unsigned seed,
+                           unsigned maxiter, double threshold, unsigned* iterations) {
+	return host_kmeans<double>(data, ld, m, n, clusters, ldc, k, membership, seed, maxiter, threshold, iterations);
+}
+int nmfamd_host_init_f32(const float* V, long ldv, int m, int n, int r, int method, unsigned seed, float* W, float* H) {
+	return host_init<float>(V, ldv, m, n, r, method, seed, W, H);
+}
+int nmfamd_host_init_f64(const double* V, long ldv, int m, int n, int r, int method, unsigned seed, double* W, double* H) {
+	return host_init<double>(V, ldv, m, n, r, method, seed, W, H);
 }
 
 double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw) {

@@ -1,11 +1,18 @@
 // host_init.cpp -- the initialisation strategies that run once per run, outside the iteration
 // loop, kept on the host (BASELINE.json north star: "the k-means/NNDSVD init stays host-side C++").
 //
-// Restates, on the CPU with OpenMP:
+// Restates on the CPU, over a small std::thread pool (no OpenMP runtime is pulled into the host
+// process), in the reference's own summation orders:
 //   k-means (Lloyd, Forgy start)        source/kmeans/kMeans.cu:126-278
 //   KMeans* strategies                  source/init/KMeansStrategy.cpp:31-65
 //   EIn-NMF membership transform        source/init/EInNMF.cu:44-91
 //   MeanColumns                         source/init/MeanColumnStrategy.cpp:43-56, KernelMeanColumn.cu:30-50
+// Summation orders kept from the reference so that memberships and centres agree bit for bit:
+//   * squared distances: 32 strided lane partials, fused multiply-add, then the xor-butterfly of
+//     sumWarpReduction (kMeans.cu:41-50, KernelHelper.cuh:31-43);
+//   * centre = (sum of members in ascending column order) / count (kMeans.cu:100-117, members
+//     sorted by (cluster, column) at :185-189);
+//   * EIn-NMF: Hillis-Steele scan over 32 lanes in double, carry rounded to T (EInNMF.cu:59-90).
 // Deliberate differences from the reference (each a defect there, see DESIGN.md "quirks"):
 //   * memberships start at "none" instead of uninitialised device memory (kMeans.cu:53-78);
 //   * every row of a centroid is updated (the reference halves its grid and skips the last
@@ -19,12 +26,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <limits>
 #include <numeric>
 #include <random>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 namespace nmfgpu {
 namespace hostinit {
@@ -74,6 +85,146 @@ std::vector<T> to_dense(const MatrixDescription<T>& M) {
 	return out;
 }
 
+// ---- threads -------------------------------------------------------------------------------
+unsigned host_threads() {
+	static const unsigned n = [] {
+		if (const char* e = std::getenv("NMFAMD_HOST_THREADS")) { int v = std::atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
+		cpu_set_t set;
+		unsigned avail = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
+		return std::max(1u, std::min(avail, 16u));   // 16 = a GPU box's CPU share per GPU
+	}();
+	return n;
+}
+
+// f(begin, end, slot) over [0, n) cut into contiguous chunks that are multiples of `align`.
+template <typename F>
+void parallel_chunks(size_t n, size_t align, size_t min_chunk, F&& f) {
+	size_t units = (n + align - 1) / align;
+	size_t want = std::max<size_t>(1, std::min<size_t>(host_threads(), n / std::max<size_t>(min_chunk, 1)));
+	size_t per = (units + want - 1) / want;
+	size_t chunks = per ? (units + per - 1) / per : 0;
+	if (chunks <= 1) { if (n) f(size_t(0), n, size_t(0)); return; }
+	std::vector<std::thread> pool;
+	pool.reserve(chunks - 1);
+	for (size_t c = 1; c < chunks; ++c)
+		pool.emplace_back([&, c] { f(c * per * align, std::min(n, (c + 1) * per * align), c); });
+	f(size_t(0), std::min(n, per * align), size_t(0));
+	for (auto& t : pool) t.join();
+}
+
+// ---- the reference's warp-shaped reductions ---------------------------------------------------
+// x86-64-v3 clones give the compiler vfmadd; the baseline clone calls libm's fma -- same bits.
+// The *_impl templates are force-inlined so that each clone compiles them for its own target.
+#define NMFAMD_CLONES __attribute__((target_clones("default", "arch=x86-64-v3")))
+#define NMFAMD_INLINE inline __attribute__((always_inline))
+
+template <typename T>
+NMFAMD_INLINE T butterfly32(T* p) {
+	for (int s = 16; s >= 1; s >>= 1)
+		for (int t = 0; t < s; ++t) p[t] += p[t + s];
+	return p[0];
+}
+
+template <typename T>
+NMFAMD_INLINE T dist_sq_impl(const T* a, const T* b, size_t m) {
+	T p[32];
+	for (int t = 0; t < 32; ++t) p[t] = T(0);
+	size_t i = 0;
+	for (; i + 32 <= m; i += 32)
+		for (int t = 0; t < 32; ++t) { T d = a[i + t] - b[i + t]; p[t] = std::fma(d, d, p[t]); }
+	for (int t = 0; i + t < m; ++t) { T d = a[i + t] - b[i + t]; p[t] = std::fma(d, d, p[t]); }
+	return butterfly32(p);
+}
+
+template <typename T>
+NMFAMD_INLINE T dot_impl(const T* a, const T* b, size_t m) {
+	T p[32];
+	for (int t = 0; t < 32; ++t) p[t] = T(0);
+	size_t i = 0;
+	for (; i + 32 <= m; i += 32)
+		for (int t = 0; t < 32; ++t) p[t] = std::fma(a[i + t], b[i + t], p[t]);
+	for (int t = 0; i + t < m; ++t) p[t] = std::fma(a[i + t], b[i + t], p[t]);
+	return butterfly32(p);
+}
+
+// nearest centre of each column in [q0, q1); returns how many memberships changed
+template <typename T>
+NMFAMD_INLINE unsigned assign_impl(const T* data, size_t m, size_t q0, size_t q1, const T* clusters, size_t ldc, size_t k, unsigned* membership) {
+	unsigned changed = 0;
+	for (size_t q = q0; q < q1; ++q) {
+		const T* x = data + q * m;
+		unsigned best = 0;
+		T bestd = dist_sq_impl(x, clusters, m);
+		for (size_t c = 1; c < k; ++c) {
+			T s = dist_sq_impl(x, clusters + c * ldc, m);
+			if (s < bestd) { bestd = s; best = (unsigned)c; }   // strict '<': first minimum wins (kMeans.cu:66-71)
+		}
+		if (membership[q] != best) { membership[q] = best; ++changed; }
+	}
+	return changed;
+}
+
+// rows [i0, i1) of every non-empty centre = sum of its members (ascending column) / count
+template <typename T>
+NMFAMD_INLINE void centres_impl(const T* data, size_t m, size_t n, size_t i0, size_t i1, T* clusters, size_t ldc, size_t k,
+                         const unsigned* membership, const unsigned* count) {
+	for (size_t c = 0; c < k; ++c)
+		if (count[c]) std::fill(clusters + c * ldc + i0, clusters + c * ldc + i1, T(0));
+	for (size_t q = 0; q < n; ++q) {
+		T* ctr = clusters + (size_t)membership[q] * ldc;
+		const T* x = data + q * m;
+		for (size_t i = i0; i < i1; ++i) ctr[i] += x[i];
+	}
+	for (size_t c = 0; c < k; ++c)
+		if (count[c]) { T* ctr = clusters + c * ldc; const T cnt = T(count[c]); for (size_t i = i0; i < i1; ++i) ctr[i] /= cnt; }
+}
+
+// EIn-NMF memberships (MODE 0), max(W^T v, 0) (MODE 1) or |W^T v| (MODE 2) for columns [q0, q1)
+template <typename T, int MODE>
+NMFAMD_INLINE void h_from_centres_impl(const T* V, const T* W, size_t m, size_t r, size_t q0, size_t q1, T* H) {
+	for (size_t q = q0; q < q1; ++q) {
+		const T* x = V + q * m;
+		T* h = H + q * r;
+		if (MODE == 0) {
+			// h_c = 1 / (d_c * sum_{c' <= c} 1 / (d_c' + 1e-9) + 1e-9): 32 centres at a time,
+			// Hillis-Steele in double, the running carry rounded to T (EInNMF.cu:59-90)
+			T carry = T(0);
+			for (size_t base = 0; base < r; base += 32) {
+				double v[32], nv[32];
+				T dist[32];
+				const size_t lanes = std::min<size_t>(32, r - base);
+				for (size_t t = 0; t < lanes; ++t) dist[t] = dist_sq_impl(W + (base + t) * m, x, m);
+				for (size_t t = 0; t < 32; ++t) v[t] = t < lanes ? 1.f / (dist[t] + 1.e-9) : 0.0;
+				for (size_t s = 1; s < 32; s *= 2) {
+					for (size_t t = 0; t < 32; ++t) nv[t] = t >= s ? v[t] + v[t - s] : v[t];
+					std::memcpy(v, nv, sizeof(v));
+				}
+				for (size_t t = 0; t < lanes; ++t) {
+					v[t] += carry;
+					h[base + t] = (T)(1.f / std::fma((double)dist[t], v[t], 1.e-9));   // d * value + 1e-9 is one DFMA under nvcc
+				}
+				carry = (T)v[31];
+			}
+		} else {
+			for (size_t c = 0; c < r; ++c) {
+				T s = dot_impl(W + c * m, x, m);
+				h[c] = MODE == 2 ? (T)std::fabs(s) : std::max(s, T(0));
+			}
+		}
+	}
+}
+
+NMFAMD_CLONES unsigned assign_cols(const float* d, size_t m, size_t q0, size_t q1, const float* c, size_t ldc, size_t k, unsigned* mb) { return assign_impl(d, m, q0, q1, c, ldc, k, mb); }
+NMFAMD_CLONES unsigned assign_cols(const double* d, size_t m, size_t q0, size_t q1, const double* c, size_t ldc, size_t k, unsigned* mb) { return assign_impl(d, m, q0, q1, c, ldc, k, mb); }
+NMFAMD_CLONES void centre_rows(const float* d, size_t m, size_t n, size_t i0, size_t i1, float* c, size_t ldc, size_t k, const unsigned* mb, const unsigned* cnt) { centres_impl(d, m, n, i0, i1, c, ldc, k, mb, cnt); }
+NMFAMD_CLONES void centre_rows(const double* d, size_t m, size_t n, size_t i0, size_t i1, double* c, size_t ldc, size_t k, const unsigned* mb, const unsigned* cnt) { centres_impl(d, m, n, i0, i1, c, ldc, k, mb, cnt); }
+NMFAMD_CLONES void h_einnmf(const float* V, const float* W, size_t m, size_t r, size_t q0, size_t q1, float* H) { h_from_centres_impl<float, 0>(V, W, m, r, q0, q1, H); }
+NMFAMD_CLONES void h_einnmf(const double* V, const double* W, size_t m, size_t r, size_t q0, size_t q1, double* H) { h_from_centres_impl<double, 0>(V, W, m, r, q0, q1, H); }
+NMFAMD_CLONES void h_wtv_nonneg(const float* V, const float* W, size_t m, size_t r, size_t q0, size_t q1, float* H) { h_from_centres_impl<float, 1>(V, W, m, r, q0, q1, H); }
+NMFAMD_CLONES void h_wtv_nonneg(const double* V, const double* W, size_t m, size_t r, size_t q0, size_t q1, double* H) { h_from_centres_impl<double, 1>(V, W, m, r, q0, q1, H); }
+NMFAMD_CLONES void h_wtv_abs(const float* V, const float* W, size_t m, size_t r, size_t q0, size_t q1, float* H) { h_from_centres_impl<float, 2>(V, W, m, r, q0, q1, H); }
+NMFAMD_CLONES void h_wtv_abs(const double* V, const double* W, size_t m, size_t r, size_t q0, size_t q1, double* H) { h_from_centres_impl<double, 2>(V, W, m, r, q0, q1, H); }
+
 // Lloyd iterations; data m x n (ld m), clusters m x k (ld ldc).  Returns iterations done.
 template <typename T>
 unsigned lloyd(const T* data, size_t m, size_t n, T* clusters, size_t ldc, size_t k, unsigned* membership,
@@ -86,21 +237,14 @@ unsigned lloyd(const T* data, size_t m, size_t n, T* clusters, size_t ldc, size_
 	for (size_t c = 0; c < k; ++c) std::memcpy(clusters + c * ldc, data + (size_t)idx[c] * m, sizeof(T) * m);
 
 	std::fill(membership, membership + n, std::numeric_limits<unsigned>::max());
+	// ~2 flops per element per centre: below ~1 Mflop per thread the fork/join costs more than it saves
+	const size_t cols_per_thread = std::max<size_t>(1, (size_t)(5e5 / double(std::max<size_t>(m * k, 1))));
 	auto assign = [&]() -> unsigned {
-		unsigned changed = 0;
-#pragma omp parallel for schedule(static) reduction(+ : changed)
-		for (long q = 0; q < (long)n; ++q) {
-			const T* x = data + (size_t)q * m;
-			unsigned best = 0; T bestd = std::numeric_limits<T>::max();
-			for (size_t c = 0; c < k; ++c) {
-				const T* ctr = clusters + c * ldc;
-				T s = 0;
-				for (size_t i = 0; i < m; ++i) { T diff = x[i] - ctr[i]; s += diff * diff; }
-				if (c == 0 || s < bestd) { bestd = s; best = (unsigned)c; }   // strict '<': first minimum wins (kMeans.cu:66-71)
-			}
-			if (membership[q] != best) { membership[q] = best; ++changed; }
-		}
-		return changed;
+		std::vector<unsigned> part(host_threads() + 1, 0u);
+		parallel_chunks(n, 1, cols_per_thread, [&](size_t q0, size_t q1, size_t slot) {
+			part[slot] = assign_cols(data, m, q0, q1, clusters, ldc, k, membership);
+		});
+		return std::accumulate(part.begin(), part.end(), 0u);
 	};
 
 	unsigned iteration = 0;
@@ -112,16 +256,11 @@ unsigned lloyd(const T* data, size_t m, size_t n, T* clusters, size_t ldc, size_
 		if (changed > 0) {
 			std::fill(count.begin(), count.end(), 0u);
 			for (size_t q = 0; q < n; ++q) ++count[membership[q]];
-			// centroid = mean of its members; an empty cluster keeps its centre (kMeans.cu:89-93)
-#pragma omp parallel for schedule(static)
-			for (long c = 0; c < (long)k; ++c) {
-				if (count[c] == 0) continue;
-				T* ctr = clusters + (size_t)c * ldc;
-				std::fill(ctr, ctr + m, T(0));
-				for (size_t q = 0; q < n; ++q)
-					if (membership[q] == (unsigned)c) { const T* x = data + q * m; for (size_t i = 0; i < m; ++i) ctr[i] += x[i]; }
-				for (size_t i = 0; i < m; ++i) ctr[i] /= T(count[c]);
-			}
+			// an empty cluster keeps its centre (kMeans.cu:89-93); threads own disjoint row ranges
+			const size_t rows_per_thread = std::max<size_t>(64, (size_t)(5e5 / double(std::max<size_t>(n, 1))));
+			parallel_chunks(m, 16, rows_per_thread, [&](size_t i0, size_t i1, size_t) {
+				centre_rows(data, m, n, i0, i1, clusters, ldc, k, membership, count.data());
+			});
 		}
 	} while (++iteration < maxiter && change > threshold);
 	if (change > 0.0) assign();   // final memberships against the last centres (kMeans.cu:262-270)
@@ -169,29 +308,12 @@ bool initialize(const NmfDescription<T>& d, T* W, T* H) {
 			fill_uniform(H, r, n, r, d.seed + 1);
 			return true;
 		}
-#pragma omp parallel for schedule(static)
-		for (long q = 0; q < (long)n; ++q) {
-			const T* x = V.data() + (size_t)q * m;
-			T* h = H + (size_t)q * r;
-			if (d.initMethod == NmfInitializationMethod::EInNMF) {
-				// h_k = 1 / (d_k * sum_{k' <= k} 1 / (d_k' + 1e-9) + 1e-9), d = squared distance to centroid k
-				T prefix = 0;
-				for (size_t c = 0; c < r; ++c) {
-					const T* w = W + c * m;
-					T dist = 0;
-					for (size_t i = 0; i < m; ++i) { T diff = w[i] - x[i]; dist += diff * diff; }
-					prefix += (T)(1.f / (dist + 1.e-9));
-					h[c] = (T)(1.f / (dist * prefix + 1.e-9));
-				}
-			} else {
-				for (size_t c = 0; c < r; ++c) {
-					const T* w = W + c * m;
-					T s = 0;
-					for (size_t i = 0; i < m; ++i) s += w[i] * x[i];
-					h[c] = d.initMethod == NmfInitializationMethod::KMeansAndAbsoluteWTV ? (T)std::fabs(s) : std::max(s, T(0));
-				}
-			}
-		}
+		const size_t cols_per_thread = std::max<size_t>(1, (size_t)(5e5 / double(std::max<size_t>(m * r, 1))));
+		parallel_chunks(n, 1, cols_per_thread, [&](size_t q0, size_t q1, size_t) {
+			if (d.initMethod == NmfInitializationMethod::EInNMF) h_einnmf(V.data(), W, m, r, q0, q1, H);
+			else if (d.initMethod == NmfInitializationMethod::KMeansAndAbsoluteWTV) h_wtv_abs(V.data(), W, m, r, q0, q1, H);
+			else h_wtv_nonneg(V.data(), W, m, r, q0, q1, H);
+		});
 		return true;
 	}
 	default:

@@ -247,3 +247,35 @@ def op_inverse(A: np.ndarray, offdiag: float = 0.0, diag: float = 0.0) -> np.nda
     if st != 0:
         raise EngineError(st, "nmfamd_op_inverse_f32")
     return out
+
+
+def host_kmeans(data: np.ndarray, k: int, *, seed: int = 0, iterations: int = 100, threshold: float = 0.005):
+    """The host-side Lloyd k-means behind computeKMeans and the KMeans*/EInNMF initialisers, without a
+    device or context (nmfamd_host_kmeans_*).  Returns (clusters m x k, membership, passes)."""
+    lib = library()
+    data = _f(data)
+    m, n = data.shape
+    clusters = np.zeros((m, k), dtype=data.dtype, order="F")
+    membership = np.zeros(n, dtype=np.uint32)
+    it = C.c_uint(0)
+    fn = getattr(lib, "nmfamd_host_kmeans_f32" if data.dtype == np.float32 else "nmfamd_host_kmeans_f64")
+    st = fn(C.c_void_p(data.ctypes.data), C.c_long(_ld(data)), m, n, C.c_void_p(clusters.ctypes.data), C.c_long(m), k,
+            C.c_void_p(membership.ctypes.data), C.c_uint(seed), C.c_uint(iterations), C.c_double(threshold), C.byref(it))
+    if st != 0:
+        raise EngineError(st, "host_kmeans")
+    return clusters, membership, int(it.value)
+
+
+def host_init(V: np.ndarray, r: int, method: int, *, seed: int = 0, want_h: bool = True):
+    """W (m x r) and H (r x n) of the MeanColumns / KMeans* / EInNMF initialisers (nmfamd_host_init_*)."""
+    lib = library()
+    V = _f(V)
+    m, n = V.shape
+    W = np.zeros((m, r), dtype=V.dtype, order="F")
+    H = np.zeros((r, n), dtype=V.dtype, order="F") if want_h else None
+    fn = getattr(lib, "nmfamd_host_init_f32" if V.dtype == np.float32 else "nmfamd_host_init_f64")
+    st = fn(C.c_void_p(V.ctypes.data), C.c_long(_ld(V)), m, n, r, int(method), C.c_uint(seed), C.c_void_p(W.ctypes.data),
+            C.c_void_p(H.ctypes.data) if want_h else None)
+    if st != 0:
+        raise EngineError(st, "host_init")
+    return W, H

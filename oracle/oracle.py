@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libnmf_oracle.so")
+_KM_PATH = os.path.join(_HERE, "_build", "libkmeans_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "libnmfgpu_refhost.so")
 
 ALGORITHMS = {"mu": 0, "gdcls": 1, "als": 2, "acls": 3, "ahcls": 4, "nsnmf": 5}
@@ -23,9 +24,11 @@ ALGORITHMS = {"mu": 0, "gdcls": 1, "als": 2, "acls": 3, "ahcls": 4, "nsnmf": 5}
 
 def build(force: bool = False) -> str:
     """Compile the oracle (and, if /root/reference is present, the reference host units)."""
-    if force or not os.path.exists(_LIB_PATH) or (
+    stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(_KM_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                           for f in ("nmf_oracle.c", "nmf_oracle_impl.h"))):
+                                           for f in ("nmf_oracle.c", "nmf_oracle_impl.h"))) or (
+        os.path.getmtime(_KM_PATH) < os.path.getmtime(os.path.join(_HERE, "kmeans_oracle.cpp")))
+    if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     if os.path.isdir("/root/reference/source/nmf") and not os.path.exists(_REF_PATH):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
@@ -58,6 +61,19 @@ def lib() -> C.CDLL:
             getattr(_lib, f"oracle_direct_frobenius_{sfx}").restype = C.c_double
             getattr(_lib, f"oracle_run_{sfx}").restype = C.c_int
     return _lib
+
+
+_km = None
+
+
+def kmeans_lib() -> C.CDLL:
+    global _km
+    if _km is None:
+        build()
+        _km = C.CDLL(_KM_PATH)
+        _km.oracle_kmeans_f32.restype = C.c_uint
+        _km.oracle_kmeans_f64.restype = C.c_uint
+    return _km
 
 
 def ref_lib():
@@ -254,3 +270,26 @@ def run_kl(V, W, H, num_iterations: int):
     frob = C.c_double(0); rmsd = C.c_double(0); kl = C.c_double(0)
     fn(m, n, r, _ptr(_f(V)), _ld(V), _ptr(_f(W)), _ld(W), _ptr(_f(H)), _ld(H), num_iterations, C.byref(frob), C.byref(rmsd), C.byref(kl))
     return {"frobenius": frob.value, "rmsd": rmsd.value, "kl": kl.value}
+
+
+def kmeans(data, k: int, *, seed: int = 0, iterations: int = 100, threshold: float = 0.005):
+    """Lloyd k-means with a Forgy start (source/kmeans/kMeans.cu:126-278).  Returns (clusters m x k, membership, passes)."""
+    data = _f(data)
+    m, n = data.shape
+    clusters = np.zeros((m, k), dtype=data.dtype, order="F")
+    membership = np.zeros(n, dtype=np.uint32)
+    fn = getattr(kmeans_lib(), f"oracle_kmeans_{_sfx(data.dtype)}")
+    it = fn(_ptr(data), C.c_long(_ld(data)), C.c_uint(m), C.c_uint(n), _ptr(clusters), C.c_long(m), C.c_uint(k),
+            _ptr(membership), C.c_uint(seed), C.c_uint(iterations), C.c_double(threshold))
+    return clusters, membership, int(it)
+
+
+def einnmf_h(V, W):
+    """EIn-NMF membership degrees of every column of V against the centres W (source/init/EInNMF.cu:44-119)."""
+    V = _f(V); W = _f(W)
+    m, n = V.shape
+    r = W.shape[1]
+    H = np.zeros((r, n), dtype=V.dtype, order="F")
+    getattr(kmeans_lib(), f"oracle_einnmf_h_{_sfx(V.dtype)}")(_ptr(V), C.c_long(_ld(V)), _ptr(W), C.c_long(_ld(W)), C.c_uint(m),
+                                                              C.c_uint(r), C.c_uint(n), _ptr(H), C.c_long(r))
+    return H

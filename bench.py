@@ -160,6 +160,7 @@ def main():
             kernel_ms, kernel_launches, pair_overhead_ms = eng.kernel_timing_read2()
             eng.kernel_timing(0)
         frob = eng.frobenius
+        product_kernel = eng.geometry()["product_kernel"]
         parallelism = "single GPU"
     else:
         from nmfgpu_amd.distributed import EngineShard, ShardedMU
@@ -185,6 +186,7 @@ def main():
         if not args.no_kernel_events:
             kernel_ms, kernel_launches, pair_overhead_ms = shard.engine.kernel_timing_read2()
         frob = drv.frobenius
+        product_kernel = shard.engine.geometry()["product_kernel"]
         if distributed:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,21 +195,33 @@ def main():
 
     if rank == 0:
         flops_per_launch = 2.0 * M * N_COLS * R               # one product against V (algorithmic, unpadded)
+        bytes_per_launch = 4.0 * M * N_COLS                   # the fp32 image of V (or V^T) one product streams
         roofline = None
         if kernel_launches > 0:
             # Event pairs over-report a launch by a few us (an EMPTY pair on the idle stream reports idle_event_pair_us; the
             # rocprofv3 trace of the same run averages ~2 us less per launch than the events).  No correction is applied:
             # `achieved` is the conservative figure.
             avg_s = kernel_ms / 1e3 / kernel_launches
-            achieved = flops_per_launch / avg_s / 1e12
-            traffic = None   # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
-            tpath = os.path.join(ROOT, "profiles", "traffic_factor_product.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                        "kernel": "k_factor_product_f32", "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
-                        "flops_per_launch": flops_per_launch}
+            common = {"avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
+                      "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch}
+            if product_kernel == 2:
+                # fp32 product on the bf16 matrix pipe (operands split exactly into 3 bf16 terms): six bf16 MFMAs replace
+                # sixteen fp32-MFMA-equivalents, and the kernel is bound by streaming the fp32 image of V from HBM
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "traffic_factor_product_x3.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                            "kernel": "k_factor_product_x3", "fp32_equivalent_tflops": flops_per_launch / avg_s / 1e12, **common}
+            else:
+                achieved = flops_per_launch / avg_s / 1e12
+                traffic = None   # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
+                tpath = os.path.join(ROOT, "profiles", "traffic_factor_product.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": "k_factor_product_f32", **common}
         if args.rccl1 and not distributed:
             parallelism += " (one-rank RCCL group: collectives issued, identities)"
         out = {
@@ -217,7 +231,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32",
-                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "parallelism": parallelism},
+                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "parallelism": parallelism,
+                       "arithmetic": ("fp32 operands and fp32 accumulation; the two big products run on the bf16 matrix pipe with every operand "
+                                      "split EXACTLY into three bf16 terms (six cross products kept, dropped terms <= 2^-23 relative): measured "
+                                      "error against fp64 equals the native fp32 MFMA kernel's (tests/test_gpu_parity.py)") if product_kernel == 2
+                                     else "fp32 MFMA instructions"},
             "frobenius_last": frob,
             "iter_flops": 4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS),
             "achieved_tflops_whole_iteration": (4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS)) * (K / elapsed) / 1e12,

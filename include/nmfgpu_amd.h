@@ -53,7 +53,9 @@ typedef struct nmfamd_params {
 	/* extensions without a reference counterpart (nmfgpu::compute: Parameter names "divergence", "sparseCompute") */
 	double divergence;      /* 0 = Frobenius objective; 1 = generalised KL divergence (Multiplicative only; implies sparse_compute) */
 	double sparse_compute;  /* 1 = keep V as CSR + CSC in HBM and use SpMM / SDDMM kernels instead of densifying (Multiplicative only) */
-	double precision;       /* 0 = native; 1 = bf16 MFMA operands in the two big products (float, Multiplicative, rank <= 64; Parameter "precision") */
+	double precision;       /* Parameter "precision", float engines only.  0 = fp32 accuracy: products on the bf16 matrix pipe with every
+	                           operand split exactly into three bf16 terms (kernels_x3.hip); -1 = native fp32 MFMA instructions;
+	                           1 = operands rounded to bf16 (reduced precision, half the bytes of V per pass) */
 } nmfamd_params;
 
 typedef struct nmfamd_engine nmfamd_engine;  /* opaque; owns every device buffer of one factorisation */
@@ -119,6 +121,8 @@ typedef struct nmfamd_geometry {
 	long padded_m, padded_n;
 	int slabs_h, slabs_w;  /* split-K slices of the two factor products */
 	long exchange_count;   /* elements of the multi-GPU exchange buffer */
+	int product_kernel;    /* 0 fp32 MFMA, 1 bf16-rounded operands, 2 fp32 by exact 3 x bf16 operand splitting, 3 fp64 MFMA,
+	                          4 VALU kernel (NMFAMD_FORCE_VALU), 5 sparse SpMM */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 
@@ -175,6 +179,14 @@ NMFAMD_API int nmfamd_op_factor_product_f64(const double* A, long lda, int X, in
 NMFAMD_API int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us, unsigned long long* stamps_out, long stamps_capacity, long* stamps_count);
 /* The same product with bf16-rounded operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation), r <= 64. */
 NMFAMD_API int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo);
+/* The same product at fp32 accuracy on the bf16 matrix pipe: both operands split exactly into three bf16 terms, six
+ * cross products, fp32 accumulation (kernels_x3.hip), r <= 64.  reps > 0 additionally times `reps` launches of the
+ * product kernel alone (HIP events) into *avg_us. */
+NMFAMD_API int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo,
+                                           int reps, double* avg_us);
+/* Diagnostic (NMFAMD_X3_VARIANT = 10..13 builds): per wave {shader cycles, 100 MHz ticks, K-steps of the main loop; 100 MHz
+ * stamps at entry, loop start, loop end, tail end, exit} of one more launch; stamps_capacity in 8-byte words; *waves receives the number of waves stamped. */
+NMFAMD_API int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves);
 /* G (r x r) = P P^T for a host r x len matrix P. */
 NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long ldg);
 NMFAMD_API int nmfamd_op_gram_f64(const double* P, long ldp, int r, int len, double* G, long ldg);

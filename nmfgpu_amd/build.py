@@ -19,12 +19,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
-SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "engine.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
+SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "engine.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
 ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 # translation units without device code or HIP runtime calls: plain C++ (function multiversioning
 # is rejected by the device pass of a -x hip compile); no implicit contraction: where the reference's
 # nvcc build fuses a multiply-add the source says std::fma)
 HOST_ONLY = {"host_init.cpp"}
+# per-source extra flags.  kernels_x3.hip: the SLP vectoriser pairs the scalar subtractions of the operand split
+# into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
+EXTRA_FLAGS = {"kernels_x3.hip": ["-fno-slp-vectorize"]}
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",
          "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -57,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if src in HOST_ONLY:
             cmd = [cc, *[f for f in FLAGS if not f.startswith("--offload-arch")], "-x", "c++", "-pthread", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
-            cmd = [cc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -221,6 +221,7 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 		out->m = g.m(); out->n = g.n(); out->r = g.r(); out->padded_rank = g.rp();
 		out->padded_m = g.mpad(); out->padded_n = g.npad();
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
+		out->product_kernel = g.product_kernel();
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
 	return NMFAMD_OK;
@@ -358,6 +359,80 @@ int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const 
 	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us) {
+	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || r > 64 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	int dev = 0; hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const int RP = 64;
+	const long Xp = pad128(X), Yp = pad128(Y);
+	const int KS = (Y + 15) / 16;
+	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;
+	plan.splits = plan_splits_x3(plan.xtiles, KS, prop.multiProcessorCount);
+	DevBuf dA, dT, dF, dFb, dS, dO;
+	const long slab_stride = (long)RP * Xp;
+	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dT.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * RP * Yp) != hipSuccess ||
+	    dFb.alloc(3 * 16 * (size_t)(KS + 1) * (RP / 32) * 64) != hipSuccess ||
+	    dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess || dO.alloc(sizeof(float) * slab_stride) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemset(dA.p, 0, sizeof(float) * Xp * Yp) != hipSuccess || hipMemset(dT.p, 0, sizeof(float) * Xp * Yp) != hipSuccess ||
+	    hipMemset(dF.p, 0, sizeof(float) * RP * Yp) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dA.p, Xp * sizeof(float), A, lda * sizeof(float), X * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dF.p, RP * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, 128 * Yp, 128, false, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_factor_product_x3(plan, (const float*)dT.p, 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (reps > 0 && avg_us) {
+		// alternate between two images of A so that no launch finds its operand in the 256 MB memory-side cache
+		// (inside an iteration the two products stream V and V^T in turn)
+		DevBuf dT2;
+		if (dT2.alloc(sizeof(float) * Xp * Yp) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+		if (hipMemcpy(dT2.p, dT.p, sizeof(float) * Xp * Yp, hipMemcpyDeviceToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+		hipEvent_t e0, e1;
+		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+		for (int i = 0; i < 4; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr);
+		(void)hipEventRecord(e0, nullptr);
+		for (int i = 0; i < reps; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr);
+		(void)hipEventRecord(e1, nullptr);
+		if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+		float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+		*avg_us = ms * 1e3 / reps;
+		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	}
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves) {
+	if (X <= 0 || Y <= 0 || !stamps_out || !waves) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	int dev = 0; hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const int RP = 64;
+	const long Xp = pad128(X), Yp = pad128(Y);
+	const int KS = (Y + 15) / 16;
+	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;
+	plan.splits = plan_splits_x3(plan.xtiles, KS, prop.multiProcessorCount);
+	const long nwaves = (long)plan.xtiles * plan.splits * 4;
+	if (stamps_capacity < 8 * nwaves) return NMFAMD_INVALID_ARGUMENT;
+	DevBuf dA, dA2, dF, dFb, dS, dT;
+	const long slab_stride = (long)RP * Xp;
+	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dA2.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * RP * Yp) != hipSuccess ||
+	    dFb.alloc(3 * 16 * (size_t)(KS + 1) * (RP / 32) * 64) != hipSuccess || dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess ||
+	    dT.alloc(sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (launch_fill_uniform<float>((float*)dA.p, (int)Xp, (int)Xp, Yp, Yp, 1, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_fill_uniform<float>((float*)dA2.p, (int)Xp, (int)Xp, Yp, Yp, 3, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemset(dT.p, 0, sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_HIP_ERROR;
+	for (int i = 0; i < 6; ++i)
+		if (launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr,
+		                             i == 5 ? (unsigned long long*)dT.p : nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	*waves = nwaves;
+	return NMFAMD_OK;
 }
 
 int nmfamd_op_factor_product_f64(const double* A, long lda, int X, int Y, const double* F, long ldf, int r, double* OUT, long ldo, int use_valu, int* out_slabs) {

@@ -61,7 +61,7 @@ Engine<T>::~Engine() {
 		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
-	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_}; for (void* b : bb) if (b) (void)hipFree(b); }
+	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -99,7 +99,7 @@ Status Engine<T>::allocate() {
 		planH_.splits = planW_.splits = 1; planH_.th = planW_.th = 128;
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
 	}
-	if (prm_.precision != 0) {
+	if (prm_.precision > 0) {
 		// bf16 operands for the two big products, dense (resident) V only; every algorithm, padded rank 64 or k * 128
 		if (!std::is_same<T, float>::value || sparse_ || !mfma) return ST_INVALID;
 		bf16_ = true;
@@ -110,6 +110,21 @@ Status Engine<T>::allocate() {
 		planH_.splits = plan_splits_bf16(planH_.xtiles, ksH_, RP_, num_cus_);
 		planW_.splits = plan_splits_bf16(planW_.xtiles, ksW_, RP_, num_cus_);
 		planHb_ = planH_; planWb_ = planW_;
+	}
+	// fp32, dense, MFMA path: both products run on the bf16 matrix pipe with every operand split exactly into
+	// three bf16 terms (fp32-level accuracy, six cross products; kernels_x3.hip) -- HBM-bound instead of bound by
+	// the fp32 MFMA rate.  precision = -1 (or NMFAMD_FP32_NATIVE) keeps the native fp32 MFMA instructions.
+	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 &&
+	    std::getenv("NMFAMD_FP32_NATIVE") == nullptr) {
+		x3_ = true;
+		planH_.th = planW_.th = 128;
+		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
+		ksW_ = (n_ + 15) / 16; ksH_ = (m_ + 15) / 16;
+		planH_.splits = plan_splits_x3(planH_.xtiles, ksH_, num_cus_);
+		planW_.splits = plan_splits_x3(planW_.xtiles, ksW_, num_cus_);
+		planHx_ = planH_; planWx_ = planW_;
+		planHx_.steps_total = ksH_; planWx_.steps_total = ksW_;
+		planHx_.nb = planWx_.nb = 2;
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
@@ -133,6 +148,14 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc(&Wtb_, 16 * (size_t)ksH_ * (RP_ / 32) * 64));
 		HIPX(hipMalloc(&Hb_, 16 * (size_t)ksW_ * (RP_ / 32) * 64));
 	} else if (!sparse_) {
+		if (x3_) {
+			// + 1: the all-zero K-step that closes the image (written here once; the update kernels never touch it)
+			const size_t bw = 3 * 16 * (size_t)(ksH_ + 1) * (RP_ / 32) * 64, bh = 3 * 16 * (size_t)(ksW_ + 1) * (RP_ / 32) * 64;
+			HIPX(hipMalloc(&Wx3_, bw));
+			HIPX(hipMalloc(&Hx3_, bh));
+			HIPX(hipMemsetAsync(Wx3_, 0, bw, stream_));
+			HIPX(hipMemsetAsync(Hx3_, 0, bh, stream_));
+		}
 		HIPX(dalloc(&V_, elemsV_));
 		HIPX(dalloc(&Vt_, elemsVt_));
 	} else {
@@ -284,13 +307,14 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false;
+		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
 		HIPX(launch_transpose<T>(stage_, mpad_, m_, r_, Wt_, RP_, stream_));
 	}
 	if (H) {
+		hx3_valid_ = false;
 		if (ldh < r_) return ST_INVALID;
 		gram_h_partials_ = false;
 		HIPX(hipMemsetAsync(H_, 0, sizeof(T) * (size_t)RP_ * npad_, stream_));
@@ -327,8 +351,8 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; }
-	if (h) gram_h_partials_ = false;
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; }
+	if (h) { gram_h_partials_ = false; hx3_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_));
 	return ST_OK;
@@ -381,7 +405,7 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_ov
 }
 
 template <typename T>
-Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
+Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked) {
 	if (sparse_) {
 		// W^T V as a row-gather SpMM over the CSC image: out(:, j) = sum_i V(i, j) F(:, i)
 		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
@@ -397,6 +421,14 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
+			record_end();
+			return ST_OK;
+		}
+		if (x3_) {
+			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
+			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS || std::getenv("NMFAMD_X3_NO_PASSENGER"))) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			record_begin();
+			HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -423,7 +455,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg) {
 }
 
 template <typename T>
-Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out) {
+Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out, bool prepacked) {
 	T* dest = (single_slab_out != nullptr && planW_.splits == 1) ? single_slab_out : slabs_;
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
@@ -439,6 +471,14 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
+			record_end();
+			return ST_OK;
+		}
+		if (x3_) {
+			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
+			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS || std::getenv("NMFAMD_X3_NO_PASSENGER"))) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			record_begin();
+			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -486,7 +526,7 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 // fp32 MFMA product at padded rank 64 with a passenger row in its grid
 template <typename T>
 bool Engine<T>::inverse_rides(const FactorProductPlan& plan) const {
-	return std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
+	return std::is_same<T, float>::value && tiled_ && !bf16_ && !x3_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
 	       std::getenv("NMFAMD_NO_OVERLAP") == nullptr && std::getenv("NMFAMD_INVERSE_SIDE_STREAM") == nullptr;
 }
 
@@ -561,12 +601,14 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 				fused_ready_ = true;
 			}
 			GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
-			if (Status s = product_h(Wt_, &rgW)) return s;
+			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
 			HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
-			                        compute_error ? 1 : 0, stream_));
+			                        compute_error ? 1 : 0, stream_, x3_ ? Hx3_ : nullptr, ksW_));
+			hx3_valid_ = x3_;
 			return ST_OK;
 		}
 	}
+	hx3_valid_ = false;
 	if (Status s = materialize_w()) return s;
 	const T* F = Wt_;
 	if (alg_ == ALG_NSNMF) {
@@ -624,7 +666,7 @@ Status Engine<T>::w_products(T* exchange) {
 			// K_W with the local H H^T reduced straight into the exchange buffer by the passenger
 			// workgroups, then the local split-K slabs summed into the exchange panel
 			GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), ex_hht, nullptr, 0};
-			if (Status s = product_w(H_, &rgH)) return s;
+			if (Status s = product_w(H_, &rgH, nullptr, x3_ && hx3_valid_)) return s;
 			HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
 		}
@@ -653,7 +695,8 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		if (fused_capable()) {
 			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T
 			HIPX(launch_mu64_update(1, Wt_, exchange, 1, 0, ex_hht, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
-			                        compute_error ? 1 : 0, stream_));
+			                        compute_error ? 1 : 0, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+			wx3_valid_ = x3_;
 			normalize_next_ = 1;
 			w_pending_ = true;
 			if (compute_error) { if (Status s = fetch_error_terms(n_)) return s; }
@@ -717,6 +760,7 @@ Status Engine<T>::materialize_w() {
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
 			w_pending_ = false;
 			fused_ready_ = false;
+			wx3_valid_ = false;
 		}
 	}
 	return ST_OK;
@@ -732,13 +776,15 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 			fused_ready_ = true;
 		}
 		GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
-		if (Status s = product_h(Wt_, &rgW)) return s;
+		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
 		HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
-		                        compute_error ? 1 : 0, stream_));
+		                        compute_error ? 1 : 0, stream_, x3_ ? Hx3_ : nullptr, ksW_));
 		GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), HHt_, nullptr, 0};
-		if (Status s = product_w(H_, &rgH)) return s;
+		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
 		HIPX(launch_mu64_update(1, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
-		                        compute_error ? 1 : 0, stream_));
+		                        compute_error ? 1 : 0, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+		wx3_valid_ = x3_;
+		hx3_valid_ = false;
 		normalize_next_ = 1;
 		w_pending_ = true;
 		if (compute_error) {

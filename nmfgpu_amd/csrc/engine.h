@@ -89,6 +89,9 @@ public:
 	long npad() const { return npad_; }
 	int slabs_h() const { return planH_.splits; }
 	int slabs_w() const { return planW_.splits; }
+	// which kernel runs the two big products: 0 fp32 MFMA, 1 bf16-rounded operands, 2 fp32 by exact 3 x bf16 splitting,
+	// 3 fp64 MFMA, 4 VALU fallback kernel (NMFAMD_FORCE_VALU), 5 sparse (SpMM)
+	int product_kernel() const { return sparse_ ? 5 : bf16_ ? 1 : x3_ ? 2 : !tiled_ ? 4 : (sizeof(T) == 8 ? 3 : 0); }
 	const char* last_error() const { return last_error_; }
 
 	// test access to device intermediates (panel layout, host copies)
@@ -97,8 +100,9 @@ public:
 private:
 	Status hip_fail(hipError_t e, const char* what);
 	Status h_step_impl(bool compute_error);
-	Status product_h(const T* F, const GramReduceArgs* rg = nullptr);   // slabs_ <- partials of F V   (r x n)
-	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
+	// prepacked: the split (x3) image of F is already in Wx3_ / Hx3_ (emitted by the update kernel that wrote F)
+	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false);   // slabs_ <- partials of F V   (r x n)
+	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
@@ -143,6 +147,12 @@ private:
 	void *Vb_ = nullptr, *Vtb_ = nullptr, *Wtb_ = nullptr, *Hb_ = nullptr;
 	int ksW_ = 0, ksH_ = 0;
 	FactorProductPlan planHb_, planWb_;
+	// fp32 products on the bf16 matrix pipe by exact 3-way operand splitting (kernels_x3.hip): the fp32 tiled
+	// images of V stay as they are, the factor panel is split into Wx3_ / Hx3_ before each product
+	bool x3_ = false;
+	bool wx3_valid_ = false, hx3_valid_ = false;   // Wx3_ / Hx3_ hold the split image of the current Wt_ / H_
+	void *Wx3_ = nullptr, *Hx3_ = nullptr;
+	FactorProductPlan planHx_, planWx_;
 	// sparse-V compute path (kernels_sparse.hip): CSR and CSC images of V, 0-based
 	bool sparse_ = false;
 	long nnz_ = 0;

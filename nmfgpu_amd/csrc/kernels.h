@@ -76,7 +76,7 @@ hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream)
 // old values scaled by `scale`; ps = tr(H^T W^T V) terms (H) / tr(H H^T W^T W) terms (W, needs Gprev).
 hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                               float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
-                              int compute_error, hipStream_t stream);
+                              int compute_error, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
 // P(c, y) *= scale(c)
 hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream);
 // G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and
@@ -188,6 +188,15 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 // K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP
 int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
+
+// ---- fp32 product by exact 3 x bf16 operand splitting (kernels_x3.hip), padded rank 64 ------------
+// The streamed matrix is the x-tiled fp32 image (tile height 128); the factor panel is split into
+// three bf16 planes in fragment order, KS K-steps plus one all-zero step: 3 * 16 bytes * (KS + 1) * (RP / 32) * 64.
+hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream);
+hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
+                                    float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
+                                    unsigned long long* stamps = nullptr);
+int plan_splits_x3(int xtiles, int KS, int num_cus);
 
 // ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------
 // out(row, :) = sum_p val[p] P(idx[p], :) over the stored entries of `row`; rows in [rows, rows_pad) are zeroed.

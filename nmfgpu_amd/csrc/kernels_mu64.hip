@@ -21,11 +21,11 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "split3.h"
 
 namespace nmfamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup = 4 waves = 64 panel columns = one contiguous 16 KiB tile of the panel.
 // Global traffic is fully coalesced: every array tile (slabs, old panel values, result) moves as
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
 	float* __restrict__ ps, int len_valid, float* __restrict__ gram_partial,
-	const float* __restrict__ Gprev, int compute_error) {
+	const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks) {
 	__shared__ __attribute__((aligned(16))) float s_num[64][68];   // reduced numerator, later the new values
 	__shared__ __attribute__((aligned(16))) float s_old[64][68];   // old values (scaled for the W update)
 	__shared__ float s_ps[2][64];
@@ -165,6 +165,25 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
 		*reinterpret_cast<f32x4*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4*>(&s_num[yl0 + 16 * j][c4]);
+	// the split (3 x bf16) image of the new panel rows for the next factor product (kernels_x3.hip): this tile is
+	// four K-steps of 16 rows; a thread emits two (K-step, column block, half, lane) slots of three fragments
+	if (x3_out != nullptr) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int slot = tid + 256 * i;
+			const int r = slot & 31, h = (slot >> 5) & 1, nb = (slot >> 6) & 1, kk = slot >> 7;
+			const long ks = 4l * blockIdx.x + kk;
+			if (ks < x3_ks) {
+				float v[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int yl = 16 * kk + 8 * h + j;
+					v[j] = blockIdx.x * 64 + yl < len_valid ? s_num[yl][32 * nb + r] : 0.f;
+				}
+				store_split3(x3_out, ks, 2, nb, h, r, v);
+			}
+		}
+	}
 	const int ab = wave >> 1, bb = wave & 1;   // wave (ab, bb) computes one 32 x 32 block over the 64 columns
 	f32x16 g;
 #pragma unroll
@@ -184,10 +203,11 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 
 hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                               float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
-                              int compute_error, hipStream_t stream) {
+                              int compute_error, hipStream_t stream, void* x3_out, int x3_ks) {
 	dim3 grid(len_pad / 64), block(256);
-	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
-	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error);
+	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
+	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks);
+	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks);
 	return hipGetLastError();
 }
 

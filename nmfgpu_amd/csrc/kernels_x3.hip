@@ -1,0 +1,360 @@
+// kernels_x3.hip -- fp32 factor product on the bf16 matrix pipe by exact operand splitting.
+//
+// Every fp32 operand is cut into three bf16 terms, a = a1 + a2 + a3 EXACTLY (8 + 8 + 8 significand
+// bits, round-to-nearest residuals), and the product keeps the six cross terms of order <= 2^-16:
+//     a b  ~=  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)          |dropped| <= ~2^-23 |a b|
+// Each term is exact in fp32 (8 x 8 bit significands) and accumulates in the fp32 accumulators of
+// v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs cost 6/16 of the fp32 MFMA work they replace, so the product
+// of a 10 000 x 5 000 fp32 matrix stops being MFMA-bound and becomes HBM-bound on the fp32 image of V.
+//
+// The streamed matrix is the SAME x-tiled fp32 image the fp32 kernel reads (kernels.hip): a lane's
+// 16-byte load is four consecutive rows of one column, i.e. one k value of four M-blocks, and the
+// eight loads of a K-step (k = 8 h + j) are exactly the eight-k bf16 operand of the 32x32x16 MFMA --
+// no transposition, splitting is three conversions and two subtractions per element in registers.
+// The factor panel is split once per product into fragment order (k_pack_panel_x3).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.h"
+#include "split3.h"
+
+namespace nmfamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Factor fragments: Fx[(((ks * NBT + nb) * 3 + plane) * 2 + h) * 32 + r][8] = plane of F(c = 32 nb + r, y = 16 ks + 8 h + j)
+__global__ __launch_bounds__(256) void k_pack_panel_x3(const float* __restrict__ P, int RP, int NBT, int len, bf16x8* __restrict__ dst, long frags) {
+	const long f = (long)blockIdx.x * 256 + threadIdx.x;   // one (ks, nb, h, r) per thread, three 16-byte fragments out
+	if (f >= frags) return;
+	const int r = (int)(f & 31), h = (int)((f >> 5) & 1);
+	const long t = f >> 6;
+	const int nb = (int)(t % NBT);
+	const long ks = t / NBT;
+	float v[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const long y = 16 * ks + 8 * h + j;
+		v[j] = y < len ? P[y * RP + 32 * nb + r] : 0.f;
+	}
+	store_split3(dst, ks, NBT, nb, h, r, v);
+}
+
+// KS K-steps cover len; the image has KS + 1: the last one is all zero (see k_factor_product_x3).
+hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream) {
+	const int NBT = RP / 32;
+	const long frags = (long)(KS + 1) * NBT * 64;
+	hipLaunchKernelGGL(k_pack_panel_x3, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, stream, P, RP, NBT, len, reinterpret_cast<bf16x8*>(dst), frags);
+	return hipGetLastError();
+}
+
+// Passenger Gram reduction (same contract as in kernels.hip / kernels_bf16.hip) for a block of NT threads.
+// The block is latency-bound (every load is a miss under the product's HBM stream), so the work is cut for
+// few round trips: NT / 64 groups each take a contiguous range of the partial matrices, a lane owns four
+// consecutive elements (16-byte loads, eight in flight), groups are added in ascending order.
+template <int NT>
+__device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, float* lds) {
+	constexpr int NG = NT / 64;
+	const int tid = threadIdx.x;
+	const int g = tid >> 6, l = tid & 63;
+	float* s_scale = lds;                     // 64
+	float* s_tmp = lds + 64;                  // NG * 256
+	const int parts = rg.parts;
+	const int p0 = (parts * g) / NG, p1 = (parts * (g + 1)) / NG;
+	if (rg.normalize) {
+		// diagonal of the full sum: column l, this group's range of parts
+		const float* dp = rg.partials + l * 65;
+		float sum = 0.f;
+		int p = p0;
+		for (; p + 8 <= p1; p += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = dp[(long)(p + u) * 4096];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) sum += v[u];
+		}
+		for (; p < p1; ++p) sum += dp[(long)p * 4096];
+		s_tmp[g * 64 + l] = sum;
+		__syncthreads();
+		if (tid < 64) {
+			float d = s_tmp[tid];
+#pragma unroll
+			for (int k = 1; k < NG; ++k) d += s_tmp[k * 64 + tid];
+			s_scale[tid] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+		}
+	} else if (tid < 64) {
+		s_scale[tid] = 1.0f;
+	}
+	__syncthreads();
+	{
+		const float* ep = rg.partials + blk * 256 + 4 * l;
+		f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+		int p = p0;
+		for (; p + 8 <= p1; p += 8) {
+			f32x4 v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(ep + (long)(p + u) * 4096);
+#pragma unroll
+			for (int u = 0; u < 8; ++u) sum += v[u];
+		}
+		for (; p < p1; ++p) sum += *reinterpret_cast<const f32x4*>(ep + (long)p * 4096);
+		*reinterpret_cast<f32x4*>(s_tmp + g * 256 + 4 * l) = sum;
+	}
+	__syncthreads();
+	if (tid < 256) {
+		const int e = blk * 256 + tid;
+		float v = s_tmp[tid];
+#pragma unroll
+		for (int k = 1; k < NG; ++k) v += s_tmp[k * 256 + tid];
+		rg.G[e] = (v * s_scale[e & 63]) * s_scale[e >> 6];
+	}
+	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
+}
+
+// Workgroup = X3_WAVES waves (four: one per SIMD, 512 registers each) = one 128-row x-tile times one
+// slice of the reduction range times one 64-column chunk of the panel (grid.y), the slice cut into
+// wave pieces of K-steps (16 y each).  A wave keeps the 128 x 64 accumulator block (8 tiles of 32 x 32),
+// streams its piece of the fp32 tile through a D-deep ring of K-steps (8 x 16 B per lane and step) and
+// the matching factor fragments (6 x 16 B) through a ring of the same depth.  Row of M-block b held by
+// lane l: 4 (l & 31) + b (the fp32 image interleaves four rows per lane).  Epilogue: the pieces are
+// summed through LDS in piece order; one fp32 slab per slice.
+// DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
+// stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
+// (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
+template <int D, int X3_WAVES, int DIAG = 0>
+__global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
+	const float* __restrict__ A, long tile_stride,
+	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
+	float* __restrict__ slabs, long slab_stride, int RP,
+	int steps_total, int xtiles, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
+	constexpr int TH = 128;
+	unsigned long long t_loop0 = 0, t_loop1 = 0, r_loop0 = 0, r_loop1 = 0, r_entry = 0, r_tail = 0;
+	if (DIAG != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	// grid.x = xtiles * splits product blocks (x-tile fastest) followed by the GRAM_REDUCE_BLOCKS passenger blocks,
+	// and no more: every block of this kernel claims a whole CU (512 registers per lane), so an idle block would
+	// still wait for a CU to drain and be launched there before the kernel can end
+	const int pblocks = xtiles * splits;
+	if (blockIdx.x >= (unsigned)pblocks) {
+		gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
+		return;
+	}
+	const int xt = blockIdx.x % xtiles, sp = blockIdx.x / xtiles;
+	const int coff = 64 * blockIdx.y;
+	const long fstep = (long)NBT * 192;                 // factor fragments per K-step
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int nw = splits * X3_WAVES;
+	const int widx = sp * X3_WAVES + wave;
+	// The reduction range is dealt out in units of D K-steps, so that every wave runs whole turns of the ring and
+	// the loop needs no tail.  Steps past the end of the range (at most D - 1, in the last unit) re-read the last
+	// valid step of A against the all-zero K-step that closes the factor image (index steps_total).
+	const int units = (steps_total + D - 1) / D;
+	const int s0 = D * (int)(((long)units * widx) / nw);
+	const int s1 = D * (int)(((long)units * (widx + 1)) / nw);
+	const int steps = s1 - s0;
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int b = 0; b < 4; ++b)
+#pragma unroll
+		for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
+
+	if (steps > 0) {
+		const float* ap = A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31;   // + (16 * step + j) * TH
+		const bf16x8* fp = F + (long)blockIdx.y * 384 + lane;                       // + step * fstep + (nb * 3 + plane) * 64
+		const int last = s1 - 1, kend = steps_total - 1;
+		f32x4 va[D][8];
+		bf16x8 fb[D][2][3];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int st = s0 + d;                                  // steps >= D here
+			const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(ap + ((long)sa * 16 + j) * TH);
+#pragma unroll
+			for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+				for (int pl = 0; pl < 3; ++pl) fb[d][nb][pl] = fp[(long)sf * fstep + (nb * 3 + pl) * 64];
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// One wave per SIMD: nothing but this wave's own instruction order overlaps the operand splitting
+		// (VALU) with the matrix pipe.  The body is a chain of phases (K-step d, M-block b): the twelve
+		// MFMAs of the phase are interleaved four-to-one with the 44 VALU instructions that split the
+		// NEXT phase's operand, and in the last phase of a step with the refill of the step's ring slot.
+		// Branch-free: the ring is refilled with clamped step indices.
+		if (DIAG != 0) { t_loop0 = __builtin_amdgcn_s_memtime(); r_loop0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+		bf16x8 op[2][3];
+		{
+			float v[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) v[j] = va[0][j][0];
+			split3(v, op[0][0], op[0][1], op[0][2]);
+		}
+		int t = 0;
+		for (; t < steps; t += D) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const int cur = (d * 4 + b) & 1, nxt = cur ^ 1;
+					const int nd = b == 3 ? (d + 1) % D : d, nbk = (b + 1) & 3;
+					{
+						float v[8];
+#pragma unroll
+						for (int j = 0; j < 8; ++j) v[j] = va[nd][j][nbk];
+						split3(v, op[nxt][0], op[nxt][1], op[nxt][2]);
+					}
+#pragma unroll
+					for (int nb = 0; nb < 2; ++nb) {
+						// smallest terms first
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][2], fb[d][nb][0], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][0], fb[d][nb][2], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][1], fb[d][nb][1], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][1], fb[d][nb][0], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][0], fb[d][nb][1], acc[b][nb], 0, 0, 0);
+						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][0], fb[d][nb][0], acc[b][nb], 0, 0, 0);
+					}
+					if (b == 3) {
+						int st = s0 + t + D + d;
+						st = st < last ? st : last;                         // past this wave's piece: a harmless re-read
+						const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
+						if (DIAG == 0 || DIAG == 2 || DIAG == 4) {
+#pragma unroll
+							for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(ap + ((long)sa * 16 + j) * TH);
+						} else {
+#pragma unroll
+							for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(va[d][j]));
+						}
+						if (DIAG == 0 || DIAG == 3 || DIAG == 4) {
+#pragma unroll
+							for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+								for (int pl = 0; pl < 3; ++pl) fb[d][nb][pl] = fp[(long)sf * fstep + (nb * 3 + pl) * 64];
+						} else {
+#pragma unroll
+							for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+								for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(fb[d][nb][pl]));
+						}
+#pragma unroll
+						for (int g = 0; g < 8; ++g) {
+							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
+							__builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+						}
+#pragma unroll
+						for (int g = 0; g < 4; ++g) {
+							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+						}
+						__builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+					} else {
+#pragma unroll
+						for (int g = 0; g < 12; ++g) {
+							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+		}
+		if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); t_loop1 = __builtin_amdgcn_s_memtime(); r_loop1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+	}
+
+	if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); r_tail = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+	// in-workgroup sum through LDS, two M-blocks (four tiles) per round; C/D map: register g of lane l
+	// is MFMA row i = (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31; output row x = 128 xt + 4 i + b.
+	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+	float* slab = slabs + (long)sp * slab_stride;
+#pragma unroll
+	for (int rd = 0; rd < 2; ++rd) {
+		if (rd > 0) __syncthreads();
+#pragma unroll
+		for (int tl = 0; tl < 4; ++tl) {
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				f32x4 v;
+				v[0] = acc[b][nb][4 * q + 0]; v[1] = acc[b][nb][4 * q + 1];
+				v[2] = acc[b][nb][4 * q + 2]; v[3] = acc[b][nb][4 * q + 3];
+				l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 16 / X3_WAVES; ++i) {
+			const int sl = wave * (16 / X3_WAVES) + i;  // slice = (tile, q)
+			const int q = sl & 3, tl = sl >> 2;
+			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+#pragma unroll
+			for (int p = 1; p < X3_WAVES; ++p) s += l4[((p * 4 + tl) * 4 + q) * 64 + lane];
+#pragma unroll
+			for (int gi = 0; gi < 4; ++gi) {
+				const int mi = gi + 8 * q + 4 * half;
+				const int x = xt * TH + 4 * mi + b;
+				slab[(long)x * RP + coff + 32 * nb + l31] = s[gi];
+			}
+		}
+	}
+	if (DIAG != 0 && stamps != nullptr) {
+		__builtin_amdgcn_s_waitcnt(0);
+		const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+		if (lane == 0) {
+			// shader cycles and 100 MHz ticks in the main loop, K-steps run there; then 100 MHz stamps of the wave's life
+			unsigned long long* o = stamps + 8 * ((long)blockIdx.x * X3_WAVES + wave);
+			o[0] = t_loop1 - t_loop0; o[1] = r_loop1 - r_loop0; o[2] = (unsigned long long)steps;
+			o[3] = r_entry; o[4] = r_loop0; o[5] = r_loop1; o[6] = r_tail; o[7] = r_end;
+		}
+	}
+}
+
+// Every wave piece (four per slice) gets at least two turns of the 3-deep ring; as many slices as fill the chip.
+int plan_splits_x3(int xtiles, int KS, int num_cus) {
+	const int by_fill = std::max(1, num_cus / std::max(1, xtiles));
+	const int by_depth = std::max(1, KS / (6 * 4));
+	return std::max(1, std::min(by_fill, by_depth));
+}
+
+template <int D, int WAVES, int DIAG = 0>
+static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
+                               float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
+	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
+	const bool wanted = rg != nullptr && rg->partials != nullptr;
+	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
+	if (wanted && !with_reduce) return hipErrorInvalidValue;
+	dim3 grid(p.xtiles * p.splits + (with_reduce ? GRAM_REDUCE_BLOCKS : 0), RP / 64, 1), block(64 * WAVES);
+	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
+	static unsigned long long lds_done = 0ull;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG>), grid, block, lds_bytes, stream,
+	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
+	return hipGetLastError();
+}
+
+// A: x-tiled fp32 image (tile height 128, zero-filled up to a multiple of 16 columns); F: k_pack_panel_x3
+// image of the RP-column panel (RP a multiple of 64; grid.y = RP / 64 passes over A); p.steps_total = K-steps
+// of 16; p.th must be 128.  The passenger Gram reduction rides only at RP = 64.
+hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
+                                    float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps) {
+	if (RP % 64 != 0 || p.th != 128) return hipErrorInvalidValue;
+	static const int variant = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
+	switch (variant) {
+	case 1: return launch_fp_x3<2, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	case 2: return launch_fp_x3<4, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	case 10: return launch_fp_x3<3, 4, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+	case 11: return launch_fp_x3<3, 4, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+	case 12: return launch_fp_x3<3, 4, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+	case 13: return launch_fp_x3<3, 4, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+	default: return launch_fp_x3<3, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	}
+}
+
+} // namespace nmfamd

@@ -25,7 +25,7 @@ class _Params(C.Structure):
 class _Geometry(C.Structure):
     _fields_ = [("m", C.c_int), ("n", C.c_int), ("r", C.c_int), ("padded_rank", C.c_int),
                 ("padded_m", C.c_long), ("padded_n", C.c_long), ("slabs_h", C.c_int), ("slabs_w", C.c_int),
-                ("exchange_count", C.c_long)]
+                ("exchange_count", C.c_long), ("product_kernel", C.c_int)]
 
 
 def device_count() -> int:
@@ -56,7 +56,7 @@ class Engine:
             raise TypeError("float32 or float64")
         self.m, self.n, self.r = m, n, r
         p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute),
-                    {"native": 0.0, "bf16": 1.0}[precision])
+                    {"native": 0.0, "bf16": 1.0, "fp32_mfma": -1.0}[precision])
         h = C.c_void_p()
         st = self._lib.nmfamd_engine_create(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), C.byref(h))
         if st != 0:

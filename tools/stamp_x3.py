@@ -1,0 +1,27 @@
+"""Main-loop cycles per K-step of the split product (diagnostic builds, NMFAMD_X3_VARIANT=10..13)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmfgpu_amd._lib import library
+
+lib = library()
+X, Y = 10000, 5000
+cap = 8 * 4 * 400 * 8
+buf = np.zeros(cap, dtype=np.uint64)
+waves = C.c_long(0)
+st = lib.nmfamd_tune_factor_product_x3(X, Y, C.c_void_p(buf.ctypes.data), C.c_long(cap), C.byref(waves))
+assert st == 0, st
+s = buf[: 8 * waves.value].reshape(-1, 8).astype(np.float64)
+s = s[s[:, 2] > 0]
+cyc, ticks, steps = s[:, 0], s[:, 1], s[:, 2]
+print(f"variant {os.environ.get('NMFAMD_X3_VARIANT')}: waves {len(s)}, steps/wave {steps.mean():.1f}, cycles/K-step median {np.median(cyc / steps):.0f} "
+      f"(p10 {np.percentile(cyc / steps, 10):.0f}, p90 {np.percentile(cyc / steps, 90):.0f}) = {np.median(cyc / steps) / 48:.1f} per MFMA; "
+      f"loop time median {np.median(ticks) / 100:.1f} us, clock {np.median(cyc / ticks) * 100:.0f} MHz")
+t0 = s[:, 3].min()
+for name, col in (("entry", 3), ("loop start", 4), ("loop end", 5), ("tail end", 6), ("exit", 7)):
+    v = (s[:, col] - t0) / 100
+    print(f"  {name:10s}: median {np.median(v):6.2f} us  min {v.min():6.2f}  max {v.max():6.2f}")

@@ -114,7 +114,8 @@ Status Engine<T>::allocate() {
 	// fp32, dense, MFMA path: both products run on the bf16 matrix pipe with every operand split exactly into
 	// three bf16 terms (fp32-level accuracy, six cross products; kernels_x3.hip) -- HBM-bound instead of bound by
 	// the fp32 MFMA rate.  precision = -1 (or NMFAMD_FP32_NATIVE) keeps the native fp32 MFMA instructions.
-	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 &&
+	// (ranks <= 32 stay on the fp32 MFMA kernel: with half its MFMA work it is HBM-bound already and needs no split image)
+	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && planH_.nb == 2 &&
 	    std::getenv("NMFAMD_FP32_NATIVE") == nullptr) {
 		x3_ = true;
 		planH_.th = planW_.th = 128;
@@ -426,7 +427,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
-			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS || std::getenv("NMFAMD_X3_NO_PASSENGER"))) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
@@ -476,7 +477,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
-			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS || std::getenv("NMFAMD_X3_NO_PASSENGER"))) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
@@ -523,10 +524,10 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 	return ST_OK;
 }
 
-// fp32 MFMA product at padded rank 64 with a passenger row in its grid
+// fp32 product (native MFMA or split-operand kernel) at padded rank 64 with passenger blocks in its grid
 template <typename T>
 bool Engine<T>::inverse_rides(const FactorProductPlan& plan) const {
-	return std::is_same<T, float>::value && tiled_ && !bf16_ && !x3_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
+	return std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
 	       std::getenv("NMFAMD_NO_OVERLAP") == nullptr && std::getenv("NMFAMD_INVERSE_SIDE_STREAM") == nullptr;
 }
 

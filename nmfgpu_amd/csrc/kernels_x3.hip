@@ -20,6 +20,7 @@
 
 #include "kernels.h"
 #include "split3.h"
+#include "inverse_gj64.h"
 
 namespace nmfamd {
 
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	// still wait for a CU to drain and be launched there before the kernel can end
 	const int pblocks = xtiles * splits;
 	if (blockIdx.x >= (unsigned)pblocks) {
-		gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
+		// the 64 x 64 inverse of the least-squares algorithms rides as ONE block right behind the product's last one
+		if (rg.inv_a != nullptr) inverse_gj64_body<float, X3_WAVES>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
+		else gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
 		return;
 	}
 	const int xt = blockIdx.x % xtiles, sp = blockIdx.x / xtiles;
@@ -327,10 +330,11 @@ template <int D, int WAVES, int DIAG = 0>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	const bool wanted = rg != nullptr && rg->partials != nullptr;
+	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr);
 	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
-	dim3 grid(p.xtiles * p.splits + (with_reduce ? GRAM_REDUCE_BLOCKS : 0), RP / 64, 1), block(64 * WAVES);
+	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);
+	dim3 grid(p.xtiles * p.splits + passengers, RP / 64, 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
 	static unsigned long long lds_done = 0ull;
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
@@ -341,7 +345,7 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 
 // A: x-tiled fp32 image (tile height 128, zero-filled up to a multiple of 16 columns); F: k_pack_panel_x3
 // image of the RP-column panel (RP a multiple of 64; grid.y = RP / 64 passes over A); p.steps_total = K-steps
-// of 16; p.th must be 128.  The passenger Gram reduction rides only at RP = 64.
+// of 16; p.th must be 128.  Passengers (Gram reduction, or the 64 x 64 inverse) ride only at RP = 64.
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps) {
 	if (RP % 64 != 0 || p.th != 128) return hipErrorInvalidValue;

@@ -623,8 +623,10 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 	const int S = planH_.splits;
 	if (alg_ == ALG_MU || alg_ == ALG_NSNMF) {
 		if (Status s = product_h(F)) return s;
+		const bool emit = x3_ && alg_ == ALG_MU && panel_update_delivers_gram(RP_, sizeof(T));   // nsNMF's W step consumes the smoothed panel
 		HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, S, slab_stride_, G_, RP_, (int)npad_, eps,
-		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_));
+		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, emit ? Hx3_ : nullptr, ksW_));
+		hx3_valid_ = emit;
 	} else {
 		T off = 0, diag = 0;
 		if (alg_ == ALG_GDCLS) diag = (T)prm_.lambda;
@@ -651,8 +653,10 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		}
 		T* hpart = nullptr;
 		if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) hpart = gramH_part_; }
+		const bool emit = x3_ && panel_update_delivers_gram(RP_, sizeof(T));
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
-		                            nullptr, n_, nullptr, nullptr, stream_, hpart));
+		                            nullptr, n_, nullptr, nullptr, stream_, hpart, emit ? Hx3_ : nullptr, ksW_));
+		hx3_valid_ = emit;
 		gram_h_partials_ = hpart != nullptr;
 	}
 	return ST_OK;
@@ -850,10 +854,10 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				if constexpr (std::is_same<T, float>::value) {
 					GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
 					rg.inv_a = HHt_; rg.inv_out = Qinv_; rg.inv_offdiag = offW; rg.inv_diag = diagW; rg.inv_r = r_;
-					if (Status s = product_w(Fh, &rg)) return s;
+					if (Status s = product_w(Fh, &rg, nullptr, x3_ && hx3_valid_ && Fh == H_)) return s;
 				}
 			} else {
-				if (Status s = product_w(Fh)) return s;
+				if (Status s = product_w(Fh, nullptr, nullptr, x3_ && hx3_valid_ && Fh == H_)) return s;
 			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;

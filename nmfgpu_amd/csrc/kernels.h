@@ -107,7 +107,7 @@ hipError_t launch_panel_update64_f32(int mode, float* P, const float* slabs, int
 // gram_partial (optional): len_pad / 64 partial 64 x 64 Gram matrices of the new rows (layout of k_mu64_update)
 hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
                                          float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
-                                         float* gram_partial = nullptr);
+                                         float* gram_partial = nullptr, void* x3_out = nullptr, int x3_ks = 0);
 // true when launch_panel_update<float> at padded rank 64 can deliver those partial Gram matrices
 bool panel_update_delivers_gram(int RP, size_t elem);
 // fp32 / padded rank 128 ... 512 (kernels_wide.hip)
@@ -125,7 +125,8 @@ hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, i
 // See k_panel_update.  sumsq_part needs (len_pad / panel_update_rows) * RP elements.
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
-                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial = nullptr);
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial = nullptr,
+                               void* x3_out = nullptr, int x3_ks = 0);   // x3_out: split image of the new panel (kernels_x3.hip); only where panel_update_delivers_gram()
 
 // sumsq_part: parts * RP partial sums followed by 16 * RP elements of scratch
 template <typename T>

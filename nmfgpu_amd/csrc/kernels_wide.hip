@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "split3.h"
 
 namespace nmfamd {
 
@@ -286,7 +287,8 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, float* __restrict__ num_out, float* __restrict__ gram_partial) {
+	float* __restrict__ sumsq_part, float* __restrict__ num_out, float* __restrict__ gram_partial,
+	bf16x8* __restrict__ x3_out, int x3_ks) {
 	constexpr int YB = 64, LD = 68;
 	__shared__ __attribute__((aligned(16))) float s_num[YB * LD];
 	__shared__ __attribute__((aligned(16))) float s_old[YB * LD];
@@ -383,6 +385,25 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 		for (int y = 0; y < YB; ++y) { const float v = s_old[y * LD + tid]; s += v * v; }
 		sumsq_part[(long)blockIdx.x * 64 + tid] = s;
 	}
+	if (x3_out != nullptr) {
+		// the split (3 x bf16) image of the new rows for the next factor product (as in k_mu64_update): four K-steps of
+		// 16 rows per tile, two (K-step, column block, half, lane) slots per thread
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int slot = tid + 256 * i;
+			const int r = slot & 31, h = (slot >> 5) & 1, nb = (slot >> 6) & 1, kk = slot >> 7;
+			const long ks = 4l * blockIdx.x + kk;
+			if (ks < x3_ks) {
+				float v[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int yl = 16 * kk + 8 * h + j;
+					v[j] = blockIdx.x * YB + yl < len_valid ? s_old[yl * LD + 32 * nb + r] : 0.f;
+				}
+				store_split3(x3_out, ks, 2, nb, h, r, v);
+			}
+		}
+	}
 	if (gram_partial != nullptr) {
 		// partial Gram matrix of the 64 new rows (layout of k_mu64_update: one 64 x 64 matrix per workgroup), so that the
 		// caller can reduce W^T W / H H^T with the 16-block reduction instead of a pass over the panel
@@ -406,11 +427,13 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 
 // 64 panel rows per workgroup: len_pad / 64 norm partials
 hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int len_pad,
-                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, float* gram_partial) {
+                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, float* gram_partial,
+                                         void* x3_out, int x3_ks) {
 	if ((mode != PANEL_MU && mode != PANEL_LS) || len_pad % 64 != 0) return hipErrorInvalidValue;
 	dim3 grid(len_pad / 64), block(256);
-	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial);
-	else hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial);
+	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
+	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial, xo, x3_ks);
+	else hipLaunchKernelGGL((k_panel_update64_lds_f32<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, gram_partial, xo, x3_ks);
 	return hipGetLastError();
 }
 

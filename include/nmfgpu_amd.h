@@ -180,7 +180,7 @@ NMFAMD_API int nmfamd_tune_factor_product(int X, int Y, int reps, double* avg_us
 /* The same product with bf16-rounded operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation), r <= 64. */
 NMFAMD_API int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo);
 /* The same product at fp32 accuracy on the bf16 matrix pipe: both operands split exactly into three bf16 terms, six
- * cross products, fp32 accumulation (kernels_x3.hip), r <= 64.  reps > 0 additionally times `reps` launches of the
+ * cross products, fp32 accumulation (kernels_x3.hip), any r.  reps > 0 additionally times `reps` launches of the
  * product kernel alone (HIP events) into *avg_us. */
 NMFAMD_API int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo,
                                            int reps, double* avg_us);

@@ -362,11 +362,11 @@ int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const 
 }
 
 int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us) {
-	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || r > 64 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
+	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
-	const int RP = 64;
+	const int RP = padded_rank(r);
 	const long Xp = pad128(X), Yp = pad128(Y);
 	const int KS = (Y + 15) / 16;
 	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;

@@ -227,6 +227,21 @@ def op_factor_product_bf16(A: np.ndarray, F: np.ndarray) -> np.ndarray:
     return out
 
 
+def op_factor_product_x3(A: np.ndarray, F: np.ndarray, reps: int = 0):
+    """OUT (r x X) = F A^T at fp32 accuracy on the bf16 matrix pipe: both operands split exactly into three bf16
+    terms, six cross products, fp32 accumulation (any r).  Returns OUT, or (OUT, microseconds per launch) if reps > 0."""
+    A = _f(A); F = _f(F)
+    X, Y = A.shape
+    r = F.shape[0]
+    out = np.zeros((r, X), dtype=np.float32, order="F")
+    us = C.c_double(0.0)
+    st = library().nmfamd_op_factor_product_x3(C.c_void_p(A.ctypes.data), C.c_long(_ld(A)), X, Y, C.c_void_p(F.ctypes.data), C.c_long(_ld(F)), r,
+                                               C.c_void_p(out.ctypes.data), C.c_long(r), int(reps), C.byref(us))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_factor_product_x3")
+    return (out, us.value) if reps > 0 else out
+
+
 def op_gram(P: np.ndarray) -> np.ndarray:
     P = _f(P)
     r, length = P.shape

@@ -658,6 +658,69 @@ def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
     assert np.abs(out - exact).max() > 10 * np.abs(out - want).max()
 
 
+# ------------------------------------------------------------------ fp32 product by exact 3 x bf16 operand splitting
+
+@pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64), (10000, 1203, 64),
+                                   (300, 500, 100), (257, 1111, 256), (129, 1, 64), (5, 7, 3), (300, 20, 256), (64, 33, 128), (640, 4100, 300)])
+def test_factor_product_split_operands_has_fp32_accuracy(X, Y, r):
+    """The default fp32 product (kernels_x3.hip): six bf16 MFMAs per block on exactly split operands.  Same bound as the
+    native fp32 MFMA kernel above -- |gpu - fp64| <= 4e-7 * sum|a*b| per element -- and an rms error within 2x of it."""
+    rng = np.random.default_rng(X * 5 + Y + r)
+    A = F((rng.random((X, Y)) - 0.25).astype(np.float32)); Fm = F((rng.random((r, Y)) - 0.3).astype(np.float32))
+    out = na.op_factor_product_x3(A, Fm)
+    want = Fm.astype(np.float64) @ A.astype(np.float64).T
+    bound = 4e-7 * (np.abs(Fm).astype(np.float64) @ np.abs(A).astype(np.float64).T) + 1e-30
+    assert (np.abs(out - want) <= bound).all()
+    native, _ = na.op_factor_product(A, Fm)
+    rms = lambda o: np.sqrt(((o - want) ** 2).mean())
+    assert rms(out) <= 2.0 * rms(native) + 1e-12
+
+
+def test_factor_product_split_is_exact_where_fp32_is_exact():
+    """hi + mid + lo reproduces all 24 significand bits of either operand: against a one-hot power-of-two partner the
+    result is a scaled copy of the operand, bit for bit (a dropped or mis-ordered plane, or a truncating cut, shows here)."""
+    rng = np.random.default_rng(7)
+    X, Y, r = 384, 96, 64
+    A = F((rng.standard_normal((X, Y)) * np.exp(4 * rng.standard_normal((X, Y)))).astype(np.float32))
+    Fm = np.zeros((r, Y), dtype=np.float32)
+    cols = rng.integers(0, Y, r); scale = np.float32(2.0) ** rng.integers(-20, 20, r)
+    Fm[np.arange(r), cols] = scale
+    out = na.op_factor_product_x3(A, F(Fm))
+    assert np.array_equal(out, (A[:, cols] * scale[None, :]).T)
+    # and the factor side: one-hot A selects factor entries
+    Fr = F((rng.standard_normal((r, Y)) * np.exp(4 * rng.standard_normal((r, Y)))).astype(np.float32))
+    A1 = np.zeros((X, Y), dtype=np.float32)
+    ys = rng.integers(0, Y, X); sc = np.float32(2.0) ** rng.integers(-20, 20, X)
+    A1[np.arange(X), ys] = sc
+    out = na.op_factor_product_x3(F(A1), Fr)
+    assert np.array_equal(out, Fr[:, ys] * sc[None, :])
+    # small integers: every partial sum is exact in fp32, whatever the order
+    Ai = F(rng.integers(0, 128, (X, 512)).astype(np.float32)); Fi = F(rng.integers(0, 128, (r, 512)).astype(np.float32))
+    assert np.array_equal(na.op_factor_product_x3(Ai, Fi), (Fi.astype(np.int64) @ Ai.astype(np.int64).T).astype(np.float32))
+
+
+@pytest.mark.parametrize("alg,r,kw", [("mu", 64, {}), ("mu", 20, {}), ("als", 64, {}), ("gdcls", 50, dict(lam=0.01)),
+                                      ("nsnmf", 64, dict(theta=0.5)), ("mu", 130, {})])
+def test_native_fp32_mfma_path_still_agrees(alg, r, kw):
+    """precision = fp32_mfma keeps the fp32 MFMA instructions (the default before the split-operand product); both
+    paths sit within the fp32 tolerance of the fp64 oracle (2e-4) and within 1e-4 of each other after 20 iterations (the
+    least-squares algorithms amplify the last-bit differences of the products through the inverse)."""
+    m, n = 1300, 900
+    V, W, H = problem(m, n, r, np.float32, seed=47)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, 20, **kw)
+    got = {}
+    for prec in ("native", "fp32_mfma"):
+        eng = na.Engine(m, n, r, alg, precision=prec, **kw)
+        assert eng.geometry()["product_kernel"] == ({"native": 2 if r > 32 else 0, "fp32_mfma": 0}[prec])
+        eng.upload(V); eng.set_factors(W, H)
+        eng.iterate(20, last_iteration=20)
+        got[prec] = eng.get_factors() + (eng.frobenius,)
+        assert rel(got[prec][0], W64) < 2e-4 and rel(got[prec][1], H64) < 2e-4
+        assert got[prec][2] == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert rel(got["native"][0], got["fp32_mfma"][0]) < 1e-4 and rel(got["native"][1], got["fp32_mfma"][1]) < 1e-4
+
+
 def test_bf16_operand_mode_tracks_fp32_within_stated_tolerance():
     """precision = bf16: operands of the two big products carry 8 significant bits; factors after 20 iterations
     agree with the fp64 oracle to 2e-2 relative (fp32 mode: 2e-4), the reported error to 1e-3."""

@@ -124,7 +124,7 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
 // stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
-template <int D, int X3_WAVES, int DIAG = 0>
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2>
 __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		return;
 	}
 	const int xt = blockIdx.x % xtiles, sp = blockIdx.x / xtiles;
-	const int coff = 64 * blockIdx.y;
+	const int coff = 32 * NBW * blockIdx.y;
 	const long fstep = (long)NBT * 192;                 // factor fragments per K-step
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
@@ -160,20 +160,20 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const int s1 = D * (int)(((long)units * (widx + 1)) / nw);
 	const int steps = s1 - s0;
 
-	f32x16 acc[4][2];
+	f32x16 acc[4][NBW];
 #pragma unroll
 	for (int b = 0; b < 4; ++b)
 #pragma unroll
-		for (int nb = 0; nb < 2; ++nb)
+		for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
 			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
 
 	if (steps > 0) {
 		const float* ap = A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31;   // + (16 * step + j) * TH
-		const bf16x8* fp = F + (long)blockIdx.y * 384 + lane;                       // + step * fstep + (nb * 3 + plane) * 64
+		const bf16x8* fp = F + (long)blockIdx.y * (NBW * 192) + lane;                      // + step * fstep + (nb * 3 + plane) * 64
 		const int last = s1 - 1, kend = steps_total - 1;
 		f32x4 va[D][8];
-		bf16x8 fb[D][2][3];
+		bf16x8 fb[D][NBW][3];
 #pragma unroll
 		for (int d = 0; d < D; ++d) {
 			const int st = s0 + d;                                  // steps >= D here
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 #pragma unroll
 			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(ap + ((long)sa * 16 + j) * TH);
 #pragma unroll
-			for (int nb = 0; nb < 2; ++nb)
+			for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
 				for (int pl = 0; pl < 3; ++pl) fb[d][nb][pl] = fp[(long)sf * fstep + (nb * 3 + pl) * 64];
 		}
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 						split3(v, op[nxt][0], op[nxt][1], op[nxt][2]);
 					}
 #pragma unroll
-					for (int nb = 0; nb < 2; ++nb) {
+					for (int nb = 0; nb < NBW; ++nb) {
 						// smallest terms first
 						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][2], fb[d][nb][0], acc[b][nb], 0, 0, 0);
 						acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[cur][0], fb[d][nb][2], acc[b][nb], 0, 0, 0);
@@ -236,32 +236,30 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 						}
 						if (DIAG == 0 || DIAG == 3 || DIAG == 4) {
 #pragma unroll
-							for (int nb = 0; nb < 2; ++nb)
+							for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
 								for (int pl = 0; pl < 3; ++pl) fb[d][nb][pl] = fp[(long)sf * fstep + (nb * 3 + pl) * 64];
 						} else {
 #pragma unroll
-							for (int nb = 0; nb < 2; ++nb)
+							for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
 								for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(fb[d][nb][pl]));
 						}
+						// 6 NBW MFMAs against 44 VALU (+ 8 + 3 NBW loads in the last phase of a step)
+						constexpr int NM = 6 * NBW, VPM = (44 + NM - 1) / NM, NL = 8 + 3 * NBW;
 #pragma unroll
-						for (int g = 0; g < 8; ++g) {
+						for (int g = 0; g < NM; ++g) {
 							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
-							__builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+							__builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // VALU
+							if (g < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
 						}
-#pragma unroll
-						for (int g = 0; g < 4; ++g) {
-							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-						}
-						__builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+						if (NL > NM) __builtin_amdgcn_sched_group_barrier(0x020, NL - NM, 0);
 					} else {
+						constexpr int NM = 6 * NBW, VPM = (44 + NM - 1) / NM;
 #pragma unroll
-						for (int g = 0; g < 12; ++g) {
+						for (int g = 0; g < NM; ++g) {
 							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+							__builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
 						}
 					}
 					__builtin_amdgcn_sched_barrier(0);
@@ -277,11 +275,11 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
-	for (int rd = 0; rd < 2; ++rd) {
+	for (int rd = 0; rd < NBW; ++rd) {        // four accumulator tiles per round
 		if (rd > 0) __syncthreads();
 #pragma unroll
 		for (int tl = 0; tl < 4; ++tl) {
-			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			const int b = (4 * rd + tl) / NBW, nb = (4 * rd + tl) % NBW;
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
 				f32x4 v;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		for (int i = 0; i < 16 / X3_WAVES; ++i) {
 			const int sl = wave * (16 / X3_WAVES) + i;  // slice = (tile, q)
 			const int q = sl & 3, tl = sl >> 2;
-			const int b = 2 * rd + (tl >> 1), nb = tl & 1;
+			const int b = (4 * rd + tl) / NBW, nb = (4 * rd + tl) % NBW;
 			f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
 #pragma unroll
 			for (int p = 1; p < X3_WAVES; ++p) s += l4[((p * 4 + tl) * 4 + q) * 64 + lane];
@@ -326,7 +324,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
-template <int D, int WAVES, int DIAG = 0>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -334,11 +332,11 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);
-	dim3 grid(p.xtiles * p.splits + passengers, RP / 64, 1), block(64 * WAVES);
+	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
 	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
@@ -350,6 +348,8 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps) {
 	if (RP % 64 != 0 || p.th != 128) return hipErrorInvalidValue;
 	static const int variant = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
+	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
+	if (RP % 128 == 0 && variant != 20) return launch_fp_x3<2, 4, 0, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	switch (variant) {
 	case 1: return launch_fp_x3<2, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	case 2: return launch_fp_x3<4, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);

@@ -123,6 +123,8 @@ typedef struct nmfamd_geometry {
 	long exchange_count;   /* elements of the multi-GPU exchange buffer */
 	int product_kernel;    /* 0 fp32 MFMA, 1 bf16-rounded operands, 2 fp32 by exact 3 x bf16 operand splitting, 3 fp64 MFMA,
 	                          4 VALU kernel (NMFAMD_FORCE_VALU), 5 sparse SpMM */
+	int resident_images;   /* dense images of V kept in HBM: 2 (V and V^T, each streamed along its output index), 1 (only V: W^T V
+	                          reads it along the reduction index; chosen when two would not fit, or by NMFAMD_ONE_IMAGE), 0 sparse */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 
@@ -184,6 +186,10 @@ NMFAMD_API int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, in
  * product kernel alone (HIP events) into *avg_us. */
 NMFAMD_API int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo,
                                            int reps, double* avg_us);
+/* The same with A stored tiled along the REDUCTION index y (the image the other product of an iteration streams along its
+ * output index): one resident image of V serves both products. */
+NMFAMD_API int nmfamd_op_factor_product_x3_ytiled(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo,
+                                                  int reps, double* avg_us);
 /* Diagnostic (NMFAMD_X3_VARIANT = 10..13 builds): per wave {shader cycles, 100 MHz ticks, K-steps of the main loop; 100 MHz
  * stamps at entry, loop start, loop end, tail end, exit} of one more launch; stamps_capacity in 8-byte words; *waves receives the number of waves stamped. */
 NMFAMD_API int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves);

@@ -221,7 +221,7 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 		out->m = g.m(); out->n = g.n(); out->r = g.r(); out->padded_rank = g.rp();
 		out->padded_m = g.mpad(); out->padded_n = g.npad();
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
-		out->product_kernel = g.product_kernel();
+		out->product_kernel = g.product_kernel(); out->resident_images = g.resident_images();
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
 	return NMFAMD_OK;
@@ -361,7 +361,7 @@ int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const 
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
-int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us) {
+static int op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us, bool y_tiled) {
 	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	int dev = 0; hipDeviceProp_t prop;
@@ -380,9 +380,12 @@ int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 	    hipMemset(dF.p, 0, sizeof(float) * RP * Yp) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(dA.p, Xp * sizeof(float), A, lda * sizeof(float), X * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(dF.p, RP * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, 128 * Yp, 128, false, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	// x-tiled image of A, or (y_tiled) the image tiled along the reduction index = the x-tiled image of A^T
+	const long tstride = y_tiled ? 128 * Xp : 128 * Yp;
+	if (y_tiled) { if (launch_tile_transposed<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 128, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR; }
+	else if (launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 128, false, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_factor_product_x3(plan, (const float*)dT.p, 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_factor_product_x3(plan, (const float*)dT.p, tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (reps > 0 && avg_us) {
@@ -393,9 +396,9 @@ int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 		if (hipMemcpy(dT2.p, dT.p, sizeof(float) * Xp * Yp, hipMemcpyDeviceToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 		hipEvent_t e0, e1;
 		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
-		for (int i = 0; i < 4; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr);
+		for (int i = 0; i < 4; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled);
 		(void)hipEventRecord(e0, nullptr);
-		for (int i = 0; i < reps; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr);
+		for (int i = 0; i < reps; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled);
 		(void)hipEventRecord(e1, nullptr);
 		if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
 		float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -403,6 +406,14 @@ int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	}
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
+int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us) {
+	return op_factor_product_x3(A, lda, X, Y, F, ldf, r, OUT, ldo, reps, avg_us, false);
+}
+
+int nmfamd_op_factor_product_x3_ytiled(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us) {
+	return op_factor_product_x3(A, lda, X, Y, F, ldf, r, OUT, ldo, reps, avg_us, true);
 }
 
 int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves) {

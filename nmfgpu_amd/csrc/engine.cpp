@@ -126,6 +126,19 @@ Status Engine<T>::allocate() {
 		planHx_ = planH_; planWx_ = planW_;
 		planHx_.steps_total = ksH_; planWx_.steps_total = ksW_;
 		planHx_.nb = planWx_.nb = 2;
+		// One resident image of V or two?  With two, each product streams its own image along its output index (the
+		// faster kernel form); with one, W^T V reads the image of V along its reduction index (y-tiled form, ~20 % slower
+		// per launch on its own).  One image wins when it fits the 256 MiB memory-side cache but two do not: both products
+		// of an iteration then find most of V there (config 2: V H^T 49 -> 37 us, iteration 126 -> 108 us).  Measured
+		// (10 000 x 5 000 scaled, r = 64): 148 MB two images 97 us / one 102; 185 MB 109 / 100; 207 MB 126 / 108; 246 MB
+		// 145 / 129; 266 MB 152 / 143; 328 MB 173 / 174; 1.6 GB 792 / 988.  Also one image when two (plus the staging
+		// image of the upload) do not fit in HBM.  NMFAMD_ONE_IMAGE = 1 / 0 forces the choice.
+		size_t free_b = 0, total_b = 0;
+		const size_t image_b = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
+		const char* force = std::getenv("NMFAMD_ONE_IMAGE");
+		if (force != nullptr) one_image_ = std::atoi(force) != 0;
+		else if (image_b > (size_t)160e6 && image_b < (size_t)300e6) one_image_ = true;
+		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 3 * image_b + (image_b >> 3) > free_b) one_image_ = true;
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
@@ -158,7 +171,7 @@ Status Engine<T>::allocate() {
 			HIPX(hipMemsetAsync(Hx3_, 0, bh, stream_));
 		}
 		HIPX(dalloc(&V_, elemsV_));
-		HIPX(dalloc(&Vt_, elemsVt_));
+		if (!one_image_) HIPX(dalloc(&Vt_, elemsVt_));
 	} else {
 		HIPX(dalloc(&t_vwh_, mpad_));
 		HIPX(dalloc(&t_kl_, mpad_));
@@ -222,9 +235,11 @@ Status Engine<T>::finish_upload(T* Vcol) {
 		}
 	} else if (tiled_) {
 		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)elemsV_, stream_));
-		HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)elemsVt_, stream_));
 		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, strideV_, planW_.th, false, stream_));
-		HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, strideVt_, planH_.th, stream_));
+		if (!one_image_) {
+			HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)elemsVt_, stream_));
+			HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, strideVt_, planH_.th, stream_));
+		}
 	} else {
 		HIPX(launch_transpose<T>(Vcol, mpad_, m_, n_, Vt_, npad_, stream_));
 	}
@@ -429,7 +444,8 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
 			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
+			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true));
+			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -1026,7 +1042,7 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
 	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
 	case 6: case 7: {
-		if (sparse_ || bf16_) return ST_INVALID;   // no fp32 dense image in sparse / bf16 mode
+		if (sparse_ || bf16_ || (one_image_ && which == 7)) return ST_INVALID;   // no fp32 dense image in sparse / bf16 mode; no V^T image
 		// V (ld mpad_) / Vt (ld npad_) as column-major images; the MFMA path keeps them x-tiled
 		const bool vt = which == 7;
 		const T* img = vt ? Vt_ : V_;

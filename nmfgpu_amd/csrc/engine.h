@@ -91,6 +91,7 @@ public:
 	int slabs_w() const { return planW_.splits; }
 	// which kernel runs the two big products: 0 fp32 MFMA, 1 bf16-rounded operands, 2 fp32 by exact 3 x bf16 splitting,
 	// 3 fp64 MFMA, 4 VALU fallback kernel (NMFAMD_FORCE_VALU), 5 sparse (SpMM)
+	int resident_images() const { return sparse_ ? 0 : (one_image_ ? 1 : 2); }
 	int product_kernel() const { return sparse_ ? 5 : bf16_ ? 1 : x3_ ? 2 : !tiled_ ? 4 : (sizeof(T) == 8 ? 3 : 0); }
 	const char* last_error() const { return last_error_; }
 
@@ -150,6 +151,10 @@ private:
 	// fp32 products on the bf16 matrix pipe by exact 3-way operand splitting (kernels_x3.hip): the fp32 tiled
 	// images of V stay as they are, the factor panel is split into Wx3_ / Hx3_ before each product
 	bool x3_ = false;
+	// one resident image of V instead of two: W^T V reads the image tiled along its reduction index (the y-tiled form of
+	// k_factor_product_x3; ~20 % slower per launch, half the memory).  Chosen when two images would not fit, or by
+	// NMFAMD_ONE_IMAGE.
+	bool one_image_ = false;
 	bool wx3_valid_ = false, hx3_valid_ = false;   // Wx3_ / Hx3_ hold the split image of the current Wt_ / H_
 	void *Wx3_ = nullptr, *Hx3_ = nullptr;
 	FactorProductPlan planHx_, planWx_;

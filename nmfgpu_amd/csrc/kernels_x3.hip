@@ -124,7 +124,7 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
 // stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2>
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false>
 __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -169,7 +169,18 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
 
 	if (steps > 0) {
-		const float* ap = A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31;   // + (16 * step + j) * TH
+		// TR = false: A is tiled along x (the output index): tile xt, K-step s, k = 8 half + j: ap + (16 s + j) TH, and
+		//   the four rows 4 l31 + b of an M-block quartet are one 16-byte load  (va[..][j] = rows b = 0..3 at k = 8 half + j).
+		// TR = true: A is tiled along y (the reduction index) -- the image the OTHER product streams along x: tile s / 8,
+		//   row (128 xt + 4 l31 + b) of that tile holds the tile's 128 y contiguously, so the 16-byte load is four
+		//   consecutive k of ONE row  (va[..][2 b + q] = row b at k = 8 half + 4 q .. + 3).  Same bytes per instruction, but
+		//   64 rows = 32 cache lines per wave instruction instead of 8 (each line serves two K-steps).
+		const float* ap = TR ? A + ((long)xt * TH + 4 * l31) * TH + 8 * half
+		                     : A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31;
+		auto a_addr = [&](int step, int i) -> const float* {
+			if (TR) return ap + (long)(step >> 3) * tile_stride + (step & 7) * 16 + (i >> 1) * TH + 4 * (i & 1);
+			return ap + ((long)step * 16 + i) * TH;
+		};
 		const bf16x8* fp = F + (long)blockIdx.y * (NBW * 192) + lane;                      // + step * fstep + (nb * 3 + plane) * 64
 		const int last = s1 - 1, kend = steps_total - 1;
 		f32x4 va[D][8];
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 			const int st = s0 + d;                                  // steps >= D here
 			const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
 #pragma unroll
-			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(ap + ((long)sa * 16 + j) * TH);
+			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(a_addr(sa, j));
 #pragma unroll
 			for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		{
 			float v[8];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) v[j] = va[0][j][0];
+			for (int j = 0; j < 8; ++j) v[j] = TR ? va[0][j >> 2][j & 3] : va[0][j][0];
 			split3(v, op[0][0], op[0][1], op[0][2]);
 		}
 		int t = 0;
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 					{
 						float v[8];
 #pragma unroll
-						for (int j = 0; j < 8; ++j) v[j] = va[nd][j][nbk];
+						for (int j = 0; j < 8; ++j) v[j] = TR ? va[nd][2 * nbk + (j >> 2)][j & 3] : va[nd][j][nbk];
 						split3(v, op[nxt][0], op[nxt][1], op[nxt][2]);
 					}
 #pragma unroll
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 						const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
 						if (DIAG == 0 || DIAG == 2 || DIAG == 4) {
 #pragma unroll
-							for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(ap + ((long)sa * 16 + j) * TH);
+							for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(a_addr(sa, j));
 						} else {
 #pragma unroll
 							for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(va[d][j]));
@@ -324,7 +335,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
-template <int D, int WAVES, int DIAG = 0, int NBW = 2>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -335,18 +346,26 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
 	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
 
+// y_tiled: A is the image tiled along the REDUCTION index (128-row tiles of y, tile_stride apart, each holding all x as
+// columns of 128 contiguous y) -- i.e. the x-tiled image of the transposed matrix; steps_total K-steps of 16 y, and the
+// image must cover 128 * xtiles columns.
 // A: x-tiled fp32 image (tile height 128, zero-filled up to a multiple of 16 columns); F: k_pack_panel_x3
 // image of the RP-column panel (RP a multiple of 64; grid.y = RP / 64 passes over A); p.steps_total = K-steps
 // of 16; p.th must be 128.  Passengers (Gram reduction, or the 64 x 64 inverse) ride only at RP = 64.
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
-                                    float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps) {
+                                    float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
+                                    bool y_tiled) {
 	if (RP % 64 != 0 || p.th != 128) return hipErrorInvalidValue;
+	if (y_tiled) {
+		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return launch_fp_x3<3, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	}
 	static const int variant = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
 	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
 	if (RP % 128 == 0 && variant != 20) return launch_fp_x3<2, 4, 0, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);

@@ -721,6 +721,38 @@ def test_native_fp32_mfma_path_still_agrees(alg, r, kw):
     assert rel(got["native"][0], got["fp32_mfma"][0]) < 1e-4 and rel(got["native"][1], got["fp32_mfma"][1]) < 1e-4
 
 
+@pytest.mark.parametrize("alg,r,kw", [("mu", 64, {}), ("als", 40, {}), ("nsnmf", 130, dict(theta=0.4))])
+def test_one_resident_image_gives_identical_factors(alg, r, kw, monkeypatch):
+    """One resident image of V (chosen automatically when one image fits the 256 MiB memory-side cache and two do not, or
+    when two would not fit in HBM; NMFAMD_ONE_IMAGE forces it): W^T V reads the image of V along its reduction index.
+    Same arithmetic in the same order => bit-identical factors and errors."""
+    m, n = 1500, 1100
+    V, W, H = problem(m, n, r, np.float32, seed=53)
+    out = {}
+    for one in (False, True):
+        monkeypatch.setenv("NMFAMD_ONE_IMAGE", "1" if one else "0")
+        eng = na.Engine(m, n, r, alg, **kw)
+        assert eng.geometry()["resident_images"] == (1 if one else 2)
+        eng.upload(V); eng.set_factors(W, H)
+        eng.iterate(12, last_iteration=12)
+        out[one] = eng.get_factors() + (eng.frobenius,)
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+    assert out[False][2] == out[True][2]
+
+
+@pytest.mark.parametrize("X,Y,r", [(300, 500, 64), (1000, 777, 40), (130, 2049, 33), (257, 1111, 256), (129, 1, 64), (5, 7, 3)])
+def test_factor_product_split_y_tiled_is_bit_identical(X, Y, r):
+    import ctypes as C
+    from nmfgpu_amd._lib import library
+    rng = np.random.default_rng(X + 3 * Y)
+    A = F((rng.random((X, Y)) - 0.2).astype(np.float32)); Fm = F(rng.random((r, Y)).astype(np.float32))
+    out = np.zeros((r, X), dtype=np.float32, order="F")
+    st = library().nmfamd_op_factor_product_x3_ytiled(C.c_void_p(A.ctypes.data), C.c_long(X), X, Y, C.c_void_p(Fm.ctypes.data), C.c_long(r), r,
+                                                      C.c_void_p(out.ctypes.data), C.c_long(r), 0, None)
+    assert st == 0
+    assert np.array_equal(out, na.op_factor_product_x3(A, Fm))
+
+
 def test_bf16_operand_mode_tracks_fp32_within_stated_tolerance():
     """precision = bf16: operands of the two big products carry 8 significant bits; factors after 20 iterations
     agree with the fp64 oracle to 2e-2 relative (fp32 mode: 2e-4), the reported error to 1e-3."""

@@ -61,7 +61,7 @@ Engine<T>::~Engine() {
 		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
-	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_}; for (void* b : bb) if (b) (void)hipFree(b); }
+	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -181,6 +181,10 @@ Status Engine<T>::allocate() {
 	}
 	HIPX(dalloc(&Wt_, panelW));
 	HIPX(dalloc(&H_, panelH));
+	// wide fp32 panels: scratch for the split image of the r x r matrix the update kernel multiplies with (kernels_wide.hip)
+	if (std::is_same<T, float>::value && panel_update_wide_available(RP_) && std::getenv("NMFAMD_FORCE_VALU") == nullptr &&
+	    std::getenv("NMFAMD_WIDE_FP32_MFMA") == nullptr)
+		HIPX(hipMalloc(&qx3_, 3 * 16 * (size_t)(RP_ / 16 + 1) * (RP_ / 32) * 64));
 	HIPX(dalloc(&slabs_, slab_elems));
 	HIPX(dalloc(&numW_, panelW));
 	HIPX(dalloc(&G_, rr));
@@ -641,7 +645,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		if (Status s = product_h(F)) return s;
 		const bool emit = x3_ && alg_ == ALG_MU && panel_update_delivers_gram(RP_, sizeof(T));   // nsNMF's W step consumes the smoothed panel
 		HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, S, slab_stride_, G_, RP_, (int)npad_, eps,
-		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, emit ? Hx3_ : nullptr, ksW_));
+		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, emit ? Hx3_ : nullptr, ksW_, qx3_));
 		hx3_valid_ = emit;
 	} else {
 		T off = 0, diag = 0;
@@ -671,7 +675,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) hpart = gramH_part_; }
 		const bool emit = x3_ && panel_update_delivers_gram(RP_, sizeof(T));
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
-		                            nullptr, n_, nullptr, nullptr, stream_, hpart, emit ? Hx3_ : nullptr, ksW_));
+		                            nullptr, n_, nullptr, nullptr, stream_, hpart, emit ? Hx3_ : nullptr, ksW_, qx3_));
 		hx3_valid_ = emit;
 		gram_h_partials_ = hpart != nullptr;
 	}
@@ -733,7 +737,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
-	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_));
+	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
 }
@@ -880,7 +884,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
-				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart));
+				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
 				if (gd_err) {
 					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
@@ -893,7 +897,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
-				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_, wpart));
+				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (compute_error) {
 					// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
 					HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));

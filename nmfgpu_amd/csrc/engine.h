@@ -157,6 +157,7 @@ private:
 	bool one_image_ = false;
 	bool wx3_valid_ = false, hx3_valid_ = false;   // Wx3_ / Hx3_ hold the split image of the current Wt_ / H_
 	void *Wx3_ = nullptr, *Hx3_ = nullptr;
+	void* qx3_ = nullptr;     // split image of the r x r operand of the wide fp32 panel update
 	FactorProductPlan planHx_, planWx_;
 	// sparse-V compute path (kernels_sparse.hip): CSR and CSC images of V, 0-based
 	bool sparse_ = false;

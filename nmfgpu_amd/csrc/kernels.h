@@ -115,8 +115,11 @@ bool panel_update_wide_available(int RP);
 bool gram_wide_available(int RP);
 // len: valid panel rows (the padding rows behind them are zero); partial: parts * RP * RP elements
 hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream);
+// q_split (optional): 3 * 16 * (RP / 16 + 1) * (RP / 32) * 64 bytes of scratch; when given, the r x r product runs on the bf16
+// matrix pipe with exactly split operands (fp32 accuracy, kernels_x3.hip) instead of the fp32 MFMA instructions
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream);
+                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
+                                        void* q_split = nullptr);
 template <typename T>
 hipError_t launch_reduce_partials(const T* partial, int parts, long stride, T* out, long count, hipStream_t stream);
 template <typename T>
@@ -126,7 +129,8 @@ hipError_t launch_normalize_panel_v2(T* P, int RP, int len_pad, T* sumsq_part, i
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
                                T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial = nullptr,
-                               void* x3_out = nullptr, int x3_ks = 0);   // x3_out: split image of the new panel (kernels_x3.hip); only where panel_update_delivers_gram()
+                               void* x3_out = nullptr, int x3_ks = 0,    // x3_out: split image of the new panel (kernels_x3.hip); only where panel_update_delivers_gram()
+                               void* q_split = nullptr);                 // scratch for the split image of Q (wide fp32 panels, see launch_panel_update_wide_f32)
 
 // sumsq_part: parts * RP partial sums followed by 16 * RP elements of scratch
 template <typename T>

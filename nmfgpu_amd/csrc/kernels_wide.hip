@@ -37,7 +37,7 @@ template <int MODE, int NCB>      // NCB = column blocks per wave = RP / 128
 __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, int RP, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, float* __restrict__ num_out) {
+	float* __restrict__ sumsq_part, float* __restrict__ num_out, const bf16x8* __restrict__ Qx3) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	const int LD = RP + 4;
 	float* s_num = lds;                       // [32][LD]
@@ -89,6 +89,51 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	for (int i = 0; i < NCB; ++i)
 #pragma unroll
 		for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
+	if (Qx3 != nullptr) {
+		// The same product at fp32 accuracy on the bf16 matrix pipe (kernels_x3.hip): Q comes pre-split into three bf16
+		// planes in fragment order (k_pack_panel_x3 of Q: A(c, k) = Q(k, c)), the LDS operand is split in registers;
+		// six 32x32x16 MFMAs per 16 k replace eight 32x32x2 fp32 ones at a quarter of their cycles each.
+		const int NBT = RP / 32, ksteps = RP / 16;
+		const bf16x8* qf = Qx3 + (long)wave * 192 + lane;        // + (ks * NBT + 4 i) * 192 + plane * 64
+		const float* vb = (MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 8 * half;
+		constexpr int DX = NCB <= 2 ? 4 : 2;
+		bf16x8 af[DX][NCB][3];
+#pragma unroll
+		for (int d = 0; d < DX; ++d)
+#pragma unroll
+			for (int i = 0; i < NCB; ++i)
+#pragma unroll
+				for (int pl = 0; pl < 3; ++pl) af[d][i][pl] = qf[((long)d * NBT + 4 * i) * 192 + pl * 64];
+		__builtin_amdgcn_sched_barrier(0);
+		for (int u = 0; u < ksteps; u += DX) {
+#pragma unroll
+			for (int d = 0; d < DX; ++d) {
+				float v[8];
+				const f32x4 b0 = *reinterpret_cast<const f32x4*>(vb + 16 * (u + d));
+				const f32x4 b1 = *reinterpret_cast<const f32x4*>(vb + 16 * (u + d) + 4);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { v[j] = b0[j]; v[4 + j] = b1[j]; }
+				bf16x8 hi, mid, lo;
+				split3(v, hi, mid, lo);
+#pragma unroll
+				for (int i = 0; i < NCB; ++i) {
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][2], hi, acc[i], 0, 0, 0);
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], lo, acc[i], 0, 0, 0);
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][1], mid, acc[i], 0, 0, 0);
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][1], hi, acc[i], 0, 0, 0);
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], mid, acc[i], 0, 0, 0);
+					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], hi, acc[i], 0, 0, 0);
+				}
+				int nu = u + DX + d;
+				nu = nu < ksteps ? nu : ksteps - 1;       // tail: harmless re-load of the last K-step
+#pragma unroll
+				for (int i = 0; i < NCB; ++i)
+#pragma unroll
+					for (int pl = 0; pl < 3; ++pl) af[d][i][pl] = qf[((long)nu * NBT + 4 * i) * 192 + pl * 64];
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	} else {
 	const float* qp = Q + (long)(4 * half) * RP + 32 * wave + l31;
 	const int groups = RP / 8;                // multiple of 16
 	// The A operands come from L2 (Q is RP x RP, shared by every workgroup): a D-deep register ring keeps
@@ -121,6 +166,8 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 				for (int gi = 0; gi < 4; ++gi) a[d][i][gi] = qp[(long)(8 * nu + gi) * RP + 128 * i];
 			__builtin_amdgcn_sched_barrier(0);
 		}
+	}
+
 	}
 
 	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave
@@ -441,22 +488,28 @@ bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && 
 
 template <int MODE, int NCB>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3) {
 	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 128);
 	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
 	static unsigned long long lds_done = 0ull;
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
-	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3));
 	return hipGetLastError();
 }
 
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream) {
+                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, void* q_split) {
 	if (!panel_update_wide_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % WIDE_YB != 0) return hipErrorInvalidValue;
+	const void* qx3 = nullptr;
+	if (q_split != nullptr) {
+		// Q (RP x RP) split into three bf16 planes in fragment order: A(c, k) = Q(k, c) = Q[k * RP + c]
+		if (hipError_t e = launch_pack_panel_x3(Q, RP, RP, q_split, RP / 16, stream); e != hipSuccess) return e;
+		qx3 = q_split;
+	}
 #define NMFAMD_WIDE(NCB)                                                                                                                   \
-	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream) \
-	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream)
+	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3) \
+	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3)
 	switch (RP / 128) {
 	case 1: NMFAMD_WIDE(1);
 	case 2: NMFAMD_WIDE(2);

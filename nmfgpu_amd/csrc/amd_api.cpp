@@ -457,6 +457,7 @@ int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long 
 	const long lp = pad128(len);
 	DevBuf dP, dPart, dG;
 	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dPart.alloc(sizeof(float) * (size_t)RP * RP * parts) != hipSuccess || dG.alloc(sizeof(float) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemset(dP.p, 0, sizeof(float) * RP * lp) != hipSuccess) return NMFAMD_HIP_ERROR;   // the panel invariant: padding rows and columns are zero
 	if (hipMemcpy2D(dP.p, RP * sizeof(float), P, ldp * sizeof(float), r * sizeof(float), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_gram<float>((const float*)dP.p, RP, len, parts, (float*)dPart.p, (float*)dG.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(G, ldg * sizeof(float), dG.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;

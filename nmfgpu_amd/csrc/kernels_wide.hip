@@ -437,8 +437,10 @@ hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, floa
 	if (!gram_wide_available(RP)) return hipErrorInvalidValue;
 	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
 	// two workgroups per CU are enough; fewer, longer slices keep the partial traffic down
-	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));      // and at least 32 K-steps per slice
 	static const bool native = std::getenv("NMFAMD_WIDE_FP32_MFMA") != nullptr;       // A/B switch: fp32 MFMA instructions
+	static const int wgs = [] { const char* e = std::getenv("NMFAMD_GRAM_WGS"); return e ? std::atoi(e) : 0; }();
+	const int target = wgs > 0 ? wgs : 512;
+	parts = std::max(1, std::min(std::min(parts, std::max(16, target / nsuper)), std::max(1, len / 64)));      // and at least 32 K-steps per slice
 	if (native) hipLaunchKernelGGL((k_gram_wide_f32<8>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	else hipLaunchKernelGGL((k_gram_wide_x3<2>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();

@@ -143,9 +143,10 @@ Status Engine<T>::allocate() {
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
 	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
-	strideV_ = (long)planW_.th * npad_;
+	img_th_ = (one_image_ && std::getenv("NMFAMD_IMAGE_TILE128") == nullptr) ? 16 : planW_.th;
+	strideV_ = (long)img_th_ * npad_;
 	strideVt_ = (long)planH_.th * mpad_;
-	elemsV_ = tiled_ ? (long)planW_.xtiles * strideV_ : mpad_ * npad_;
+	elemsV_ = mpad_ * npad_;     // tiled or not: every tile spans all columns
 	elemsVt_ = tiled_ ? (long)planH_.xtiles * strideVt_ : mpad_ * npad_;
 	slab_stride_ = (long)RP_ * std::max(mpad_, npad_);
 	const long slab_elems = slab_stride_ * std::max(planH_.splits, planW_.splits);
@@ -239,7 +240,7 @@ Status Engine<T>::finish_upload(T* Vcol) {
 		}
 	} else if (tiled_) {
 		HIPX(hipMemsetAsync(V_, 0, sizeof(T) * (size_t)elemsV_, stream_));
-		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, strideV_, planW_.th, false, stream_));
+		HIPX(launch_tile<T>(Vcol, mpad_, m_, n_, V_, strideV_, img_th_, false, stream_));
 		if (!one_image_) {
 			HIPX(hipMemsetAsync(Vt_, 0, sizeof(T) * (size_t)elemsVt_, stream_));
 			HIPX(launch_tile_transposed<T>(Vcol, mpad_, m_, n_, Vt_, strideVt_, planH_.th, stream_));
@@ -448,7 +449,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
 			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true));
+			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_));
 			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
@@ -499,7 +500,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
 			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
 			record_begin();
-			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg));
+			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_));
 			record_end();
 			return ST_OK;
 		}
@@ -1056,7 +1057,7 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 		T* tmp = nullptr;
 		HIPX(hipMalloc((void**)&tmp, sizeof(T) * (size_t)avail));
 		hipError_t e = hipMemsetAsync(tmp, 0, sizeof(T) * (size_t)avail, stream_);
-		if (e == hipSuccess) e = vt ? launch_tile<T>(img, npad_, n_, m_, tmp, strideVt_, planH_.th, true, stream_) : launch_tile<T>(img, mpad_, m_, n_, tmp, strideV_, planW_.th, true, stream_);
+		if (e == hipSuccess) e = vt ? launch_tile<T>(img, npad_, n_, m_, tmp, strideVt_, planH_.th, true, stream_) : launch_tile<T>(img, mpad_, m_, n_, tmp, strideV_, img_th_, true, stream_);
 		if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(T) * count, hipMemcpyDeviceToHost, stream_);
 		if (e == hipSuccess) e = hipStreamSynchronize(stream_);
 		(void)hipFree(tmp);

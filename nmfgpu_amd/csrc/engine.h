@@ -155,6 +155,7 @@ private:
 	// k_factor_product_x3; ~20 % slower per launch, half the memory).  Chosen when two images would not fit, or by
 	// NMFAMD_ONE_IMAGE.
 	bool one_image_ = false;
+	int img_th_ = 128;        // rows per tile of the V image: 16 with one resident image (both kernel forms read contiguously), else the plan's
 	bool wx3_valid_ = false, hx3_valid_ = false;   // Wx3_ / Hx3_ hold the split image of the current Wt_ / H_
 	void *Wx3_ = nullptr, *Hx3_ = nullptr;
 	void* qx3_ = nullptr;     // split image of the r x r operand of the wide fp32 panel update

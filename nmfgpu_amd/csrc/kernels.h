@@ -200,7 +200,7 @@ int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
 hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream);
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
-                                    unsigned long long* stamps = nullptr, bool y_tiled = false);
+                                    unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128);
 int plan_splits_x3(int xtiles, int KS, int num_cus);
 
 // ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------

@@ -124,7 +124,7 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
 // stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false>
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128>
 __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -175,9 +175,20 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		//   row (128 xt + 4 l31 + b) of that tile holds the tile's 128 y contiguously, so the 16-byte load is four
 		//   consecutive k of ONE row  (va[..][2 b + q] = row b at k = 8 half + 4 q .. + 3).  Same bytes per instruction, but
 		//   64 rows = 32 cache lines per wave instruction instead of 8 (each line serves two K-steps).
-		const float* ap = TR ? A + ((long)xt * TH + 4 * l31) * TH + 8 * half
-		                     : A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31;
+		// IMG = tile height of the image (rows of the tiled index per tile).  128: as described above.  16 (one resident
+		//   image, see Engine): a tile is 16 rows, so that BOTH forms stream contiguous memory -- x-tiled: the 128 output rows
+		//   are eight tiles, a lane quartet (l31 >> 2) per tile, 1 KiB contiguous per tile and K-step; y-tiled: a K-step IS a
+		//   tile, the 16 k of a row are 64 contiguous bytes and the 128 rows of the wave 8 KiB contiguous (with 128-row tiles
+		//   a K-step takes 64 bytes out of each of 128 rows 512 bytes apart and every row is revisited eight times).
+		const float* ap = IMG == 16 ? (TR ? A + ((long)xt * TH + 4 * l31) * 16 + 8 * half
+		                                  : A + ((long)xt * 8 + (l31 >> 2)) * tile_stride + (8 * half) * 16 + 4 * (l31 & 3))
+		                            : (TR ? A + ((long)xt * TH + 4 * l31) * TH + 8 * half
+		                                  : A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31);
 		auto a_addr = [&](int step, int i) -> const float* {
+			if (IMG == 16) {
+				if (TR) return ap + (long)step * tile_stride + (i >> 1) * 16 + 4 * (i & 1);
+				return ap + ((long)step * 16 + i) * 16;
+			}
 			if (TR) return ap + (long)(step >> 3) * tile_stride + (step & 7) * 16 + (i >> 1) * TH + 4 * (i & 1);
 			return ap + ((long)step * 16 + i) * TH;
 		};
@@ -335,7 +346,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
-template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -346,22 +357,29 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
 	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
 
 // y_tiled: A is the image tiled along the REDUCTION index (128-row tiles of y, tile_stride apart, each holding all x as
 // columns of 128 contiguous y) -- i.e. the x-tiled image of the transposed matrix; steps_total K-steps of 16 y, and the
-// image must cover 128 * xtiles columns.
+// image must cover 128 * xtiles columns.  image_tile: rows of the tiled index per tile of the image, 128 (tile_stride = 128 *
+// columns) or 16 (tile_stride = 16 * columns; both forms then read contiguous memory, see the kernel).
 // A: x-tiled fp32 image (tile height 128, zero-filled up to a multiple of 16 columns); F: k_pack_panel_x3
 // image of the RP-column panel (RP a multiple of 64; grid.y = RP / 64 passes over A); p.steps_total = K-steps
 // of 16; p.th must be 128.  Passengers (Gram reduction, or the 64 x 64 inverse) ride only at RP = 64.
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
-                                    bool y_tiled) {
-	if (RP % 64 != 0 || p.th != 128) return hipErrorInvalidValue;
+                                    bool y_tiled, int image_tile) {
+	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
+	if (image_tile == 16) {
+		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
+		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return y_tiled ? launch_fp_x3<3, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
+		               : launch_fp_x3<3, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	}
 	if (y_tiled) {
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		return launch_fp_x3<3, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);

@@ -124,7 +124,7 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
 // stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128>
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false>
 __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -192,6 +192,16 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 			if (TR) return ap + (long)(step >> 3) * tile_stride + (step & 7) * 16 + (i >> 1) * TH + 4 * (i & 1);
 			return ap + ((long)step * 16 + i) * TH;
 		};
+		// YLDS (y-tiled form on 16-row tiles): the K-step -- 128 rows x 64 B, 8 KiB contiguous -- is loaded lane-linear
+		//   (instruction i, lane l: bytes 1024 i + 16 l = row 16 i + (l >> 2), chunk l & 3: the access pattern of the x-tiled
+		//   form) into the landing ring va[], parked in one of two wave-private LDS slots as [row][16 + 4] floats, and every
+		//   lane reads its own row back (MFMA row r of M-block b = tile row 32 b + r; row stride 80 B: conflict-free
+		//   ds_read_b128).
+		const float* gp = A + (long)xt * TH * 16 + 4 * lane;
+		auto g_addr = [&](int step, int i) -> const float* { return gp + (long)step * tile_stride + i * 256; };
+		float* lw = lds + wave * (2 * 128 * 20);                                           // two slots of 128 x 20 floats
+		const int wofs = (lane >> 2) * 20 + 4 * (lane & 3);                                // + i * 320, + slot * 2560
+		const int rofs = l31 * 20 + 8 * half;                                              // + b * 640, + slot * 2560
 		const bf16x8* fp = F + (long)blockIdx.y * (NBW * 192) + lane;                      // + step * fstep + (nb * 3 + plane) * 64
 		const int last = s1 - 1, kend = steps_total - 1;
 		f32x4 va[D][8];
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 			const int st = s0 + d;                                  // steps >= D here
 			const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
 #pragma unroll
-			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(a_addr(sa, j));
+			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(YLDS ? g_addr(sa, j) : a_addr(sa, j));
 #pragma unroll
 			for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -215,7 +225,29 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		// Branch-free: the ring is refilled with clamped step indices.
 		if (DIAG != 0) { t_loop0 = __builtin_amdgcn_s_memtime(); r_loop0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
 		bf16x8 op[2][3];
-		{
+		f32x4 raw[2][2];
+		if (YLDS) {
+			// steps 0 and 1 go to LDS slots 0 and 1; their landing registers take steps D and D + 1
+#pragma unroll
+			for (int d = 0; d < 2; ++d) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(lw + d * 2560 + j * 320 + wofs) = va[d][j];
+				int st = s0 + D + d;
+				st = st < last ? st : last;
+				const int sa = st < kend ? st : kend;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(g_addr(sa, j));
+			}
+			// LDS reads run two phases ahead of the MFMAs that use them: raw[q & 1] holds the operand of phase q, read during
+			// phase q - 2 and split during phase q - 1 (one wave per SIMD: a read consumed in the phase that issues it would
+			// expose the LDS latency four times per K-step)
+			raw[0][0] = *reinterpret_cast<const f32x4*>(lw + rofs); raw[0][1] = *reinterpret_cast<const f32x4*>(lw + rofs + 4);
+			raw[1][0] = *reinterpret_cast<const f32x4*>(lw + 640 + rofs); raw[1][1] = *reinterpret_cast<const f32x4*>(lw + 640 + rofs + 4);
+			float v[8];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { v[j] = raw[0][0][j]; v[4 + j] = raw[0][1][j]; }
+			split3(v, op[0][0], op[0][1], op[0][2]);
+		} else {
 			float v[8];
 #pragma unroll
 			for (int j = 0; j < 8; ++j) v[j] = TR ? va[0][j >> 2][j & 3] : va[0][j][0];
@@ -229,7 +261,17 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 				for (int b = 0; b < 4; ++b) {
 					const int cur = (d * 4 + b) & 1, nxt = cur ^ 1;
 					const int nd = b == 3 ? (d + 1) % D : d, nbk = (b + 1) & 3;
-					{
+					if (YLDS) {
+						// split the operand of the next phase (read from LDS one phase ago), then read the one after it
+						float v[8];
+#pragma unroll
+						for (int j = 0; j < 4; ++j) { v[j] = raw[nxt][0][j]; v[4 + j] = raw[nxt][1][j]; }
+						split3(v, op[nxt][0], op[nxt][1], op[nxt][2]);
+						const int b2 = (b + 2) & 3;
+						const int slot = (t + d + (b >= 2 ? 1 : 0)) & 1;            // K-step of phase p + 2: this one or the next
+						const float* rp = lw + slot * 2560 + b2 * 640 + rofs;
+						raw[cur][0] = *reinterpret_cast<const f32x4*>(rp); raw[cur][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+					} else {
 						float v[8];
 #pragma unroll
 						for (int j = 0; j < 8; ++j) v[j] = TR ? va[nd][2 * nbk + (j >> 2)][j & 3] : va[nd][j][nbk];
@@ -249,7 +291,19 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 						int st = s0 + t + D + d;
 						st = st < last ? st : last;                         // past this wave's piece: a harmless re-read
 						const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
-						if (DIAG == 0 || DIAG == 2 || DIAG == 4) {
+						if (YLDS) {
+							// K-step t + d is done with its LDS slot: park step t + d + 2 there (it landed in ring slot (d + 2) % D,
+							// loaded D steps ago) and send that ring slot for step t + d + 2 + D
+							const int rs = (d + 2) % D;
+							const int slot = (t + d) & 1;
+#pragma unroll
+							for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(lw + slot * 2560 + j * 320 + wofs) = va[rs][j];
+							int s2 = s0 + t + d + 2 + D;
+							s2 = s2 < last ? s2 : last;
+							const int sa2 = s2 < kend ? s2 : kend;
+#pragma unroll
+							for (int j = 0; j < 8; ++j) va[rs][j] = *reinterpret_cast<const f32x4*>(g_addr(sa2, j));
+						} else if (DIAG == 0 || DIAG == 2 || DIAG == 4) {
 #pragma unroll
 							for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(a_addr(sa, j));
 						} else {
@@ -294,6 +348,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); r_tail = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
 	// in-workgroup sum through LDS, two M-blocks (four tiles) per round; C/D map: register g of lane l
 	// is MFMA row i = (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31; output row x = 128 xt + 4 i + b.
+	if (YLDS) __syncthreads();            // the epilogue image overlays the staging slots of every wave
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
@@ -322,7 +377,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) {
 				const int mi = gi + 8 * q + 4 * half;
-				const int x = xt * TH + 4 * mi + b;
+				const int x = xt * TH + (YLDS ? 32 * b + mi : 4 * mi + b);
 				slab[(long)x * RP + coff + 32 * nb + l31] = s[gi];
 			}
 		}
@@ -346,7 +401,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
-template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -355,10 +410,10 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
-	const size_t lds_bytes = std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float));
+	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static unsigned long long lds_done = 0ull;
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
@@ -377,6 +432,8 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	if (image_tile == 16) {
 		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		static const bool ydirect = std::getenv("NMFAMD_X3_YDIRECT") != nullptr;          // A/B switch: row-per-lane global loads
+		if (y_tiled && !ydirect) return launch_fp_x3<3, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		return y_tiled ? launch_fp_x3<3, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		               : launch_fp_x3<3, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}

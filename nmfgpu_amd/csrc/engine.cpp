@@ -115,8 +115,12 @@ Status Engine<T>::allocate() {
 	// three bf16 terms (fp32-level accuracy, six cross products; kernels_x3.hip) -- HBM-bound instead of bound by
 	// the fp32 MFMA rate.  precision = -1 (or NMFAMD_FP32_NATIVE) keeps the native fp32 MFMA instructions.
 	// (ranks <= 32 stay on the fp32 MFMA kernel: with half its MFMA work it is HBM-bound already and needs no split image)
-	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && planH_.nb == 2 &&
+	// ... except where one image in the memory-side cache pays more than the halved MFMA work (§3: 107 -> 100 us at config 2's shape)
+	const size_t image_bytes = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
+	const bool cache_window = image_bytes > (size_t)160e6 && image_bytes < (size_t)300e6 && std::getenv("NMFAMD_ONE_IMAGE") == nullptr;
+	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && (planH_.nb == 2 || cache_window) &&
 	    std::getenv("NMFAMD_FP32_NATIVE") == nullptr) {
+		planH_.nb = planW_.nb = 2;
 		x3_ = true;
 		planH_.th = planW_.th = 128;
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);

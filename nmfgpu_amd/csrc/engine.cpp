@@ -647,7 +647,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 	gram_w_ready_ = false;      // consumed (the inverse passenger / update below read G_; W changes in the W step)
 	const int S = planH_.splits;
 	if (alg_ == ALG_MU || alg_ == ALG_NSNMF) {
-		if (Status s = product_h(F)) return s;
+		if (Status s = product_h(F, nullptr, x3_ && wx3_valid_ && F == Wt_)) return s;
 		const bool emit = x3_ && alg_ == ALG_MU && panel_update_delivers_gram(RP_, sizeof(T));   // nsNMF's W step consumes the smoothed panel
 		HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, S, slab_stride_, G_, RP_, (int)npad_, eps,
 		                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, emit ? Hx3_ : nullptr, ksW_, qx3_));
@@ -669,11 +669,11 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			if constexpr (std::is_same<T, float>::value) {
 				GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
 				rg.inv_a = G_; rg.inv_out = Qinv_; rg.inv_offdiag = off; rg.inv_diag = diag; rg.inv_r = r_;
-				if (Status s = product_h(F, &rg)) return s;
+				if (Status s = product_h(F, &rg, x3_ && wx3_valid_ && F == Wt_)) return s;
 			}
 		} else {
 			if (Status s = normal_inverse_fork(G_, off, diag)) return s;
-			if (Status s = product_h(F)) return s;
+			if (Status s = product_h(F, nullptr, x3_ && wx3_valid_ && F == Wt_)) return s;
 			if (Status s = normal_inverse_join()) return s;
 		}
 		T* hpart = nullptr;
@@ -742,6 +742,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
+	wx3_valid_ = false;
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
@@ -770,7 +771,9 @@ Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (from_gram_partials) {
 			HIPX(launch_gram64_from_partials(gramW_part_, (int)(mpad_ / 64), G_, scale_, stream_));
-			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
+			// the scaling pass also leaves the split image of the normalised W for the next W^T V
+			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+			wx3_valid_ = x3_;
 			gram_w_ready_ = true;
 			return ST_OK;
 		}
@@ -888,6 +891,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
+				wx3_valid_ = false;
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
@@ -901,6 +905,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
+				wx3_valid_ = false;
 				HIPX(launch_panel_update<T>(PANEL_LS, Wt_, slabs_, S, slab_stride_, Qinv_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (compute_error) {

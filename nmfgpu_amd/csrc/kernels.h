@@ -78,7 +78,7 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
                               float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
                               int compute_error, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
 // P(c, y) *= scale(c)
-hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream);
+hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
 // G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and
 // G <- diag(scale) G diag(scale): the stand-alone (not passenger) form of the Gram reduction
 hipError_t launch_gram64_from_partials(const float* partials, int parts, float* G, float* scale, hipStream_t stream);

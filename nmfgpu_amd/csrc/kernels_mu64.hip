@@ -318,7 +318,32 @@ __global__ __launch_bounds__(256) void k_mu64_apply_scale(float* __restrict__ P,
 	*reinterpret_cast<f32x4*>(P + 4 * e) = v;
 }
 
-hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream) {
+// The same pass also writing the split (3 x bf16) image of the scaled panel for the next factor product
+// (kernels_x3.hip): a workgroup is one K-step of 16 panel rows.
+__global__ __launch_bounds__(256) void k_mu64_apply_scale_x3(float* __restrict__ P, const float* __restrict__ scale, bf16x8* __restrict__ x3_out, int x3_ks) {
+	__shared__ __attribute__((aligned(16))) float s_v[16][68];
+	const int tid = threadIdx.x;
+	const long e = (long)blockIdx.x * 256 + tid;
+	f32x4 v = *reinterpret_cast<f32x4*>(P + 4 * e);
+	v *= *reinterpret_cast<const f32x4*>(scale + (4 * tid) % 64);
+	*reinterpret_cast<f32x4*>(P + 4 * e) = v;
+	*reinterpret_cast<f32x4*>(&s_v[tid >> 4][4 * (tid & 15)]) = v;
+	__syncthreads();
+	if (tid < 128 && (int)blockIdx.x < x3_ks) {
+		const int r = tid & 31, h = (tid >> 5) & 1, nb = tid >> 6;
+		float w[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) w[j] = s_v[8 * h + j][32 * nb + r];
+		store_split3(x3_out, blockIdx.x, 2, nb, h, r, w);
+	}
+}
+
+// x3_out (optional): split image of the scaled panel, x3_ks K-steps of 16 rows (len_pad is a multiple of 128)
+hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream, void* x3_out, int x3_ks) {
+	if (x3_out != nullptr) {
+		hipLaunchKernelGGL(k_mu64_apply_scale_x3, dim3((unsigned)(len_pad / 16)), dim3(256), 0, stream, P, scale, reinterpret_cast<bf16x8*>(x3_out), x3_ks);
+		return hipGetLastError();
+	}
 	const long count4 = (long)len_pad * 64 / 4;
 	hipLaunchKernelGGL(k_mu64_apply_scale, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, stream, P, count4, scale);
 	return hipGetLastError();

@@ -1,0 +1,37 @@
+"""bench.py's one-line JSON contract, on the GPU: a short default run must print exactly one JSON object with the metric,
+the whole-job value, the roofline object of the dominant kernel (live HIP-event timing) and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_bench_line_has_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("NMF MU iterations/sec") and d["unit"] == "iterations/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-6) and d["value"] > 1000
+    cfg = d["config"]
+    assert cfg["rows"] == 10000 and cfg["columns_per_gpu"] == 5000 and cfg["features"] == 64 and "model" not in cfg
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0.05 < r["frac"] < 1.2
+    assert r["launches"] > 0 and r["avg_launch_us"] > 10
+    if r["bound"] == "hbm":
+        assert r["achieved"] == pytest.approx(r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+    # the iteration converged to the same error as every other path on this input (oracle: 2022.63 after 220 iterations;
+    # here after 50)
+    assert 2000 < d["frobenius_last"] < 2100

@@ -438,9 +438,16 @@ int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, 
 	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemset(dT.p, 0, sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_HIP_ERROR;
-	for (int i = 0; i < 6; ++i)
-		if (launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr,
-		                             i == 5 ? (unsigned long long*)dT.p : nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	// NMFAMD_X3_VARIANT >= 30: the y-tiled form on 16-row tiles (any buffer of the right size is an image of random data)
+	const char* ve = std::getenv("NMFAMD_X3_VARIANT");
+	const bool ytiled = ve != nullptr && std::atoi(ve) >= 30;
+	unsigned long long* dummy = nullptr;
+	for (int i = 0; i < 6; ++i) {
+		unsigned long long* st = i == 5 ? (unsigned long long*)dT.p : (ytiled ? (unsigned long long*)dT.p : dummy);
+		hipError_t e = ytiled ? launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 16 * Xp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, st, true, 16)
+		                      : launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, st);
+		if (e != hipSuccess) return NMFAMD_HIP_ERROR;
+	}
 	if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	*waves = nwaves;
 	return NMFAMD_OK;

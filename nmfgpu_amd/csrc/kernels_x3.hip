@@ -429,6 +429,17 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
                                     bool y_tiled, int image_tile) {
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
+	if (image_tile == 16 && y_tiled && RP == 64 && stamps != nullptr) {
+		// stamped diagnostic builds of the y-tiled form with row-per-lane loads (tools/stamp_x3.py, NMFAMD_X3_VARIANT = 30..33)
+		static const int yv = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();
+		switch (yv) {
+		case 30: return launch_fp_x3<3, 4, 1, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+		case 31: return launch_fp_x3<3, 4, 2, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+		case 32: return launch_fp_x3<3, 4, 3, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+		case 34: return launch_fp_x3<3, 4, 4, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);   // through LDS
+		default: return launch_fp_x3<3, 4, 4, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+		}
+	}
 	if (image_tile == 16) {
 		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);

@@ -28,6 +28,12 @@ PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s spec (6.29 TB/s meas
 
 # --workload c4 (NOT the default and not the BASELINE metric line): one column shard of BASELINE config 4 per GPU
 C4 = {"rows": 50000, "columns_per_gpu": 6250, "features": 256, "theta": 0.5}
+# --workload c3: BASELINE configs[2], sparse CSR V, KL-divergence MU (SURVEY.md section 8d's synthetic input)
+C3 = {"rows": 100000, "columns": 20000, "features": 128, "row_nnz_mean": 200}
+# --workload c5 / c5-gdcls: BASELINE configs[4], the constrained variants at config 2's shape; parameter values of the
+# reference's example (example/main.cpp:119-126)
+C5 = {"ahcls": dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01), "gdcls": dict(lam=0.01)}
+PEAK_L2_GATHER_GBS = 18000.0    # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCD's L2
 
 
 def make_problem(shard: int, m: int = M, n: int = N_COLS, r: int = R):
@@ -41,19 +47,39 @@ def make_problem(shard: int, m: int = M, n: int = N_COLS, r: int = R):
     return V, W, H
 
 
-def cpu_baseline(V, W, H, budget_s: float = 20.0):
+def make_sparse_problem(m: int = C3["rows"], n: int = C3["columns"], r: int = C3["features"], mean: int = C3["row_nnz_mean"], seed: int = 1):
+    """BASELINE configs[2]: CSR int32, per-row count ~ Poisson(mean) clipped to >= 1, columns
+    uniform (duplicates inside a row removed, so the count is a hair below the draw), values U{1..5}, base 0;
+    W0, H0 = U(0,1].  Returns (values f32, rowPtr, columnIndices, W0, H0)."""
+    rng = np.random.default_rng(seed)
+    counts = np.maximum(rng.poisson(mean, size=m), 1).astype(np.int64)
+    rows = np.repeat(np.arange(m, dtype=np.int64), counts)
+    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
+    key = np.unique(rows * n + cols)                     # sorted by (row, column), duplicates dropped
+    rows = (key // n).astype(np.int64)
+    idx = (key % n).astype(np.int32)
+    ptr = np.zeros(m + 1, dtype=np.int64)
+    np.add.at(ptr, rows + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    val = rng.integers(1, 6, size=idx.size).astype(np.float32)
+    W = np.asfortranarray((1.0 - rng.random((r, m))).astype(np.float32).T)
+    H = np.asfortranarray((1.0 - rng.random((n, r))).astype(np.float32).T)
+    return val, ptr, idx, W, H
+
+
+def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
     """The oracle (our CPU port of the reference's iteration) timed on this box's host cores."""
     from oracle import oracle
     Wc, Hc = W.copy(order="F"), H.copy(order="F")
     t0 = time.perf_counter()
-    oracle.run("mu", V, Wc, Hc, 1)
+    oracle.run(algorithm, V, Wc, Hc, 1, **kw)
     first = time.perf_counter() - t0
     iters = int(max(1, min(10, budget_s // max(first, 1e-3))))
     t0 = time.perf_counter()
-    oracle.run("mu", V, Wc, Hc, iters)
+    oracle.run(algorithm, V, Wc, Hc, iters, **kw)
     dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{iters} MU iterations of the full 10000x5000 r=64 fp32 problem (oracle/nmf_oracle.c, OpenMP)"}
+            "sample": f"{iters} {algorithm.upper()} iterations of the full 10000x5000 r=64 fp32 problem (oracle/nmf_oracle.c, OpenMP)"}
 
 
 def cpu_baseline_blas(V, W, H, threads: int, budget_s: float = 6.0):
@@ -102,11 +128,20 @@ def main():
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
     ap.add_argument("--rccl1", action="store_true", help="with --sharded at N = 1: one-rank RCCL group, the all-reduce / all-gather are issued for real (identities): "
                                                          "the fixed cost of the collective calls on one GPU")
-    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
-                    help="c2 (default) = BASELINE configs[1], the metric line; c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands)")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
+                    help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
+                         "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
     args = ap.parse_args()
     if args.workload == "c4":
         return main_c4(args)
+    if args.workload == "c3":
+        return main_c3(args)
+    algorithm, alg_kw = "mu", {}
+    if args.workload.startswith("c5"):
+        algorithm = "gdcls" if args.workload.endswith("gdcls") else "ahcls"
+        alg_kw = C5[algorithm]
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--workload c5 is a single-GPU workload (BASELINE configs[4]: algorithm-dispatch coverage on 1 x MI355X)")
 
     import torch
     import nmfgpu_amd as na
@@ -143,7 +178,7 @@ def main():
 
     kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
     if not distributed and not args.sharded:
-        eng = na.Engine(M, N_COLS, R, "mu", dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream)
+        eng = na.Engine(M, N_COLS, R, algorithm, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, **alg_kw)
         eng.upload(V)
         eng.set_factors(W, H)
         eng.iterate(Wm, first_iteration=1, error_every=10)
@@ -224,29 +259,98 @@ def main():
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": "k_factor_product_f32", **common}
         if args.rccl1 and not distributed:
             parallelism += " (one-rank RCCL group: collectives issued, identities)"
+        names = {"mu": "MU", "ahcls": "AHCLS", "gdcls": "GDCLS"}
         out = {
-            "metric": "NMF MU iterations/sec, dense 10kx5k r=64",
+            "metric": f"NMF {names[algorithm]} iterations/sec, dense 10kx5k r=64",
             "value": world * K / elapsed,
             "unit": "iterations/s" if world == 1 else "shard-iterations/s (one 10000x5000 column shard per GPU)",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32",
+            "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32" if algorithm == "mu" else
+                                   f"configs[4]: {names[algorithm]} at dense random V 10000x5000, r=64, fp32, parameters {alg_kw}",
                        "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "parallelism": parallelism,
                        "arithmetic": ("fp32 operands and fp32 accumulation; the two big products run on the bf16 matrix pipe with every operand "
                                       "split EXACTLY into three bf16 terms (six cross products kept, dropped terms <= 2^-23 relative): measured "
                                       "error against fp64 equals the native fp32 MFMA kernel's (tests/test_gpu_parity.py)") if product_kernel == 2
                                      else "fp32 MFMA instructions"},
             "frobenius_last": frob,
-            "iter_flops": 4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS),
-            "achieved_tflops_whole_iteration": (4.0 * M * N_COLS * R + 4.0 * R * R * (M + N_COLS)) * (K / elapsed) / 1e12,
+            # MU 4 m n r + 4 r^2 (m + n); the constrained variants add ~6 r^2 (m + n) for the two solve chains
+            "iter_flops": 4.0 * M * N_COLS * R + (4.0 if algorithm == "mu" else 10.0) * R * R * (M + N_COLS),
+            "achieved_tflops_whole_iteration": (4.0 * M * N_COLS * R + (4.0 if algorithm == "mu" else 10.0) * R * R * (M + N_COLS)) * (K / elapsed) / 1e12,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(V, W, H)
-            out["cpu_baseline_blas"] = cpu_baseline_blas(V, W, H, out["cpu_baseline"]["cores"])
+            out["cpu_baseline"] = cpu_baseline(V, W, H, algorithm=algorithm, **alg_kw)
+            if algorithm == "mu":
+                out["cpu_baseline_blas"] = cpu_baseline_blas(V, W, H, out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     if distributed or (args.sharded and args.rccl1):
         dist.destroy_process_group()
+
+
+def main_c3(args):
+    """BASELINE configs[2] on one GPU: CSR V 100000 x 20000 at 1 % (2e7 stored entries), r = 128, multiplicative update on
+    the generalised KL divergence; V stays sparse in HBM (CSR + CSC images), one step = one iteration = 2 SDDMM + 2 SpMM.
+    Same timing contract as the default.  roofline: the SDDMM kernel (two launches per iteration, the largest share)."""
+    import torch
+    import nmfgpu_amd as na
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload c3 is a single-GPU workload (BASELINE configs[2]: 1 x MI355X)")
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(0)
+    m, n, r = C3["rows"], C3["columns"], C3["features"]
+    val, ptr, idx, W, H = make_sparse_problem()
+    nnz = int(len(val))
+    K, Wm = args.steps, args.warmup
+    eng = na.Engine(m, n, r, "mu", dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, divergence="kl")
+    eng.upload_sparse(1, val, ptr, idx, 0)
+    eng.set_factors(W, H)
+    eng.iterate(Wm, first_iteration=1, error_every=10)
+    eng.synchronize()
+    if not args.no_kernel_events:
+        eng.kernel_timing(args.event_stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.iterate(K, first_iteration=Wm + 1, error_every=10)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
+    rp = eng.geometry()["padded_rank"]
+    # SURVEY 8d, per SDDMM launch: value + index of every stored entry in, one quotient out, one pass over both factors
+    hbm_bytes = 12.0 * nnz + 4.0 * (m + 1) + 4.0 * rp * (m + n)
+    gather_bytes = 4.0 * rp * nnz                      # one 512-byte row of H per stored entry, served from cache
+    roofline = None
+    if kernel_launches > 0:
+        avg_s = kernel_ms / 1e3 / kernel_launches
+        roofline = {"bound": "hbm", "achieved": hbm_bytes / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": hbm_bytes / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_sddmm_quotient",
+                    "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": hbm_bytes,
+                    "note": "the binding resource is the cache-level gather of factor rows, not HBM (SURVEY 8d): see `gather`",
+                    "gather": {"achieved": gather_bytes / avg_s / 1e9, "peak": PEAK_L2_GATHER_GBS, "unit": "GB/s",
+                               "frac": gather_bytes / avg_s / 1e9 / PEAK_L2_GATHER_GBS, "bytes_per_launch": gather_bytes}}
+    out = {"metric": "NMF KL-divergence MU iterations/sec, sparse CSR 100kx20k 1% r=128",
+           "value": K / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[2]: sparse CSR V 100000x20000 at 1% (Poisson(200) entries per row, values 1..5), r=128, MU on the KL divergence, fp32",
+                      "rows": m, "columns": n, "features": r, "stored_entries": nnz, "error_every": 10, "parallelism": "single GPU"},
+           "frobenius_last": eng.frobenius, "kl_divergence_last": eng.kl_divergence,
+           "iter_flops": 8.0 * nnz * r, "achieved_tflops_whole_iteration": 8.0 * nnz * r * (K / elapsed) / 1e12,
+           "gather_gbs_whole_iteration": 4.0 * gather_bytes * (K / elapsed) / 1e9, "roofline": roofline}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        Wc, Hc = W.copy(order="F"), H.copy(order="F")
+        t0 = time.perf_counter()
+        oracle.run_kl_csr(m, n, val, ptr, idx, Wc, Hc, 1)
+        first = time.perf_counter() - t0
+        iters = int(max(1, min(10, 20.0 // max(first, 1e-3))))
+        t0 = time.perf_counter()
+        oracle.run_kl_csr(m, n, val, ptr, idx, Wc, Hc, iters)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"{iters} KL-MU iterations of the full problem over the stored entries (oracle_kl_run_csr, C + OpenMP, fp32)"}
+    print(json.dumps(out), flush=True)
 
 
 def main_c4(args):

@@ -1011,13 +1011,18 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
 	const int norm_parts = (int)(mpad_ / 128);
 	// H step (quotients only: the error terms refer to the pair (W_{k-1}, H_k) of the second evaluation)
+	// (kernel timing, bench.py --workload c3: the SDDMM is the dominant kernel of this iteration, two launches)
+	record_begin();
 	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, (T*)nullptr, (T*)nullptr, m_, stream_));
+	record_end();
 	HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
 	HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
 	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
 	HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
 	// W step (the quotient is re-evaluated with the new H); per-row error terms on error iterations only
+	record_begin();
 	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr, m_, stream_));
+	record_end();
 	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sH_, stream_));
 	if (compute_error) {
 		// Frobenius error by the reference's trace formula with (W_{k-1}, H_k); KL divergence next to it

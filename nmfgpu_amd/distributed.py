@@ -40,6 +40,11 @@ class EngineShard:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         m, n = V_local.shape
         r = W.shape[1]
+        for name, a, shape in (("W", W, (m, r)), ("H_local", H_local, (r, n))):
+            if a.dtype != V_local.dtype:
+                raise TypeError(f"{name} must share V_local's dtype {V_local.dtype}, got {a.dtype}")
+            if a.shape != shape:
+                raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if algorithm not in ("mu", "nsnmf"):
             raise ValueError("the sharded iteration covers the multiplicative algorithms: 'mu' and 'nsnmf'")

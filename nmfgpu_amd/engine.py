@@ -85,7 +85,10 @@ class Engine:
 
     def upload(self, V: np.ndarray):
         V = _f(V)
-        assert V.dtype == self.dtype and V.shape == (self.m, self.n)
+        if V.dtype != self.dtype:
+            raise TypeError(f"V must be {self.dtype}, got {V.dtype}")
+        if V.shape != (self.m, self.n):
+            raise ValueError(f"V must have shape {(self.m, self.n)}, got {V.shape}")
         self._check(self._lib.nmfamd_engine_upload_dense(self._h, C.c_void_p(V.ctypes.data), C.c_long(_ld(V))), "upload_dense")
 
     def upload_sparse(self, fmt: int, values: np.ndarray, a: np.ndarray, b: np.ndarray, base: int = 0):
@@ -95,6 +98,15 @@ class Engine:
                                                           C.c_void_p(b.ctypes.data), C.c_long(len(values)), base), "upload_sparse")
 
     def set_factors(self, W: Optional[np.ndarray], H: Optional[np.ndarray]):
+        # the C side sees raw pointers and leading dimensions only: a float64 W on a float32 engine, or a wrong shape,
+        # would be reinterpreted (or read out of bounds) silently
+        for name, a, shape in (("W", W, (self.m, self.r)), ("H", H, (self.r, self.n))):
+            if a is None:
+                continue
+            if not isinstance(a, np.ndarray) or a.dtype != self.dtype:
+                raise TypeError(f"{name} must be a {self.dtype} ndarray, got {getattr(a, 'dtype', type(a))}")
+            if a.shape != shape:
+                raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
         wp = C.c_void_p(_f(W).ctypes.data) if W is not None else None
         hp = C.c_void_p(_f(H).ctypes.data) if H is not None else None
         self._check(self._lib.nmfamd_engine_set_factors(self._h, wp, C.c_long(_ld(W) if W is not None else 0),

@@ -610,6 +610,110 @@ int FN(oracle_kl_run)(int m, int n, int r, const T* V, int ldv, T* W, int ldw, T
 	return numIterations;
 }
 
+/* The same KL iteration evaluated over the STORED entries of a CSR matrix (0-based): the form BASELINE config 3
+ * (100 000 x 20 000 at 1 %) needs -- the dense form above would hold 2 x 10^9 elements.  Zero entries contribute
+ * nothing to any sum (Q = 0), so this is the arithmetic of oracle_kl_run with the products written per entry:
+ *   WH(i, j) = sum_c W(i, c) H(c, j) in ascending c;  (W^T Q)(:, j) over the rows of column j in ascending i;
+ *   (Q H^T)(i, :) over the columns of row i in ascending j.  W is m x r, H r x n, both column-major.
+ * No reference counterpart (the reference densifies sparse input, Matrix.h:145-232): PARITY UNPINNED. */
+int FN(oracle_kl_run_csr)(int m, int n, int r, const int* ptr, const int* idx, const T* val, T* W, int ldw, T* H, int ldh,
+                          int numIterations, double* out_frob, double* out_rmsd, double* out_kl) {
+	const T eps = EPS_T;
+	if (r > 1024) return -1;   /* per-thread accumulators live on the stack */
+	const long nnz = ptr[m];
+	int* cptr = (int*)calloc((size_t)n + 1, sizeof(int));
+	int* crow = (int*)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+	long* cmap = (long*)malloc(sizeof(long) * (size_t)(nnz > 0 ? nnz : 1));
+	for (long p = 0; p < nnz; ++p) ++cptr[idx[p] + 1];
+	for (int j = 0; j < n; ++j) cptr[j + 1] += cptr[j];
+	{
+		int* fill = (int*)malloc(sizeof(int) * (size_t)n);
+		memcpy(fill, cptr, sizeof(int) * (size_t)n);
+		for (int i = 0; i < m; ++i) for (int p = ptr[i]; p < ptr[i + 1]; ++p) { const int d = fill[idx[p]]++; crow[d] = i; cmap[d] = p; }
+		free(fill);
+	}
+	T* Wr = (T*)malloc(sizeof(T) * (size_t)m * r);      /* row-major copy of W: W(i, :) contiguous */
+	T* Q = (T*)malloc(sizeof(T) * (size_t)(nnz > 0 ? nnz : 1));
+	T* sW = (T*)malloc(sizeof(T) * (size_t)r);
+	T* sH = (T*)malloc(sizeof(T) * (size_t)r);
+	T* G = (T*)malloc(sizeof(T) * (size_t)r * r);
+	T* HHt = (T*)malloc(sizeof(T) * (size_t)r * r);
+	T* psRow = (T*)malloc(sizeof(T) * (size_t)m);
+	double* dRow = (double*)malloc(sizeof(double) * (size_t)m);
+	T* psR = (T*)malloc(sizeof(T) * (size_t)r);
+	T* vtv = (T*)malloc(sizeof(T) * (size_t)n);
+	double sumv = 0;
+	for (int j = 0; j < n; ++j) { T s = 0; for (int p = cptr[j]; p < cptr[j + 1]; ++p) { const T v = val[cmap[p]]; s += v * v; sumv += (double)v; } vtv[j] = s; }
+	qsort(vtv, n, sizeof(T), FN(cmp_asc));
+	double frob = 0, rmsd = 0, kl = 0;
+	for (int it = 1; it <= numIterations; ++it) {
+		const int computeError = (it % 10 == 0) || it == numIterations;
+		for (int half = 0; half < 2; ++half) {
+			if (half == 0) {
+#pragma omp parallel for schedule(static)
+				for (int i = 0; i < m; ++i) for (int c = 0; c < r; ++c) Wr[(size_t)i * r + c] = W[(size_t)c * ldw + i];
+			}
+			/* quotients on the stored entries (and, second evaluation of an error iteration, the per-row error terms) */
+#pragma omp parallel for schedule(dynamic, 64)
+			for (int i = 0; i < m; ++i) {
+				const T* wi = Wr + (size_t)i * r;
+				T t = 0; double d = 0;
+				for (int p = ptr[i]; p < ptr[i + 1]; ++p) {
+					const T* hj = H + (size_t)idx[p] * ldh;
+					T wh = 0;
+					for (int c = 0; c < r; ++c) wh += wi[c] * hj[c];
+					const T v = val[p];
+					Q[p] = v / (wh + eps);
+					if (half == 1 && computeError) { t += v * wh; if (v > 0) d += (double)v * log((double)v / (double)(wh + eps)); }
+				}
+				if (half == 1 && computeError) { psRow[i] = t; dRow[i] = d; }
+			}
+			if (half == 0) {
+				for (int c = 0; c < r; ++c) { T s = 0; for (int i = 0; i < m; ++i) s += W[(size_t)c * ldw + i]; sW[c] = s; }
+#pragma omp parallel for schedule(dynamic, 64)
+				for (int j = 0; j < n; ++j) {
+					T* hj = H + (size_t)j * ldh;
+					T acc[1024];
+					for (int c = 0; c < r; ++c) acc[c] = 0;
+					for (int p = cptr[j]; p < cptr[j + 1]; ++p) {
+						const T q = Q[cmap[p]];
+						const T* wi = Wr + (size_t)crow[p] * r;
+						for (int c = 0; c < r; ++c) acc[c] += q * wi[c];
+					}
+					for (int c = 0; c < r; ++c) hj[c] = hj[c] * acc[c] / (sW[c] + eps);
+				}
+			}
+		}
+		for (int c = 0; c < r; ++c) { T s = 0; for (int j = 0; j < n; ++j) s += H[(size_t)j * ldh + c]; sH[c] = s; }
+		if (computeError) {
+			double d = 0;
+			for (int i = 0; i < m; ++i) d += dRow[i];
+			FN(gemm_tn)(m, r, r, W, ldw, W, ldw, G, r);
+			FN(gemm_nt)(r, n, r, H, ldh, H, ldh, HHt, r);
+			FN(trace_multiplication)(0, r, r, HHt, r, G, r, psR);
+			frob = FN(oracle_resolve_frobenius)(vtv, n, psRow, m, psR, r);
+			rmsd = frob / sqrt((double)((unsigned)m * (unsigned)n));
+			for (int c = 0; c < r; ++c) d += (double)sW[c] * (double)sH[c];
+			kl = d - sumv;
+		}
+#pragma omp parallel for schedule(dynamic, 64)
+		for (int i = 0; i < m; ++i) {
+			T acc[1024];
+			for (int c = 0; c < r; ++c) acc[c] = 0;
+			for (int p = ptr[i]; p < ptr[i + 1]; ++p) {
+				const T q = Q[p];
+				const T* hj = H + (size_t)idx[p] * ldh;
+				for (int c = 0; c < r; ++c) acc[c] += q * hj[c];
+			}
+			for (int c = 0; c < r; ++c) W[(size_t)c * ldw + i] = W[(size_t)c * ldw + i] * acc[c] / (sH[c] + eps);
+		}
+		FN(normalize_columns)(m, r, W, ldw);
+	}
+	*out_frob = frob; *out_rmsd = rmsd; *out_kl = kl;
+	free(cptr); free(crow); free(cmap); free(Wr); free(Q); free(sW); free(sH); free(G); free(HHt); free(psRow); free(dRow); free(psR); free(vtv);
+	return numIterations;
+}
+
 /* Exposed single products / kernels so the parity tests can check each HIP kernel on its own. */
 void FN(oracle_gemm_tn)(int m, int ka, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) { FN(gemm_tn)(m, ka, kb, A, lda, B, ldb, C, ldc); }
 void FN(oracle_gemm_nt)(int m, int n, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) { FN(gemm_nt)(m, n, kb, A, lda, B, ldb, C, ldc); }

@@ -272,6 +272,27 @@ def run_kl(V, W, H, num_iterations: int):
     return {"frobenius": frob.value, "rmsd": rmsd.value, "kl": kl.value}
 
 
+def run_kl_csr(rows: int, cols: int, values, row_ptr, col_idx, W, H, num_iterations: int):
+    """The KL-divergence update over the stored entries of a 0-based CSR matrix (oracle_kl_run_csr): the form BASELINE
+    config 3 needs.  W and H are updated in place.  Returns dict(frobenius, rmsd, kl)."""
+    values = np.ascontiguousarray(values)
+    s = _sfx(values.dtype)
+    assert W.dtype == values.dtype and H.dtype == values.dtype
+    r = W.shape[1]
+    assert W.shape == (rows, r) and H.shape == (r, cols)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32); col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    assert len(row_ptr) == rows + 1 and row_ptr[0] == 0 and row_ptr[-1] == len(values) == len(col_idx)
+    set_threads_for(float(len(values)) * r * 8)
+    fn = getattr(lib(), f"oracle_kl_run_csr_{s}")
+    fn.restype = C.c_int
+    frob = C.c_double(0); rmsd = C.c_double(0); kl = C.c_double(0)
+    it = fn(rows, cols, r, _ptr(row_ptr), _ptr(col_idx), _ptr(values), _ptr(_f(W)), _ld(W), _ptr(_f(H)), _ld(H), num_iterations,
+            C.byref(frob), C.byref(rmsd), C.byref(kl))
+    if it < 0:
+        raise ValueError("rank above 1024")
+    return {"frobenius": frob.value, "rmsd": rmsd.value, "kl": kl.value}
+
+
 def kmeans(data, k: int, *, seed: int = 0, iterations: int = 100, threshold: float = 0.005):
     """Lloyd k-means with a Forgy start (source/kmeans/kMeans.cu:126-278).  Returns (clusters m x k, membership, passes)."""
     data = _f(data)

@@ -302,3 +302,22 @@ def test_oracle_reproduces_its_frozen_trajectories():
     res = oracle.run_kl(V, W, H, gold["iterations"])
     assert res["kl"] == pytest.approx(gold["kl"]["kl"], rel=1e-11) and res["frobenius"] == pytest.approx(gold["kl"]["frobenius"], rel=1e-11)
     assert W.sum() == pytest.approx(gold["kl"]["w_sum"], rel=1e-11)
+
+
+def test_kl_over_stored_entries_equals_the_dense_kl_restatement():
+    """oracle_kl_run_csr (BASELINE config 3's form) against oracle_kl_run on the densified matrix: zero entries contribute
+    nothing, so the two are the same arithmetic up to the order of the inner sums."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        m, n, r = 120, 90, 7
+        D = ((rng.random((m, n)) < 0.2) * rng.integers(1, 6, size=(m, n))).astype(dtype)
+        D[5, :] = 0; D[:, 11] = 0                                       # an empty row and an empty column
+        W = np.asfortranarray((1 - rng.random((m, r))).astype(dtype)); H = np.asfortranarray((1 - rng.random((r, n))).astype(dtype))
+        Wa, Ha = W.copy(order="F"), H.copy(order="F")
+        a = oracle.run_kl(np.asfortranarray(D), Wa, Ha, 20)
+        s = sp.csr_matrix(D)
+        Wb, Hb = W.copy(order="F"), H.copy(order="F")
+        b = oracle.run_kl_csr(m, n, s.data.astype(dtype), s.indptr, s.indices, Wb, Hb, 20)
+        assert np.abs(Wa - Wb).max() <= tol and np.abs(Ha - Hb).max() <= tol * max(1.0, np.abs(Ha).max())
+        assert b["kl"] == pytest.approx(a["kl"], rel=max(tol, 1e-12)) and b["frobenius"] == pytest.approx(a["frobenius"], rel=max(tol, 1e-12))

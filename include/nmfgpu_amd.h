@@ -153,6 +153,35 @@ NMFAMD_API long nmfamd_engine_error_terms_to_device(nmfamd_engine* e, void* dst_
 NMFAMD_API double nmfamd_resolve_frobenius_f32(const float* vtv_sorted, long n_vtv, float* htwtv, long n_htwtv, float* hhtwtw, long n_hhtwtw);
 NMFAMD_API double nmfamd_resolve_frobenius_f64(const double* vtv_sorted, long n_vtv, double* htwtv, long n_htwtv, double* hhtwtw, long n_hhtwtw);
 
+/* ---- the same sharded iteration driven natively (no torch in the loop) -------------------------------------------
+ * A communicator is one rank of an RCCL clique, created through RCCL's C API (librccl.so is loaded on first use):
+ * rank 0 obtains 128 bytes of unique id, hands them to the other ranks by whatever means the caller has (bench.py:
+ * torch.distributed's store; nmfgpu::compute with Parameter "numGpus": threads of one process share it directly), and every
+ * rank calls nmfamd_comm_create_rccl with ITS HIP device current -- the call blocks until all `world` ranks have arrived.
+ * A sharded run binds one engine (created with nmfamd_engine_create_blocks(..., row_blocks = world)) to one communicator:
+ *   mode 0  reduce-scatter of (V H^T)^T by row blocks of W + all-reduce of H H^T -> every rank updates its m / world rows
+ *           -> all-reduce of the r column sums of squares -> normalise -> all-gather of the row blocks   
+ *   mode 1  one all-reduce of the whole exchange buffer, identical W update on every rank
+ * rows / total_columns: shape of the WHOLE matrix; this rank's engine holds the columns
+ * [total_columns * rank / world, total_columns * (rank + 1) / world).  nmfamd_sharded_iterate numbers iterations like
+ * nmfamd_engine_iterate and only ENQUEUES work; _frobenius / _rmsd wait for the gathered error terms of the most recent
+ * error iteration and run the reference's sorted host summation on them (FrobeniusResolver.cpp:29-51). */
+typedef struct nmfamd_comm nmfamd_comm;
+typedef struct nmfamd_sharded nmfamd_sharded;
+NMFAMD_API int nmfamd_comm_rccl_available(void);
+NMFAMD_API int nmfamd_comm_unique_id(void* out_128_bytes);
+NMFAMD_API int nmfamd_comm_create_rccl(const void* id_128_bytes, int world, int rank, nmfamd_comm** out);
+NMFAMD_API void nmfamd_comm_destroy(nmfamd_comm* c);
+/* nmfamd_engine_create with the padded row count rounded up to a multiple of 128 * row_blocks (equal row blocks of W) */
+NMFAMD_API int nmfamd_engine_create_blocks(int m, int n, int r, int algorithm, const nmfamd_params* params, int elem_bytes, void* stream,
+                                           int row_blocks, nmfamd_engine** out);
+NMFAMD_API int nmfamd_sharded_create(nmfamd_engine* e, nmfamd_comm* c, int mode, long rows, long total_columns, nmfamd_sharded** out);
+NMFAMD_API void nmfamd_sharded_destroy(nmfamd_sharded* s);
+NMFAMD_API int nmfamd_sharded_iterate(nmfamd_sharded* s, int count, int first_iteration, int error_every, int last_iteration);
+NMFAMD_API double nmfamd_sharded_frobenius(nmfamd_sharded* s);
+NMFAMD_API double nmfamd_sharded_rmsd(nmfamd_sharded* s);
+NMFAMD_API const char* nmfamd_sharded_last_error(const nmfamd_sharded* s);
+
 /* The host-side initialisers (run once per run, before the iteration loop; host memory only, no device or
  * context needed).  k-means: Lloyd with a Forgy start (source/kmeans/kMeans.cu:126-278); data is m x n with
  * leading dimension ld, clusters m x k (ldc), membership n entries; *iterations receives the passes done.

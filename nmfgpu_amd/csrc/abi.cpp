@@ -27,6 +27,7 @@
 #include "../../include/nmfgpu.h"
 #include "engine.h"
 #include "host_init.h"
+#include "runner.h"
 
 namespace nmfgpu {
 namespace {
@@ -144,37 +145,6 @@ ResultType from_status(nmfamd::Status s) {
 }
 
 template <typename T>
-nmfamd::Status upload_input(nmfamd::Engine<T>& engine, const MatrixDescription<T>& V) {
-	switch (V.format) {
-	case StorageFormat::Dense: return engine.upload_dense(V.dense.values, V.dense.leadingDimension);
-	case StorageFormat::CSR: return engine.upload_sparse(1, V.csr.values, V.csr.rowPtr, V.csr.columnIndices, V.csr.nnz, V.csr.base == IndexBase::One ? 1 : 0);
-	case StorageFormat::CSC: return engine.upload_sparse(2, V.csc.values, V.csc.columnPtr, V.csc.rowIndices, V.csc.nnz, V.csc.base == IndexBase::One ? 1 : 0);
-	case StorageFormat::COO: return engine.upload_sparse(3, V.coo.values, V.coo.rowIndices, V.coo.columnIndices, V.coo.nnz, V.coo.base == IndexBase::One ? 1 : 0);
-	}
-	return nmfamd::ST_INVALID;
-}
-
-// InitializationStrategy::create + initializeMatrixW/H (source/init/InitializationStrategy.cpp:36-47)
-template <typename T>
-nmfamd::Status initialize_factors(nmfamd::Engine<T>& engine, NmfDescription<T>& d, bool want_h) {
-	const unsigned m = d.inputMatrix.rows, n = d.inputMatrix.columns, r = d.features;
-	switch (d.initMethod) {
-	case NmfInitializationMethod::CopyExisting:
-		if (d.outputMatrixW.format != StorageFormat::Dense || d.outputMatrixH.format != StorageFormat::Dense) return nmfamd::ST_INVALID;
-		return engine.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
-		                          want_h ? d.outputMatrixH.dense.values : nullptr, d.outputMatrixH.dense.leadingDimension);
-	case NmfInitializationMethod::AllRandomValues:
-		return engine.randomize_factors(d.seed, true, want_h);
-	default: {
-		// MeanColumns / k-means based strategies run on the host (north star: "init stays host-side C++")
-		std::vector<T> W((size_t)m * r), H(want_h ? (size_t)r * n : 0);
-		if (!hostinit::initialize<T>(d, W.data(), want_h ? H.data() : nullptr)) return nmfamd::ST_INVALID;
-		return engine.set_factors(W.data(), m, want_h ? H.data() : nullptr, r);
-	}
-	}
-}
-
-template <typename T>
 ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 	if (g_context == nullptr) return ResultType::ErrorNotInitialized;
 
@@ -241,6 +211,24 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		return ResultType::ErrorInvalidArgument;
 	}
 
+	// Parameter "numGpus" = N > 1 (extension; the reference is single-GPU, SingleGpuDispatcher.h:36): column shards of V on N
+	// rank threads inside this one call.  "shardMode": 0 (default) reduce-scatter by row blocks of W, 1 replicated W update.
+	int num_gpus = 1, shard_mode = nmfamd::SHARD_ROW_BLOCKS;
+	{
+		int idx = parameter_index(d.parameters, d.numParameters, "numGpus");
+		if (idx >= 0) num_gpus = (int)d.parameters[idx].value;
+		idx = parameter_index(d.parameters, d.numParameters, "shardMode");
+		if (idx >= 0) shard_mode = d.parameters[idx].value != 0 ? nmfamd::SHARD_REPLICATED : nmfamd::SHARD_ROW_BLOCKS;
+		if (num_gpus > 1) {
+			const bool mult = d.algorithm == NmfAlgorithm::Multiplicative || d.algorithm == NmfAlgorithm::nsNMF;
+			if (!mult || d.useConstantBasisVectors || prm.divergence != 0 || prm.sparse_compute != 0 || d.inputMatrix.format != StorageFormat::Dense ||
+			    num_gpus > 16 || (unsigned)num_gpus > d.inputMatrix.columns) {
+				log_error("[ERROR] 'numGpus' > 1 needs a dense input matrix, the Multiplicative or nsNMF algorithm without constant basis vectors, and at most 16 ranks!");
+				return ResultType::ErrorInvalidArgument;
+			}
+		}
+	}
+
 	if (!ensure_stream(*g_context)) {
 		log_error("[ERROR] No usable HIP device: the factorisation kernels are gfx950 code objects and there is no CPU fallback!");
 		return ResultType::ErrorExternalLibrary;
@@ -250,13 +238,16 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 	SummaryImpl* summary = static_cast<SummaryImpl*>(summary_iface);
 	if (summary) summary->reset();
 
-	const unsigned m = d.inputMatrix.rows, n = d.inputMatrix.columns;
-	nmfamd::Engine<T> engine((int)m, (int)n, (int)d.features, static_cast<int>(d.algorithm), prm);
-	engine.set_stream(g_context->stream);
-	nmfamd::Status st = engine.allocate();
-	if (st != nmfamd::ST_OK) { log_error("[ERROR] Device allocation failed!"); return from_status(st); }
-	st = upload_input(engine, d.inputMatrix);
-	if (st != nmfamd::ST_OK) { log_error("[ERROR] Upload of the input matrix failed!"); return from_status(st); }
+	std::unique_ptr<runner::Runner<T>> run_ptr;
+	if (num_gpus > 1) run_ptr.reset(new runner::TeamRunner<T>(d, prm, num_gpus, g_context->deviceID, shard_mode));
+	else run_ptr.reset(new runner::SingleRunner<T>(d, prm, g_context->stream));
+	runner::Runner<T>& engine = *run_ptr;
+	nmfamd::Status st = engine.setup(d);
+	if (st != nmfamd::ST_OK) {
+		log_error("[ERROR] Device allocation or upload of the input matrix failed!");
+		if (*engine.last_error()) log_error(engine.last_error());
+		return from_status(st);
+	}
 
 	// what the loop reads is snapshotted here, like DispatcherConfig (source/nmf/Dispatcher.h:28-45)
 	const unsigned numIterations = d.numIterations, numRuns = d.numRuns;
@@ -272,7 +263,8 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 
 	if (allowed(Verbosity::Summary)) {
 		char line[256];
-		std::snprintf(line, sizeof(line), " Executing %u run(s) of the '%s' algorithm on HIP device #%d: \n", numRuns, algorithm_name(d.algorithm), g_context->deviceID);
+		if (num_gpus > 1) std::snprintf(line, sizeof(line), " Executing %u run(s) of the '%s' algorithm on %d ranks from HIP device #%d (%s): \n", numRuns, algorithm_name(d.algorithm), num_gpus, g_context->deviceID, engine.describe());
+		else std::snprintf(line, sizeof(line), " Executing %u run(s) of the '%s' algorithm on HIP device #%d: \n", numRuns, algorithm_name(d.algorithm), g_context->deviceID);
 		log_summary(line);
 	}
 
@@ -285,14 +277,16 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		const bool gdcls_const = d.algorithm == NmfAlgorithm::GDCLS && constW;  // GDCLS :147-157 skips the draw
 		if (!gdcls_const) d.seed = static_cast<unsigned>(seed_stream());
 		if (!gdcls_const) {
-			st = initialize_factors(engine, d, want_h);
+			if (d.initMethod == NmfInitializationMethod::CopyExisting &&
+			    (d.outputMatrixW.format != StorageFormat::Dense || d.outputMatrixH.format != StorageFormat::Dense)) return ResultType::ErrorInvalidArgument;
+			st = engine.init_run(d, want_h);
 			if (st != nmfamd::ST_OK) { log_error("[ERROR] Initialisation of W / H failed!"); return from_status(st); }
 		}
 		if (constW) {
-			st = engine.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension, nullptr, 0);
+			st = engine.set_constant_w(d);
 			if (st != nmfamd::ST_OK) return from_status(st);
 		}
-		(void)hipStreamSynchronize(g_context->stream);
+		engine.synchronize();
 
 		auto started = std::chrono::high_resolution_clock::now();
 		long long elapsed_ms = 0;
@@ -301,7 +295,11 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		for (; iteration <= numIterations && !(interrupted = (interrupt != nullptr && interrupt())); ++iteration) {
 			const bool computeError = iteration % 10 == 0 || iteration == numIterations;
 			st = engine.iterate(computeError, constW);
-			if (st != nmfamd::ST_OK) { log_error("[ERROR] A HIP call failed inside the iteration loop!"); return from_status(st); }
+			if (st != nmfamd::ST_OK) {
+				log_error("[ERROR] A HIP call failed inside the iteration loop!");
+				if (*engine.last_error()) log_error(engine.last_error());
+				return from_status(st);
+			}
 			if (computeError) {
 				elapsed_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - started).count();
 				const double current = thresholdType == NmfThresholdType::Frobenius ? engine.frobenius() : engine.rmsd();
@@ -327,15 +325,14 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 				rec.numIterations = iteration;
 				summary->insert(rec);
 			}
-			st = engine.get_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
-			                        d.outputMatrixH.dense.values, d.outputMatrixH.dense.leadingDimension);
+			st = engine.store(d);
 			if (st != nmfamd::ST_OK) return from_status(st);
 			best = engine.frobenius();
 			stored = true;
 		}
 		print_row(numRuns > 1, true, run, numRuns, iteration, engine.frobenius(), engine.rmsd(), delta, elapsed_ms, stored ? "Stored" : "Discarded");
 	}
-	(void)hipStreamSynchronize(g_context->stream);
+	engine.synchronize();
 	return interrupted ? ResultType::ErrorUserInterrupt : ResultType::Success;
 }
 

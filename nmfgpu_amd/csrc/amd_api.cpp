@@ -8,8 +8,10 @@
 #include <vector>
 
 #include "../../include/nmfgpu_amd.h"
+#include "comm.h"
 #include "engine.h"
 #include "host_init.h"
+#include "sharded.h"
 
 using namespace nmfamd;
 
@@ -17,6 +19,16 @@ struct nmfamd_engine {
 	int elem_bytes;
 	std::unique_ptr<Engine<float>> f;
 	std::unique_ptr<Engine<double>> d;
+};
+
+struct nmfamd_comm {
+	std::unique_ptr<Comm> c;
+};
+
+struct nmfamd_sharded {
+	int elem_bytes;
+	std::unique_ptr<ShardedRank<float>> f;
+	std::unique_ptr<ShardedRank<double>> d;
 };
 
 namespace {
@@ -130,7 +142,11 @@ const char* nmfamd_engine_last_error(const nmfamd_engine* e) {
 }
 
 int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params* params, int elem_bytes, void* stream, nmfamd_engine** out) {
-	if (!out || (elem_bytes != 4 && elem_bytes != 8)) return NMFAMD_INVALID_ARGUMENT;
+	return nmfamd_engine_create_blocks(m, n, r, algorithm, params, elem_bytes, stream, 1, out);
+}
+
+int nmfamd_engine_create_blocks(int m, int n, int r, int algorithm, const nmfamd_params* params, int elem_bytes, void* stream, int row_blocks, nmfamd_engine** out) {
+	if (!out || (elem_bytes != 4 && elem_bytes != 8) || row_blocks < 1 || row_blocks > 64) return NMFAMD_INVALID_ARGUMENT;
 	*out = nullptr;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	AlgorithmParams p;
@@ -140,8 +156,8 @@ int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params
 	e->elem_bytes = elem_bytes;
 	Status st;
 	try {
-		if (elem_bytes == 4) { e->f.reset(new Engine<float>(m, n, r, algorithm, p)); e->f->set_stream((hipStream_t)stream); st = e->f->allocate(); }
-		else { e->d.reset(new Engine<double>(m, n, r, algorithm, p)); e->d->set_stream((hipStream_t)stream); st = e->d->allocate(); }
+		if (elem_bytes == 4) { e->f.reset(new Engine<float>(m, n, r, algorithm, p)); e->f->set_stream((hipStream_t)stream); e->f->set_row_blocks(row_blocks); st = e->f->allocate(); }
+		else { e->d.reset(new Engine<double>(m, n, r, algorithm, p)); e->d->set_stream((hipStream_t)stream); e->d->set_row_blocks(row_blocks); st = e->d->allocate(); }
 	} catch (const std::bad_alloc&) { delete e; return NMFAMD_NO_HOST_MEMORY; }
 	if (st != ST_OK) { delete e; return (int)st; }
 	*out = e;
@@ -149,6 +165,48 @@ int nmfamd_engine_create(int m, int n, int r, int algorithm, const nmfamd_params
 }
 
 void nmfamd_engine_destroy(nmfamd_engine* e) { delete e; }
+
+int nmfamd_comm_rccl_available(void) { return rccl_available() ? 1 : 0; }
+
+int nmfamd_comm_unique_id(void* out_128_bytes) { return (int)rccl_unique_id(out_128_bytes); }
+
+int nmfamd_comm_create_rccl(const void* id_128_bytes, int world, int rank, nmfamd_comm** out) {
+	if (!out) return NMFAMD_INVALID_ARGUMENT;
+	*out = nullptr;
+	nmfamd_comm* c = new (std::nothrow) nmfamd_comm();
+	if (!c) return NMFAMD_NO_HOST_MEMORY;
+	Status st = rccl_comm_create(id_128_bytes, world, rank, &c->c);
+	if (st != ST_OK) { delete c; return (int)st; }
+	*out = c;
+	return NMFAMD_OK;
+}
+
+void nmfamd_comm_destroy(nmfamd_comm* c) { delete c; }
+
+int nmfamd_sharded_create(nmfamd_engine* e, nmfamd_comm* c, int mode, long rows, long total_columns, nmfamd_sharded** out) {
+	if (!e || !c || !c->c || !out) return NMFAMD_INVALID_ARGUMENT;
+	*out = nullptr;
+	nmfamd_sharded* s = new (std::nothrow) nmfamd_sharded();
+	if (!s) return NMFAMD_NO_HOST_MEMORY;
+	s->elem_bytes = e->elem_bytes;
+	Status st;
+	if (e->elem_bytes == 4) { s->f.reset(new ShardedRank<float>(e->f.get(), c->c.get(), mode, rows, total_columns)); st = s->f->prepare(); }
+	else { s->d.reset(new ShardedRank<double>(e->d.get(), c->c.get(), mode, rows, total_columns)); st = s->d->prepare(); }
+	if (st != ST_OK) { delete s; return (int)st; }
+	*out = s;
+	return NMFAMD_OK;
+}
+
+void nmfamd_sharded_destroy(nmfamd_sharded* s) { delete s; }
+
+int nmfamd_sharded_iterate(nmfamd_sharded* s, int count, int first_iteration, int error_every, int last_iteration) {
+	if (!s) return NMFAMD_INVALID_ARGUMENT;
+	return (int)(s->elem_bytes == 4 ? s->f->run(count, first_iteration, error_every, last_iteration) : s->d->run(count, first_iteration, error_every, last_iteration));
+}
+
+double nmfamd_sharded_frobenius(nmfamd_sharded* s) { return !s ? 0.0 : (s->elem_bytes == 4 ? s->f->frobenius() : s->d->frobenius()); }
+double nmfamd_sharded_rmsd(nmfamd_sharded* s) { return !s ? 0.0 : (s->elem_bytes == 4 ? s->f->rmsd() : s->d->rmsd()); }
+const char* nmfamd_sharded_last_error(const nmfamd_sharded* s) { return !s ? "" : (s->elem_bytes == 4 ? s->f->last_error() : s->d->last_error()); }
 
 int nmfamd_engine_upload_dense(nmfamd_engine* e, const void* V, long ld) {
 	return dispatch(e, [&](Engine<float>& g) { return g.upload_dense((const float*)V, ld); },

@@ -146,6 +146,7 @@ Status Engine<T>::allocate() {
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
+	if (row_blocks_ > 1) { const long g = 128l * row_blocks_; mpad_ = ((mpad_ + g - 1) / g) * g; }   // equal row blocks of whole 128-row tiles
 	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
 	img_th_ = (one_image_ && std::getenv("NMFAMD_IMAGE_TILE128") == nullptr) ? 16 : planW_.th;
 	strideV_ = (long)img_th_ * npad_;
@@ -374,12 +375,12 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 }
 
 template <typename T>
-Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h) {
+Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
 	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
-	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_));
+	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
 	return ST_OK;
 }
 
@@ -745,6 +746,37 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	wx3_valid_ = false;
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
+	return ST_OK;
+}
+
+// ---- row-block form of the W step (one block per rank, see engine.h) -----------------------------------------------
+template <typename T>
+Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq) {
+	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
+	if (rows <= 0 || rows % 128 != 0 || row0 < 0 || row0 % 128 != 0 || row0 + rows > mpad_) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	if (Status s = materialize_w()) return s;           // (a pending column scale belongs to the old W; fold it in first)
+	if (compute_error) {
+		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
+			HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
+			wtw = G2_;
+		}
+		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_));
+		if (Status s = fetch_error_terms(n_)) return s;
+	}
+	const long valid = std::max<long>(0, std::min<long>(rows, (long)m_ - row0));
+	HIPX(launch_panel_update<T>(PANEL_MU, Wt_ + row0 * RP_, num_rows, 1, 0, hht, RP_, (int)rows, eps, nullptr, (int)valid, sumsq_part_, nullptr, stream_,
+	                            nullptr, nullptr, 0, qx3_));
+	HIPX(launch_reduce_partials<T>(sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)rows), RP_, colsq, RP_, stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::w_normalize_rows(long row0, long rows, T* colsq) {
+	if (rows <= 0 || rows % 128 != 0 || row0 < 0 || row0 + rows > mpad_) return ST_INVALID;
+	// colsq: the r sums of squares over ALL rows (one "partial"): kernel::normalizeColumns' sum > 0 ? x / sqrt(sum) : x
+	HIPX(launch_normalize_panel_v2<T>(Wt_ + row0 * RP_, RP_, (int)rows, colsq, 1, stream_));
 	return ST_OK;
 }
 

@@ -37,6 +37,9 @@ public:
 	~Engine();
 
 	Status allocate();
+	// Row-block form of the sharded W step (sharded.cpp): the padded row count becomes a multiple of 128 * blocks, so that
+	// the Wt panel splits into `blocks` equal row blocks.  Call before allocate().
+	void set_row_blocks(int blocks) { row_blocks_ = blocks > 1 ? blocks : 1; }
 	void set_stream(hipStream_t s) { stream_ = s; }
 	hipStream_t stream() const { return stream_; }
 
@@ -47,7 +50,8 @@ public:
 	// W: host m x r (ld), H: host r x n (ld).  Either pointer may be null (leave as is).
 	Status set_factors(const T* W, long ldw, const T* H, long ldh);
 	Status get_factors(T* W, long ldw, T* H, long ldh);   // nsNMF returns W S, like the reference
-	Status randomize_factors(unsigned seed, bool w, bool h);
+	// h_first_column: global index of this engine's first column (column shards draw their part of ONE stream)
+	Status randomize_factors(unsigned seed, bool w, bool h, long h_first_column = 0);
 
 	// One iteration.  With compute_error the frobenius()/rmsd() values are refreshed (host sync).
 	Status iterate(bool compute_error, bool constant_w);
@@ -59,6 +63,16 @@ public:
 	Status w_products(T* exchange);
 	Status w_finish(const T* exchange, bool compute_error);
 	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_; }
+	// Row-block form of w_finish (reduce-scatter by row blocks of W -> every GPU updates its rows -> all-reduce
+	// of the r column-norm partials -> all-gather of the normalised rows).  num_rows: the reduced (V H^T)^T rows
+	// [row0, row0 + rows) in panel layout; hht: the reduced H H^T.  w_update_rows leaves the r partial sums of squares of
+	// the new rows in colsq (device, RP elements); after their all-reduce w_normalize_rows scales the block, and once the
+	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
+	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
+	Status w_normalize_rows(long row0, long rows, T* colsq);
+	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; }
+	T* w_panel() { return Wt_; }
+	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
 	const std::vector<T>& terms_htwtv() { finalize_error(false); return h_psN_; }
 	const std::vector<T>& terms_hhtwtw() { finalize_error(false); return h_psR_; }
@@ -122,6 +136,7 @@ private:
 	void record_end();
 
 	int m_, n_, r_, RP_, alg_;
+	int row_blocks_ = 1;
 	AlgorithmParams prm_;
 	long mpad_, npad_;
 	long strideV_ = 0, strideVt_ = 0, elemsV_ = 0, elemsVt_ = 0;   // x-tiled images of V / Vt

@@ -165,8 +165,9 @@ template <typename T>
 hipError_t launch_densify(int format, const T* values, const int* ptr, const int* idx, const int* idx2, long nnz, int outer, int base,
                           T* V, long ldv, int rows, int cols, hipStream_t stream);
 
+// element (c, y) = draw number (y + y_first) * r + c of the counter-based stream (y_first: a column shard's first global column)
 template <typename T>
-hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream);
+hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream, long y_first = 0);
 
 // ---- fp64 MFMA factor product (kernels_f64.hip): same x-tiled image of A (tile height 128), K-steps of four y ----
 FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus);

@@ -1002,13 +1002,13 @@ template hipError_t launch_densify<double>(int, const double*, const int*, const
 // closed source, so only the distribution -- uniform on (0,1], same seed for W and H -- is
 // reproduced).  Counter-based generator: splitmix64 of (seed, element index).
 template <typename T>
-__global__ void k_fill_uniform(T* __restrict__ P, int RP, int r, long len, long len_pad, uint64_t seed) {
+__global__ void k_fill_uniform(T* __restrict__ P, int RP, int r, long len, long len_pad, uint64_t seed, long y_first) {
 	long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= len_pad * RP) return;
 	long y = e / RP; int c = (int)(e % RP);
 	T v = T(0);
 	if (y < len && c < r) {
-		uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(y * (long)r + c) + 0x632BE59BD9B4E019ull;
+		uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)((y + y_first) * (long)r + c) + 0x632BE59BD9B4E019ull;
 		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
 		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 		z = z ^ (z >> 31);
@@ -1019,13 +1019,13 @@ __global__ void k_fill_uniform(T* __restrict__ P, int RP, int r, long len, long 
 }
 
 template <typename T>
-hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream) {
+hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint64_t seed, hipStream_t stream, long y_first) {
 	long count = len_pad * RP;
-	hipLaunchKernelGGL((k_fill_uniform<T>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, P, RP, r, len, len_pad, seed);
+	hipLaunchKernelGGL((k_fill_uniform<T>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, P, RP, r, len, len_pad, seed, y_first);
 	return hipGetLastError();
 }
-template hipError_t launch_fill_uniform<float>(float*, int, int, long, long, uint64_t, hipStream_t);
-template hipError_t launch_fill_uniform<double>(double*, int, int, long, long, uint64_t, hipStream_t);
+template hipError_t launch_fill_uniform<float>(float*, int, int, long, long, uint64_t, hipStream_t, long);
+template hipError_t launch_fill_uniform<double>(double*, int, int, long, long, uint64_t, hipStream_t, long);
 
 // ------------------------------------------------------------------------------------------
 // x-tiled storage of the streamed matrix (see k_factor_product_f32): A(x, y) at

@@ -1,0 +1,284 @@
+// runner.h -- what nmfgpu::compute's run / iteration loop (abi.cpp) drives: one engine on one GPU, or a team of
+// rank threads with one column shard per GPU (internal header, included by abi.cpp only).
+//
+// The reference's dispatcher owns one IAlgorithm on one device (source/nmf/SingleGpuDispatcher.cpp:132-241).  Here the
+// same loop talks to a Runner; with Parameter "numGpus" = N > 1 the runner is a TeamRunner: the calling thread is rank 0,
+// N - 1 worker threads are the other ranks, every rank owns V(:, J_g), H(:, J_g), a replica of W and a communicator
+// (sharded.h), and the whole factorisation stays inside the one blocking compute() call.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/nmfgpu.h"
+#include "comm.h"
+#include "engine.h"
+#include "host_init.h"
+#include "sharded.h"
+
+namespace nmfgpu {
+namespace runner {
+
+using nmfamd::Status;
+
+template <typename T>
+class Runner {
+public:
+	virtual ~Runner() {}
+	// allocate device state and upload the input matrix
+	virtual Status setup(const NmfDescription<T>& d) = 0;
+	// start values of one run (d.seed holds the run's seed); want_h: the algorithm starts from H as well
+	virtual Status init_run(NmfDescription<T>& d, bool want_h) = 0;
+	virtual Status set_constant_w(NmfDescription<T>& d) = 0;
+	virtual Status iterate(bool compute_error, bool constant_w) = 0;
+	virtual double frobenius() = 0;
+	virtual double rmsd() = 0;
+	virtual Status store(NmfDescription<T>& d) = 0;      // the factors into the caller's buffers
+	virtual void synchronize() = 0;
+	virtual const char* describe() const = 0;
+	virtual const char* last_error() const { return ""; }
+};
+
+template <typename T>
+Status upload_input(nmfamd::Engine<T>& engine, const MatrixDescription<T>& V) {
+	switch (V.format) {
+	case StorageFormat::Dense: return engine.upload_dense(V.dense.values, V.dense.leadingDimension);
+	case StorageFormat::CSR: return engine.upload_sparse(1, V.csr.values, V.csr.rowPtr, V.csr.columnIndices, V.csr.nnz, V.csr.base == IndexBase::One ? 1 : 0);
+	case StorageFormat::CSC: return engine.upload_sparse(2, V.csc.values, V.csc.columnPtr, V.csc.rowIndices, V.csc.nnz, V.csc.base == IndexBase::One ? 1 : 0);
+	case StorageFormat::COO: return engine.upload_sparse(3, V.coo.values, V.coo.rowIndices, V.coo.columnIndices, V.coo.nnz, V.coo.base == IndexBase::One ? 1 : 0);
+	}
+	return nmfamd::ST_INVALID;
+}
+
+// ---- one engine on the context's device ------------------------------------------------------------------------------
+template <typename T>
+class SingleRunner : public Runner<T> {
+public:
+	SingleRunner(const NmfDescription<T>& d, const nmfamd::AlgorithmParams& prm, hipStream_t stream)
+		: engine_((int)d.inputMatrix.rows, (int)d.inputMatrix.columns, (int)d.features, static_cast<int>(d.algorithm), prm) { engine_.set_stream(stream); }
+	Status setup(const NmfDescription<T>& d) override {
+		if (Status st = engine_.allocate()) return st;
+		return upload_input(engine_, d.inputMatrix);
+	}
+	// InitializationStrategy::create + initializeMatrixW/H (source/init/InitializationStrategy.cpp:36-47)
+	Status init_run(NmfDescription<T>& d, bool want_h) override {
+		const unsigned m = d.inputMatrix.rows, n = d.inputMatrix.columns, r = d.features;
+		switch (d.initMethod) {
+		case NmfInitializationMethod::CopyExisting:
+			return engine_.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
+			                           want_h ? d.outputMatrixH.dense.values : nullptr, d.outputMatrixH.dense.leadingDimension);
+		case NmfInitializationMethod::AllRandomValues:
+			return engine_.randomize_factors(d.seed, true, want_h);
+		default: {
+			// MeanColumns / k-means based strategies run on the host (north star: "init stays host-side C++")
+			std::vector<T> W((size_t)m * r), H(want_h ? (size_t)r * n : 0);
+			if (!hostinit::initialize<T>(d, W.data(), want_h ? H.data() : nullptr)) return nmfamd::ST_INVALID;
+			return engine_.set_factors(W.data(), m, want_h ? H.data() : nullptr, r);
+		}
+		}
+	}
+	Status set_constant_w(NmfDescription<T>& d) override {
+		return engine_.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension, nullptr, 0);
+	}
+	Status iterate(bool compute_error, bool constant_w) override { return engine_.iterate(compute_error, constant_w); }
+	double frobenius() override { return engine_.frobenius(); }
+	double rmsd() override { return engine_.rmsd(); }
+	Status store(NmfDescription<T>& d) override {
+		return engine_.get_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
+		                           d.outputMatrixH.dense.values, d.outputMatrixH.dense.leadingDimension);
+	}
+	void synchronize() override { (void)hipStreamSynchronize(engine_.stream()); }
+	const char* describe() const override { return "one GPU"; }
+
+private:
+	nmfamd::Engine<T> engine_;
+};
+
+// ---- N rank threads, one column shard each -----------------------------------------------------------------------------
+// Transport: RCCL when every rank has a device of its own, the in-process peer-read transport when ranks share a device
+// (more ranks than GPUs: one-GPU boxes, tests) or NMFAMD_COMM=p2p asks for it.
+template <typename T>
+class TeamRunner : public Runner<T> {
+public:
+	TeamRunner(const NmfDescription<T>& d, const nmfamd::AlgorithmParams& prm, int ranks, int first_device, int mode)
+		: prm_(prm), world_(ranks), first_device_(first_device), mode_(mode), m_(d.inputMatrix.rows), n_(d.inputMatrix.columns), r_(d.features),
+		  alg_(static_cast<int>(d.algorithm)) {}
+
+	~TeamRunner() override {
+		if (!workers_.empty()) {
+			command(CMD_EXIT);
+			for (std::thread& t : workers_) t.join();
+		}
+		// rank 0's objects are released here, on the thread (and device) that created them
+		(void)hipSetDevice(first_device_);
+		ranks_.clear();
+	}
+
+	Status setup(const NmfDescription<T>& d) override {
+		int ndev = 0;
+		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
+		if (d.inputMatrix.format != StorageFormat::Dense || world_ < 2 || world_ > 16 || (long)world_ > (long)n_) return nmfamd::ST_INVALID;
+		const char* force = std::getenv("NMFAMD_COMM");
+		const bool shared = world_ > ndev;
+		local_ = shared || (force != nullptr && (std::strcmp(force, "p2p") == 0 || std::strcmp(force, "local") == 0)) || !nmfamd::rccl_available();
+		if (force != nullptr && std::strcmp(force, "rccl") == 0) { if (shared || !nmfamd::rccl_available()) return nmfamd::ST_INVALID; local_ = false; }
+		for (int g = 0; g < world_; ++g) {
+			ranks_.emplace_back(new Rank());
+			ranks_[g]->device = (first_device_ + g) % ndev;
+			nmfamd::shard_columns((long)n_, world_, g, &ranks_[g]->col0, &ranks_[g]->ncols);
+		}
+		rendezvous_ = nmfamd::local_group_create(world_);
+		if (local_) transport_group_ = nmfamd::local_group_create(world_);
+		else if (nmfamd::rccl_unique_id(unique_id_) != nmfamd::ST_OK) return nmfamd::ST_HIP_ERROR;
+		input_ = &d;
+		for (int g = 1; g < world_; ++g) workers_.emplace_back([this, g] { worker(g); });
+		return command(CMD_SETUP);
+	}
+
+	Status init_run(NmfDescription<T>& d, bool want_h) override {
+		init_method_ = d.initMethod; seed_ = d.seed; want_h_ = want_h;
+		hostW_ = nullptr; hostH_ = nullptr; ldw_ = ldh_ = 0;
+		std::vector<T> W, H;
+		if (d.initMethod == NmfInitializationMethod::CopyExisting) {
+			hostW_ = d.outputMatrixW.dense.values; ldw_ = d.outputMatrixW.dense.leadingDimension;
+			hostH_ = d.outputMatrixH.dense.values; ldh_ = d.outputMatrixH.dense.leadingDimension;
+		} else if (d.initMethod != NmfInitializationMethod::AllRandomValues) {
+			// the host-side initialisers see the whole matrix, once; every rank takes W and its columns of H
+			W.resize((size_t)m_ * r_); H.resize(want_h ? (size_t)r_ * n_ : 0);
+			if (!hostinit::initialize<T>(d, W.data(), want_h ? H.data() : nullptr)) return nmfamd::ST_INVALID;
+			hostW_ = W.data(); ldw_ = m_; hostH_ = want_h ? H.data() : nullptr; ldh_ = r_;
+		}
+		return command(CMD_INIT);
+	}
+	Status set_constant_w(NmfDescription<T>&) override { return nmfamd::ST_INVALID; }
+	Status iterate(bool compute_error, bool constant_w) override {
+		if (constant_w) return nmfamd::ST_INVALID;
+		compute_error_ = compute_error;
+		return command(CMD_ITERATE);
+	}
+	double frobenius() override { return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->frobenius() : 0.0; }
+	double rmsd() override { return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->rmsd() : 0.0; }
+	Status store(NmfDescription<T>& d) override {
+		outW_ = d.outputMatrixW.dense.values; out_ldw_ = d.outputMatrixW.dense.leadingDimension;
+		outH_ = d.outputMatrixH.dense.values; out_ldh_ = d.outputMatrixH.dense.leadingDimension;
+		return command(CMD_STORE);
+	}
+	void synchronize() override { (void)command(CMD_SYNC); }
+	const char* describe() const override { return local_ ? "column shards, in-process peer-read transport" : "column shards, RCCL"; }
+	const char* last_error() const override { return error_.c_str(); }
+
+private:
+	enum Command { CMD_SETUP, CMD_INIT, CMD_ITERATE, CMD_STORE, CMD_SYNC, CMD_EXIT };
+	struct Rank {
+		int device = 0;
+		long col0 = 0, ncols = 0;
+		hipStream_t stream = nullptr;
+		std::unique_ptr<nmfamd::Engine<T>> eng;
+		std::unique_ptr<nmfamd::Comm> comm;
+		std::unique_ptr<nmfamd::ShardedRank<T>> sh;
+		Status status = nmfamd::ST_OK;
+		~Rank() { sh.reset(); comm.reset(); eng.reset(); if (stream) (void)hipStreamDestroy(stream); }
+	};
+
+	// the calling thread is rank 0: publish the command, run rank 0's share, collect every rank's status
+	Status command(Command c) {
+		command_ = c;
+		nmfamd::local_group_barrier(*rendezvous_);
+		execute(0, c);
+		nmfamd::local_group_barrier(*rendezvous_);
+		for (const std::unique_ptr<Rank>& rk : ranks_)
+			if (rk->status != nmfamd::ST_OK) {
+				const char* a = rk->sh ? rk->sh->last_error() : "";
+				const char* b = rk->eng ? rk->eng->last_error() : "";
+				const char* c2 = rk->comm ? rk->comm->last_error() : "";
+				error_ = std::string(a && *a ? a : (b && *b ? b : c2));
+				return rk->status;
+			}
+		return nmfamd::ST_OK;
+	}
+	void worker(int g) {
+		for (;;) {
+			nmfamd::local_group_barrier(*rendezvous_);
+			const Command c = command_;
+			if (c != CMD_EXIT) execute(g, c);
+			else { Rank& rk = *ranks_[g]; (void)hipSetDevice(rk.device); rk.sh.reset(); rk.comm.reset(); rk.eng.reset(); if (rk.stream) { (void)hipStreamDestroy(rk.stream); rk.stream = nullptr; } }
+			nmfamd::local_group_barrier(*rendezvous_);
+			if (c == CMD_EXIT) return;
+		}
+	}
+	void execute(int g, Command c) {
+		Rank& rk = *ranks_[g];
+		if (c == CMD_EXIT) return;
+		if (rk.status != nmfamd::ST_OK && c != CMD_SETUP) {
+			// a rank that failed keeps taking part in the rendezvous but does no more work; its peers' collectives
+			// end through the transport's abort flag (in-process) -- with RCCL a failed rank is fatal for the call
+			if (transport_group_) nmfamd::local_group_abort(*transport_group_);
+			return;
+		}
+		switch (c) {
+		case CMD_SETUP: rk.status = do_setup(g); break;
+		case CMD_INIT: rk.status = do_init(g); break;
+		case CMD_ITERATE: rk.status = rk.sh->iterate(compute_error_); break;
+		case CMD_STORE: {
+			T* hcols = outH_ + (size_t)rk.col0 * out_ldh_;
+			rk.status = rk.eng->get_factors(g == 0 ? outW_ : nullptr, out_ldw_, hcols, out_ldh_);
+			break;
+		}
+		case CMD_SYNC: if (hipStreamSynchronize(rk.stream) != hipSuccess) rk.status = nmfamd::ST_HIP_ERROR; break;
+		default: break;
+		}
+	}
+	Status do_setup(int g) {
+		Rank& rk = *ranks_[g];
+		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
+		if (hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; return nmfamd::ST_HIP_ERROR; }
+		rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm_));
+		rk.eng->set_stream(rk.stream);
+		if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
+		Status st = rk.eng->allocate();
+		// every rank must reach the communicator's rendezvous, whatever happened before it
+		const MatrixDescription<T>& V = input_->inputMatrix;
+		if (st == nmfamd::ST_OK) st = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+		Status ct = local_ ? nmfamd::local_comm_create(transport_group_, g, &rk.comm) : nmfamd::rccl_comm_create(unique_id_, world_, g, &rk.comm);
+		if (st != nmfamd::ST_OK) return st;
+		if (ct != nmfamd::ST_OK) return ct;
+		rk.sh.reset(new nmfamd::ShardedRank<T>(rk.eng.get(), rk.comm.get(), mode_, (long)m_, (long)n_));
+		return rk.sh->prepare();
+	}
+	Status do_init(int g) {
+		Rank& rk = *ranks_[g];
+		if (init_method_ == NmfInitializationMethod::AllRandomValues)
+			return rk.eng->randomize_factors(seed_, true, want_h_, rk.col0);     // one stream for all shards
+		const T* h = (want_h_ && hostH_ != nullptr) ? hostH_ + (size_t)rk.col0 * ldh_ : nullptr;
+		return rk.eng->set_factors(hostW_, ldw_, h, ldh_);
+	}
+
+	nmfamd::AlgorithmParams prm_;
+	int world_, first_device_, mode_;
+	unsigned m_, n_, r_;
+	int alg_;
+	bool local_ = true;
+	std::vector<std::unique_ptr<Rank>> ranks_;
+	std::string error_;
+	std::vector<std::thread> workers_;
+	std::shared_ptr<nmfamd::LocalGroup> rendezvous_, transport_group_;
+	unsigned char unique_id_[nmfamd::COMM_UNIQUE_ID_BYTES] = {0};
+	// the command and its arguments (written by rank 0 before the rendezvous that releases the workers)
+	Command command_ = CMD_SYNC;
+	const NmfDescription<T>* input_ = nullptr;
+	NmfInitializationMethod init_method_ = NmfInitializationMethod::CopyExisting;
+	unsigned seed_ = 0;
+	bool want_h_ = true, compute_error_ = false;
+	const T* hostW_ = nullptr; const T* hostH_ = nullptr; long ldw_ = 0, ldh_ = 0;
+	T* outW_ = nullptr; T* outH_ = nullptr; long out_ldw_ = 0, out_ldh_ = 0;
+};
+
+} // namespace runner
+} // namespace nmfgpu

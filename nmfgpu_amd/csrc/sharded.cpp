@@ -1,0 +1,138 @@
+// sharded.cpp -- one rank of the column-sharded multiplicative update (see sharded.h).
+#include "sharded.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace nmfamd {
+
+template <typename T>
+ShardedRank<T>::ShardedRank(Engine<T>* engine, Comm* comm, int mode, long rows, long total_columns)
+	: eng_(engine), comm_(comm), mode_(mode), rows_(rows), total_columns_(total_columns) {}
+
+template <typename T>
+ShardedRank<T>::~ShardedRank() {
+	if (exchange_) (void)hipFree(exchange_);
+	if (blk_) (void)hipFree(blk_);
+	if (colsq_) (void)hipFree(colsq_);
+	if (err_dev_) (void)hipFree(err_dev_);
+	if (err_pin_) (void)hipHostFree(err_pin_);
+	if (err_event_) (void)hipEventDestroy(err_event_);
+}
+
+template <typename T>
+Status ShardedRank<T>::prepare() {
+	if (!eng_ || !comm_ || (mode_ != SHARD_ROW_BLOCKS && mode_ != SHARD_REPLICATED)) return ST_INVALID;
+	const int world = comm_->world(), rank = comm_->rank();
+	long first = 0, count = 0;
+	shard_columns(total_columns_, world, rank, &first, &count);
+	if (count != eng_->n() || rows_ != eng_->m()) { last_error_ = "shard shape does not match shard_columns()"; return ST_INVALID; }
+	const long RP = eng_->rp(), mpad = eng_->mpad();
+	hipStream_t s = eng_->stream();
+	auto dalloc = [&](T** p, long elems) -> bool {
+		if (hipMalloc((void**)p, sizeof(T) * (size_t)elems) != hipSuccess) return false;
+		return hipMemsetAsync(*p, 0, sizeof(T) * (size_t)elems, s) == hipSuccess;
+	};
+	if (!dalloc(&exchange_, eng_->exchange_count())) return fail("hipMalloc(exchange)");
+	if (mode_ == SHARD_ROW_BLOCKS) {
+		if (mpad % (128l * world) != 0) { last_error_ = "engine was not created with set_row_blocks(world)"; return ST_INVALID; }
+		blk_rows_ = mpad / world;
+		if (!dalloc(&blk_, RP * blk_rows_) || !dalloc(&colsq_, RP)) return fail("hipMalloc(row block)");
+	}
+	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); nloc_max_ = std::max(nloc_max_, c); }
+	const long L = slot_len();
+	if (!dalloc(&err_dev_, L * world)) return fail("hipMalloc(error terms)");
+	if (hipHostMalloc((void**)&err_pin_, sizeof(T) * (size_t)(L * world)) != hipSuccess) return fail("hipHostMalloc(error terms)");
+	if (hipEventCreateWithFlags(&err_event_, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+
+	// the sorted tr(V^T V) terms of ALL columns, once (V does not change): gather the local vectors through the
+	// error-term buffer, sort the concatenation on the host
+	const std::vector<T>& local = eng_->terms_vtv_sorted();
+	if ((long)local.size() != count) { last_error_ = "upload V before prepare()"; return ST_INVALID; }
+	if (count > 0 && hipMemcpyAsync(err_dev_ + (long)rank * L, local.data(), sizeof(T) * (size_t)count, hipMemcpyHostToDevice, s) != hipSuccess) return fail("hipMemcpyAsync(vtv)");
+	if (Status st = comm_->all_gather_inplace(err_dev_, L, (int)sizeof(T), s)) { last_error_ = comm_->last_error(); return st; }
+	if (hipMemcpyAsync(err_pin_, err_dev_, sizeof(T) * (size_t)(L * world), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync(vtv back)");
+	if (hipStreamSynchronize(s) != hipSuccess) return fail("hipStreamSynchronize");
+	vtv_all_.clear();
+	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); vtv_all_.insert(vtv_all_.end(), err_pin_ + (long)p * L, err_pin_ + (long)p * L + c); }
+	std::sort(vtv_all_.begin(), vtv_all_.end());
+	if (hipMemsetAsync(err_dev_, 0, sizeof(T) * (size_t)(L * world), s) != hipSuccess) return fail("hipMemsetAsync");
+	return ST_OK;
+}
+
+template <typename T>
+Status ShardedRank<T>::iterate(bool compute_error) {
+	const int world = comm_->world(), rank = comm_->rank();
+	const long RP = eng_->rp(), mpad = eng_->mpad();
+	const int eb = (int)sizeof(T);
+	hipStream_t s = eng_->stream();
+	auto comm_fail = [&](Status st) { last_error_ = comm_->last_error(); return st; };
+	if (Status st = eng_->h_step(compute_error)) { last_error_ = eng_->last_error(); return st; }
+	if (Status st = eng_->w_products(exchange_)) { last_error_ = eng_->last_error(); return st; }
+	if (mode_ == SHARD_REPLICATED) {
+		if (world > 1) { if (Status st = comm_->all_reduce(exchange_, eng_->exchange_count(), eb, s)) return comm_fail(st); }
+		if (Status st = eng_->w_finish(exchange_, compute_error)) { last_error_ = eng_->last_error(); return st; }
+	} else {
+		T* hht = exchange_ + RP * mpad;
+		const long row0 = (long)rank * blk_rows_;
+		// m x r sums by row blocks (every link carries 1/N of the panel), the r x r sums to everybody
+		comm_->group_begin();
+		Status a = comm_->reduce_scatter(exchange_, blk_, RP * blk_rows_, eb, s);
+		Status b = a == ST_OK ? comm_->all_reduce(hht, RP * RP, eb, s) : a;
+		Status c = comm_->group_end();
+		if (a != ST_OK || b != ST_OK || c != ST_OK) return comm_fail(a != ST_OK ? a : (b != ST_OK ? b : c));
+		if (Status st = eng_->w_update_rows(blk_, hht, row0, blk_rows_, compute_error, colsq_)) { last_error_ = eng_->last_error(); return st; }
+		if (Status st = comm_->all_reduce(colsq_, RP, eb, s)) return comm_fail(st);
+		if (Status st = eng_->w_normalize_rows(row0, blk_rows_, colsq_)) { last_error_ = eng_->last_error(); return st; }
+		if (Status st = comm_->all_gather_inplace(eng_->w_panel(), RP * blk_rows_, eb, s)) return comm_fail(st);
+		eng_->w_rows_replaced();
+	}
+	if (compute_error) return launch_error_gather();
+	return ST_OK;
+}
+
+template <typename T>
+Status ShardedRank<T>::launch_error_gather() {
+	finalize();        // the previous error iteration's terms arrived long ago; the landing buffer is reused
+	const int world = comm_->world(), rank = comm_->rank();
+	const long L = slot_len();
+	hipStream_t s = eng_->stream();
+	if (eng_->error_terms_to_device(err_dev_ + (long)rank * L, L) < 0) return fail("error_terms_to_device");
+	if (Status st = comm_->all_gather_inplace(err_dev_, L, (int)sizeof(T), s)) { last_error_ = comm_->last_error(); return st; }
+	if (hipMemcpyAsync(err_pin_, err_dev_, sizeof(T) * (size_t)(L * world), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync(error terms)");
+	if (hipEventRecord(err_event_, s) != hipSuccess) return fail("hipEventRecord");
+	err_pending_ = true;
+	return ST_OK;
+}
+
+template <typename T>
+void ShardedRank<T>::finalize() {
+	if (!err_pending_) return;
+	err_pending_ = false;
+	(void)hipEventSynchronize(err_event_);
+	const int world = comm_->world(), rank = comm_->rank();
+	const long L = slot_len();
+	std::vector<T> htwtv, hhtwtw;
+	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); htwtv.insert(htwtv.end(), err_pin_ + (long)p * L, err_pin_ + (long)p * L + c); }
+	// the r terms of tr(H H^T W^T W) come from the reduced H H^T and the replicated W^T W: identical on every rank
+	const T* mine = err_pin_ + (long)rank * L + eng_->n();
+	hhtwtw.assign(mine, mine + eng_->r());
+	frob_ = resolve_frobenius<T>(vtv_all_, htwtv, hhtwtw);
+	rmsd_ = frob_ / std::sqrt((double)(unsigned)((unsigned)rows_ * (unsigned)total_columns_));   // (unsigned product, like the reference)
+}
+
+template <typename T>
+Status ShardedRank<T>::run(int count, int first_iteration, int error_every, int last_iteration) {
+	for (int k = 0; k < count; ++k) {
+		const int it = first_iteration + k;
+		const bool err = (error_every > 0 && it % error_every == 0) || (last_iteration > 0 && it == last_iteration);
+		if (Status st = iterate(err)) return st;
+	}
+	return ST_OK;
+}
+
+template class ShardedRank<float>;
+template class ShardedRank<double>;
+
+} // namespace nmfamd

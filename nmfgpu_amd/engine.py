@@ -49,7 +49,7 @@ class Engine:
 
     def __init__(self, m: int, n: int, r: int, algorithm: str = "mu", dtype=np.float32, stream: int = 0,
                  lam=0.0, lambda_w=0.0, lambda_h=0.0, alpha_w=0.0, alpha_h=0.0, theta=0.0, divergence: str = "frobenius",
-                 sparse_compute: bool = False, precision: str = "native"):
+                 sparse_compute: bool = False, precision: str = "native", row_blocks: int = 1):
         self._lib = library()
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -58,7 +58,8 @@ class Engine:
         p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute),
                     {"native": 0.0, "bf16": 1.0, "fp32_mfma": -1.0}[precision])
         h = C.c_void_p()
-        st = self._lib.nmfamd_engine_create(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), C.byref(h))
+        # row_blocks > 1: the padded row count is a multiple of 128 * row_blocks (row-block form of the sharded W step)
+        st = self._lib.nmfamd_engine_create_blocks(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), int(row_blocks), C.byref(h))
         if st != 0:
             raise EngineError(st, "nmfamd_engine_create")
         self._h = h
@@ -191,6 +192,96 @@ class Engine:
         out = np.zeros(count, dtype=self.dtype)
         self._check(self._lib.nmfamd_engine_debug_read(self._h, which, C.c_void_p(out.ctypes.data), C.c_long(count)), "debug_read")
         return out
+
+
+class RcclComm:
+    """One rank of an RCCL clique, created through RCCL's C API inside libnmfgpu64.so (no torch).  Rank 0 calls
+    RcclComm.unique_id() and hands the 128 bytes to the other ranks; every rank then constructs its communicator with
+    its HIP device current (blocks until all ranks have arrived)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        self._lib = library()
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        h = C.c_void_p()
+        st = self._lib.nmfamd_comm_create_rccl(C.c_char_p(unique_id), int(world), int(rank), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_comm_create_rccl")
+        self._h = h
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def available() -> bool:
+        return bool(library().nmfamd_comm_rccl_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        st = library().nmfamd_comm_unique_id(buf)
+        if st != 0:
+            raise EngineError(st, "nmfamd_comm_unique_id")
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+SHARD_ROW_BLOCKS, SHARD_REPLICATED = 0, 1
+
+
+class ShardedRun:
+    """The column-sharded iteration driven natively (include/nmfgpu_amd.h, nmfamd_sharded_*): `engine` holds this rank's
+    columns [total_columns * rank / world, total_columns * (rank + 1) / world) and was created with row_blocks = world."""
+
+    def __init__(self, engine: Engine, comm: RcclComm, rows: int, total_columns: int, mode: int = SHARD_ROW_BLOCKS):
+        self._lib = library()
+        self.engine, self.comm = engine, comm          # keep both alive
+        h = C.c_void_p()
+        st = self._lib.nmfamd_sharded_create(engine._h, comm._h, int(mode), C.c_long(rows), C.c_long(total_columns), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_sharded_create")
+        self._h = h
+        self._lib.nmfamd_sharded_frobenius.restype = C.c_double
+        self._lib.nmfamd_sharded_rmsd.restype = C.c_double
+        self._lib.nmfamd_sharded_last_error.restype = C.c_char_p
+
+    def iterate(self, count: int, first_iteration: int = 1, error_every: int = 10, last_iteration: int = 0):
+        st = self._lib.nmfamd_sharded_iterate(self._h, int(count), int(first_iteration), int(error_every), int(last_iteration))
+        if st != 0:
+            raise EngineError(st, "nmfamd_sharded_iterate", (self._lib.nmfamd_sharded_last_error(self._h) or b"").decode())
+
+    @property
+    def frobenius(self) -> float:
+        return float(self._lib.nmfamd_sharded_frobenius(self._h))
+
+    @property
+    def rmsd(self) -> float:
+        return float(self._lib.nmfamd_sharded_rmsd(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_columns(total: int, world: int, rank: int):
+    """(first, count) of the columns rank `rank` holds when `total` columns are dealt to `world` ranks (sharded.h)."""
+    a, b = (total * rank) // world, (total * (rank + 1)) // world
+    return a, b - a
 
 
 def resolve_frobenius(vtv_sorted: np.ndarray, htwtv: np.ndarray, hhtwtw: np.ndarray) -> float:

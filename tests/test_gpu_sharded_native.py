@@ -1,0 +1,131 @@
+"""The column-sharded iteration INSIDE the library: nmfgpu::compute with Parameter "numGpus", rank
+threads, reduce-scatter by row blocks of W -> row-block update -> all-reduce of the column norms -> all-gather, and the
+same iteration through the native sharded API with an RCCL communicator (RCCL's C API, no torch).
+
+The box has ONE GPU: ranks of a "numGpus" team share it and talk through the in-process peer-read transport (RCCL refuses
+two ranks on one device); RCCL itself is exercised with a one-rank clique, where every collective is issued for real."""
+import numpy as np
+import pytest
+
+import nmfgpu_amd as na
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def F(a):
+    return np.asfortranarray(a)
+
+
+def rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-300)
+
+
+def problem(m, n, r, dtype, seed=1):
+    rng = np.random.default_rng(seed)
+    return (F(rng.random((m, n)).astype(dtype)), F((1.0 - rng.random((m, r))).astype(dtype)), F((1.0 - rng.random((r, n))).astype(dtype)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _library_is_native():
+    assert na.device_count() >= 1, "GPU tests need a HIP device"
+    assert na.initialize() in (na.ResultType.Success, na.ResultType.ErrorAlreadyInitialized)
+    na.set_verbosity(na.Verbosity.Nothing)
+    yield
+    na.finalize()
+
+
+@pytest.mark.parametrize("alg,r,params,dtype,tol", [
+    (na.NmfAlgorithm.Multiplicative, 16, {}, np.float32, 2e-4),
+    (na.NmfAlgorithm.Multiplicative, 64, {}, np.float32, 2e-4),
+    (na.NmfAlgorithm.Multiplicative, 100, {}, np.float32, 2e-4),
+    (na.NmfAlgorithm.nsNMF, 40, {"theta": 0.4}, np.float32, 2e-4),
+    (na.NmfAlgorithm.Multiplicative, 20, {}, np.float64, 1e-9),
+])
+@pytest.mark.parametrize("ranks,mode", [(2, 0), (2, 1), (3, 0)])
+def test_compute_with_numgpus_matches_oracle_and_single_gpu(alg, r, params, dtype, tol, ranks, mode):
+    m, n, iters = 700, 530, 30                       # 530 columns on 3 ranks: ragged shards
+    V, W0, H0 = problem(m, n, r, dtype, seed=r + ranks)
+    name = "mu" if alg == na.NmfAlgorithm.Multiplicative else "nsnmf"
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
+    ref = oracle.run(name, V64, W64, H64, iters, theta=params.get("theta", 0.0))
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    s1 = na.Summary()
+    assert na.compute(V, W1, H1, algorithm=alg, iterations=iters, parameters=params, summary=s1) == na.ResultType.Success
+    Wn, Hn = W0.copy(order="F"), H0.copy(order="F")
+    sn = na.Summary()
+    p = dict(params, numGpus=ranks, shardMode=mode)
+    assert na.compute(V, Wn, Hn, algorithm=alg, iterations=iters, parameters=p, summary=sn) == na.ResultType.Success
+    assert rel(Wn, W64) < tol and rel(Hn, H64) < tol
+    assert rel(Wn, W1) < tol and rel(Hn, H1) < tol
+    assert sn.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert sn.record(0).frobenius == pytest.approx(s1.record(0).frobenius, rel=1e-6)
+    assert sn.record(0).rmsd == pytest.approx(s1.record(0).rmsd, rel=1e-6)
+    assert sn.record(0).numIterations == iters
+
+
+def test_compute_with_numgpus_random_init_draws_one_stream_for_all_shards():
+    """AllRandomValues on N ranks: every rank fills its columns of H from the position those columns have in the ONE stream,
+    so the start -- and with it the whole run -- is the single-GPU run's up to rounding."""
+    m, n, r = 500, 410, 12
+    V, _, _ = problem(m, n, r, np.float32, seed=5)
+    out = []
+    for ranks in (1, 2):
+        W = F(np.zeros((m, r), dtype=np.float32)); H = F(np.zeros((r, n), dtype=np.float32))
+        p = {"numGpus": ranks} if ranks > 1 else {}
+        for iters in (0, 25):
+            s = na.Summary()
+            assert na.compute(V, W, H, init=na.NmfInitializationMethod.AllRandomValues, iterations=iters, seed=9, parameters=p, summary=s) == na.ResultType.Success
+            out.append((W.copy(), H.copy(), s.record(0).frobenius))
+    (W0a, H0a, _), (Wa, Ha, fa), (W0b, H0b, _), (Wb, Hb, fb) = out
+    assert np.array_equal(W0a, W0b) and np.array_equal(H0a, H0b)          # identical start values, bit for bit
+    assert rel(Wb, Wa) < 2e-4 and rel(Hb, Ha) < 2e-4 and fb == pytest.approx(fa, rel=1e-5)
+
+
+def test_compute_with_numgpus_kmeans_init_threshold_stop_and_runs():
+    """Host-side initialiser once for the whole matrix, several runs, threshold stop: same bookkeeping as on one GPU."""
+    m, n, r = 300, 260, 6
+    V, _, _ = problem(m, n, r, np.float32, seed=8)
+    res = []
+    for ranks in (1, 2):
+        W = F(np.zeros((m, r), dtype=np.float32)); H = F(np.zeros((r, n), dtype=np.float32))
+        s = na.Summary()
+        p = {"numGpus": ranks} if ranks > 1 else {}
+        assert na.compute(V, W, H, init=na.NmfInitializationMethod.KMeansAndNonNegativeWTV, iterations=200, runs=3, seed=3, threshold=0.05,
+                          parameters=p, summary=s) == na.ResultType.Success
+        res.append((W, H, [s.record(i) for i in range(s.record_count())], s.best_run()))
+    (W1, H1, rec1, b1), (W2, H2, rec2, b2) = res
+    assert len(rec1) == len(rec2) and b1 == b2
+    for a, b in zip(rec1, rec2):
+        assert a.numIterations == b.numIterations and a.frobenius == pytest.approx(b.frobenius, rel=1e-5)
+    assert rel(W2, W1) < 5e-4 and rel(H2, H1) < 5e-4
+
+
+def test_compute_with_numgpus_rejects_what_does_not_shard():
+    V, W, H = problem(60, 50, 4, np.float32)
+    assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.ALS, iterations=2, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success
+
+
+@pytest.mark.parametrize("alg,r,kw,mode", [("mu", 64, {}, na.SHARD_ROW_BLOCKS), ("mu", 64, {}, na.SHARD_REPLICATED), ("mu", 20, {}, na.SHARD_ROW_BLOCKS),
+                                           ("nsnmf", 130, dict(theta=0.5), na.SHARD_ROW_BLOCKS)])
+def test_native_sharded_run_over_a_one_rank_rccl_clique(alg, r, kw, mode):
+    """RCCL through its C API (librccl.so loaded by the library): ncclReduceScatter / ncclAllReduce / ncclAllGather are all
+    issued on the engine's stream; with one rank they are identities, so the result is the single-GPU factorisation."""
+    assert na.RcclComm.available()
+    m, n, iters = 640, 500, 30
+    V, W, H = problem(m, n, r, np.float32, seed=r)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)
+    comm = na.RcclComm(na.RcclComm.unique_id(), 1, 0)
+    eng = na.Engine(m, n, r, alg, row_blocks=1, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    run = na.ShardedRun(eng, comm, m, n, mode)
+    run.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4
+    assert run.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert run.rmsd == pytest.approx(ref["rmsd"], rel=1e-5)
+    run.close(); eng.close(); comm.close()

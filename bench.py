@@ -131,11 +131,24 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
                          "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default) = one 10000x5000 column shard per GPU; strong = the ONE 10000x5000 problem of configs[1] "
+                         "column-sharded over the N GPUs (BASELINE north_star's 1/2/4/8-GPU series); strong implies --native-comm")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="drive the sharded iteration inside libnmfgpu64.so (RCCL through its C API, reduce-scatter by row blocks of W) "
+                         "instead of the torch.distributed wrapper; torch.distributed then only carries the RCCL unique id and the timing")
+    ap.add_argument("--torch-comm", action="store_true", help="N > 1: drive the sharded iteration from Python through torch.distributed (the round-1 wrapper) instead of natively")
+    ap.add_argument("--shard-mode", type=int, choices=[-1, 0, 1], default=-1,
+                    help="native loop: 0 reduce-scatter / all-gather by row blocks of W, 1 one all-reduce + replicated update, "
+                         "-1 (default) by message size: row blocks when the m x r panel is 8 MB or more (config 4), else the single all-reduce")
     args = ap.parse_args()
-    if args.workload == "c4":
-        return main_c4(args)
     if args.workload == "c3":
         return main_c3(args)
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.workload in ("c2", "c4") and not args.torch_comm and (args.native_comm or args.scaling == "strong" or multi):
+        return main_native(args)
+    if args.workload == "c4":
+        return main_c4(args)
     algorithm, alg_kw = "mu", {}
     if args.workload.startswith("c5"):
         algorithm = "gdcls" if args.workload.endswith("gdcls") else "ahcls"
@@ -285,6 +298,106 @@ def main():
                 out["cpu_baseline_blas"] = cpu_baseline_blas(V, W, H, out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     if distributed or (args.sharded and args.rccl1):
+        dist.destroy_process_group()
+
+
+def main_native(args):
+    """configs[1] column-sharded with the iteration driven natively (nmfamd_sharded_*): RCCL through its C API on the
+    engine's stream, no Python between the kernels and the collectives of an iteration.  strong: the one 10000 x 5000
+    matrix split over the ranks (value = iterations/s of THAT problem); weak: one 10000 x 5000 shard per rank."""
+    import torch
+    import nmfgpu_amd as na
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if not na.RcclComm.available():
+        raise SystemExit("librccl.so could not be loaded")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    strong = args.scaling == "strong"
+    c4 = args.workload == "c4"
+    rows, cols, feats = (C4["rows"], C4["columns_per_gpu"], C4["features"]) if c4 else (M, N_COLS, R)
+    alg, alg_kw = ("nsnmf", dict(theta=C4["theta"], precision="bf16")) if c4 else ("mu", {})
+    if strong:
+        if c4:
+            raise SystemExit("--scaling strong is defined for configs[1] (the north_star's 1/2/4/8-GPU series)")
+        V, W, H = make_problem(0)
+        c0, nc = na.shard_columns(cols, world, rank)
+        V = np.asfortranarray(V[:, c0:c0 + nc]); H = np.asfortranarray(H[:, c0:c0 + nc])
+        total_columns = cols
+    else:
+        V, W, H = make_problem(rank, rows, cols, feats)
+        nc, total_columns = cols, cols * world
+    mode = args.shard_mode if args.shard_mode >= 0 else (0 if 4.0 * rows * feats >= 8e6 else 1)
+    uid = [na.RcclComm.unique_id() if rank == 0 else None]
+    if distributed:
+        dist.broadcast_object_list(uid, src=0)
+    comm = na.RcclComm(uid[0], world, rank)
+    eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, row_blocks=world, **alg_kw)
+    eng.upload(V)
+    eng.set_factors(W, H)
+    run = na.ShardedRun(eng, comm, rows, total_columns, mode)
+    K, Wm = args.steps, args.warmup
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # set-up, not steps (as in the torch-driven path): the first collectives of a communicator and the first launches
+    run.iterate((240 if distributed else 30) if not c4 else 12, first_iteration=1, error_every=10)
+    eng.synchronize()
+    eng.set_factors(W, H)
+    run.iterate(Wm, first_iteration=1, error_every=10)
+    eng.synchronize()
+    if not args.no_kernel_events:
+        eng.kernel_timing(args.event_stride)
+    barrier()
+    t0 = time.perf_counter()
+    run.iterate(K, first_iteration=Wm + 1, error_every=10)
+    eng.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
+    frob = run.frobenius
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        bytes_per_launch = (2.0 if c4 else 4.0) * rows * nc    # this rank's image of its columns of V (bf16 at config 4), one product
+        roofline = None
+        if kernel_launches > 0:
+            avg_s = kernel_ms / 1e3 / kernel_launches
+            roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "factor product (rank 0's launches)",
+                        "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
+        mode_text = ("reduce-scatter of (V H^T)^T by row blocks of W + all-reduce of H H^T, row-block W update, all-reduce of the column norms, "
+                     "all-gather of W") if mode == 0 else "one all-reduce of (V H^T | H H^T), replicated W update"
+        out = {"metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256" if c4 else "NMF MU iterations/sec, dense 10kx5k r=64",
+               "value": (K if strong else world * K) / elapsed,
+               "unit": "iterations/s" if (strong or world == 1) else f"shard-iterations/s (one {rows}x{cols} column shard per GPU)",
+               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+               "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if c4 else "f32", "data": "synthetic",
+               "config": {"workload": ("configs[3] per GPU: dense random V 50000x6250 column shard, r=256, nsNMF theta=0.5, bf16 MFMA operands" if c4 else
+                                       "configs[1]: dense random V 10000x5000, r=64, MU Frobenius, fp32, column-sharded over the GPUs" if strong else
+                                       "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32"),
+                          "rows": rows, "columns_per_gpu": nc, "total_columns": total_columns, "features": feats, "error_every": 10,
+                          "parallelism": f"column shards x{world}, native loop (RCCL C API): {mode_text}"},
+               "frobenius_last": frob, "roofline": roofline}
+        print(json.dumps(out), flush=True)
+    run.close(); eng.close(); comm.close()
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -141,6 +141,16 @@ NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* o
 NMFAMD_API int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error);
 NMFAMD_API int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange);
 NMFAMD_API int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_error);
+/* Row-block form of nmfamd_engine_w_finish for callers that reduce-scatter the panel themselves (the torch-facing wrapper
+ * nmfgpu_amd/distributed.py; the native loop nmfamd_sharded_* does the same inside the library): num_rows = the reduced
+ * (V H^T)^T rows [row0, row0 + rows) in panel layout (DEVICE), hht = the reduced H H^T (DEVICE, padded_rank^2), colsq =
+ * padded_rank DEVICE elements that receive the sums of squares of the new rows.  After the all-reduce of colsq:
+ * _w_normalize_rows; after the all-gather of every rank's rows into nmfamd_engine_w_panel(): _w_rows_replaced.
+ * rows and row0 are multiples of 128 (engine created with nmfamd_engine_create_blocks). */
+NMFAMD_API int nmfamd_engine_w_update_rows(nmfamd_engine* e, const void* num_rows, const void* hht, long row0, long rows, int compute_error, void* colsq);
+NMFAMD_API int nmfamd_engine_w_normalize_rows(nmfamd_engine* e, long row0, long rows, void* colsq);
+NMFAMD_API int nmfamd_engine_w_rows_replaced(nmfamd_engine* e);
+NMFAMD_API void* nmfamd_engine_w_panel(nmfamd_engine* e);     /* DEVICE pointer: padded_m rows of padded_rank elements */
 /* which: 0 = sorted tr(V^T V) terms (n), 1 = tr(H^T W^T V) terms (n), 2 = tr(H H^T W^T W) terms (r).
  * Returns the number of elements copied (<= capacity), negative on error. */
 NMFAMD_API long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capacity);

@@ -302,6 +302,22 @@ int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_e
 	                   [&](Engine<double>& g) { return g.w_finish((const double*)exchange, compute_error != 0); });
 }
 
+int nmfamd_engine_w_update_rows(nmfamd_engine* e, const void* num_rows, const void* hht, long row0, long rows, int compute_error, void* colsq) {
+	return dispatch(e, [&](Engine<float>& g) { return g.w_update_rows((const float*)num_rows, (const float*)hht, row0, rows, compute_error != 0, (float*)colsq); },
+	                   [&](Engine<double>& g) { return g.w_update_rows((const double*)num_rows, (const double*)hht, row0, rows, compute_error != 0, (double*)colsq); });
+}
+int nmfamd_engine_w_normalize_rows(nmfamd_engine* e, long row0, long rows, void* colsq) {
+	return dispatch(e, [&](Engine<float>& g) { return g.w_normalize_rows(row0, rows, (float*)colsq); },
+	                   [&](Engine<double>& g) { return g.w_normalize_rows(row0, rows, (double*)colsq); });
+}
+int nmfamd_engine_w_rows_replaced(nmfamd_engine* e) {
+	return dispatch(e, [&](Engine<float>& g) { g.w_rows_replaced(); return ST_OK; }, [&](Engine<double>& g) { g.w_rows_replaced(); return ST_OK; });
+}
+void* nmfamd_engine_w_panel(nmfamd_engine* e) {
+	if (!e) return nullptr;
+	return e->elem_bytes == 4 ? (void*)e->f->w_panel() : (void*)e->d->w_panel();
+}
+
 long nmfamd_engine_error_terms(nmfamd_engine* e, int which, void* out, long capacity) {
 	if (!e || !out || which < 0 || which > 2) return -1;
 	auto copy = [&](auto& g) -> long {

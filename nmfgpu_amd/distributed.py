@@ -13,6 +13,14 @@ nsNMF (AlgorithmNonSmoothNMF.h:174-218) shards the same way: the H step uses the
 carries the sums over the SMOOTHED local columns [ (V_g (S H_g)^T)^T | (S H_g)(S H_g)^T ], the W update is
 replicated.  51.2 MB + 256 KB per iteration at 50000 x 50000, r = 256 (BASELINE config 4).
 
+mode = "row_blocks" (SURVEY 8e's second form; what the native loop nmfamd_sharded_* and nmfgpu::compute with
+Parameter "numGpus" do inside the library, sharded.cpp) replaces the all-reduce + replicated update by
+
+    reduce_scatter  the m x r panel by row blocks of W (+ all_reduce of the r x r H H^T)
+    w_update_rows   every rank updates ITS m / N rows of W, leaves r partial sums of squares
+    all_reduce      of those r sums; w_normalize_rows
+    all_gather      of the row blocks: every rank holds the same bits of the new W
+
 Every rank applies the identical W update to identical reduced sums, so the replicas stay
 bit-identical without a broadcast.  On error iterations the per-column terms of tr(H^T W^T V)
 are all-gathered so that the host-side sorted summation (source/nmf/FrobeniusResolver.cpp:29-51)
@@ -31,7 +39,7 @@ class EngineShard:
     """Product backend: one nmfgpu_amd.Engine on this rank's GPU, exchange buffer owned by torch."""
 
     def __init__(self, V_local: np.ndarray, W: np.ndarray, H_local: np.ndarray, device=None,
-                 algorithm: str = "mu", theta: float = 0.0, precision: str = "native"):
+                 algorithm: str = "mu", theta: float = 0.0, precision: str = "native", row_blocks: int = 1):
         import torch
         from .engine import Engine
         self.torch = torch
@@ -48,13 +56,39 @@ class EngineShard:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if algorithm not in ("mu", "nsnmf"):
             raise ValueError("the sharded iteration covers the multiplicative algorithms: 'mu' and 'nsnmf'")
-        self.engine = Engine(m, n, r, algorithm, dtype=V_local.dtype, stream=stream, theta=theta, precision=precision)
+        self.engine = Engine(m, n, r, algorithm, dtype=V_local.dtype, stream=stream, theta=theta, precision=precision, row_blocks=row_blocks)
         self.engine.upload(V_local)
         self.engine.set_factors(W, H_local)
-        count = self.engine.geometry()["exchange_count"]
+        g = self.engine.geometry()
+        count = g["exchange_count"]
         tdtype = torch.float32 if V_local.dtype == np.float32 else torch.float64
         self.exchange = torch.zeros(count, dtype=tdtype, device=self.device)
         self.dtype = V_local.dtype
+        # row-block form: the exchange buffer is [panel: padded_m rows of padded_rank | H H^T]; the engine's own W panel
+        # is wrapped as a tensor so that the all-gather lands in it directly
+        self.padded_rank, self.padded_m = g["padded_rank"], g["padded_m"]
+        self.row_blocks = row_blocks
+        self.panel = self.exchange[: self.padded_rank * self.padded_m]
+        self.hht = self.exchange[self.padded_rank * self.padded_m:]
+        self.colsq = torch.zeros(self.padded_rank, dtype=tdtype, device=self.device)
+
+        class _Raw:       # the W panel inside the engine (device memory the library owns)
+            pass
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {"shape": (self.padded_rank * self.padded_m,), "typestr": "<f4" if tdtype == torch.float32 else "<f8",
+                                        "data": (self.engine.w_panel_ptr(), False), "version": 2}
+        self._raw = raw
+        self.w_panel = torch.as_tensor(raw, device=self.device)
+
+    def w_update_rows(self, block, row0: int, rows: int, compute_error: bool):
+        self.engine.w_update_rows(block.data_ptr(), self.hht.data_ptr(), row0, rows, compute_error, self.colsq.data_ptr())
+        return self.colsq
+
+    def w_normalize_rows(self, row0: int, rows: int):
+        self.engine.w_normalize_rows(row0, rows, self.colsq.data_ptr())
+
+    def w_rows_replaced(self):
+        self.engine.w_rows_replaced()
 
     def h_step(self, compute_error: bool):
         self.engine.h_step(compute_error)
@@ -91,12 +125,16 @@ class EngineShard:
 class ShardedMU:
     """Drives one backend per rank through the sharded iteration; `dist` is torch.distributed."""
 
-    def __init__(self, backend, total_columns: int, rows: int, group=None, force_collectives: bool = False):
+    def __init__(self, backend, total_columns: int, rows: int, group=None, force_collectives: bool = False, mode: str = "replicated"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.backend = backend
         self.group = group
+        if mode not in ("replicated", "row_blocks"):
+            raise ValueError("mode: 'replicated' or 'row_blocks'")
+        self.mode = mode
+        self._rs_native = True
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_collectives: issue the all-reduce / all-gather even in a one-rank group (they are identities there);
         # lets a single-GPU box exercise the RCCL calls, their stream ordering against the engine's kernels included
@@ -165,13 +203,53 @@ class ShardedMU:
         dist.all_gather(outs, t, group=self.group)
         return np.concatenate([o.cpu().numpy() for o in outs])
 
+    def _reduce_scatter(self, out, panel):
+        """out <- this rank's block of the sum of `panel` over the ranks.  gloo has no reduce_scatter: one reduce per block."""
+        dist = self.dist
+        if self._rs_native:
+            try:
+                dist.reduce_scatter_tensor(out, panel, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._rs_native = False
+        rank = dist.get_rank(self.group)
+        for p, chunk in enumerate(panel.chunk(self.world)):
+            dist.reduce(chunk, dst=dist.get_global_rank(self.group, p) if self.group is not None else p, op=dist.ReduceOp.SUM, group=self.group)
+            if p == rank:
+                out.copy_(chunk)
+
+    def _iterate_row_blocks(self, compute_error: bool):
+        b, dist = self.backend, self.dist
+        rank = dist.get_rank(self.group) if self.collectives and dist.is_initialized() else 0
+        rows = b.padded_m // self.world
+        if rows * self.world != b.padded_m or rows % 128 != 0:
+            raise ValueError("row_blocks: the backend's padded row count must be a multiple of 128 * world (EngineShard(row_blocks=world))")
+        row0 = rank * rows
+        block = b.panel[row0 * b.padded_rank:(row0 + rows) * b.padded_rank]
+        if self.collectives:
+            mine = self.torch.empty_like(block)
+            self._reduce_scatter(mine, b.panel)
+            dist.all_reduce(b.hht, op=dist.ReduceOp.SUM, group=self.group)
+            block = mine
+        colsq = b.w_update_rows(block, row0, rows, compute_error)
+        if self.collectives:
+            dist.all_reduce(colsq, op=dist.ReduceOp.SUM, group=self.group)
+        b.w_normalize_rows(row0, rows)
+        if self.collectives:
+            mine = b.w_panel[row0 * b.padded_rank:(row0 + rows) * b.padded_rank].clone()
+            dist.all_gather(list(b.w_panel.chunk(self.world)), mine, group=self.group)
+        b.w_rows_replaced()
+
     def iterate(self, compute_error: bool = False):
         b = self.backend
         b.h_step(compute_error)
         b.w_products()
-        if self.collectives:
-            self.dist.all_reduce(b.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
-        b.w_finish(compute_error)
+        if self.mode == "row_blocks":
+            self._iterate_row_blocks(compute_error)
+        else:
+            if self.collectives:
+                self.dist.all_reduce(b.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
+            b.w_finish(compute_error)
         if compute_error:
             if self._vtv_all is None:      # once per factorisation (V does not change)
                 self._vtv_all = np.sort(self._all_gather_host(b.error_terms(0)))

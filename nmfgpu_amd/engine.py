@@ -171,6 +171,22 @@ class Engine:
     def w_finish(self, exchange_ptr: int, compute_error: bool = False):
         self._check(self._lib.nmfamd_engine_w_finish(self._h, C.c_void_p(exchange_ptr), int(compute_error)), "w_finish")
 
+    # ---- row-block form of the sharded W step (engine created with row_blocks = world) ----
+    def w_update_rows(self, num_rows_ptr: int, hht_ptr: int, row0: int, rows: int, compute_error: bool, colsq_ptr: int):
+        self._check(self._lib.nmfamd_engine_w_update_rows(self._h, C.c_void_p(num_rows_ptr), C.c_void_p(hht_ptr), C.c_long(row0), C.c_long(rows),
+                                                          int(compute_error), C.c_void_p(colsq_ptr)), "w_update_rows")
+
+    def w_normalize_rows(self, row0: int, rows: int, colsq_ptr: int):
+        self._check(self._lib.nmfamd_engine_w_normalize_rows(self._h, C.c_long(row0), C.c_long(rows), C.c_void_p(colsq_ptr)), "w_normalize_rows")
+
+    def w_rows_replaced(self):
+        self._check(self._lib.nmfamd_engine_w_rows_replaced(self._h), "w_rows_replaced")
+
+    def w_panel_ptr(self) -> int:
+        fn = self._lib.nmfamd_engine_w_panel
+        fn.restype = C.c_void_p
+        return int(fn(self._h))
+
     def error_terms(self, which: int) -> np.ndarray:
         cap = max(self.n, self.r)
         out = np.zeros(cap, dtype=self.dtype)

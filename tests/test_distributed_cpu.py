@@ -26,16 +26,24 @@ def _free_port():
 class OracleShard:
     """Test-only backend: the sharded MU steps restated with oracle primitives (float64)."""
 
-    def __init__(self, V_local, W, H_local, theta=None):
+    def __init__(self, V_local, W, H_local, theta=None, row_blocks=1):
         import torch
         from oracle import oracle
         self.o = oracle
+        self.torch = torch
         self.V = np.asfortranarray(V_local)
         self.W = np.asfortranarray(W.copy())
         self.H = np.asfortranarray(H_local.copy())
         m, r = self.W.shape
         self.m, self.r = m, r
-        self.exchange = torch.zeros(r * m + r * r, dtype=torch.float64)
+        # the engine's geometry in miniature: panel layout [row][rank], rows padded to whole 128-row tiles per row block
+        self.padded_rank = r
+        self.padded_m = m if row_blocks == 1 else -(-m // (128 * row_blocks)) * 128 * row_blocks
+        self.exchange = torch.zeros(r * self.padded_m + r * r, dtype=torch.float64)
+        self.panel = self.exchange[: r * self.padded_m]
+        self.hht = self.exchange[r * self.padded_m:]
+        self.w_panel = torch.zeros(r * self.padded_m, dtype=torch.float64)
+        self.colsq = torch.zeros(r, dtype=torch.float64)
         self.eps = np.finfo(np.float64).eps
         self.vtv = oracle.vtv_sorted(self.V)
         self.psN = None
@@ -60,19 +68,50 @@ class OracleShard:
         HHt = o.gemm_nt(Hs, Hs)                   # r x r
         ex = self.exchange.numpy()
         ex[: self.r * self.m] = np.ascontiguousarray(MR).ravel()     # panel layout [x][c]
-        ex[self.r * self.m:] = HHt.ravel(order="F")
+        ex[self.r * self.padded_m:] = HHt.ravel(order="F")
 
     def w_finish(self, compute_error):
         o = self.o
         ex = self.exchange.numpy()
         MR = np.asfortranarray(ex[: self.r * self.m].reshape(self.m, self.r))
-        HHt = np.asfortranarray(ex[self.r * self.m:].reshape(self.r, self.r, order="F"))
+        HHt = np.asfortranarray(ex[self.r * self.padded_m:].reshape(self.r, self.r, order="F"))
         if compute_error:
             wtw = self.G if self.S is None else o.gemm_tn(self.W, self.W)     # nsNMF: unsmoothed W^T W (:201-202)
             self.psR = o.trace_multiplication(False, HHt, wtw)
         MR2 = o.gemm_nn(self.W, HHt)
         o.multiply_divide(self.W, MR, MR2)
         o.normalize_columns(self.W)
+
+    # ---- row-block form (what sharded.cpp / Engine::w_update_rows do on the GPU) ----
+    def w_update_rows(self, block, row0, rows, compute_error):
+        o = self.o
+        HHt = np.asfortranarray(self.hht.numpy().reshape(self.r, self.r, order="F"))
+        if compute_error:
+            wtw = self.G if self.S is None else o.gemm_tn(self.W, self.W)
+            self.psR = o.trace_multiplication(False, HHt, wtw)
+        lo, hi = min(row0, self.m), min(row0 + rows, self.m)
+        self._rows = (lo, hi)
+        sq = np.zeros(self.r)
+        if hi > lo:
+            Wb = np.asfortranarray(self.W[lo:hi, :])
+            MR = np.asfortranarray(block.numpy().reshape(rows, self.r)[: hi - lo, :])
+            MR2 = o.gemm_nn(Wb, HHt)
+            o.multiply_divide(Wb, MR, MR2)
+            self._Wb = Wb
+            sq = (Wb * Wb).sum(axis=0)
+        self.colsq.copy_(self.torch.from_numpy(sq))
+        return self.colsq
+
+    def w_normalize_rows(self, row0, rows):
+        lo, hi = self._rows
+        out = self.w_panel.numpy().reshape(self.padded_m, self.r)
+        if hi > lo:
+            s = self.colsq.numpy()
+            nrm = np.where(s > 0, np.sqrt(s), 1.0)                    # sum > 0 ? x / sqrt(sum) : x   (KernelNormalizeColumns.cu:37-58)
+            out[lo:hi, :] = self._Wb / nrm
+
+    def w_rows_replaced(self):
+        self.W = np.asfortranarray(self.w_panel.numpy().reshape(self.padded_m, self.r)[: self.m, :].copy())
 
     def error_terms(self, which):
         return [self.vtv, self.psN, self.psR][which]
@@ -84,7 +123,7 @@ class OracleShard:
         return (self.W if self.S is None else self.o.gemm_nn(self.W, self.S)), self.H
 
 
-def _worker(rank, world, port, m, n, r, iters, out_dir, theta):
+def _worker(rank, world, port, m, n, r, iters, out_dir, theta, mode="replicated"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from nmfgpu_amd.distributed import ShardedMU
@@ -95,21 +134,24 @@ def _worker(rank, world, port, m, n, r, iters, out_dir, theta):
     V = rng.random((m, n)); W = 1.0 - rng.random((m, r)); H = 1.0 - rng.random((r, n))
     per = n // world
     cols = slice(rank * per, (rank + 1) * per)
-    backend = OracleShard(V[:, cols], W, H[:, cols], theta)
-    drv = ShardedMU(backend, total_columns=n, rows=m)
+    backend = OracleShard(V[:, cols], W, H[:, cols], theta, row_blocks=world if mode == "row_blocks" else 1)
+    drv = ShardedMU(backend, total_columns=n, rows=m, mode=mode)
     drv.run(iters, first_iteration=1, error_every=10, last_iteration=iters)
     Wg, Hg = backend.factors()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=Wg, H=Hg, frob=drv.frobenius, rmsd=drv.rmsd)
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["replicated", "row_blocks"])
 @pytest.mark.parametrize("theta", [None, 0.5], ids=["mu", "nsnmf"])
-def test_sharded_mu_two_ranks_equals_single_process(tmp_path, theta):
+def test_sharded_mu_two_ranks_equals_single_process(tmp_path, theta, mode):
+    """mode row_blocks: reduce-scatter of the panel by row blocks of W -> row-block update -> all-reduce of the column sums of
+    squares -> all-gather; m = 160 on two ranks: rank 0 owns rows 0..127, rank 1 rows 128..159 plus padding."""
     import torch.multiprocessing as mp
     from oracle import oracle
-    m, n, r, iters, world = 60, 48, 5, 25, 2
+    m, n, r, iters, world = (160 if mode == "row_blocks" else 60), 48, 5, 25, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, n, r, iters, str(tmp_path), theta), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, m, n, r, iters, str(tmp_path), theta, mode), nprocs=world, join=True)
     rng = np.random.default_rng(5)
     V = np.asfortranarray(rng.random((m, n))); W = np.asfortranarray(1.0 - rng.random((m, r))); H = np.asfortranarray(1.0 - rng.random((r, n)))
     ref = oracle.run("mu", V, W, H, iters) if theta is None else oracle.run("nsnmf", V, W, H, iters, theta=theta)

@@ -31,8 +31,9 @@ def _rel(a, b):
     return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64))
 
 
+@pytest.mark.parametrize("mode", ["replicated", "row_blocks"])
 @pytest.mark.parametrize("alg,r,theta", [("mu", 16, 0.0), ("mu", 64, 0.0), ("nsnmf", 16, 0.5), ("nsnmf", 200, 0.3)])
-def test_sharded_engine_world1_matches_oracle(alg, r, theta):
+def test_sharded_engine_world1_matches_oracle(alg, r, theta, mode):
     import torch  # noqa: F401  (device memory for the exchange buffer)
     from nmfgpu_amd.distributed import EngineShard, ShardedMU
     from oracle import oracle
@@ -41,7 +42,7 @@ def test_sharded_engine_world1_matches_oracle(alg, r, theta):
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
     ref = oracle.run(alg, V64, W64, H64, iters, theta=theta)
     shard = EngineShard(V, W, H, algorithm=alg, theta=theta)
-    drv = ShardedMU(shard, total_columns=n, rows=m)
+    drv = ShardedMU(shard, total_columns=n, rows=m, mode=mode)
     drv.run(iters, first_iteration=1, error_every=10, last_iteration=iters)
     Wg, Hg = shard.factors()
     assert _rel(Wg, W64) < 2e-4 and _rel(Hg, H64) < 2e-4
@@ -54,7 +55,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, m, n, r, iters, out_dir, alg, theta, precision):
+def _worker(rank, world, port, m, n, r, iters, out_dir, alg, theta, precision, mode="replicated"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -66,23 +67,24 @@ def _worker(rank, world, port, m, n, r, iters, out_dir, alg, theta, precision):
     V, W, H = _problem(m, n, r)
     per = n // world
     cols = slice(rank * per, (rank + 1) * per)
-    shard = EngineShard(F(V[:, cols]), W, F(H[:, cols]), algorithm=alg, theta=theta, precision=precision)
-    drv = ShardedMU(shard, total_columns=n, rows=m)
+    shard = EngineShard(F(V[:, cols]), W, F(H[:, cols]), algorithm=alg, theta=theta, precision=precision, row_blocks=world if mode == "row_blocks" else 1)
+    drv = ShardedMU(shard, total_columns=n, rows=m, mode=mode)
     drv.run(iters, first_iteration=1, error_every=10, last_iteration=iters)
     Wg, Hg = shard.factors()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=Wg, H=Hg, frob=drv.frobenius)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("alg,r,theta,precision,tol", [("mu", 16, 0.0, "native", 2e-4), ("nsnmf", 256, 0.5, "native", 2e-4),
-                                                       ("nsnmf", 256, 0.5, "bf16", 2e-2)])
-def test_sharded_engine_two_ranks_on_one_gpu(tmp_path, alg, r, theta, precision, tol):
+@pytest.mark.parametrize("alg,r,theta,precision,tol,mode", [("mu", 16, 0.0, "native", 2e-4, "replicated"), ("nsnmf", 256, 0.5, "native", 2e-4, "replicated"),
+                                                            ("nsnmf", 256, 0.5, "bf16", 2e-2, "replicated"), ("mu", 64, 0.0, "native", 2e-4, "row_blocks"),
+                                                            ("nsnmf", 256, 0.5, "bf16", 2e-2, "row_blocks")])
+def test_sharded_engine_two_ranks_on_one_gpu(tmp_path, alg, r, theta, precision, tol, mode):
     """Two ranks on the one GPU of the box, gloo for the exchange.  The last case is BASELINE config 4 in
     miniature: nsNMF, r = 256, bf16 operands, column shards."""
     import torch.multiprocessing as mp
     from oracle import oracle
     m, n, iters, world = 384, 512, 20, 2
-    mp.spawn(_worker, args=(world, _free_port(), m, n, r, iters, str(tmp_path), alg, theta, precision), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), m, n, r, iters, str(tmp_path), alg, theta, precision, mode), nprocs=world, join=True)
     V, W, H = _problem(m, n, r)
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
     ref = oracle.run(alg, V64, W64, H64, iters, theta=theta)

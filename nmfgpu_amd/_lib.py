@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "lib", "libnmfgpu64.so")
+# NMFAMD_LIBRARY: another build of the SAME library (A/B measurements of kernel variants); never a fallback
+_PATH = os.environ.get("NMFAMD_LIBRARY") or os.path.join(_HERE, "lib", "libnmfgpu64.so")
 _lib = None
 
 

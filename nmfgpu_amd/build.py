@@ -28,6 +28,8 @@ HOST_ONLY = {"host_init.cpp"}
 # per-source extra flags.  kernels_x3.hip: the SLP vectoriser pairs the scalar subtractions of the operand split
 # into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
 EXTRA_FLAGS = {"kernels_x3.hip": ["-fno-slp-vectorize"]}
+# experiment switches: NMFAMD_CXXFLAGS="-DNAME=1 ..." is appended to every compile (and forces nothing: use --force)
+USER_FLAGS = os.environ.get("NMFAMD_CXXFLAGS", "").split()
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",
          "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -60,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if src in HOST_ONLY:
             cmd = [cc, *[f for f in FLAGS if not f.startswith("--offload-arch")], "-x", "c++", "-pthread", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
-            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), *USER_FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

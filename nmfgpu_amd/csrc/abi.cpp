@@ -376,7 +376,11 @@ NMFGPU_EXPORT ResultType getInformationForGpuIndex(unsigned index, GpuInformatio
 	if (hipGetDevice(&old) != hipSuccess) { (void)hipGetLastError(); return ResultType::ErrorDeviceSelection; }
 	if (hipSetDevice(int(index)) != hipSuccess) { (void)hipGetLastError(); return ResultType::ErrorDeviceSelection; }
 	hipDeviceProp_t props;
-	if (hipGetDeviceProperties(&props, int(index)) == hipSuccess) { std::strncpy(info.name, props.name, sizeof(info.name) - 1); info.name[sizeof(info.name) - 1] = '\0'; }
+	if (hipGetDeviceProperties(&props, int(index)) == hipSuccess) {
+		// (the marketing name comes from libdrm's amdgpu.ids, which some installations lack: fall back to the architecture name)
+		const char* name = props.name[0] != '\0' ? props.name : props.gcnArchName;
+		std::strncpy(info.name, name, sizeof(info.name) - 1); info.name[sizeof(info.name) - 1] = '\0';
+	}
 	else std::strcpy(info.name, "N/A");
 	hipError_t e = hipMemGetInfo(&info.freeMemory, &info.totalMemory);
 	(void)hipSetDevice(old);

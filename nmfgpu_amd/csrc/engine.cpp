@@ -216,6 +216,7 @@ Status Engine<T>::allocate() {
 			overlap_inverse_ = true;
 		}
 	}
+	gram_image_ = x3_ && fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr;
 	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
@@ -430,11 +431,44 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_ov
 	}
 }
 
+// Passenger arguments for the Gram matrix of W (of_w) or H of the rank-64 fast path: from the split image of the panel
+// (gram_image_) or from the partial matrices the 64-column update kernel left behind.
+template <typename T>
+GramReduceArgs Engine<T>::gram_args(bool of_w, float* G, float* scale, int normalize) const {
+	GramReduceArgs rg = {of_w ? gramW_part_ : gramH_part_, (int)((of_w ? mpad_ : npad_) / 64), G, scale, normalize};
+	if (gram_image_) { rg.partials = nullptr; rg.parts = 0; rg.image = of_w ? Wx3_ : Hx3_; rg.image_ks = of_w ? ksH_ : ksW_; }
+	return rg;
+}
+
+template <typename T>
+Status Engine<T>::standalone_gram(const GramReduceArgs& rg) {
+	if (rg.image != nullptr) HIPX(launch_gram_from_image(rg.image, rg.image_ks, rg.G, rg.scale, rg.normalize, stream_));
+	else HIPX(launch_mu64_gram_reduce(rg, stream_));
+	return ST_OK;
+}
+
+// U_H / U_W of the rank-64 fast path (kernels_mu64.hip)
+template <typename T>
+Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error) {
+	if constexpr (std::is_same<T, float>::value) {
+		const float eps = std::numeric_limits<float>::epsilon();
+		float* P = is_w ? Wt_ : H_;
+		float* ps = is_w ? psR_ : psN_;
+		const int len = is_w ? m_ : n_, len_pad = (int)(is_w ? mpad_ : npad_);
+		void* xo = x3_ ? (is_w ? Wx3_ : Hx3_) : nullptr;
+		const int xks = is_w ? ksH_ : ksW_;
+		if (gram_image_) HIPX(launch_mu64_update32(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? G_ : nullptr, compute_error ? 1 : 0, stream_, xo, xks));
+		else HIPX(launch_mu64_update(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? gramW_part_ : gramH_part_, is_w ? G_ : nullptr,
+		                             compute_error ? 1 : 0, stream_, xo, xks));
+	}
+	return ST_OK;
+}
+
 template <typename T>
 Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked) {
 	if (sparse_) {
 		// W^T V as a row-gather SpMM over the CSC image: out(:, j) = sum_i V(i, j) F(:, i)
-		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
+		if (rg) { if (Status st = standalone_gram(*rg)) return st; }
 		record_begin();
 		HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, csc_val_, F, RP_, slabs_, n_, (int)npad_, stream_));
 		record_end();
@@ -444,7 +478,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		if (bf16_) {
 			// bf16 operands: the factor panel is re-rounded and re-ordered for every product
 			HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
-			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
@@ -452,7 +486,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
-			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_));
 			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
@@ -460,7 +494,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 			return ST_OK;
 		}
 		if (tiled_) {
-			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && planH_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_f32(planH_, Vt_, strideVt_, F, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
@@ -486,7 +520,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	T* dest = (single_slab_out != nullptr && planW_.splits == 1) ? single_slab_out : slabs_;
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
-		if (rg) HIPX(launch_mu64_gram_reduce(*rg, stream_));
+		if (rg) { if (Status st = standalone_gram(*rg)) return st; }
 		record_begin();
 		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, csr_val_, F, RP_, dest, m_, (int)mpad_, stream_));
 		record_end();
@@ -495,7 +529,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
 			HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
-			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
@@ -503,14 +537,14 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
-			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS)) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_));
 			record_end();
 			return ST_OK;
 		}
 		if (tiled_) {
-			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { HIPX(launch_mu64_gram_reduce(*rg, stream_)); rg = nullptr; }
+			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
@@ -623,14 +657,13 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		if (fused_capable()) {
 			// sharded form of the four-launch iteration (kernels_mu64.hip): K_H + U_H here
 			if (!fused_ready_) {
-				HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
+				if (!gram_image_) HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
 				normalize_next_ = 0;
 				fused_ready_ = true;
 			}
-			GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
+			GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-			HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
-			                        compute_error ? 1 : 0, stream_, x3_ ? Hx3_ : nullptr, ksW_));
+			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, G_, compute_error)) return s;
 			hx3_valid_ = x3_;
 			return ST_OK;
 		}
@@ -696,7 +729,7 @@ Status Engine<T>::w_products(T* exchange) {
 		if (fused_capable()) {
 			// K_W with the local H H^T reduced straight into the exchange buffer by the passenger
 			// workgroups, then the local split-K slabs summed into the exchange panel
-			GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), ex_hht, nullptr, 0};
+			GramReduceArgs rgH = gram_args(false, ex_hht, nullptr, 0);
 			if (Status s = product_w(H_, &rgH, nullptr, x3_ && hx3_valid_)) return s;
 			HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
@@ -725,8 +758,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
 			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T
-			HIPX(launch_mu64_update(1, Wt_, exchange, 1, 0, ex_hht, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
-			                        compute_error ? 1 : 0, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+			if (Status s = mu64_update(true, exchange, 1, 0, ex_hht, compute_error)) return s;
 			wx3_valid_ = x3_;
 			normalize_next_ = 1;
 			w_pending_ = true;
@@ -820,8 +852,8 @@ Status Engine<T>::materialize_w() {
 	if constexpr (std::is_same<T, float>::value) {
 		if (w_pending_) {
 			// column norms from the partial Grams of the unnormalised W, then W <- W diag(scale)
-			GramReduceArgs rg = {gramW_part_, (int)(mpad_ / 64), G2_, scale_, 1};
-			HIPX(launch_mu64_gram_reduce(rg, stream_));
+			GramReduceArgs rg = gram_args(true, G2_, scale_, 1);
+			if (Status s = standalone_gram(rg)) return s;
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
 			w_pending_ = false;
 			fused_ready_ = false;
@@ -836,18 +868,16 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 	if constexpr (std::is_same<T, float>::value) {
 		const float eps = std::numeric_limits<float>::epsilon();
 		if (!fused_ready_) {
-			HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
+			if (!gram_image_) HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
 			normalize_next_ = 0;
 			fused_ready_ = true;
 		}
-		GramReduceArgs rgW = {gramW_part_, (int)(mpad_ / 64), G_, scale_, normalize_next_};
+		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-		HIPX(launch_mu64_update(0, H_, slabs_, planH_.splits, slab_stride_, G_, scale_, eps, psN_, n_, (int)npad_, gramH_part_, nullptr,
-		                        compute_error ? 1 : 0, stream_, x3_ ? Hx3_ : nullptr, ksW_));
-		GramReduceArgs rgH = {gramH_part_, (int)(npad_ / 64), HHt_, nullptr, 0};
+		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, G_, compute_error)) return s;
+		GramReduceArgs rgH = gram_args(false, HHt_, nullptr, 0);
 		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
-		HIPX(launch_mu64_update(1, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, scale_, eps, psR_, m_, (int)mpad_, gramW_part_, G_,
-		                        compute_error ? 1 : 0, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+		if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, HHt_, compute_error)) return s;
 		wx3_valid_ = x3_;
 		hx3_valid_ = false;
 		normalize_next_ = 1;

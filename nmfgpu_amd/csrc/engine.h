@@ -185,6 +185,11 @@ private:
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
 	bool fused_ready_ = false, w_pending_ = false;
+	// split-operand path: Gram matrices from the split images (gram_image.h), 32-column update kernel -- no partial Gram matrices
+	bool gram_image_ = false;
+	GramReduceArgs gram_args(bool of_w, float* G, float* scale, int normalize) const;
+	Status standalone_gram(const GramReduceArgs& rg);
+	Status mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error);
 	// generic rank-64 fp32 path: the update kernel leaves partial Gram matrices of what it wrote (gram_from_update())
 	bool gram_w_ready_ = false;      // G_ holds W^T W of the current (normalised) W
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H

@@ -45,6 +45,10 @@ struct GramReduceArgs {
 	float* inv_out = nullptr;
 	float inv_offdiag = 0.f, inv_diag = 0.f;
 	int inv_r = 0;
+	// third kind (split-operand product only): G straight from the panel's split image instead of from partial matrices
+	// (gram_image.h); image_ks = K-steps of 16 panel rows in the image (the all-zero step that closes it not counted)
+	const void* image = nullptr;
+	int image_ks = 0;
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 
@@ -77,6 +81,15 @@ hipError_t launch_mu64_gram_reduce(const GramReduceArgs& rg, hipStream_t stream)
 hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                               float eps, float* ps, int len_valid, int len_pad, float* gram_partial, const float* Gprev,
                               int compute_error, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
+// The same update on 32-column tiles WITHOUT the partial Gram matrices (twice the workgroups, half the serial MFMA work per
+// workgroup, no Gram in the critical path): for callers that take the Gram matrices from the split image (gram_image.h).
+// x3_out is mandatory here.
+hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
+                                float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
+                                void* x3_out, int x3_ks);
+// G (64 x 64) = P P^T from the split image of P (image_ks K-steps); normalize / scale as in GramReduceArgs.  Stand-alone form
+// of the passenger workgroups of the split-operand product launch.
+hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream);
 // P(c, y) *= scale(c)
 hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
 // G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and

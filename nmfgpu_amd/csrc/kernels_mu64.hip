@@ -23,6 +23,7 @@
 
 #include "kernels.h"
 #include "split3.h"
+#include "gram_image.h"
 
 namespace nmfamd {
 
@@ -212,6 +213,173 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 	static const int dbg = [] { const char* e = getenv("NMFAMD_U_SKIP"); return e ? atoi(e) : 0; }();
 	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks, dbg);
 	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks, dbg);
+	return hipGetLastError();
+}
+
+// ---- the same update on 32-column tiles, Gram matrices taken elsewhere (gram_image.h) --------------------------------
+// Measured on k_mu64_update at config 2 (profiles/r02_update_kernel_parts.md): of 9.4 / 10.8 us per launch the partial
+// Gram costs 2.0 - 2.4, the r x r product 2.2 - 2.4, the split image 1.3 - 1.7, and 5 - 6 us are the floor of one round trip
+// (launch, slabs in, LDS, panel out) -- the kernel is ONE wave of workgroups on 79 / 157 of 256 CUs, so its time is the
+// serial chain of one workgroup.  Here: half the tile (twice the workgroups, half the MFMA chain per workgroup), the r x r
+// product on v_mfma_f32_16x16x4_f32 with the K order chosen so that both operands are 16-byte reads (lane group q of the
+// MFMA holds c' = 16 q + t in step t), no Gram.
+// Workgroup = 4 waves = 32 panel columns.  Wave w owns result rows c = 16 w .. 16 w + 15 for both 16-column halves.
+template <bool IS_W>
+__global__ __launch_bounds__(256) void k_mu64_update32(
+	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
+	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
+	float* __restrict__ ps, int len_valid, const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks) {
+	typedef float f32x4v __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) float s_num[32][68];   // reduced numerator, later the new values
+	__shared__ __attribute__((aligned(16))) float s_old[32][68];   // old values (scaled for the W update)
+	__shared__ float s_ps[4][32];
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int q = lane >> 4, l15 = lane & 15;
+	const long tile = (long)blockIdx.x * 32 * 64;
+	const int c4 = (4 * tid) & 63;          // this thread's four panel rows in the linear pass
+	const int yl0 = tid >> 4;               // its panel column in step j is yl0 + 16 j
+
+	// ---- linear pass: slab sum (slab order), pending scale, into LDS ---------------------------
+	f32x4v nl[2], ol[2];
+	{
+		f32x4v t[7][2];
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const long e = tile + 4 * (tid + 256 * j);
+			nl[j] = *reinterpret_cast<const f32x4v*>(slabs + e);
+			ol[j] = *reinterpret_cast<const f32x4v*>(P + e);
+#pragma unroll
+			for (int u = 0; u < 7; ++u) {
+				const int k = 1 + u < S ? 1 + u : 0;   // clamped duplicate, discarded below
+				t[u][j] = *reinterpret_cast<const f32x4v*>(slabs + (long)k * slab_stride + e);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 7; ++u)
+			if (1 + u < S) {
+#pragma unroll
+				for (int j = 0; j < 2; ++j) nl[j] += t[u][j];
+			}
+		for (int k0 = 8; k0 < S; k0 += 7) {      // more than eight slabs: further batches of seven
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+#pragma unroll
+				for (int u = 0; u < 7; ++u) {
+					const int k = k0 + u < S ? k0 + u : 0;
+					t[u][j] = *reinterpret_cast<const f32x4v*>(slabs + (long)k * slab_stride + tile + 4 * (tid + 256 * j));
+				}
+#pragma unroll
+			for (int u = 0; u < 7; ++u)
+				if (k0 + u < S) {
+#pragma unroll
+					for (int j = 0; j < 2; ++j) nl[j] += t[u][j];
+				}
+		}
+	}
+	const f32x4v sc = *reinterpret_cast<const f32x4v*>(scale + c4);
+	// A operand of the r x r product: Q(c = 16 wave + l15, c' = 16 q + t), t = 0 .. 15 (Q is symmetric: a row is a column)
+	f32x4v qa[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		// the pending column scale of W goes on the numerator W^T V (H update) or on W itself (W update)
+		if (IS_W) ol[j] *= sc; else nl[j] *= sc;
+		*reinterpret_cast<f32x4v*>(&s_num[yl0 + 16 * j][c4]) = nl[j];
+		*reinterpret_cast<f32x4v*>(&s_old[yl0 + 16 * j][c4]) = ol[j];
+	}
+	__syncthreads();
+
+	// ---- den = Q * old on the matrix pipe, two independent 16 x 16 accumulators per wave -------
+	f32x4v ob[2][4];
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+		for (int u = 0; u < 4; ++u) ob[yt][u] = *reinterpret_cast<const f32x4v*>(&s_old[16 * yt + l15][16 * q + 4 * u]);
+	f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+	for (int u = 0; u < 4; ++u)
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u][g], ob[0][u][g], acc[0], 0, 0, 0);
+			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u][g], ob[1][u][g], acc[1], 0, 0, 0);
+		}
+	// C/D map: register g of lane (q, l15) is row c = 16 wave + 4 q + g, column y = 16 yt + l15
+#pragma unroll
+	for (int yt = 0; yt < 2; ++yt) {
+		const int y = 16 * yt + l15;
+		const f32x4v oldv = *reinterpret_cast<const f32x4v*>(&s_old[y][16 * wave + 4 * q]);
+		const f32x4v numv = *reinterpret_cast<const f32x4v*>(&s_num[y][16 * wave + 4 * q]);
+		f32x4v o;
+		float psum = 0.f;
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			o[g] = oldv[g] * numv[g] / (acc[yt][g] + eps);
+			psum += o[g] * numv[g];
+		}
+		// each (column, four rows) of s_num is read and then overwritten by exactly one lane
+		*reinterpret_cast<f32x4v*>(&s_num[y][16 * wave + 4 * q]) = o;
+		if (!IS_W && compute_error) {
+			psum += __shfl_xor(psum, 16);
+			psum += __shfl_xor(psum, 32);
+			if (q == 0) s_ps[wave][y] = psum;
+		}
+	}
+	if (IS_W && compute_error && blockIdx.x == 0) {
+		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (AlgorithmMultiplicativeFrobenius.h:212)
+		for (int d = wave * 16; d < wave * 16 + 16; ++d) {
+			float v = Q[(long)lane * 64 + d] * Gprev[(long)d * 64 + lane];
+			for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w);
+			if (lane == 0) ps[d] = v;
+		}
+	}
+	__syncthreads();
+	if (!IS_W && compute_error && tid < 32) {
+		// per-column terms of tr(H^T W^T V) (kernel::traceMultiplication, AlgorithmMultiplicativeFrobenius.h:194-197)
+		const int ycol = blockIdx.x * 32 + tid;
+		if (ycol < len_valid) ps[ycol] = ((s_ps[0][tid] + s_ps[1][tid]) + s_ps[2][tid]) + s_ps[3][tid];
+	}
+	// ---- result out (coalesced) and the split image of the two K-steps this tile is --------------
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+		*reinterpret_cast<f32x4v*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4v*>(&s_num[yl0 + 16 * j][c4]);
+	{
+		const int r = tid & 31, h = (tid >> 5) & 1, nb = (tid >> 6) & 1, kk = tid >> 7;
+		const long ks = 2l * blockIdx.x + kk;
+		if (ks < x3_ks) {
+			float v[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int yl = 16 * kk + 8 * h + j;
+				v[j] = blockIdx.x * 32 + yl < len_valid ? s_num[yl][32 * nb + r] : 0.f;
+			}
+			store_split3(x3_out, ks, 2, nb, h, r, v);
+		}
+	}
+}
+
+hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
+                                float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
+                                void* x3_out, int x3_ks) {
+	if (x3_out == nullptr || len_pad % 32 != 0) return hipErrorInvalidValue;
+	dim3 grid(len_pad / 32), block(256);
+	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
+	if (is_w) hipLaunchKernelGGL((k_mu64_update32<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks);
+	else hipLaunchKernelGGL((k_mu64_update32<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks);
+	return hipGetLastError();
+}
+
+// Stand-alone form of the Gram-from-image passengers (callers that have no product launch to ride in)
+__global__ __launch_bounds__(256) void k_gram_image(GramReduceArgs rg) {
+	__shared__ __attribute__((aligned(16))) float lds[3456];
+	gram_image_block(rg, blockIdx.x, lds);
+}
+
+hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream) {
+	GramReduceArgs rg = {nullptr, 0, G, scale, normalize};
+	rg.image = image; rg.image_ks = image_ks;
+	hipLaunchKernelGGL(k_gram_image, dim3(GRAM_REDUCE_BLOCKS), dim3(256), 0, stream, rg);
 	return hipGetLastError();
 }
 

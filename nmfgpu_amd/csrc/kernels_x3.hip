@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "split3.h"
 #include "inverse_gj64.h"
+#include "gram_image.h"
 
 namespace nmfamd {
 
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	if (blockIdx.x >= (unsigned)pblocks) {
 		// the 64 x 64 inverse of the least-squares algorithms rides as ONE block right behind the product's last one
 		if (rg.inv_a != nullptr) inverse_gj64_body<float, X3_WAVES>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
+		else if (rg.image != nullptr) { if (X3_WAVES == 4) gram_image_block(rg, blockIdx.x - pblocks, lds); }
 		else gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
 		return;
 	}
@@ -405,7 +407,7 @@ template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG 
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr);
+	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
 	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);

@@ -25,6 +25,11 @@
 
 namespace nmfamd {
 
+#ifndef NMFAMD_XCD_REMAP
+#define NMFAMD_XCD_REMAP 1
+#endif
+constexpr bool XCD_REMAP = NMFAMD_XCD_REMAP != 0;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Factor fragments: Fx[(((ks * NBT + nb) * 3 + plane) * 2 + h) * 32 + r][8] = plane of F(c = 32 nb + r, y = 16 ks + 8 h + j)
@@ -146,7 +151,15 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		else gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
 		return;
 	}
-	const int xt = blockIdx.x % xtiles, sp = blockIdx.x / xtiles;
+	// XCD-aware placement (speed only): blocks b and b + 8 share an XCD and its L2; each XCD takes a CONTIGUOUS range of
+	// (slice, x-tile) pairs, so the workgroups that stream the same factor fragments -- one K slice -- sit on one or two XCDs
+	// and that slice of the factor image is fetched into one or two L2s instead of all eight
+	int vb = blockIdx.x;
+	if (XCD_REMAP) {
+		const int q8 = pblocks / 8, r8 = pblocks % 8, xcd = vb % 8, idx = vb / 8;
+		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+	}
+	const int xt = vb % xtiles, sp = vb / xtiles;
 	const int coff = 32 * NBW * blockIdx.y;
 	const long fstep = (long)NBT * 192;                 // factor fragments per K-step
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -54,7 +54,7 @@ Status Engine<T>::hip_fail(hipError_t e, const char* what) {
 
 template <typename T>
 Engine<T>::~Engine() {
-	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, psR_, stage_};
+	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, stage_};   // (psR_ lives behind psN_)
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
 	{
@@ -69,8 +69,7 @@ Engine<T>::~Engine() {
 	if (ev_fork_) (void)hipEventDestroy(ev_fork_);
 	if (ev_join_) (void)hipEventDestroy(ev_join_);
 	if (aux_) (void)hipStreamDestroy(aux_);
-	if (pin_psN_) (void)hipHostFree(pin_psN_);
-	if (pin_psR_) (void)hipHostFree(pin_psR_);
+	if (pin_psN_) (void)hipHostFree(pin_psN_);   // (pin_psR_ lives behind it)
 	for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
 }
 
@@ -199,8 +198,10 @@ Status Engine<T>::allocate() {
 	HIPX(dalloc(&Qinv_, rr));
 	HIPX(dalloc(&gram_part_, rr * gram_parts_));
 	HIPX(dalloc(&sumsq_part_, ((long)std::max(panel_update_parts(RP_, sizeof(T), (int)mpad_), (int)(mpad_ / panel_update_rows(RP_, sizeof(T)))) + 16) * RP_));
-	HIPX(dalloc(&psN_, std::max<long>(npad_, RP_)));
-	HIPX(dalloc(&psR_, RP_));
+	// the two error-term vectors share one allocation (and one pinned landing buffer): ONE device-to-host copy per error iteration
+	ps_stride_ = std::max<long>(npad_, RP_);
+	HIPX(dalloc(&psN_, ps_stride_ + RP_));
+	psR_ = psN_ + ps_stride_;
 	HIPX(dalloc(&stage_, std::max(mpad_, npad_) * RP_));
 	if (alg_ == ALG_NSNMF) {
 		HIPX(dalloc(&Ws_, panelW));
@@ -222,8 +223,8 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
 	}
-	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)std::max<long>(n_, r_)));
-	HIPX(hipHostMalloc((void**)&pin_psR_, sizeof(T) * (size_t)r_));
+	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
+	pin_psR_ = pin_psN_ + ps_stride_;
 	HIPX(hipEventCreateWithFlags(&err_event_, hipEventDisableTiming));
 	HIPX(hipStreamSynchronize(stream_));
 	return ST_OK;
@@ -603,8 +604,8 @@ Status Engine<T>::normal_inverse_join() {
 template <typename T>
 Status Engine<T>::fetch_error_terms(int count_n) {
 	finalize_error(false);   // the pinned buffers are about to be reused; an older fetch is long complete
-	HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * count_n, hipMemcpyDeviceToHost, stream_));
-	HIPX(hipMemcpyAsync(pin_psR_, psR_, sizeof(T) * r_, hipMemcpyDeviceToHost, stream_));
+	(void)count_n;
+	HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
 	HIPX(hipEventRecord(err_event_, stream_));
 	err_pending_ = true;
 	err_count_ = count_n;

@@ -195,6 +195,7 @@ private:
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;
+	long ps_stride_ = 0;
 	double* inv_work_ = nullptr;
 	T* stage_ = nullptr;                      // upload/download staging (max(m, n) x r)
 	long slab_stride_ = 0;

@@ -33,7 +33,10 @@ enum {
 	NMFAMD_NO_DEVICE_MEMORY = 2,
 	NMFAMD_NO_HOST_MEMORY = 3,
 	NMFAMD_HIP_ERROR = 4,
-	NMFAMD_NO_DEVICE = 5
+	NMFAMD_NO_DEVICE = 5,
+	NMFAMD_VALUE_RANGE = 6   /* upload: V holds infinities, NaN, |v| > 2^126 or 0 < |v| < 2^-100, which the default fp32 product (operands split
+	                            exactly into three bf16 terms) does not cover: create the engine with nmfamd_params.precision = -1 (native fp32
+	                            MFMA instructions).  nmfgpu::compute and the Python Engine do that by themselves. */
 };
 
 /* algorithm ids = nmfgpu::NmfAlgorithm (include/nmfgpu.h:107-114) */

@@ -49,7 +49,13 @@ def _deps() -> float:
     return newest
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag: the measurement build (-DNMFAMD_DIAG_BUILD, csrc/tuning.h) -> lib/libnmfgpu64_diag.so; select it with NMFAMD_LIBRARY."""
+    global LIB, OBJDIR, USER_FLAGS
+    if diag:
+        LIB = os.path.join(LIBDIR, "libnmfgpu64_diag.so")
+        OBJDIR = os.path.join(LIBDIR, "obj_diag")
+        USER_FLAGS = [*USER_FLAGS, "-DNMFAMD_DIAG_BUILD"]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
@@ -84,4 +90,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, diag="--diag" in sys.argv))

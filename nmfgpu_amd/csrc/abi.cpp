@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -33,9 +34,9 @@ namespace nmfgpu {
 namespace {
 
 // ---- logging (source/common/Logging.h:89-109: one process-wide verbosity) ------------------
-Verbosity g_verbosity = Verbosity::Summary;
+std::atomic<Verbosity> g_verbosity{Verbosity::Summary};
 
-bool allowed(Verbosity level) { return static_cast<int>(g_verbosity) >= static_cast<int>(level); }
+bool allowed(Verbosity level) { return static_cast<int>(g_verbosity.load(std::memory_order_relaxed)) >= static_cast<int>(level); }
 
 void log_error(const char* text) { std::cerr << text << std::endl; }
 void log_summary(const char* text) { if (allowed(Verbosity::Summary)) { std::cout << text; std::cout.flush(); } }
@@ -388,7 +389,7 @@ NMFGPU_EXPORT ResultType getInformationForGpuIndex(unsigned index, GpuInformatio
 	return ResultType::Success;
 }
 
-NMFGPU_EXPORT void setVerbosity(Verbosity verbosity) { g_verbosity = verbosity; }
+NMFGPU_EXPORT void setVerbosity(Verbosity verbosity) { g_verbosity.store(verbosity, std::memory_order_relaxed); }
 
 NMFGPU_EXPORT ISummary* ISummary::create() { return new SummaryImpl(); }
 

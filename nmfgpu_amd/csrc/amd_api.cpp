@@ -10,6 +10,7 @@
 #include "../../include/nmfgpu_amd.h"
 #include "comm.h"
 #include "engine.h"
+#include "tuning.h"
 #include "host_init.h"
 #include "sharded.h"
 
@@ -513,7 +514,7 @@ int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, 
 	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemset(dT.p, 0, sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_HIP_ERROR;
 	// NMFAMD_X3_VARIANT >= 30: the y-tiled form on 16-row tiles (any buffer of the right size is an image of random data)
-	const char* ve = std::getenv("NMFAMD_X3_VARIANT");
+	const char* ve = tuning_env("NMFAMD_X3_VARIANT");
 	const bool ytiled = ve != nullptr && std::atoi(ve) >= 30;
 	unsigned long long* dummy = nullptr;
 	for (int i = 0; i < 6; ++i) {

@@ -9,6 +9,7 @@
 // but the eight vendor-BLAS calls + five custom kernels of one iteration collapse into the
 // fused kernels of kernels.hip (see DESIGN.md section 4 for the mapping).
 #include "engine.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +42,15 @@ double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv
 template double resolve_frobenius<float>(const std::vector<float>&, std::vector<float>&, std::vector<float>&);
 template double resolve_frobenius<double>(const std::vector<double>&, std::vector<double>&, std::vector<double>&);
 
+// Size of the device's memory-side cache (AMD Infinity Cache): not in hipDeviceProp_t, so a table by architecture -- 256 MiB
+// on gfx942 / gfx950 in SPX mode (/opt/skills/guides/MI355X_MICROARCH.md, "Infinity Cache (L3) 256 MiB") -- which
+// NMFAMD_MALL_MB overrides (other parts, partitioned modes, several engines sharing the cache).  0 = unknown: no window.
+static size_t memory_side_cache_bytes(const hipDeviceProp_t& prop) {
+	if (const char* e = std::getenv("NMFAMD_MALL_MB")) { const long mb = std::atol(e); return mb > 0 ? (size_t)mb << 20 : 0; }
+	if (std::strncmp(prop.gcnArchName, "gfx942", 6) == 0 || std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) return (size_t)256 << 20;
+	return 0;
+}
+
 template <typename T>
 Engine<T>::Engine(int m, int n, int r, int algorithm, const AlgorithmParams& params)
 	: m_(m), n_(n), r_(r), RP_(padded_rank(r)), alg_(algorithm), prm_(params), mpad_(pad128(m)), npad_(pad128(n)) {}
@@ -57,6 +67,7 @@ Engine<T>::~Engine() {
 	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, stage_};   // (psR_ lives behind psN_)
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
+	if (range_flag_) (void)hipFree(range_flag_);
 	{
 		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
 		for (void* b : sp) if (b) (void)hipFree(b);
@@ -88,7 +99,7 @@ Status Engine<T>::allocate() {
 	planW_ = f64 ? plan_factor_product_f64(m_, n_, RP_, num_cus_) : plan_factor_product(m_, n_, RP_, num_cus_);
 	const bool mfma = std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 	// ranks <= 32: the fp32 product computes 32 panel columns instead of 64 (half the MFMA work; the kernel turns HBM-bound)
-	if (RP_ == 64 && r_ <= 32 && std::getenv("NMFAMD_FP_FULL_WIDTH") == nullptr) { planH_.nb = f64 ? 2 : 1; planW_.nb = planH_.nb; }      // (fp64 counts 16-column tiles)
+	if (RP_ == 64 && r_ <= 32 && tuning_env("NMFAMD_FP_FULL_WIDTH") == nullptr) { planH_.nb = f64 ? 2 : 1; planW_.nb = planH_.nb; }      // (fp64 counts 16-column tiles)
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
 	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;
@@ -115,10 +126,13 @@ Status Engine<T>::allocate() {
 	// the fp32 MFMA rate.  precision = -1 (or NMFAMD_FP32_NATIVE) keeps the native fp32 MFMA instructions.
 	// (ranks <= 32 stay on the fp32 MFMA kernel: with half its MFMA work it is HBM-bound already and needs no split image)
 	// ... except where one image in the memory-side cache pays more than the halved MFMA work (§3: 107 -> 100 us at config 2's shape)
+	// One resident image pays when it fits the memory-side (Infinity) cache and two do not: a window around the cache size,
+	// computed once (cache_window_) from the device (memory_side_cache_bytes)
 	const size_t image_bytes = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
-	const bool cache_window = image_bytes > (size_t)160e6 && image_bytes < (size_t)300e6 && std::getenv("NMFAMD_ONE_IMAGE") == nullptr;
+	const size_t mall = memory_side_cache_bytes(prop);
+	const bool cache_window = mall > 0 && (double)image_bytes > 0.6 * (double)mall && (double)image_bytes < 1.12 * (double)mall && std::getenv("NMFAMD_ONE_IMAGE") == nullptr;
 	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && (planH_.nb == 2 || cache_window) &&
-	    std::getenv("NMFAMD_FP32_NATIVE") == nullptr) {
+	    tuning_env("NMFAMD_FP32_NATIVE") == nullptr) {
 		planH_.nb = planW_.nb = 2;
 		x3_ = true;
 		planH_.th = planW_.th = 128;
@@ -140,14 +154,14 @@ Status Engine<T>::allocate() {
 		const size_t image_b = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
 		const char* force = std::getenv("NMFAMD_ONE_IMAGE");
 		if (force != nullptr) one_image_ = std::atoi(force) != 0;
-		else if (image_b > (size_t)160e6 && image_b < (size_t)300e6) one_image_ = true;
+		else if (cache_window) one_image_ = true;
 		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 3 * image_b + (image_b >> 3) > free_b) one_image_ = true;
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
 	if (row_blocks_ > 1) { const long g = 128l * row_blocks_; mpad_ = ((mpad_ + g - 1) / g) * g; }   // equal row blocks of whole 128-row tiles
 	npad_ = pad128(std::max<long>(n_, (long)planH_.xtiles * planH_.th));
-	img_th_ = (one_image_ && std::getenv("NMFAMD_IMAGE_TILE128") == nullptr) ? 16 : planW_.th;
+	img_th_ = (one_image_ && tuning_env("NMFAMD_IMAGE_TILE128") == nullptr) ? 16 : planW_.th;
 	strideV_ = (long)img_th_ * npad_;
 	strideVt_ = (long)planH_.th * mpad_;
 	elemsV_ = mpad_ * npad_;     // tiled or not: every tile spans all columns
@@ -188,7 +202,7 @@ Status Engine<T>::allocate() {
 	HIPX(dalloc(&H_, panelH));
 	// wide fp32 panels: scratch for the split image of the r x r matrix the update kernel multiplies with (kernels_wide.hip)
 	if (std::is_same<T, float>::value && panel_update_wide_available(RP_) && std::getenv("NMFAMD_FORCE_VALU") == nullptr &&
-	    std::getenv("NMFAMD_WIDE_FP32_MFMA") == nullptr)
+	    tuning_env("NMFAMD_WIDE_FP32_MFMA") == nullptr)
 		HIPX(hipMalloc(&qx3_, 3 * 16 * (size_t)(RP_ / 16 + 1) * (RP_ / 32) * 64));
 	HIPX(dalloc(&slabs_, slab_elems));
 	HIPX(dalloc(&numW_, panelW));
@@ -203,6 +217,7 @@ Status Engine<T>::allocate() {
 	HIPX(dalloc(&psN_, ps_stride_ + RP_));
 	psR_ = psN_ + ps_stride_;
 	HIPX(dalloc(&stage_, std::max(mpad_, npad_) * RP_));
+	HIPX(hipMalloc((void**)&range_flag_, sizeof(int)));
 	if (alg_ == ALG_NSNMF) {
 		HIPX(dalloc(&Ws_, panelW));
 		HIPX(dalloc(&Hs_, panelH));
@@ -210,7 +225,7 @@ Status Engine<T>::allocate() {
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
-		if (std::getenv("NMFAMD_NO_OVERLAP") == nullptr) {
+		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr) {
 			HIPX(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
 			HIPX(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 			HIPX(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -237,9 +252,12 @@ Status Engine<T>::allocate() {
 // is a temporary.  Generic path: V_ IS the column-major image and Vt_ its plain transpose.
 template <typename T>
 Status Engine<T>::finish_upload(T* Vcol) {
-	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_));
+	int odd_values = 0;
+	HIPX(hipMemsetAsync(range_flag_, 0, sizeof(int), stream_));
+	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_, x3_ ? range_flag_ : nullptr));
 	h_vtv_.resize(n_);
 	HIPX(hipMemcpyAsync(h_vtv_.data(), psN_, sizeof(T) * n_, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipMemcpyAsync(&odd_values, range_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_));
 	if (bf16_) {
 		if constexpr (std::is_same<T, float>::value) {
 			HIPX(launch_pack_stream_bf16(Vcol, mpad_, m_, n_, false, Vb_, planW_.xtiles, ksW_, stream_));
@@ -257,6 +275,10 @@ Status Engine<T>::finish_upload(T* Vcol) {
 	}
 	HIPX(hipStreamSynchronize(stream_));
 	std::sort(h_vtv_.begin(), h_vtv_.end());
+	if (x3_ && odd_values != 0) {
+		last_error_ = "V holds values outside the exact range of the split-operand product (not finite, |v| > 2^126 or 0 < |v| < 2^-100): use precision = -1";
+		return ST_VALUE_RANGE;
+	}
 	return ST_OK;
 }
 
@@ -589,7 +611,7 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 template <typename T>
 bool Engine<T>::inverse_rides(const FactorProductPlan& plan) const {
 	return std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ == 64 && r_ <= 64 && plan.xtiles >= GRAM_REDUCE_BLOCKS &&
-	       std::getenv("NMFAMD_NO_OVERLAP") == nullptr && std::getenv("NMFAMD_INVERSE_SIDE_STREAM") == nullptr;
+	       tuning_env("NMFAMD_NO_OVERLAP") == nullptr && tuning_env("NMFAMD_INVERSE_SIDE_STREAM") == nullptr;
 }
 
 template <typename T>
@@ -825,7 +847,7 @@ bool Engine<T>::fused_capable() const {
 template <typename T>
 bool Engine<T>::gram_from_update() const {
 	return std::is_same<T, float>::value && alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS && panel_update_delivers_gram(RP_, sizeof(T)) &&
-	       std::getenv("NMFAMD_NO_GRAM_FROM_UPDATE") == nullptr;
+	       tuning_env("NMFAMD_NO_GRAM_FROM_UPDATE") == nullptr;
 }
 
 // Column normalisation of W after its update (kernel::normalizeColumns).  With partial Gram matrices of the unnormalised W

@@ -25,7 +25,9 @@ struct AlgorithmParams {
 };
 
 // Status codes shared with nmfgpu_amd.h (NMFAMD_*).
-enum Status { ST_OK = 0, ST_INVALID = 1, ST_NO_DEVICE_MEMORY = 2, ST_NO_HOST_MEMORY = 3, ST_HIP_ERROR = 4, ST_NO_DEVICE = 5 };
+// ST_VALUE_RANGE: V holds values the split-operand product is not exact for (infinities, NaN, |v| > 2^126, 0 < |v| < 2^-100):
+// the caller recreates the engine with precision = -1 (native fp32 MFMA instructions) -- nmfgpu::compute does that by itself
+enum Status { ST_OK = 0, ST_INVALID = 1, ST_NO_DEVICE_MEMORY = 2, ST_NO_HOST_MEMORY = 3, ST_HIP_ERROR = 4, ST_NO_DEVICE = 5, ST_VALUE_RANGE = 6 };
 
 inline int padded_rank(int r) { return r <= 64 ? 64 : ((r + 127) / 128) * 128; }
 inline long pad128(long v) { return ((v + 127) / 128) * 128; }
@@ -198,6 +200,7 @@ private:
 	long ps_stride_ = 0;
 	double* inv_work_ = nullptr;
 	T* stage_ = nullptr;                      // upload/download staging (max(m, n) x r)
+	int* range_flag_ = nullptr;               // device word, see launch_column_sumsq
 	long slab_stride_ = 0;
 	int gram_parts_ = 128;
 	FactorProductPlan planH_, planW_;

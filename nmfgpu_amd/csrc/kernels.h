@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace nmfamd {
 
 // How one factor product OUT(c, x) = sum_y F(c, y) A(x, y) is cut into workgroups.
@@ -23,13 +25,15 @@ FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);
 // `parts` partial 64 x 64 Gram matrices into G, optionally turning its diagonal into column scales.
 // Raises a kernel's dynamic LDS limit once per DEVICE (the attribute is per device; a process may switch
 // devices through nmfgpu::chooseGpu).  `done` is the caller's static bit mask, one bit per device ordinal.
-inline hipError_t allow_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
+// (several threads may compute at once -- per-thread contexts, rank threads of a "numGpus" team: the mask is atomic; a lost
+// race only repeats the idempotent hipFuncSetAttribute)
+inline hipError_t allow_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
-	if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+	if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
 	e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-	if (e == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+	if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
 	return e;
 }
 
@@ -169,8 +173,11 @@ hipError_t launch_inverse_small(T* A, int RP, int r, T* Ainv, double* work, T of
 template <typename T>
 hipError_t launch_transpose(const T* src, long lds, int rows, int cols, T* dst, long ldd, hipStream_t stream);
 
+// range_flag (optional, fp32): bit 0 is set when V holds a value outside what the split-operand product (kernels_x3.hip) is
+// exact for -- not finite, |v| > 2^126 (the first bf16 cut would round to infinity) or 0 < |v| < 2^-100 (the third term would
+// fall into the flushed bf16 subnormals)
 template <typename T>
-hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream);
+hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream, int* range_flag = nullptr);
 
 // format: 1 CSR (ptr = rowPtr, idx = column indices), 2 CSC (ptr = columnPtr, idx = row indices),
 // 3 COO (idx = row indices, idx2 = column indices); outer = rows (CSR) / columns (CSC).

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "tuning.h"
 #include "inverse_gj64.h"
 
 namespace nmfamd {
@@ -378,7 +379,7 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), p.chunks), block(512);      // passengers only ever with one chunk (RP == 64)
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f32<XB, D, STAMP, DIAG, NB>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_f32<XB, D, STAMP, DIAG, NB>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, with_reduce ? *rg : none, stamps);
@@ -389,7 +390,7 @@ static hipError_t launch_fp_d(const FactorProductPlan& p, const float* A, long t
 static int fp_depth() {
 	static int d = -1;
 	if (d < 0) {
-		const char* e = getenv("NMFAMD_FP_DEPTH");
+		const char* e = tuning_env("NMFAMD_FP_DEPTH");
 		d = e ? atoi(e) : 8;
 		if (d != 4 && d != 6 && d != 8) d = 8;
 	}
@@ -402,17 +403,21 @@ static hipError_t launch_fp(const FactorProductPlan& p, const float* A, long til
 	// ranks <= 32 (plan.nb == 1, padded rank 64): only the first 32 panel columns are computed and written; the other
 	// 32 columns of every slab stay at the zeros they were allocated with
 	if (p.nb == 1 && RP == 64 && XB == 4) return launch_fp_d<4, 8, false, 0, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
+#ifdef NMFAMD_DIAG_BUILD
 	switch (fp_depth()) {
 	case 4: return launch_fp_d<XB, 4, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
 	case 6: return launch_fp_d<XB, 6, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
-	default: return launch_fp_d<XB, 8, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
+	default: break;
 	}
+#endif
+	return launch_fp_d<XB, 8, false>(p, A, tile_stride, F, RP, slabs, slab_stride, rg, nullptr, stream);
 }
 
 hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
                                              float* slabs, long slab_stride, unsigned long long* stamps, hipStream_t stream) {
+#ifdef NMFAMD_DIAG_BUILD
 	static int diag = -1;
-	if (diag < 0) { const char* e = getenv("NMFAMD_FP_DIAG"); diag = e ? atoi(e) : 0; }
+	if (diag < 0) { const char* e = tuning_env("NMFAMD_FP_DIAG"); diag = e ? atoi(e) : 0; }
 	if (p.th == 160) return launch_fp_d<5, 8, true, 0>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 	switch (diag) {
 	case 1: return launch_fp_d<4, 8, true, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
@@ -420,6 +425,10 @@ hipError_t launch_factor_product_f32_stamped(const FactorProductPlan& p, const f
 	case 3: return launch_fp_d<4, 8, true, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 	default: return launch_fp_d<4, 8, true, 0>(p, A, tile_stride, F, RP, slabs, slab_stride, nullptr, stamps, stream);
 	}
+#else
+	(void)p; (void)A; (void)tile_stride; (void)F; (void)RP; (void)slabs; (void)slab_stride; (void)stamps; (void)stream;
+	return hipErrorNotSupported;      // stamped kernels exist in the diagnostic build only (tuning.h)
+#endif
 }
 
 hipError_t launch_factor_product_f32(const FactorProductPlan& p, const float* A, long tile_stride, const float* F, int RP,
@@ -658,14 +667,14 @@ int panel_update_rows(int RP, size_t elem) {
 static bool use_wide_update(int RP) { return panel_update_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr; }
 
 int panel_update_parts(int RP, size_t elem, int len_pad) {
-	if (elem == 4 && RP == 64) return std::getenv("NMFAMD_UPDATE64_OLD") ? len_pad / 128 : len_pad / 64;   // k_panel_update64_lds_f32 (old: k_panel_update64_f32)
+	if (elem == 4 && RP == 64) return tuning_env("NMFAMD_UPDATE64_OLD") ? len_pad / 128 : len_pad / 64;   // k_panel_update64_lds_f32 (old: k_panel_update64_f32)
 	if (elem == 4 && use_wide_update(RP)) return len_pad / 32;   // k_panel_update_wide_f32
 	if (elem == 8 && panel_update_wide_f64_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return len_pad / 16;   // k_panel_update_wide_f64
 	return len_pad / panel_update_rows(RP, elem);
 }
 
 bool panel_update_delivers_gram(int RP, size_t elem) {
-	return elem == 4 && RP == 64 && std::getenv("NMFAMD_UPDATE64_OLD") == nullptr && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
+	return elem == 4 && RP == 64 && tuning_env("NMFAMD_UPDATE64_OLD") == nullptr && std::getenv("NMFAMD_FORCE_VALU") == nullptr;
 }
 
 template <typename T>
@@ -674,7 +683,7 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 	if ((gram_partial != nullptr || x3_out != nullptr) && !(panel_update_delivers_gram(RP, sizeof(T)) && mode != MODE_SET)) return hipErrorInvalidValue;
 	if constexpr (std::is_same<T, float>::value) {
 		if (RP == 64 && mode != MODE_SET) {
-			if (std::getenv("NMFAMD_UPDATE64_OLD")) return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
+			if (tuning_env("NMFAMD_UPDATE64_OLD")) return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 			return launch_panel_update64_lds_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, gram_partial, x3_out, x3_ks);
 		}
 		if (use_wide_update(RP) && mode != MODE_SET)
@@ -918,9 +927,10 @@ template hipError_t launch_inverse_small<double>(double*, int, int, double*, dou
 // ------------------------------------------------------------------------------------------
 // dst(j, i) = src(i, j); src is rows x cols with leading dimension lds_, dst has leading dimension ldd.
 template <typename T>
-__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, long lds_, int rows, int cols, T* __restrict__ dst, long ldd) {
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, long lds_, int rows, int cols, T* __restrict__ dst, long ldd, unsigned gx) {
 	__shared__ T tile[32][33];
-	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	// one-dimensional grid (grid.y stops at 65 535: a 2.1 M-row panel would not launch): block b = (b % gx, b / gx)
+	const int i0 = (int)(blockIdx.x % gx) * 32, j0 = (int)(blockIdx.x / gx) * 32;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 	for (int jj = ty; jj < 32; jj += 8) {
 		int i = i0 + tx, j = j0 + jj;
@@ -935,8 +945,9 @@ __global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, lo
 
 template <typename T>
 hipError_t launch_transpose(const T* src, long lds_, int rows, int cols, T* dst, long ldd, hipStream_t stream) {
-	dim3 grid((rows + 31) / 32, (cols + 31) / 32), block(256);
-	hipLaunchKernelGGL((k_transpose<T>), grid, block, 0, stream, src, lds_, rows, cols, dst, ldd);
+	const unsigned gx = (unsigned)((rows + 31) / 32), gy = (unsigned)((cols + 31) / 32);
+	if ((unsigned long long)gx * gy > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL((k_transpose<T>), dim3(gx * gy), dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd, gx);
 	return hipGetLastError();
 }
 template hipError_t launch_transpose<float>(const float*, long, int, int, float*, long, hipStream_t);
@@ -945,11 +956,17 @@ template hipError_t launch_transpose<double>(const double*, long, int, int, doub
 // ps(j) = sum_i V(i, j)^2 -- the per-column terms of tr(V^T V)
 // (kernel::traceMultiplication<true>(V, V), AlgorithmMultiplicativeFrobenius.h:119-121)
 template <typename T>
-__global__ __launch_bounds__(256) void k_column_sumsq(const T* __restrict__ V, long ldv, int rows, T* __restrict__ ps) {
+__global__ __launch_bounds__(256) void k_column_sumsq(const T* __restrict__ V, long ldv, int rows, T* __restrict__ ps, int* __restrict__ range_flag) {
 	__shared__ T red[256];
 	const T* col = V + (long)blockIdx.x * ldv;
 	T s = 0;
-	for (int i = threadIdx.x; i < rows; i += 256) s += col[i] * col[i];
+	bool odd = false;      // a value the exact three-way bf16 split of kernels_x3.hip does not cover (see launch_column_sumsq)
+	for (int i = threadIdx.x; i < rows; i += 256) {
+		const T v = col[i];
+		s += v * v;
+		if (sizeof(T) == 4) { const float a = fabsf((float)v); odd |= !(a <= 0x1p126f) || (a != 0.f && a < 0x1p-100f); }
+	}
+	if (range_flag != nullptr && __any(odd) && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
 	red[threadIdx.x] = s;
 	__syncthreads();
 	for (int w = 128; w > 0; w >>= 1) {
@@ -960,12 +977,12 @@ __global__ __launch_bounds__(256) void k_column_sumsq(const T* __restrict__ V, l
 }
 
 template <typename T>
-hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream) {
-	hipLaunchKernelGGL((k_column_sumsq<T>), dim3(cols), dim3(256), 0, stream, V, ldv, rows, ps);
+hipError_t launch_column_sumsq(const T* V, long ldv, int rows, int cols, T* ps, hipStream_t stream, int* range_flag) {
+	hipLaunchKernelGGL((k_column_sumsq<T>), dim3(cols), dim3(256), 0, stream, V, ldv, rows, ps, range_flag);
 	return hipGetLastError();
 }
-template hipError_t launch_column_sumsq<float>(const float*, long, int, int, float*, hipStream_t);
-template hipError_t launch_column_sumsq<double>(const double*, long, int, int, double*, hipStream_t);
+template hipError_t launch_column_sumsq<float>(const float*, long, int, int, float*, hipStream_t, int*);
+template hipError_t launch_column_sumsq<double>(const double*, long, int, int, double*, hipStream_t, int*);
 
 // Sparse -> dense on the device, honouring the index base
 // (reference: cusparse csr2dense / csc2dense / coo2csr+csr2dense, Matrix.h:145-232).
@@ -1044,9 +1061,9 @@ __global__ __launch_bounds__(256) void k_tile(const T* __restrict__ src, long ld
 
 // dst(j, i) = src(i, j): column-major src (rows = I, cols = J, ld) -> tiled dst of the transpose.
 template <typename T>
-__global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ src, long ld, int I, int J, T* __restrict__ dst, long tile_stride, int th) {
+__global__ __launch_bounds__(256) void k_tile_transposed(const T* __restrict__ src, long ld, int I, int J, T* __restrict__ dst, long tile_stride, int th, unsigned gx) {
 	__shared__ T tile[32][33];
-	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	const int i0 = (int)(blockIdx.x % gx) * 32, j0 = (int)(blockIdx.x / gx) * 32;      // one-dimensional grid, see k_transpose
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 	for (int jj = ty; jj < 32; jj += 8) {
 		const int i = i0 + tx, j = j0 + jj;
@@ -1069,7 +1086,9 @@ template hipError_t launch_tile<double>(const double*, long, int, int, double*, 
 
 template <typename T>
 hipError_t launch_tile_transposed(const T* src, long ld, int I, int J, T* dst, long tile_stride, int th, hipStream_t stream) {
-	hipLaunchKernelGGL((k_tile_transposed<T>), dim3((I + 31) / 32, (J + 31) / 32), dim3(256), 0, stream, src, ld, I, J, dst, tile_stride, th);
+	const unsigned gx = (unsigned)((I + 31) / 32), gy = (unsigned)((J + 31) / 32);
+	if ((unsigned long long)gx * gy > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL((k_tile_transposed<T>), dim3(gx * gy), dim3(256), 0, stream, src, ld, I, J, dst, tile_stride, th, gx);
 	return hipGetLastError();
 }
 template hipError_t launch_tile_transposed<float>(const float*, long, int, int, float*, long, int, hipStream_t);

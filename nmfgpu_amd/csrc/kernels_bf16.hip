@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "tuning.h"
 
 namespace nmfamd {
 
@@ -436,7 +437,7 @@ static hipError_t launch_fp_bf16_staged(const FactorProductPlan& p, const void* 
                                         float* slabs, long slab_stride, hipStream_t stream) {
 	dim3 grid(p.xtiles, p.splits, RP / 256), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_bf16_staged<SETS>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_bf16_staged<SETS>), grid, block, lds_bytes, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
@@ -452,7 +453,7 @@ static hipError_t launch_fp_bf16(const FactorProductPlan& p, const void* A, int 
 	if (rg != nullptr && rg->partials != nullptr && (!with_reduce || CH != 1)) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles, p.splits + (with_reduce ? 1 : 0), RP / (64 * CH)), block(512);
 	const size_t lds_bytes = 8 * 4 * 4 * 64 * sizeof(f32x4);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_bf16<D, CH>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_bf16<D, CH>), grid, block, lds_bytes, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, reinterpret_cast<const bf16x8*>(F), RP / 32,
@@ -475,7 +476,7 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 	constexpr int D = 4;
 	if (RP == 64) return launch_fp_bf16<D, 1>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	if (RP % 256 == 0) {
-		static const bool unstaged = std::getenv("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
+		static const bool unstaged = tuning_env("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
 		if (unstaged) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 		if (rg != nullptr && rg->partials != nullptr) return hipErrorInvalidValue;
 		return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);

@@ -177,12 +177,12 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 	dim3 grid(p.xtiles, p.splits, p.chunks), block(512);
 	if (p.nb == 2 && RP == 64) {
 		// ranks <= 32: the first 32 panel columns only (the rest of every slab stays at its initial zeros)
-		static unsigned long long lds_done2 = 0ull;
+		static std::atomic<unsigned long long> lds_done2{0ull};
 		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 2>), (int)lds_bytes, lds_done2); e != hipSuccess) return e;
 		hipLaunchKernelGGL((k_factor_product_f64<D, 2>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
 		return hipGetLastError();
 	}
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 4>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_f64<D, 4>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
 	return hipGetLastError();
@@ -433,7 +433,7 @@ static hipError_t launch_wide_f64(double* P, const double* slabs, int S, long sl
                                   double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
 	const size_t lds_bytes = sizeof(double) * (2 * 16 * (size_t)(RP + 4) + 64);
 	const size_t max_bytes = sizeof(double) * (2 * 16 * (size_t)(64 * NCT + 4) + 64);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f64<MODE, NCT>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT>), dim3(len_pad / 16), dim3(256), lds_bytes, stream,
 	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);

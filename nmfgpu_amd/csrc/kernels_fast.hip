@@ -127,7 +127,7 @@ template hipError_t launch_reduce_partials<float>(const float*, int, long, float
 template hipError_t launch_reduce_partials<double>(const double*, int, long, double*, long, hipStream_t);
 
 hipError_t launch_gram64_f32(const float* P, int len, int parts, float* partial, float* G, hipStream_t stream) {
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_gram64_f32), 65536, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL(k_gram64_f32, dim3(parts), dim3(256), 65536, stream, P, len, parts, partial);
 	hipError_t e = hipGetLastError();

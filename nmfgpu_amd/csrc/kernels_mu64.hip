@@ -19,7 +19,6 @@
 // instead of before the products) this is the reference's arithmetic; tolerances in tests/.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "kernels.h"
 #include "split3.h"
@@ -44,7 +43,7 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
 	float* __restrict__ ps, int len_valid, float* __restrict__ gram_partial,
-	const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks, int dbg_skip) {
+	const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks) {
 	__shared__ __attribute__((aligned(16))) float s_num[64][68];   // reduced numerator, later the new values
 	__shared__ __attribute__((aligned(16))) float s_old[64][68];   // old values (scaled for the W update)
 	__shared__ float s_ps[2][64];
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 			ol[j] = *reinterpret_cast<const f32x4*>(P + e);
 #pragma unroll
 			for (int u = 0; u < 7; ++u) {
-				const int k = (1 + u < S && !(dbg_skip & 8)) ? 1 + u : 0;   // clamped duplicate, discarded below
+				const int k = 1 + u < S ? 1 + u : 0;   // clamped duplicate, discarded below
 				t[u][j] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + e);
 			}
 		}
@@ -123,7 +122,6 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 	f32x16 acc;
 #pragma unroll
 	for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-	if (!(dbg_skip & 4))
 #pragma unroll
 	for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -170,7 +168,7 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 		*reinterpret_cast<f32x4*>(P + tile + 4 * (tid + 256 * j)) = *reinterpret_cast<const f32x4*>(&s_num[yl0 + 16 * j][c4]);
 	// the split (3 x bf16) image of the new panel rows for the next factor product (kernels_x3.hip): this tile is
 	// four K-steps of 16 rows; a thread emits two (K-step, column block, half, lane) slots of three fragments
-	if (x3_out != nullptr && !(dbg_skip & 2)) {
+	if (x3_out != nullptr) {
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
 			const int slot = tid + 256 * i;
@@ -187,7 +185,6 @@ __global__ __launch_bounds__(256) void k_mu64_update(
 			}
 		}
 	}
-	if (dbg_skip & 1) return;
 	const int ab = wave >> 1, bb = wave & 1;   // wave (ab, bb) computes one 32 x 32 block over the 64 columns
 	f32x16 g;
 #pragma unroll
@@ -210,9 +207,8 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
                               int compute_error, hipStream_t stream, void* x3_out, int x3_ks) {
 	dim3 grid(len_pad / 64), block(256);
 	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
-	static const int dbg = [] { const char* e = getenv("NMFAMD_U_SKIP"); return e ? atoi(e) : 0; }();
-	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks, dbg);
-	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks, dbg);
+	if (is_w) hipLaunchKernelGGL((k_mu64_update<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks);
+	else hipLaunchKernelGGL((k_mu64_update<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, gram_partial, Gprev, compute_error, xo, x3_ks);
 	return hipGetLastError();
 }
 

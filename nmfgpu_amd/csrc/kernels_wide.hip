@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "tuning.h"
 #include "split3.h"
 
 namespace nmfamd {
@@ -437,8 +438,8 @@ hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, floa
 	if (!gram_wide_available(RP)) return hipErrorInvalidValue;
 	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
 	// two workgroups per CU are enough; fewer, longer slices keep the partial traffic down
-	static const bool native = std::getenv("NMFAMD_WIDE_FP32_MFMA") != nullptr;       // A/B switch: fp32 MFMA instructions
-	static const int wgs = [] { const char* e = std::getenv("NMFAMD_GRAM_WGS"); return e ? std::atoi(e) : 0; }();
+	static const bool native = tuning_env("NMFAMD_WIDE_FP32_MFMA") != nullptr;       // A/B switch: fp32 MFMA instructions
+	static const int wgs = [] { const char* e = tuning_env("NMFAMD_GRAM_WGS"); return e ? std::atoi(e) : 0; }();
 	const int target = wgs > 0 ? wgs : 512;
 	parts = std::max(1, std::min(std::min(parts, std::max(16, target / nsuper)), std::max(1, len / 64)));      // and at least 32 K-steps per slice
 	if (native) hipLaunchKernelGGL((k_gram_wide_f32<8>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
@@ -615,7 +616,7 @@ static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_str
                               float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3) {
 	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 128);
 	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
 	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3));

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "tuning.h"
 #include "split3.h"
 #include "inverse_gj64.h"
 #include "gram_image.h"
@@ -426,7 +427,7 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
-	static unsigned long long lds_done = 0ull;
+	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
@@ -444,9 +445,10 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
                                     bool y_tiled, int image_tile) {
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
+#ifdef NMFAMD_DIAG_BUILD
 	if (image_tile == 16 && y_tiled && RP == 64 && stamps != nullptr) {
 		// stamped diagnostic builds of the y-tiled form with row-per-lane loads (tools/stamp_x3.py, NMFAMD_X3_VARIANT = 30..33)
-		static const int yv = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();
+		static const int yv = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();
 		switch (yv) {
 		case 30: return launch_fp_x3<3, 4, 1, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
 		case 31: return launch_fp_x3<3, 4, 2, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
@@ -455,10 +457,13 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		default: return launch_fp_x3<3, 4, 4, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
 		}
 	}
+#else
+	if (stamps != nullptr) return hipErrorNotSupported;      // stamped kernels exist in the diagnostic build only (tuning.h)
+#endif
 	if (image_tile == 16) {
 		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		static const bool ydirect = std::getenv("NMFAMD_X3_YDIRECT") != nullptr;          // A/B switch: row-per-lane global loads
+		static const bool ydirect = tuning_env("NMFAMD_X3_YDIRECT") != nullptr;          // A/B switch: row-per-lane global loads
 		if (y_tiled && !ydirect) return launch_fp_x3<3, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		return y_tiled ? launch_fp_x3<3, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		               : launch_fp_x3<3, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
@@ -467,9 +472,10 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		return launch_fp_x3<3, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
-	static const int variant = [] { const char* e = std::getenv("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
+	static const int variant = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
 	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
 	if (RP % 128 == 0 && variant != 20) return launch_fp_x3<2, 4, 0, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+#ifdef NMFAMD_DIAG_BUILD
 	switch (variant) {
 	case 1: return launch_fp_x3<2, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	case 2: return launch_fp_x3<4, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
@@ -477,8 +483,10 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	case 11: return launch_fp_x3<3, 4, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
 	case 12: return launch_fp_x3<3, 4, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
 	case 13: return launch_fp_x3<3, 4, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-	default: return launch_fp_x3<3, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	default: break;
 	}
+#endif
+	return launch_fp_x3<3, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 }
 
 } // namespace nmfamd

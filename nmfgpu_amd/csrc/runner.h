@@ -61,44 +61,58 @@ Status upload_input(nmfamd::Engine<T>& engine, const MatrixDescription<T>& V) {
 template <typename T>
 class SingleRunner : public Runner<T> {
 public:
-	SingleRunner(const NmfDescription<T>& d, const nmfamd::AlgorithmParams& prm, hipStream_t stream)
-		: engine_((int)d.inputMatrix.rows, (int)d.inputMatrix.columns, (int)d.features, static_cast<int>(d.algorithm), prm) { engine_.set_stream(stream); }
+	SingleRunner(const NmfDescription<T>& d, const nmfamd::AlgorithmParams& prm, hipStream_t stream) : prm_(prm), stream_(stream) { create(d); }
 	Status setup(const NmfDescription<T>& d) override {
-		if (Status st = engine_.allocate()) return st;
-		return upload_input(engine_, d.inputMatrix);
+		if (Status st = engine_->allocate()) return st;
+		Status st = upload_input(*engine_, d.inputMatrix);
+		if (st == nmfamd::ST_VALUE_RANGE) {
+			// infinities, NaN, |v| > 2^126 or 0 < |v| < 2^-100 in V: the split-operand product is not the fp32 product there;
+			// take the native fp32 MFMA instructions (what Parameter "precision" = -1 selects)
+			prm_.precision = -1;
+			create(d);
+			if (Status s2 = engine_->allocate()) return s2;
+			st = upload_input(*engine_, d.inputMatrix);
+		}
+		return st;
 	}
 	// InitializationStrategy::create + initializeMatrixW/H (source/init/InitializationStrategy.cpp:36-47)
 	Status init_run(NmfDescription<T>& d, bool want_h) override {
 		const unsigned m = d.inputMatrix.rows, n = d.inputMatrix.columns, r = d.features;
 		switch (d.initMethod) {
 		case NmfInitializationMethod::CopyExisting:
-			return engine_.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
+			return engine_->set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
 			                           want_h ? d.outputMatrixH.dense.values : nullptr, d.outputMatrixH.dense.leadingDimension);
 		case NmfInitializationMethod::AllRandomValues:
-			return engine_.randomize_factors(d.seed, true, want_h);
+			return engine_->randomize_factors(d.seed, true, want_h);
 		default: {
 			// MeanColumns / k-means based strategies run on the host (north star: "init stays host-side C++")
 			std::vector<T> W((size_t)m * r), H(want_h ? (size_t)r * n : 0);
 			if (!hostinit::initialize<T>(d, W.data(), want_h ? H.data() : nullptr)) return nmfamd::ST_INVALID;
-			return engine_.set_factors(W.data(), m, want_h ? H.data() : nullptr, r);
+			return engine_->set_factors(W.data(), m, want_h ? H.data() : nullptr, r);
 		}
 		}
 	}
 	Status set_constant_w(NmfDescription<T>& d) override {
-		return engine_.set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension, nullptr, 0);
+		return engine_->set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension, nullptr, 0);
 	}
-	Status iterate(bool compute_error, bool constant_w) override { return engine_.iterate(compute_error, constant_w); }
-	double frobenius() override { return engine_.frobenius(); }
-	double rmsd() override { return engine_.rmsd(); }
+	Status iterate(bool compute_error, bool constant_w) override { return engine_->iterate(compute_error, constant_w); }
+	double frobenius() override { return engine_->frobenius(); }
+	double rmsd() override { return engine_->rmsd(); }
 	Status store(NmfDescription<T>& d) override {
-		return engine_.get_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
+		return engine_->get_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
 		                           d.outputMatrixH.dense.values, d.outputMatrixH.dense.leadingDimension);
 	}
-	void synchronize() override { (void)hipStreamSynchronize(engine_.stream()); }
+	void synchronize() override { (void)hipStreamSynchronize(engine_->stream()); }
 	const char* describe() const override { return "one GPU"; }
 
 private:
-	nmfamd::Engine<T> engine_;
+	void create(const NmfDescription<T>& d) {
+		engine_.reset(new nmfamd::Engine<T>((int)d.inputMatrix.rows, (int)d.inputMatrix.columns, (int)d.features, static_cast<int>(d.algorithm), prm_));
+		engine_->set_stream(stream_);
+	}
+	nmfamd::AlgorithmParams prm_;
+	hipStream_t stream_;
+	std::unique_ptr<nmfamd::Engine<T>> engine_;
 };
 
 // ---- N rank threads, one column shard each -----------------------------------------------------------------------------
@@ -246,6 +260,19 @@ private:
 		// every rank must reach the communicator's rendezvous, whatever happened before it
 		const MatrixDescription<T>& V = input_->inputMatrix;
 		if (st == nmfamd::ST_OK) st = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+		// values outside the exact range of the split-operand product in ANY shard: every rank switches to the native fp32
+		// MFMA instructions (the ranks must run the same arithmetic: W is replicated)
+		if (st == nmfamd::ST_VALUE_RANGE) odd_values_.store(true, std::memory_order_release);
+		nmfamd::local_group_barrier(*rendezvous_);
+		if (odd_values_.load(std::memory_order_acquire) && (st == nmfamd::ST_OK || st == nmfamd::ST_VALUE_RANGE)) {
+			nmfamd::AlgorithmParams native = prm_;
+			native.precision = -1;
+			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, native));
+			rk.eng->set_stream(rk.stream);
+			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
+			st = rk.eng->allocate();
+			if (st == nmfamd::ST_OK) st = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+		}
 		Status ct = local_ ? nmfamd::local_comm_create(transport_group_, g, &rk.comm) : nmfamd::rccl_comm_create(unique_id_, world_, g, &rk.comm);
 		if (st != nmfamd::ST_OK) return st;
 		if (ct != nmfamd::ST_OK) return ct;
@@ -265,6 +292,7 @@ private:
 	unsigned m_, n_, r_;
 	int alg_;
 	bool local_ = true;
+	std::atomic<bool> odd_values_{false};
 	std::vector<std::unique_ptr<Rank>> ranks_;
 	std::string error_;
 	std::vector<std::thread> workers_;

@@ -9,7 +9,8 @@ import numpy as np
 from ._lib import library
 
 ALGORITHMS = {"mu": 0, "gdcls": 1, "als": 2, "acls": 3, "ahcls": 4, "nsnmf": 5}
-_STATUS = {0: "ok", 1: "invalid argument", 2: "out of device memory", 3: "out of host memory", 4: "HIP error", 5: "no HIP device"}
+_STATUS = {0: "ok", 1: "invalid argument", 2: "out of device memory", 3: "out of host memory", 4: "HIP error", 5: "no HIP device",
+           6: "values outside the exact range of the split-operand product"}
 
 
 class EngineError(RuntimeError):
@@ -55,19 +56,27 @@ class Engine:
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("float32 or float64")
         self.m, self.n, self.r = m, n, r
-        p = _Params(lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute),
-                    {"native": 0.0, "bf16": 1.0, "fp32_mfma": -1.0}[precision])
-        h = C.c_void_p()
-        # row_blocks > 1: the padded row count is a multiple of 128 * row_blocks (row-block form of the sharded W step)
-        st = self._lib.nmfamd_engine_create_blocks(m, n, r, ALGORITHMS[algorithm], C.byref(p), self.dtype.itemsize, C.c_void_p(stream), int(row_blocks), C.byref(h))
-        if st != 0:
-            raise EngineError(st, "nmfamd_engine_create")
-        self._h = h
+        self._ctor = dict(algorithm=algorithm, stream=stream, row_blocks=row_blocks,
+                          params=[lam, lambda_w, lambda_h, alpha_w, alpha_h, theta, {"frobenius": 0.0, "kl": 1.0}[divergence], float(sparse_compute),
+                                  {"native": 0.0, "bf16": 1.0, "fp32_mfma": -1.0}[precision]])
+        self._h = None
+        self._create()
         self._lib.nmfamd_engine_frobenius.restype = C.c_double
         self._lib.nmfamd_engine_rmsd.restype = C.c_double
         self._lib.nmfamd_engine_kl_divergence.restype = C.c_double
         self._lib.nmfamd_engine_last_error.restype = C.c_char_p
         self._lib.nmfamd_engine_error_terms.restype = C.c_long
+
+    def _create(self):
+        c = self._ctor
+        p = _Params(*c["params"])
+        h = C.c_void_p()
+        # row_blocks > 1: the padded row count is a multiple of 128 * row_blocks (row-block form of the sharded W step)
+        st = self._lib.nmfamd_engine_create_blocks(self.m, self.n, self.r, ALGORITHMS[c["algorithm"]], C.byref(p), self.dtype.itemsize,
+                                                   C.c_void_p(c["stream"]), int(c["row_blocks"]), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_engine_create")
+        self._h = h
 
     def _check(self, st: int, what: str):
         if st != 0:
@@ -90,13 +99,24 @@ class Engine:
             raise TypeError(f"V must be {self.dtype}, got {V.dtype}")
         if V.shape != (self.m, self.n):
             raise ValueError(f"V must have shape {(self.m, self.n)}, got {V.shape}")
-        self._check(self._lib.nmfamd_engine_upload_dense(self._h, C.c_void_p(V.ctypes.data), C.c_long(_ld(V))), "upload_dense")
+        self._upload(lambda: self._lib.nmfamd_engine_upload_dense(self._h, C.c_void_p(V.ctypes.data), C.c_long(_ld(V))), "upload_dense")
+
+    def _upload(self, call, what: str):
+        st = call()
+        if st == 6 and self._ctor["params"][8] == 0.0:
+            # NMFAMD_VALUE_RANGE: infinities, NaN, |v| > 2^126 or 0 < |v| < 2^-100 in V -- the split-operand product is not the
+            # fp32 product there; recreate the engine on the native fp32 MFMA instructions, as nmfgpu::compute does
+            self.close()
+            self._ctor["params"][8] = -1.0
+            self._create()
+            st = call()
+        self._check(st, what)
 
     def upload_sparse(self, fmt: int, values: np.ndarray, a: np.ndarray, b: np.ndarray, base: int = 0):
         values = np.ascontiguousarray(values, dtype=self.dtype)
         a = np.ascontiguousarray(a, dtype=np.int32); b = np.ascontiguousarray(b, dtype=np.int32)
-        self._check(self._lib.nmfamd_engine_upload_sparse(self._h, fmt, C.c_void_p(values.ctypes.data), C.c_void_p(a.ctypes.data),
-                                                          C.c_void_p(b.ctypes.data), C.c_long(len(values)), base), "upload_sparse")
+        self._upload(lambda: self._lib.nmfamd_engine_upload_sparse(self._h, fmt, C.c_void_p(values.ctypes.data), C.c_void_p(a.ctypes.data),
+                                                                   C.c_void_p(b.ctypes.data), C.c_long(len(values)), base), "upload_sparse")
 
     def set_factors(self, W: Optional[np.ndarray], H: Optional[np.ndarray]):
         # the C side sees raw pointers and leading dimensions only: a float64 W on a float32 engine, or a wrong shape,

@@ -36,6 +36,21 @@ C5 = {"ahcls": dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01), "
 PEAK_L2_GATHER_GBS = 18000.0    # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCD's L2
 
 
+def measured_traffic(name: str, source: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py writes
+    profiles/traffic_<name>.json together with the sha256 of the kernel source it measured).  Counters cannot be collected
+    inside this process, so the figure is only reported while the kernel source is still the one that was measured."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    if not os.path.exists(path):
+        return None, "no PMC measurement committed"
+    d = json.load(open(path))
+    src = os.path.join(ROOT, source)
+    if d.get("source_sha256") != (hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None):
+        return None, f"stale: {source} changed since profiles/traffic_{name}.json was measured"
+    return d.get("hbm_bytes_per_launch"), f"profiles/traffic_{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel source hash matches)"
+
+
 def make_problem(shard: int, m: int = M, n: int = N_COLS, r: int = R):
     """V = U[0,1) fp32 from mt19937(1 + shard); W0, H0 = U(0,1] from seeds 2, 3."""
     rs = np.random.RandomState(1 + shard)
@@ -255,21 +270,19 @@ def main():
             if product_kernel == 2:
                 # fp32 product on the bf16 matrix pipe (operands split exactly into 3 bf16 terms): six bf16 MFMAs replace
                 # sixteen fp32-MFMA-equivalents, and the kernel is bound by streaming the fp32 image of V from HBM
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "traffic_factor_product_x3.json")
-                if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic, traffic_source = measured_traffic("factor_product_x3", "nmfgpu_amd/csrc/kernels_x3.hip")
+                # `achieved` is the rate at which the kernel consumes the fp32 image of V (algorithmic bytes / launch time): with
+                # ONE resident image (config 2) part of it is served by the 256 MiB memory-side cache, so this is an effective
+                # bandwidth against the HBM peak, not a DRAM measurement; `traffic` is what leaves L2 (FETCH_SIZE x 2 + WRITE_SIZE)
                 roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                            "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                            "achieved_is": "effective bandwidth: algorithmic bytes of V per launch / launch time (memory-side cache hits included)",
                             "kernel": "k_factor_product_x3", "fp32_equivalent_tflops": flops_per_launch / avg_s / 1e12, **common}
             else:
                 achieved = flops_per_launch / avg_s / 1e12
-                traffic = None   # HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected in-process)
-                tpath = os.path.join(ROOT, "profiles", "traffic_factor_product.json")
-                if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic, traffic_source = measured_traffic("factor_product", "nmfgpu_amd/csrc/kernels.hip")
                 roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": "k_factor_product_f32", **common}
+                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_factor_product_f32", **common}
         if args.rccl1 and not distributed:
             parallelism += " (one-rank RCCL group: collectives issued, identities)"
         names = {"mu": "MU", "ahcls": "AHCLS", "gdcls": "GDCLS"}

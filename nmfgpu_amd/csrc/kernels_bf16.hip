@@ -432,6 +432,177 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16_staged(
 	}
 }
 
+// ---- 256 panel columns per pass, round 2 ----------------------------------------------------------------------------------
+// The staged kernel above keeps eight waves at 256 registers (4 column chunks x 2 K pieces of a 128-row tile) and pays a
+// barrier per two K-steps: 182 us per launch at config 4's shard against 100 us of HBM time and 83 us of matrix-pipe time,
+// MFMA pipe busy 45 % of the waves' life (profiles/r01_pmc_factor_product_bf16_f64.md).  Here:
+//   * workgroup = 4 waves, ONE per SIMD, = NRB = 7 row blocks of 32 (224 rows) x 256 columns x one K slice; wave w owns the
+//     64 columns 64 w .. 64 w + 63 of all seven blocks: 14 accumulator tiles = 224 AGPRs, 14 MFMAs per K-step.  Seven
+//     blocks, not four: the factor fragments of a K-step (8 KiB) are fetched once per 7 KiB of A instead of once per 4 KiB,
+//     and config 4's 1 563 row blocks make 224 workgroups -- one round on 256 CUs -- instead of 391 in two rounds;
+//   * A: every wave loads two of the tile's blocks per K-step into a D-deep register ring, parks a landed step in a
+//     three-slot LDS ring (8 ds_write_b128 per step and workgroup), all four waves read their operands from there;
+//   * F: a wave's two factor blocks go straight into its own D-deep register ring (no LDS at all);
+//   * one barrier per K-step; the loop body is branch-free (hipcc then counts vmcnt exactly): K-steps past the end of the
+//     slice load a block of zeros; every memory instruction sits BETWEEN two MFMAs (sched_group_barrier): with the groups in
+//     a row the same kernel ran 188 us, interleaved 159, with scalar-base addressing and no per-step selects 155.
+// Tried first and dropped: both operands by LDS-DMA (global_load_lds_dwordx4 into an 11 + 10 slot ring, 136 - 157 KiB of LDS,
+// counted vmcnt per loader wave, raw s_barrier): 165 us, and 156 us with the MFMAs removed -- 15 KiB per K-step and CU through
+// the DMA path top out near 37 GB/s per CU whatever the depth of the request ring (4 / 8 / 9 steps).
+constexpr int BFD_NRB = 7;            // row blocks per workgroup
+#ifndef BFD_R2_D
+#define BFD_R2_D 8                    // register-ring depth (4 .. 12 measure the same)
+#endif
+__device__ bf16x8 g_bf_zero_block[64];      // one all-zero fragment block: the A operand of K-steps past the end of a slice
+template <int NRB, int D>
+__global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
+	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
+	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
+	static_assert(D % 2 == 0 && NRB <= 8, "ring depth even (two operand sets), at most eight row blocks");
+	__shared__ __attribute__((aligned(16))) bf16x8 l8[3 * 512];      // [slot of 3][block 0..7][lane]
+	const int nblk = tiles * splits;
+	int vb = blockIdx.x;
+	{
+		const int q8 = nblk / 8, r8 = nblk % 8, xcd = vb % 8, idx = vb / 8;      // XCD-aware placement, as in kernels_x3.hip
+		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+	}
+	const int t = vb % tiles, sp = vb / tiles, grp = blockIdx.y;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const int gb0 = t * NRB;
+	const int b0 = (int)(((long)steps_total * sp) / splits);
+	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
+	const int n = b1 - b0;
+	const int last = n > 0 ? n - 1 : 0;
+	const long fstep = (long)NBT * 64;
+
+	// loader role: blocks 2 wave, 2 wave + 1 of the tile (beyond NRB - 1: a repeat of the last block, parked in the slot's
+	// spare eighth block), clamped to the image.  Wave-uniform bases + the lane's fixed offset: the loads take the scalar-base
+	// form and cost no address arithmetic on the vector ALU.  Steps past the end of the K slice read a block of zeros
+	// (g_bf_zero_block) instead of the image, so that nothing has to be selected when a step is parked.
+	const bf16x8* abase[2];
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		const int u = 2 * wave + j;
+		int gb = gb0 + (u < NRB ? u : NRB - 1);
+		gb = gb < total_blocks ? gb : total_blocks - 1;
+		abase[j] = A + (long)(gb >> 2) * tile_frags + (long)b0 * 256 + (gb & 3) * 64;
+	}
+	const bf16x8* fbase = F + ((long)b0 * NBT + grp * 8 + 2 * wave) * 64;
+	const bf16x8* zbase = g_bf_zero_block;
+	auto a_src = [&](int j, int k) -> const bf16x8* { return k < n ? abase[j] + (long)k * 256 : zbase; };      // scalar select
+	auto f_src = [&](int k) -> const bf16x8* { return fbase + (long)(k < last ? k : last) * fstep; };
+	const int pblk = 2 * wave * 64 + lane;                    // this wave's two blocks inside a slot (+ 64 for the second)
+
+	f32x16 acc[NRB][2];
+#pragma unroll
+	for (int b = 0; b < NRB; ++b)
+#pragma unroll
+		for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
+
+	bf16x8 stA[D][2], stF[D][2];
+#pragma unroll
+	for (int q = 0; q < D; ++q) {
+		stA[q][0] = a_src(0, q)[lane]; stA[q][1] = a_src(1, q)[lane];
+		stF[q][0] = f_src(q)[lane]; stF[q][1] = f_src(q)[64 + lane];
+	}
+	// steps 0 and 1 parked, their ring slots reloaded with steps D and D + 1
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		l8[q * 512 + pblk] = stA[q][0];
+		l8[q * 512 + pblk + 64] = stA[q][1];
+		stA[q][0] = a_src(0, D + q)[lane]; stA[q][1] = a_src(1, D + q)[lane];
+	}
+	__syncthreads();
+	bf16x8 va[2][NRB];
+#pragma unroll
+	for (int b = 0; b < NRB; ++b) va[0][b] = l8[b * 64 + lane];
+	__builtin_amdgcn_sched_barrier(0);
+
+	const int n_pad = ((n + D - 1) / D) * D;
+	int rd = 1, wr = 2;                                  // LDS slots of step s + 1 (to read) and s + 2 (to park)
+	for (int t0 = 0; t0 < n_pad; t0 += D) {
+#pragma unroll
+		for (int u = 0; u < D; ++u) {
+			const int s = t0 + u;
+			__syncthreads();      // step s + 1 visible; the slot of step s + 2 (= step s - 1) free
+			// Everything below is ONE scheduling region: the fourteen MFMAs of step s, and between them (one wave per SIMD
+			// overlaps nothing but its own instruction order; PMC of the first version with the groups in a row: matrix pipe
+			// busy 45 % of the wave's life, 24 % issue stalls outside it) the park of step s + 2, the A loads of step
+			// s + 2 + D, the operand reads of step s + 1 and the F loads of step s + D - 1 (into the ring slot step s - 1 has
+			// just left).
+			l8[wr * 512 + pblk] = stA[(u + 2) % D][0];
+			l8[wr * 512 + pblk + 64] = stA[(u + 2) % D][1];
+			stA[(u + 2) % D][0] = a_src(0, s + 2 + D)[lane];
+			stA[(u + 2) % D][1] = a_src(1, s + 2 + D)[lane];
+#pragma unroll
+			for (int b = 0; b < NRB; ++b) va[(u + 1) & 1][b] = l8[rd * 512 + b * 64 + lane];
+			stF[(u + D - 1) % D][0] = f_src(s + D - 1)[lane];
+			stF[(u + D - 1) % D][1] = f_src(s + D - 1)[64 + lane];
+#pragma unroll
+			for (int b = 0; b < NRB; ++b) {
+				acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u][0], acc[b][0], 0, 0, 0);
+				acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u][1], acc[b][1], 0, 0, 0);
+			}
+			// MFMA, then one memory instruction, fourteen times: 2 LDS writes, 2 + 2 loads, 7 (NRB) LDS reads
+#pragma unroll
+			for (int i = 0; i < 2 * NRB; ++i) {
+				__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+				if (i < 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // DS write
+				else if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read (A)
+				else if (i < 4 + NRB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+				else if (i < 6 + NRB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (F)
+			}
+			rd = rd == 2 ? 0 : rd + 1;
+			wr = wr == 2 ? 0 : wr + 1;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+
+	// epilogue: C/D map of the 32 x 32 MFMA: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31
+	float* slab = slabs + (long)sp * slab_stride;
+#pragma unroll
+	for (int b = 0; b < NRB; ++b) {
+		const int gb = gb0 + b;
+		if (gb < total_blocks) {
+#pragma unroll
+			for (int nb = 0; nb < 2; ++nb) {
+				const int c = 256 * grp + 64 * wave + 32 * nb + l31;
+#pragma unroll
+				for (int g = 0; g < 16; ++g) {
+					const int x = 32 * gb + (g & 3) + 8 * (g >> 2) + 4 * half;
+					slab[(long)x * RP + c] = acc[b][nb][g];
+				}
+			}
+		}
+	}
+}
+
+// workgroups along x and K slices of the round-2 kernel for `xtiles` 128-row tiles and KS K-steps
+static void plan_bf16_dma(int xtiles, int KS, int num_cus, int* tiles, int* splits) {
+	*tiles = (4 * xtiles + BFD_NRB - 1) / BFD_NRB;
+	const int by_fill = std::max(1, num_cus / std::max(1, *tiles));
+	const int by_depth = std::max(1, KS / 48);               // at least 48 K-steps per slice: the rings are 8 deep
+	*splits = std::max(1, std::min(by_fill, by_depth));
+}
+
+static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
+                                     float* slabs, long slab_stride, hipStream_t stream) {
+	int tiles = 0, splits = 0, dev = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+	plan_bf16_dma(p.xtiles, KS, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, &tiles, &splits);
+	if (splits != p.splits) return hipErrorInvalidValue;      // the caller sized its slabs with plan_splits_bf16
+	dim3 grid(tiles * splits, RP / 256), block(256);
+	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D>), grid, block, 0, stream,
+	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
+	                   slabs, slab_stride, RP, KS, splits, tiles);
+	return hipGetLastError();
+}
+
 template <int SETS>
 static hipError_t launch_fp_bf16_staged(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                         float* slabs, long slab_stride, hipStream_t stream) {
@@ -463,6 +634,11 @@ static hipError_t launch_fp_bf16(const FactorProductPlan& p, const void* A, int 
 
 // Every wave piece gets at least 8 K-steps (the ring is 4 deep); as many slices as fill the chip.
 int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus) {
+	if (RP % 256 == 0 && tuning_env("NMFAMD_BF_STAGED") == nullptr && tuning_env("NMFAMD_BF_UNSTAGED") == nullptr) {
+		int tiles = 0, splits = 0;
+		plan_bf16_dma(xtiles, KS, num_cus, &tiles, &splits);
+		return splits;
+	}
 	const int KP = RP == 64 ? 8 : (RP % 256 == 0 ? 2 : 4);
 	const int by_fill = std::max(1, num_cus / std::max(1, xtiles));
 	const int by_depth = std::max(1, KS / (8 * KP));
@@ -479,7 +655,9 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 		static const bool unstaged = tuning_env("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
 		if (unstaged) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 		if (rg != nullptr && rg->partials != nullptr) return hipErrorInvalidValue;
-		return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
+		static const bool staged = tuning_env("NMFAMD_BF_STAGED") != nullptr;          // A/B switch: the round-1 kernel
+		if (staged) return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
+		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream);
 	}
 	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	return hipErrorInvalidValue;

@@ -651,7 +651,9 @@ def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
     out = na.op_factor_product_bf16(A, Fm)
     Ab, Fb = _round_bf16(A).astype(np.float64), _round_bf16(Fm).astype(np.float64)
     want = Fb @ Ab.T
-    bound = 4e-7 * (np.abs(Fb) @ np.abs(Ab).T) + 1e-30
+    # fp32 accumulation in K order; the 256-column kernel keeps ONE chain per output element over its whole K slice (no K
+    # pieces inside the workgroup), so the largest of 10^7 elements sits a little above the 4e-7 of the split chains
+    bound = (8e-7 if r > 128 else 4e-7) * (np.abs(Fb) @ np.abs(Ab).T) + 1e-30
     assert (np.abs(out - want) <= bound).all()
     # and it is NOT the fp32 product: the rounding of the operands is visible
     exact = Fm.astype(np.float64) @ A.astype(np.float64).T

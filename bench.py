@@ -416,8 +416,8 @@ def main_native(args):
 
 def main_c3(args):
     """BASELINE configs[2] on one GPU: CSR V 100000 x 20000 at 1 % (2e7 stored entries), r = 128, multiplicative update on
-    the generalised KL divergence; V stays sparse in HBM (CSR + CSC images), one step = one iteration = 2 SDDMM + 2 SpMM.
-    Same timing contract as the default.  roofline: the SDDMM kernel (two launches per iteration, the largest share)."""
+    the generalised KL divergence; V stays sparse in HBM (CSR + CSC images), one step = one iteration = two fused half-steps
+    (quotient V ./ (W H) and numerator in one gather pass each).  Same timing contract as the default.  roofline: that kernel."""
     import torch
     import nmfgpu_amd as na
     if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
@@ -444,14 +444,15 @@ def main_c3(args):
     elapsed = time.perf_counter() - t0
     kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
     rp = eng.geometry()["padded_rank"]
-    # SURVEY 8d, per SDDMM launch: value + index of every stored entry in, one quotient out, one pass over both factors
-    hbm_bytes = 12.0 * nnz + 4.0 * (m + 1) + 4.0 * rp * (m + n)
-    gather_bytes = 4.0 * rp * nnz                      # one 512-byte row of H per stored entry, served from cache
+    # per launch of the fused half-step kernel (two per iteration; SURVEY 8d's accounting): value + index of every stored entry
+    # in, the row pointers, one pass over both factors, the numerator panel out (average of the H and the W half-step)
+    hbm_bytes = 8.0 * nnz + 2.0 * (m + n + 2) + 4.0 * rp * (m + n) + 2.0 * rp * (m + n)
+    gather_bytes = 4.0 * rp * nnz                      # one 512-byte factor row per stored entry, served from cache
     roofline = None
     if kernel_launches > 0:
         avg_s = kernel_ms / 1e3 / kernel_launches
         roofline = {"bound": "hbm", "achieved": hbm_bytes / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": hbm_bytes / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_sddmm_quotient",
+                    "frac": hbm_bytes / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_kl_fused",
                     "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": hbm_bytes,
                     "note": "the binding resource is the cache-level gather of factor rows, not HBM (SURVEY 8d): see `gather`",
                     "gather": {"achieved": gather_bytes / avg_s / 1e9, "peak": PEAK_L2_GATHER_GBS, "unit": "GB/s",
@@ -463,7 +464,7 @@ def main_c3(args):
                       "rows": m, "columns": n, "features": r, "stored_entries": nnz, "error_every": 10, "parallelism": "single GPU"},
            "frobenius_last": eng.frobenius, "kl_divergence_last": eng.kl_divergence,
            "iter_flops": 8.0 * nnz * r, "achieved_tflops_whole_iteration": 8.0 * nnz * r * (K / elapsed) / 1e12,
-           "gather_gbs_whole_iteration": 4.0 * gather_bytes * (K / elapsed) / 1e9, "roofline": roofline}
+           "gather_gbs_whole_iteration": 2.0 * gather_bytes * (K / elapsed) / 1e9, "roofline": roofline}
     if not args.no_cpu_baseline:
         from oracle import oracle
         Wc, Hc = W.copy(order="F"), H.copy(order="F")

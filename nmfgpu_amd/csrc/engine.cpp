@@ -1067,15 +1067,17 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 	const size_t ni = sizeof(int) * (size_t)std::max<long>(nnz, 1), nv = sizeof(T) * (size_t)std::max<long>(nnz, 1);
 	HIPX(hipMalloc((void**)&csr_ptr_, sizeof(int) * (m_ + 1)));
 	HIPX(hipMalloc((void**)&csc_ptr_, sizeof(int) * (n_ + 1)));
-	HIPX(hipMalloc((void**)&csr_idx_, ni)); HIPX(hipMalloc((void**)&csc_idx_, ni)); HIPX(hipMalloc((void**)&csc_from_csr_, ni));
+	// (the quotient buffers and the CSR -> CSC permutation only serve round 1's two-pass KL step, a measurement switch)
+	const bool two_pass = tuning_env("NMFAMD_KL_TWO_PASS") != nullptr;
+	HIPX(hipMalloc((void**)&csr_idx_, ni)); HIPX(hipMalloc((void**)&csc_idx_, ni));
 	HIPX(hipMalloc((void**)&csr_val_, nv)); HIPX(hipMalloc((void**)&csc_val_, nv));
-	HIPX(hipMalloc((void**)&q_, nv)); HIPX(hipMalloc((void**)&q2_, nv));
+	if (two_pass) { HIPX(hipMalloc((void**)&csc_from_csr_, ni)); HIPX(hipMalloc((void**)&q_, nv)); HIPX(hipMalloc((void**)&q2_, nv)); }
 	HIPX(hipMemcpyAsync(csr_ptr_, csr_ptr.data(), sizeof(int) * (m_ + 1), hipMemcpyHostToDevice, stream_));
 	HIPX(hipMemcpyAsync(csc_ptr_, csc_ptr.data(), sizeof(int) * (n_ + 1), hipMemcpyHostToDevice, stream_));
 	if (nnz > 0) {
 		HIPX(hipMemcpyAsync(csr_idx_, csr_idx.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemcpyAsync(csc_idx_, csc_idx.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
-		HIPX(hipMemcpyAsync(csc_from_csr_, from_csr.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
+		if (two_pass) HIPX(hipMemcpyAsync(csc_from_csr_, from_csr.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemcpyAsync(csr_val_, csr_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemcpyAsync(csc_val_, csc_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 	}
@@ -1095,18 +1097,29 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	if (!sparse_ || nnz_ < 0) return ST_INVALID;
 	const T eps = std::numeric_limits<T>::epsilon();
 	const int norm_parts = (int)(mpad_ / 128);
-	// H step (quotients only: the error terms refer to the pair (W_{k-1}, H_k) of the second evaluation)
-	// (kernel timing, bench.py --workload c3: the SDDMM is the dominant kernel of this iteration, two launches)
+	const bool two_pass = tuning_env("NMFAMD_KL_TWO_PASS") != nullptr;      // A/B: round 1's SDDMM + permute + SpMM per half-step
+	// H step (no error terms here: they refer to the pair (W_{k-1}, H_k) of the second evaluation).  One pass over the CSC
+	// image: quotient and numerator W^T Q together, one gathered row of W per stored entry (kernels_sparse.hip, k_kl_fused).
 	record_begin();
-	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, (T*)nullptr, (T*)nullptr, m_, stream_));
+	if (two_pass) {
+		HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, (T*)nullptr, (T*)nullptr, m_, stream_));
+		HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
+		HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
+	} else {
+		HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
+	}
 	record_end();
-	HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
-	HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
 	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
 	HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
-	// W step (the quotient is re-evaluated with the new H); per-row error terms on error iterations only
+	// W step (the quotient is re-evaluated with the new H), over the CSR image; per-row error terms on error iterations only
 	record_begin();
-	HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr, m_, stream_));
+	if (two_pass) {
+		HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr, m_, stream_));
+		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, q_, H_, RP_, slabs_, m_, (int)mpad_, stream_));
+	} else {
+		HIPX(launch_kl_fused<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, slabs_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr,
+		                        m_, (int)mpad_, stream_));
+	}
 	record_end();
 	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sH_, stream_));
 	if (compute_error) {
@@ -1129,7 +1142,6 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		for (int c = 0; c < r_; ++c) d += (double)sW[c] * (double)sH[c];
 		kl_ = d;
 	}
-	HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, q_, H_, RP_, slabs_, m_, (int)mpad_, stream_));
 	HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
 	return ST_OK;

@@ -232,6 +232,11 @@ hipError_t launch_spmm_rows(const int* ptr, const int* idx, const T* val, const 
 template <typename T>
 hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
                                  T* q, T* t_vwh, T* t_kl, int rows, hipStream_t stream);
+// KL half-step in one pass: out(row, :) = sum_p val[p] / (A(row,:).B(idx[p],:) + eps) * B(idx[p], :) (quotient and numerator
+// together, one gather per stored entry); rows in [rows, rows_pad) are zeroed; optional per-row error terms as above
+template <typename T>
+hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream);
 template <typename T>
 hipError_t launch_permute(const T* src, const int* perm, T* dst, long count, hipStream_t stream);
 // sums(c) = sum_y P(c, y); partial: (len_pad / 128) * RP elements of scratch

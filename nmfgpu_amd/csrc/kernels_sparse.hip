@@ -177,6 +177,103 @@ hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, c
 template hipError_t launch_sddmm_quotient<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, hipStream_t);
 template hipError_t launch_sddmm_quotient<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, hipStream_t);
 
+// KL half-step in ONE pass over the stored entries of a row: quotient and numerator together,
+//     out(row, :) = sum_p  val[p] / (A(row, :) . B(idx[p], :) + eps)  *  B(idx[p], :)
+// H step: CSC arrays, A = H (the column's own factor row), B = Wt;  W step: CSR arrays, A = Wt, B = H.
+// The gathered row B(idx[p], :) serves the dot product AND the accumulation while it sits in registers, so an iteration
+// gathers 2 x nnz factor rows instead of 4 x nnz, the quotients are never stored, and nothing has to be permuted
+// between the CSR and the CSC order (round 1: SDDMM, permute, SpMM per half-step; 4.70 -> 2.9 ms per iteration at BASELINE
+// config 3 -- the gathers were, and are, at the cache levels' row-gather rates).
+// One wave per row; a group of 16 lanes owns one entry, each lane RP / 16 contiguous factor rows; two entries per group in
+// flight.  Fixed order: lane segments, butterfly inside the group (dot), per-group running sums, groups 0 .. 3 at the end.
+// TERMS: the per-row error terms t_vwh(row) = sum val * wh, t_kl(row) = sum val * log(val / wh) (W step of error iterations).
+template <typename T, int VEC, bool TERMS>
+__global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                                  const T* __restrict__ A, const T* __restrict__ B, T eps,
+                                                  T* __restrict__ out, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows, int rows_pad) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int row = blockIdx.x * 4 + wave;
+	if (row >= rows_pad) return;
+	constexpr int RP = 64 * VEC, SEG = 4 * VEC;
+	const int g = lane >> 4, sl = lane & 15;
+	T acc[SEG];
+#pragma unroll
+	for (int e = 0; e < SEG; ++e) acc[e] = 0;
+	T s_vwh = 0, s_kl = 0;
+	if (row < rows) {
+		T a[SEG];
+#pragma unroll
+		for (int e = 0; e < SEG; ++e) a[e] = A[(long)row * RP + sl * SEG + e];
+		const int p_begin = ptr[row], p_end = ptr[row + 1];
+		for (int p0 = p_begin; p0 < p_end; p0 += 8) {
+			const int pa = p0 + g, pb = p0 + 4 + g;
+			const bool va = pa < p_end, vb = pb < p_end;
+			const int ja = idx[va ? pa : p_begin], jb = idx[vb ? pb : p_begin];
+			const T xa = va ? val[pa] : T(0), xb = vb ? val[pb] : T(0);
+			const T* ba = B + (long)ja * RP + sl * SEG;
+			const T* bb = B + (long)jb * RP + sl * SEG;
+			T ra[SEG], rb[SEG];
+#pragma unroll
+			for (int e = 0; e < SEG; ++e) { ra[e] = ba[e]; rb[e] = bb[e]; }
+			T da = 0, db = 0;
+#pragma unroll
+			for (int e = 0; e < SEG; ++e) { da += a[e] * ra[e]; db += a[e] * rb[e]; }
+#pragma unroll
+			for (int w = 8; w > 0; w >>= 1) { da += __shfl_xor(da, w, 16); db += __shfl_xor(db, w, 16); }
+			// (an entry past the end has value 0: quotient 0, nothing accumulated)
+			const T qa = xa / (da + eps), qb = xb / (db + eps);
+#pragma unroll
+			for (int e = 0; e < SEG; ++e) acc[e] += qa * ra[e];
+#pragma unroll
+			for (int e = 0; e < SEG; ++e) acc[e] += qb * rb[e];
+			if (TERMS && sl == 0) {
+				if (va) { s_vwh += xa * da; if (xa > T(0)) s_kl += xa * (T)log((double)xa / (double)(da + eps)); }
+				if (vb) { s_vwh += xb * db; if (xb > T(0)) s_kl += xb * (T)log((double)xb / (double)(db + eps)); }
+			}
+		}
+	}
+	// groups 0 .. 3 in order: (g0 + g1) + (g2 + g3) on every lane, then lanes 0 .. 15 hold the row
+#pragma unroll
+	for (int e = 0; e < SEG; ++e) {
+		const T o = __shfl_xor(acc[e], 16);
+		const T lo = (g & 1) ? o + acc[e] : acc[e] + o;          // pair sum, lower group first
+		const T p2 = __shfl_xor(lo, 32);
+		acc[e] = (g & 2) ? p2 + lo : lo + p2;
+	}
+	if (g == 0) {
+		T* dst = out + (long)row * RP + sl * SEG;
+#pragma unroll
+		for (int e = 0; e < SEG; ++e) dst[e] = acc[e];
+	}
+	if (TERMS && row < rows) {
+		const T v0 = __shfl(s_vwh, 0), v1 = __shfl(s_vwh, 16), v2 = __shfl(s_vwh, 32), v3 = __shfl(s_vwh, 48);
+		const T k0 = __shfl(s_kl, 0), k1 = __shfl(s_kl, 16), k2 = __shfl(s_kl, 32), k3 = __shfl(s_kl, 48);
+		if (lane == 0) { t_vwh[row] = ((v0 + v1) + v2) + v3; t_kl[row] = ((k0 + k1) + k2) + k3; }
+	}
+}
+
+// out: rows_pad x RP numerator panel (rows in [rows, rows_pad) zeroed); t_vwh == nullptr: no per-row error terms
+template <typename T>
+hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream) {
+	dim3 grid((rows_pad + 3) / 4), block(256);
+	const bool terms = t_vwh != nullptr && t_kl != nullptr;
+#define NMFAMD_KLF(VEC)                                                                                                                        \
+	if (terms) hipLaunchKernelGGL((k_kl_fused<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad); \
+	else hipLaunchKernelGGL((k_kl_fused<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad);      \
+	break
+	switch (RP / 64) {
+	case 1: NMFAMD_KLF(1);
+	case 2: NMFAMD_KLF(2);
+	case 4: NMFAMD_KLF(4);
+	default: return hipErrorInvalidValue;
+	}
+#undef NMFAMD_KLF
+	return hipGetLastError();
+}
+template hipError_t launch_kl_fused<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, int, hipStream_t);
+template hipError_t launch_kl_fused<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, int, hipStream_t);
+
 // dst[p] = src[perm[p]]: the quotients in the other storage order
 template <typename T>
 __global__ void k_permute(const T* __restrict__ src, const int* __restrict__ perm, T* __restrict__ dst, long count) {

@@ -355,7 +355,7 @@ def main_native(args):
     uid = [na.RcclComm.unique_id() if rank == 0 else None]
     if distributed:
         dist.broadcast_object_list(uid, src=0)
-    comm = na.RcclComm(uid[0], world, rank)
+    comm = na.RcclComm(uid[0], world, rank)       # blocks until every rank has joined the clique
     eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, row_blocks=world, **alg_kw)
     eng.upload(V)
     eng.set_factors(W, H)

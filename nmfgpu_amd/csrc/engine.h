@@ -184,6 +184,11 @@ private:
 	T *csr_val_ = nullptr, *csc_val_ = nullptr, *q_ = nullptr, *q2_ = nullptr;
 	T *t_vwh_ = nullptr, *t_kl_ = nullptr, *rowsum_part_ = nullptr, *sW_ = nullptr, *sH_ = nullptr;
 	double sum_v_ = 0, kl_ = 0;
+	// KL error terms travel like the Frobenius ones: pinned landing buffer [t_vwh (m) | t_kl (m) | sW (RP) | sH (RP) | psR (RP)],
+	// copied stream-ordered, summed on the host only when somebody reads the error
+	T* pin_kl_ = nullptr;
+	bool kl_pending_ = false, kl_unresolved_ = false;
+	std::vector<T> h_klrow_, h_sW_, h_sH_;
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
 	bool fused_ready_ = false, w_pending_ = false;

@@ -48,8 +48,10 @@ def main():
                      "bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request), average per launch over all forms",
            "source": SOURCE, "source_sha256": hashlib.sha256(open(os.path.join(ROOT, SOURCE), "rb").read()).hexdigest(),
            "bench_arguments": extra}
-    with open(os.path.join(ROOT, OUT), "w") as f:
-        json.dump(out, f, indent=1)
+    # (gpurun brings back gpurun_out/ only: keep a copy there to commit as profiles/... from the CPU container)
+    for path in (os.path.join(ROOT, OUT), os.path.join(ROOT, "gpurun_out", os.path.basename(OUT))):
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
 

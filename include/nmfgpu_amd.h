@@ -240,6 +240,11 @@ NMFAMD_API int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, floa
 NMFAMD_API int nmfamd_op_gram_f64(const double* P, long ldp, int r, int len, double* G, long ldg);
 /* Ainv = (A + regulariser)^-1 for a host r x r matrix (offdiag / diag added as KernelFillMatrix.cu:29-45). */
 NMFAMD_API int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float diag, float* Ainv, long ldi);
+/* The passes between the update of a factor panel and the next product at padded rank 256 with bf16 product operands (129 <= r <= 256):
+ * optional column normalisation (colsq: r sums of squares or NULL), nsNMF smoothing by theta, bf16 rounding; the Gram matrix of the panel and of
+ * the smoothed panel.  P, P_out, pack_out: [len][ldp / r] rows of r values; G_raw, G_smooth: [r][r].  Outputs may be NULL. */
+NMFAMD_API int nmfamd_op_factor_passes_f32(const float* P, long ldp, int r, int len, const float* colsq, float theta, float* P_out, float* pack_out,
+                                           float* G_raw, float* G_smooth, int reps, double* avg_us_finish, double* avg_us_gram);
 /* Test access to an engine's device intermediates in panel layout: which = 0 Wt, 1 H, 2 W^T W,
  * 3 H H^T, 4 slabs, 5 inverse, 6 V, 7 Vt. */
 NMFAMD_API int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count);

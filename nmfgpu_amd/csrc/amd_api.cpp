@@ -571,4 +571,68 @@ int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float 
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
+// Test / measurement entry of kernels_tri.hip (padded rank 256): the passes between a factor update and the next product.
+// P: [len][ldp] panel rows; colsq (r values) or NULL; theta: nsNMF smoothing.  Outputs (any may be NULL): P_out = the panel after the optional
+// column normalisation; pack_out [len][r] = the bf16 fragments of the smoothed panel, widened back to fp32; G_raw / G_smooth [r][r].
+int nmfamd_op_factor_passes_f32(const float* P, long ldp, int r, int len, const float* colsq, float theta, float* P_out, float* pack_out,
+                                float* G_raw, float* G_smooth, int reps, double* avg_us_finish, double* avg_us_gram) {
+	if (!P || r <= 0 || len <= 0 || ldp < r) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r);
+	if (!tri_kernels_available(RP)) return NMFAMD_INVALID_ARGUMENT;
+	const long lp = pad128(len), KS = (len + 15) / 16;
+	const size_t pack_bytes = 16 * (size_t)KS * (RP / 32) * 64;
+	int dev = 0, cus = 256;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+	DevBuf dP, dP0, dSq, dPack, dPart, dG, dGs;
+	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dP0.alloc(sizeof(float) * RP * lp) != hipSuccess || dSq.alloc(sizeof(float) * RP) != hipSuccess ||
+	    dPack.alloc(pack_bytes) != hipSuccess || dPart.alloc(sizeof(float) * (size_t)gram_tri_partial_elems(cus)) != hipSuccess ||
+	    dG.alloc(sizeof(float) * RP * RP) != hipSuccess || dGs.alloc(sizeof(float) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemset(dP0.p, 0, sizeof(float) * RP * lp) != hipSuccess || hipMemset(dSq.p, 0, sizeof(float) * RP) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dP0.p, RP * sizeof(float), P, ldp * sizeof(float), r * sizeof(float), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (colsq && hipMemcpy(dSq.p, colsq, sizeof(float) * r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const float off = theta / (float)(unsigned)r, diag = (float)((1.0 - theta) + off);
+	hipEvent_t e0, e1;
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const int n_reps = reps > 0 ? reps : 1;
+	float ms_finish = 0.f, ms_gram = 0.f;
+	for (int it = 0; it < n_reps; ++it) {
+		// (the normalisation is in place: every repetition starts from the caller's panel)
+		if (hipMemcpyAsync(dP.p, dP0.p, sizeof(float) * RP * lp, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		float ms = 0.f;
+		(void)hipEventRecord(e0, nullptr);
+		if (launch_finish_panel_bf16((float*)dP.p, RP, r, 0, lp, colsq ? (const float*)dSq.p : nullptr, 1, off, diag, dPack.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		(void)hipEventRecord(e1, nullptr);
+		if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+		ms_finish += ms;
+		(void)hipEventRecord(e0, nullptr);
+		if (launch_gram_tri((const float*)dP.p, RP, len, cus, (float*)dPart.p, (float*)dG.p, cus, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (launch_smooth_gram((const float*)dG.p, (float*)dGs.p, RP, r, off, diag, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		(void)hipEventRecord(e1, nullptr);
+		if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return NMFAMD_HIP_ERROR;
+		ms_gram += ms;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	if (avg_us_finish) *avg_us_finish = 1e3 * ms_finish / n_reps;
+	if (avg_us_gram) *avg_us_gram = 1e3 * ms_gram / n_reps;
+	if (P_out && hipMemcpy2D(P_out, ldp * sizeof(float), dP.p, RP * sizeof(float), r * sizeof(float), len, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (G_raw && hipMemcpy2D(G_raw, r * sizeof(float), dG.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (G_smooth && hipMemcpy2D(G_smooth, r * sizeof(float), dGs.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (pack_out) {
+		std::vector<uint16_t> h(pack_bytes / 2);
+		if (hipMemcpy(h.data(), dPack.p, pack_bytes, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+		const int NBT = RP / 32;
+		for (long y = 0; y < len; ++y)
+			for (int c = 0; c < r; ++c) {
+				const long frag = ((y / 16) * NBT + c / 32) * 64 + ((y / 8) & 1) * 32 + (c & 31);
+				const uint32_t bits = (uint32_t)h[frag * 8 + (y & 7)] << 16;
+				float f;
+				std::memcpy(&f, &bits, 4);
+				pack_out[y * r + c] = f;
+			}
+	}
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
 } // extern "C"

@@ -72,7 +72,7 @@ Engine<T>::~Engine() {
 		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
-	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_}; for (void* b : bb) if (b) (void)hipFree(b); }
+	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -220,9 +220,18 @@ Status Engine<T>::allocate() {
 	psR_ = psN_ + ps_stride_;
 	HIPX(dalloc(&stage_, std::max(mpad_, npad_) * RP_));
 	HIPX(hipMalloc((void**)&range_flag_, sizeof(int)));
+	if constexpr (std::is_same<T, float>::value) {
+		tri_ = bf16_ && tri_kernels_available(RP_) && (alg_ == ALG_MU || alg_ == ALG_NSNMF);
+		if (tri_) {
+			HIPX(hipMalloc((void**)&gram_tri_part_, sizeof(float) * (size_t)gram_tri_partial_elems(num_cus_)));
+			HIPX(dalloc(&Gw_raw_, rr));
+			HIPX(dalloc(&Gh_raw_, rr));
+			HIPX(dalloc(&colsq_, (long)RP_ * colsq_stage_parts()));
+		}
+	}
 	if (alg_ == ALG_NSNMF) {
-		HIPX(dalloc(&Ws_, panelW));
-		HIPX(dalloc(&Hs_, panelH));
+		HIPX(dalloc(&Ws_, panelW));                       // (tri_: only get_factors() materialises W S)
+		if (!tri_) HIPX(dalloc(&Hs_, panelH));
 	}
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
@@ -359,7 +368,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false;
+		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -403,7 +412,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; }
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -502,7 +511,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
 			// bf16 operands: the factor panel is re-rounded and re-ordered for every product
-			HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
+			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
 			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
@@ -553,7 +562,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
-			HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
+			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
 			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
@@ -713,6 +722,15 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 	}
 	hx3_valid_ = false;
 	if (Status s = materialize_w()) return s;
+	if constexpr (std::is_same<T, float>::value) {
+		if (tri_) {
+			if (Status s = tri_prepare_w()) return s;
+			if (Status s = product_h(Wt_, nullptr, true)) return s;
+			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps,
+			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+			return ST_OK;
+		}
+	}
 	const T* F = Wt_;
 	if (alg_ == ALG_NSNMF) {
 		const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -778,6 +796,14 @@ Status Engine<T>::w_products(T* exchange) {
 			return ST_OK;
 		}
 	}
+	if constexpr (std::is_same<T, float>::value) {
+		if (tri_) {
+			if (Status s = tri_prepare_h(ex_hht)) return s;
+			if (Status s = product_w(H_, nullptr, exchange, true)) return s;
+			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
+			return ST_OK;
+		}
+	}
 	const T* Fh = H_;
 	if (alg_ == ALG_NSNMF) {
 		// the smoothed local columns S H_g enter both sums (AlgorithmNonSmoothNMF.h:194-197,213)
@@ -812,14 +838,21 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	if (compute_error) {
 		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
-			HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
-			wtw = G2_;
+			if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);      // (by-product of this iteration's H step)
+			else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 		}
 		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	wx3_valid_ = false;
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+	if constexpr (std::is_same<T, float>::value) {
+		if (tri_) {
+			HIPX(launch_colsq_stage(sumsq_part_, RP_, panel_update_parts(RP_, sizeof(T), (int)mpad_), colsq_, nullptr, stream_));
+			colsq_parts_ = colsq_stage_parts();
+			return w_normalize_rows(0, mpad_, colsq_);
+		}
+	}
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
 }
@@ -834,8 +867,8 @@ Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long
 	if (compute_error) {
 		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
-			HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
-			wtw = G2_;
+			if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
+			else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 		}
 		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_));
 		if (Status s = fetch_error_terms(n_)) return s;
@@ -843,6 +876,12 @@ Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long
 	const long valid = std::max<long>(0, std::min<long>(rows, (long)m_ - row0));
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_ + row0 * RP_, num_rows, 1, 0, hht, RP_, (int)rows, eps, nullptr, (int)valid, sumsq_part_, nullptr, stream_,
 	                            nullptr, nullptr, 0, qx3_));
+	if constexpr (std::is_same<T, float>::value) {
+		if (tri_) {
+			HIPX(launch_colsq_stage(sumsq_part_, RP_, panel_update_parts(RP_, sizeof(T), (int)rows), colsq_, colsq, stream_));
+			return ST_OK;
+		}
+	}
 	HIPX(launch_reduce_partials<T>(sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)rows), RP_, colsq, RP_, stream_));
 	return ST_OK;
 }
@@ -851,7 +890,58 @@ template <typename T>
 Status Engine<T>::w_normalize_rows(long row0, long rows, T* colsq) {
 	if (rows <= 0 || rows % 128 != 0 || row0 < 0 || row0 + rows > mpad_) return ST_INVALID;
 	// colsq: the r sums of squares over ALL rows (one "partial"): kernel::normalizeColumns' sum > 0 ? x / sqrt(sum) : x
+	if constexpr (std::is_same<T, float>::value) {
+		if (tri_) {
+			// the same pass leaves the bf16 fragments of the smoothed rows for the next W^T V
+			T off, diag;
+			tri_smoothing(&off, &diag);
+			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, row0, rows, colsq, colsq == colsq_ ? colsq_parts_ : 1, off, diag, Wtb_, ksH_, stream_));
+			tri_rows_cover_ = row0 == 0 && rows == mpad_;
+			wtb_valid_ = tri_rows_cover_;
+			tri_gw_ready_ = false;
+			return ST_OK;
+		}
+	}
 	HIPX(launch_normalize_panel_v2<T>(Wt_ + row0 * RP_, RP_, (int)rows, colsq, 1, stream_));
+	return ST_OK;
+}
+
+// ---- padded rank 256, bf16 product operands (kernels_tri.hip) ---------------------------------------------------------------------
+template <typename T>
+void Engine<T>::tri_smoothing(T* offdiag, T* diag) const {
+	if (alg_ == ALG_NSNMF) {
+		*offdiag = (T)prm_.theta / (T)(unsigned)r_;
+		*diag = (T)((1.0 - (T)prm_.theta) + *offdiag);
+	} else { *offdiag = 0; *diag = 1; }
+}
+
+template <typename T>
+Status Engine<T>::tri_prepare_w() {
+	if constexpr (std::is_same<T, float>::value) {
+		T off, diag;
+		tri_smoothing(&off, &diag);
+		if (!wtb_valid_) {
+			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, 0, mpad_, nullptr, 0, off, diag, Wtb_, ksH_, stream_));
+			wtb_valid_ = true;
+		}
+		if (!tri_gw_ready_) {
+			HIPX(launch_gram_tri(Wt_, RP_, m_, num_cus_, gram_tri_part_, Gw_raw_, num_cus_, stream_));
+			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, stream_));
+			tri_gw_ready_ = true;
+		}
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::tri_prepare_h(T* hht) {
+	if constexpr (std::is_same<T, float>::value) {
+		T off, diag;
+		tri_smoothing(&off, &diag);
+		HIPX(launch_finish_panel_bf16(H_, RP_, r_, 0, npad_, nullptr, 0, off, diag, Hb_, ksW_, stream_));
+		HIPX(launch_gram_tri(H_, RP_, n_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
+		HIPX(launch_smooth_gram(Gh_raw_, hht, RP_, r_, off, diag, stream_));
+	}
 	return ST_OK;
 }
 
@@ -946,13 +1036,16 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 
 	if (!(constant_w && !compute_error)) {
 		const T* Fh = H_;
-		if (alg_ == ALG_NSNMF) {
+		bool hht_done = false;
+		if (tri_) {
+			if (Status s = tri_prepare_h(HHt_)) return s;
+			hht_done = true;
+		} else if (alg_ == ALG_NSNMF) {
 			const T off = (T)prm_.theta / (T)(unsigned)r_;
 			const T diag = (T)((1.0 - (T)prm_.theta) + off);
 			HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, diag, stream_));
 			Fh = Hs_;
 		}
-		bool hht_done = false;
 		if constexpr (std::is_same<T, float>::value) {
 			if (gram_h_partials_ && Fh == H_) {
 				// H H^T from the partial Gram matrices the H update left behind
@@ -964,8 +1057,8 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 		if (compute_error) {
 			const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
-				HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_));
-				wtw = G2_;
+				if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
+				else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 			} else if (alg_ != ALG_MU) wtw = G2_;               // LS algorithms: copy saved before the regulariser
 			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_));
 		}
@@ -990,7 +1083,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					if (Status s = product_w(Fh, &rg, nullptr, x3_ && hx3_valid_ && Fh == H_)) return s;
 				}
 			} else {
-				if (Status s = product_w(Fh, nullptr, nullptr, x3_ && hx3_valid_ && Fh == H_)) return s;
+				if (Status s = product_w(Fh, nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;
 			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;
@@ -999,7 +1092,11 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				wx3_valid_ = false;
 				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
-				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
+				if (tri_) {
+					if constexpr (std::is_same<T, float>::value) HIPX(launch_colsq_stage(sumsq_part_, RP_, norm_parts, colsq_, nullptr, stream_));
+					colsq_parts_ = colsq_stage_parts();
+					if (Status s = w_normalize_rows(0, mpad_, reinterpret_cast<T*>(colsq_))) return s;
+				} else if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
 				if (gd_err) {
 					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
 					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));

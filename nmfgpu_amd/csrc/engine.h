@@ -72,7 +72,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; }
+	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
@@ -199,6 +199,17 @@ private:
 	Status mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error);
 	// generic rank-64 fp32 path: the update kernel leaves partial Gram matrices of what it wrote (gram_from_update())
 	bool gram_w_ready_ = false;      // G_ holds W^T W of the current (normalised) W
+	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams
+	// it (normalise + smooth + bf16 fragments), Gram matrices of the smoothed panels from the unsmoothed ones (S G S)
+	bool tri_ = false;
+	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current (smoothed) W
+	bool tri_gw_ready_ = false;      // Gw_raw_ / G_ describe the current W
+	bool tri_rows_cover_ = false;    // the last w_normalize_rows() covered every row of W
+	int colsq_parts_ = 1;            // staged partial vectors in colsq_ (kernels_tri.hip: launch_colsq_stage)
+	float *gram_tri_part_ = nullptr, *Gw_raw_ = nullptr, *Gh_raw_ = nullptr, *colsq_ = nullptr;
+	void tri_smoothing(T* offdiag, T* diag) const;
+	Status tri_prepare_w();          // Wtb_, Gw_raw_, G_ for the H step
+	Status tri_prepare_h(T* hht);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;

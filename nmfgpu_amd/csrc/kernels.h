@@ -210,6 +210,21 @@ hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs
 // panel [y][RP] (RP = 64 or a multiple of 128; 16 * KS * RP / 32 * 64 bytes).
 hipError_t launch_pack_stream_bf16(const float* src, long ld, int X, int Y, bool transposed, void* dst, int xtiles, int KS, hipStream_t stream);
 hipError_t launch_pack_panel_bf16(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream);
+
+// kernels_tri.hip -- factor-side passes at padded rank 256 with bf16 product operands (config 4)
+bool tri_kernels_available(int RP);
+// rows [row0, row0 + rows) of the panel P (multiples of 32): optional column normalisation in place (colsq = colsq_parts vectors of RP partial sums of squares
+// over ALL rows, added in order; or nullptr), nsNMF smoothing with (offdiag, diag) in registers, bf16 fragments of the smoothed rows into the pack `dst`
+// (K-steps >= KS are not written)
+hipError_t launch_finish_panel_bf16(float* P, int RP, int r, long row0, long rows, const float* colsq, int colsq_parts, float offdiag, float diag, void* dst, long KS, hipStream_t stream);
+// the update kernel's per-workgroup sums of squares (`parts` vectors of RP) -> colsq_stage_parts() staged vectors (and, final_sum != nullptr, their sum)
+int colsq_stage_parts();
+hipError_t launch_colsq_stage(const float* part, int RP, int parts, float* staged, float* final_sum, hipStream_t stream);
+// G (RP x RP, both triangles, exactly symmetric) = P^T P over `len` panel rows; partial: gram_tri_partial_elems(max_parts) floats
+hipError_t launch_gram_tri(const float* P, int RP, int len, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream);
+long gram_tri_partial_elems(int max_parts);
+// Gs = S G S, S = (diag - offdiag) I + offdiag 1 1^T on the first r rows / columns
+hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float offdiag, float diag, hipStream_t stream);
 hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 // K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP

@@ -403,6 +403,28 @@ def op_inverse(A: np.ndarray, offdiag: float = 0.0, diag: float = 0.0) -> np.nda
     return out
 
 
+def op_factor_passes(P: np.ndarray, theta: float = 0.0, colsq: Optional[np.ndarray] = None, reps: int = 0):
+    """The passes between the update of a factor panel and the next product at padded rank 256 with bf16 product operands
+    (kernels_tri.hip).  P: (len, r) panel rows, 129 <= r <= 256.  Returns a dict: `panel` (after the optional column normalisation
+    by the r sums of squares `colsq`), `pack` (the smoothed panel as the bf16 product operand, widened to fp32), `gram` (P^T P of
+    the returned panel), `gram_smoothed`, and with reps > 0 `us_finish`, `us_gram` (microseconds per launch group)."""
+    P = np.ascontiguousarray(P, dtype=np.float32)
+    length, r = P.shape
+    out = {"panel": np.zeros_like(P), "pack": np.zeros_like(P), "gram": np.zeros((r, r), np.float32), "gram_smoothed": np.zeros((r, r), np.float32)}
+    sq = None if colsq is None else np.ascontiguousarray(colsq, dtype=np.float32)
+    if sq is not None and sq.shape != (r,):
+        raise ValueError("colsq must hold r values")
+    t0, t1 = C.c_double(0.0), C.c_double(0.0)
+    st = library().nmfamd_op_factor_passes_f32(C.c_void_p(P.ctypes.data), C.c_long(r), r, length, C.c_void_p(sq.ctypes.data) if sq is not None else None,
+                                               C.c_float(theta), C.c_void_p(out["panel"].ctypes.data), C.c_void_p(out["pack"].ctypes.data),
+                                               C.c_void_p(out["gram"].ctypes.data), C.c_void_p(out["gram_smoothed"].ctypes.data), int(reps), C.byref(t0), C.byref(t1))
+    if st != 0:
+        raise EngineError(st, "nmfamd_op_factor_passes_f32")
+    if reps > 0:
+        out["us_finish"], out["us_gram"] = t0.value, t1.value
+    return out
+
+
 def host_kmeans(data: np.ndarray, k: int, *, seed: int = 0, iterations: int = 100, threshold: float = 0.005):
     """The host-side Lloyd k-means behind computeKMeans and the KMeans*/EInNMF initialisers, without a
     device or context (nmfamd_host_kmeans_*).  Returns (clusters m x k, membership, passes)."""

@@ -1,0 +1,71 @@
+"""Padded rank 256 with bf16 product operands (BASELINE config 4): the passes between the update of a factor panel and the next
+product that streams it (nmfgpu_amd/csrc/kernels_tri.hip) against numpy restatements of what the reference computes there:
+kernel::normalizeColumns (source/kernels/KernelNormalizeColumns.cu:37-58), the smoothing product with S
+(source/nmf/AlgorithmNonSmoothNMF.h:131-134,175,194) and syrk of the smoothed matrix (:176,196)."""
+import numpy as np
+import pytest
+
+import nmfgpu_amd as na
+
+pytestmark = pytest.mark.gpu
+
+
+def _round_bf16(a):
+    """fp32 -> bf16, round to nearest even, widened back (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _smooth(P, theta):
+    r = P.shape[1]
+    S = (1.0 - theta) * np.eye(r) + theta / r * np.ones((r, r))
+    return P.astype(np.float64) @ S
+
+
+@pytest.mark.parametrize("length,r,theta,normalise", [(1000, 256, 0.5, True), (777, 200, 0.4, True), (50, 129, 0.0, False), (4096, 256, 0.7, False),
+                                                      (33, 256, 0.5, True)])
+def test_factor_passes_against_numpy(length, r, theta, normalise):
+    rng = np.random.default_rng(length + r)
+    P = rng.random((length, r), dtype=np.float32) + 0.01
+    P[:, 3] = 0.0                                         # an all-zero column keeps its values (sum > 0 ? x / sqrt(sum) : x)
+    colsq = (P.astype(np.float64) ** 2).sum(axis=0).astype(np.float32) if normalise else None
+    out = na.op_factor_passes(P, theta=theta, colsq=colsq)
+
+    want = P.copy()
+    if normalise:
+        nrm = np.sqrt(colsq)
+        for c in range(r):
+            if colsq[c] > 0:
+                want[:, c] = P[:, c] / nrm[c]             # fp32 division by the fp32 root, as the kernel
+    assert np.array_equal(out["panel"], want), "normalised panel differs from the fp32 division"
+
+    sm = _smooth(out["panel"], theta)
+    # the operand of the product: the smoothed value rounded ONCE to bf16 (the fp32 smoothing in between may move a value that sits on a
+    # rounding boundary to the neighbour: one bf16 ulp = 2^-8 relative)
+    pack = out["pack"].astype(np.float64)
+    assert np.all(np.abs(pack - sm) <= 2.0 ** -8 * np.abs(sm) + 1e-30)
+    exact = _round_bf16(sm.astype(np.float32))
+    assert np.mean(pack == exact) > 0.99
+
+    G = out["panel"].astype(np.float64).T @ out["panel"].astype(np.float64)
+    scale = np.sqrt(np.outer(np.diag(G), np.diag(G))) + 1e-30
+    assert np.max(np.abs(out["gram"] - G) / np.maximum(scale, 1e-30)) < 4e-7      # fp32-level: the split-operand product's bound
+    assert np.array_equal(out["gram"], out["gram"].T), "Gram matrix must be exactly symmetric"
+    Gs = sm.T @ sm
+    assert np.max(np.abs(out["gram_smoothed"] - Gs) / np.max(np.abs(Gs))) < 1e-6
+    assert np.array_equal(out["gram_smoothed"], out["gram_smoothed"].T)
+
+
+def test_theta_zero_is_the_identity():
+    rng = np.random.default_rng(5)
+    P = rng.random((300, 256), dtype=np.float32)
+    out = na.op_factor_passes(P, theta=0.0)
+    assert np.array_equal(out["panel"], P)
+    assert np.array_equal(out["pack"], _round_bf16(P))
+    assert np.array_equal(out["gram"], out["gram_smoothed"])
+
+
+def test_rejected_shapes():
+    with pytest.raises(na.EngineError):
+        na.op_factor_passes(np.ones((64, 64), np.float32))          # padded rank 64: other kernels serve it

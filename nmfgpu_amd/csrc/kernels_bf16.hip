@@ -459,7 +459,15 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
 	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
 	static_assert(D % 2 == 0 && NRB <= 8, "ring depth even (two operand sets), at most eight row blocks");
-	__shared__ __attribute__((aligned(16))) bf16x8 l8[3 * 512];      // [slot of 3][block 0..7][lane]
+#ifndef BFD_PAIR
+#define BFD_PAIR 0
+#endif
+	// BFD_PAIR = 1: one barrier per TWO K-steps -- a step is parked four steps ahead into a six-slot ring (the pair being read, the pair
+	// that is visible and read next, the pair being written).  Measured the same as one barrier per step (156 us either way), as did
+	// ring depths 4 .. 12: with the MFMAs removed the kernel takes 155 us, with A served from cache instead of HBM 125 us, with F
+	// from cache 158 us (profiles/r02_c4_kernel_experiments.md) -- the loop is bound by its own memory skeleton, not by the barrier.
+	constexpr int AHEAD = BFD_PAIR ? 4 : 2, SLOTS = BFD_PAIR ? 6 : 3;
+	__shared__ __attribute__((aligned(16))) bf16x8 l8[SLOTS * 512];      // [slot][block 0..7][lane]
 	const int nblk = tiles * splits;
 	int vb = blockIdx.x;
 	{
@@ -509,9 +517,9 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 		stA[q][0] = a_src(0, q)[lane]; stA[q][1] = a_src(1, q)[lane];
 		stF[q][0] = f_src(q)[lane]; stF[q][1] = f_src(q)[64 + lane];
 	}
-	// steps 0 and 1 parked, their ring slots reloaded with steps D and D + 1
+	// steps 0 .. AHEAD - 1 parked, their ring slots reloaded with steps D ...
 #pragma unroll
-	for (int q = 0; q < 2; ++q) {
+	for (int q = 0; q < AHEAD; ++q) {
 		l8[q * 512 + pblk] = stA[q][0];
 		l8[q * 512 + pblk + 64] = stA[q][1];
 		stA[q][0] = a_src(0, D + q)[lane]; stA[q][1] = a_src(1, D + q)[lane];
@@ -523,21 +531,21 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	__builtin_amdgcn_sched_barrier(0);
 
 	const int n_pad = ((n + D - 1) / D) * D;
-	int rd = 1, wr = 2;                                  // LDS slots of step s + 1 (to read) and s + 2 (to park)
+	int rd = 1, wr = AHEAD;                              // LDS slots of step s + 1 (to read) and s + AHEAD (to park)
 	for (int t0 = 0; t0 < n_pad; t0 += D) {
 #pragma unroll
 		for (int u = 0; u < D; ++u) {
 			const int s = t0 + u;
-			__syncthreads();      // step s + 1 visible; the slot of step s + 2 (= step s - 1) free
+			if (!BFD_PAIR || (u & 1) == 0) __syncthreads();      // step s + 1 visible; the slot of step s + AHEAD free
 			// Everything below is ONE scheduling region: the fourteen MFMAs of step s, and between them (one wave per SIMD
 			// overlaps nothing but its own instruction order; PMC of the first version with the groups in a row: matrix pipe
 			// busy 45 % of the wave's life, 24 % issue stalls outside it) the park of step s + 2, the A loads of step
 			// s + 2 + D, the operand reads of step s + 1 and the F loads of step s + D - 1 (into the ring slot step s - 1 has
 			// just left).
-			l8[wr * 512 + pblk] = stA[(u + 2) % D][0];
-			l8[wr * 512 + pblk + 64] = stA[(u + 2) % D][1];
-			stA[(u + 2) % D][0] = a_src(0, s + 2 + D)[lane];
-			stA[(u + 2) % D][1] = a_src(1, s + 2 + D)[lane];
+			l8[wr * 512 + pblk] = stA[(u + AHEAD) % D][0];
+			l8[wr * 512 + pblk + 64] = stA[(u + AHEAD) % D][1];
+			stA[(u + AHEAD) % D][0] = a_src(0, s + AHEAD + D)[lane];
+			stA[(u + AHEAD) % D][1] = a_src(1, s + AHEAD + D)[lane];
 #pragma unroll
 			for (int b = 0; b < NRB; ++b) va[(u + 1) & 1][b] = l8[rd * 512 + b * 64 + lane];
 			stF[(u + D - 1) % D][0] = f_src(s + D - 1)[lane];
@@ -556,8 +564,8 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 				else if (i < 4 + NRB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
 				else if (i < 6 + NRB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (F)
 			}
-			rd = rd == 2 ? 0 : rd + 1;
-			wr = wr == 2 ? 0 : wr + 1;
+			rd = rd == SLOTS - 1 ? 0 : rd + 1;
+			wr = wr == SLOTS - 1 ? 0 : wr + 1;
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}

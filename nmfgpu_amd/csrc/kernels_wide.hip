@@ -609,6 +609,179 @@ hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs,
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// MODE_MU on long panels (the W update of config 4: 50 000 x 256): 64 panel rows per workgroup.
+// k_panel_update_wide_f32 streams the whole split image of Q (6 RP^2 bytes: 393 KB at rank 256) from L2 once per 32 rows --
+// 614 MB of L2 traffic per W update, as much time as the MFMAs themselves.  Here a workgroup covers two row blocks per
+// fragment of Q (half the L2 traffic, two independent accumulator chains per fragment), keeps ONE fp32 image in LDS (the old
+// values: B operand, then the new values for the coalesced write-out) and takes the numerator straight from global memory in
+// the C/D layout, requested before the MFMA loop.  Same arithmetic and summation order per element as k_panel_update_wide_f32
+// with split operands; the norm partials stay one vector per 32 rows (panel_update_parts()).
+// ------------------------------------------------------------------------------------------
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void k_panel_update_wide64_mu(
+	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride, int RP, float eps, float* __restrict__ ps, int len_valid,
+	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	constexpr int YB = 64;
+	const int LD = RP + 4;
+	float* s_old = lds;                       // [64][LD]
+	float* s_ps = lds + YB * LD;              // [4][64]
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const long base = (long)blockIdx.x * YB * RP;
+	const int q4 = RP / 4;
+
+	// The old panel values reach LDS one K-step ahead of the MFMAs that read them: the 64 x 16 chunk of K-step u is one 16-byte
+	// load per thread (row tid / 4, piece tid % 4), DC chunks in flight.  A staging phase of the whole tile in front of the MFMA
+	// loop made every workgroup of the launch wait for HBM at the same time and multiply at the same time.
+	constexpr int DC = 4, DX = 2;
+	const int ksteps = RP / 16, NBT = RP / 32;
+	const float* gsrc = P + base + (long)(tid >> 2) * RP + 4 * (tid & 3);
+	float* sdst = s_old + (tid >> 2) * LD + 4 * (tid & 3);
+	f32x4 ch[DC];
+#pragma unroll
+	for (int d = 0; d < DC; ++d) ch[d] = *reinterpret_cast<const f32x4*>(gsrc + 16 * d);
+
+	f32x16 acc[2][NCB];
+#pragma unroll
+	for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[rb][i][g] = 0.f;
+	const bf16x8* qf = Qx3 + (long)wave * 192 + lane;        // + (ks * NBT + 4 i) * 192 + plane * 64
+	const float* vb = s_old + l31 * LD + 8 * half;
+	bf16x8 af[DX][NCB][3];
+#pragma unroll
+	for (int d = 0; d < DX; ++d)
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) af[d][i][pl] = qf[((long)d * NBT + 4 * i) * 192 + pl * 64];
+	*reinterpret_cast<f32x4*>(sdst) = ch[0];
+	ch[0] = *reinterpret_cast<const f32x4*>(gsrc + 16 * DC);
+
+	// D(c, y) = sum_k Q(k, c) old(y, k), six bf16 MFMAs per 16 k on exactly split operands
+	for (int u = 0; u < ksteps; u += DC) {
+#pragma unroll
+		for (int d = 0; d < DC; ++d) {
+			const int ks = u + d;
+			__syncthreads();                                  // chunk ks is in LDS
+			if (ks + 1 < ksteps) {
+				*reinterpret_cast<f32x4*>(sdst + 16 * (ks + 1)) = ch[(d + 1) % DC];
+				int nc = ks + 1 + DC;
+				nc = nc < ksteps ? nc : ksteps - 1;           // tail: harmless re-load
+				ch[(d + 1) % DC] = *reinterpret_cast<const f32x4*>(gsrc + 16 * nc);
+			}
+			bf16x8 hi[2], mid[2], lo[2];
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) {
+				float v[8];
+				const f32x4 b0 = *reinterpret_cast<const f32x4*>(vb + 32 * rb * LD + 16 * ks);
+				const f32x4 b1 = *reinterpret_cast<const f32x4*>(vb + 32 * rb * LD + 16 * ks + 4);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { v[j] = b0[j]; v[4 + j] = b1[j]; }
+				split3(v, hi[rb], mid[rb], lo[rb]);
+			}
+			const int dq = d % DX;
+#pragma unroll
+			for (int i = 0; i < NCB; ++i)
+#pragma unroll
+				for (int rb = 0; rb < 2; ++rb) {
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][2], hi[rb], acc[rb][i], 0, 0, 0);
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][0], lo[rb], acc[rb][i], 0, 0, 0);
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][1], mid[rb], acc[rb][i], 0, 0, 0);
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][1], hi[rb], acc[rb][i], 0, 0, 0);
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][0], mid[rb], acc[rb][i], 0, 0, 0);
+					acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dq][i][0], hi[rb], acc[rb][i], 0, 0, 0);
+				}
+			int nu = ks + DX;
+			nu = nu < ksteps ? nu : ksteps - 1;       // tail: harmless re-load of the last K-step
+#pragma unroll
+			for (int i = 0; i < NCB; ++i)
+#pragma unroll
+				for (int pl = 0; pl < 3; ++pl) af[dq][i][pl] = qf[((long)nu * NBT + 4 * i) * 192 + pl * 64];
+		}
+	}
+
+	// the numerator in the C/D layout: lane (y = l31 + 32 rb, half) owns c = 32 (wave + 4 i) + 8 q + 4 half + gi
+	f32x4 num[2][NCB][4];
+#pragma unroll
+	for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const long off = base + (long)(32 * rb + l31) * RP + 32 * (wave + 4 * i) + 8 * q + 4 * half;
+				f32x4 v = *reinterpret_cast<const f32x4*>(slabs + off);
+				for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + off);
+				num[rb][i][q] = v;
+			}
+
+	// element-wise step in the C/D layout
+	f32x4 nv[2][NCB][4];
+	float psum[2] = {0.f, 0.f};
+#pragma unroll
+	for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int c = 32 * (wave + 4 * i) + 8 * q + 4 * half;
+				const f32x4 old = *reinterpret_cast<const f32x4*>(s_old + (32 * rb + l31) * LD + c);
+				f32x4 o;
+#pragma unroll
+				for (int gi = 0; gi < 4; ++gi) o[gi] = old[gi] * num[rb][i][q][gi] / (acc[rb][i][4 * q + gi] + eps);
+#pragma unroll
+				for (int gi = 0; gi < 4; ++gi) psum[rb] += o[gi] * num[rb][i][q][gi];
+				nv[rb][i][q] = o;
+			}
+	__syncthreads();
+#pragma unroll
+	for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(s_old + (32 * rb + l31) * LD + 32 * (wave + 4 * i) + 8 * q + 4 * half) = nv[rb][i][q];
+		psum[rb] += __shfl_xor(psum[rb], 32);
+		if (half == 0) s_ps[wave * 64 + 32 * rb + l31] = psum[rb];
+	}
+	__syncthreads();
+
+	// coalesced write-out, per-row error terms, per-column sums of squares (one vector per 32 rows)
+	for (int e = tid; e < YB * q4; e += 256) {
+		const int y = e / q4, c4 = e - y * q4;
+		*reinterpret_cast<f32x4*>(P + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_old + y * LD + 4 * c4);
+	}
+	if (ps != nullptr && tid < YB) {
+		const int y = blockIdx.x * YB + tid;
+		if (y < len_valid) ps[y] = ((s_ps[tid] + s_ps[64 + tid]) + s_ps[128 + tid]) + s_ps[192 + tid];
+	}
+	if (sumsq_part != nullptr) {
+		for (int e = tid; e < 2 * RP; e += 256) {
+			const int rb = e / RP, c = e - rb * RP;
+			float s = 0.f;
+#pragma unroll 8
+			for (int y = 0; y < 32; ++y) { const float v = s_old[(32 * rb + y) * LD + c]; s += v * v; }
+			sumsq_part[((long)blockIdx.x * 2 + rb) * RP + c] = s;
+		}
+	}
+}
+
+template <int NCB>
+static hipError_t launch_wide64(float* P, const float* slabs, int S, long slab_stride, int RP, int len_pad, float eps, float* ps, int len_valid,
+                                float* sumsq_part, hipStream_t stream, const void* qx3) {
+	const size_t lds_bytes = sizeof(float) * (64 * (size_t)(RP + 4) + 256);
+	const size_t max_bytes = sizeof(float) * (64 * (size_t)(128 * NCB + 4) + 256);
+	static std::atomic<unsigned long long> lds_done{0ull};
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide64_mu<NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_panel_update_wide64_mu<NCB>), dim3(len_pad / 64), dim3(256), lds_bytes, stream,
+	                   P, slabs, S, slab_stride, RP, eps, ps, len_valid, sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	return hipGetLastError();
+}
+
 bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }
 
 template <int MODE, int NCB>
@@ -632,6 +805,10 @@ hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, 
 		if (hipError_t e = launch_pack_panel_x3(Q, RP, RP, q_split, RP / 16, stream); e != hipSuccess) return e;
 		qx3 = q_split;
 	}
+	// long panels, multiplicative update, split operands: 64 rows per workgroup (k_panel_update_wide64_mu)
+	if (mode == PANEL_MU && qx3 != nullptr && num_out == nullptr && len_pad % 64 == 0 && len_pad >= 64 * 512 && RP <= 256)
+		return RP == 128 ? launch_wide64<1>(P, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, qx3)
+		                 : launch_wide64<2>(P, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, qx3);
 #define NMFAMD_WIDE(NCB)                                                                                                                   \
 	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3) \
 	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3)

@@ -69,3 +69,37 @@ def test_theta_zero_is_the_identity():
 def test_rejected_shapes():
     with pytest.raises(na.EngineError):
         na.op_factor_passes(np.ones((64, 64), np.float32))          # padded rank 64: other kernels serve it
+
+
+# ------------------------------------------------------------------ long panels: 64 rows per workgroup in the wide update kernel
+from oracle import oracle  # noqa: E402
+
+
+def _F(a):
+    return np.asfortranarray(a)
+
+
+def _rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-300)
+
+
+@pytest.mark.parametrize("m,n,r,alg,kw", [(33000, 150, 130, "mu", {}), (150, 33000, 130, "mu", {}), (33000, 140, 256, "nsnmf", dict(theta=0.5)),
+                                           (33000, 150, 100, "mu", {})])
+def test_long_panels_match_the_oracle(m, n, r, alg, kw):
+    """Panels of >= 32 768 rows at padded ranks 128 / 256 take k_panel_update_wide64_mu (kernels_wide.hip): the W update when
+    m is long, the H update (with the per-column error terms) when n is.  Same tolerances as every fp32 engine test."""
+    rng = np.random.default_rng(m + n + r)
+    V = _F(rng.random((m, n)).astype(np.float32))
+    W = _F((1.0 - rng.random((m, r))).astype(np.float32))
+    H = _F((1.0 - rng.random((r, n))).astype(np.float32))
+    iters = 10
+    V64, W64, H64 = (_F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)          # (updates W64 / H64 in place)
+    eng = na.Engine(m, n, r, alg, **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert _rel(Wg, W64) < 2e-4 and _rel(Hg, H64) < 2e-4
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+    if alg == "mu":
+        np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)

@@ -608,7 +608,7 @@ int nmfamd_op_factor_passes_f32(const float* P, long ldp, int r, int len, const 
 		ms_finish += ms;
 		(void)hipEventRecord(e0, nullptr);
 		if (launch_gram_tri((const float*)dP.p, RP, len, cus, (float*)dPart.p, (float*)dG.p, cus, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-		if (launch_smooth_gram((const float*)dG.p, (float*)dGs.p, RP, r, off, diag, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (launch_smooth_gram((const float*)dG.p, (float*)dGs.p, RP, r, off, diag, nullptr, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 		(void)hipEventRecord(e1, nullptr);
 		if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return NMFAMD_HIP_ERROR;
 		ms_gram += ms;

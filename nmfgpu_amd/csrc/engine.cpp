@@ -205,7 +205,11 @@ Status Engine<T>::allocate() {
 	// wide fp32 panels: scratch for the split image of the r x r matrix the update kernel multiplies with (kernels_wide.hip)
 	if (std::is_same<T, float>::value && panel_update_wide_available(RP_) && std::getenv("NMFAMD_FORCE_VALU") == nullptr &&
 	    tuning_env("NMFAMD_WIDE_FP32_MFMA") == nullptr)
-		HIPX(hipMalloc(&qx3_, 3 * 16 * (size_t)(RP_ / 16 + 1) * (RP_ / 32) * 64));
+	{
+		const size_t qb = 3 * 16 * (size_t)(RP_ / 16 + 1) * (RP_ / 32) * 64;
+		HIPX(hipMalloc(&qx3_, qb));
+		HIPX(hipMemsetAsync(qx3_, 0, qb, stream_));      // (the closing all-zero K-step: k_smooth_gram writes the others only)
+	}
 	HIPX(dalloc(&slabs_, slab_elems));
 	HIPX(dalloc(&numW_, panelW));
 	HIPX(dalloc(&G_, rr));
@@ -368,7 +372,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false;
+		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -412,7 +416,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; }
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -726,8 +730,10 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		if (tri_) {
 			if (Status s = tri_prepare_w()) return s;
 			if (Status s = product_h(Wt_, nullptr, true)) return s;
-			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps,
+			// (qx3_holds_g_: k_smooth_gram left the split image of G_ in qx3_ -- Q = nullptr tells the update kernel so)
+			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, qx3_holds_g_ ? nullptr : G_, RP_, (int)npad_, eps,
 			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+			qx3_holds_g_ = false;
 			return ST_OK;
 		}
 	}
@@ -798,7 +804,7 @@ Status Engine<T>::w_products(T* exchange) {
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (tri_) {
-			if (Status s = tri_prepare_h(ex_hht)) return s;
+			if (Status s = tri_prepare_h(ex_hht, false)) return s;
 			if (Status s = product_w(H_, nullptr, exchange, true)) return s;
 			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
@@ -845,14 +851,8 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	wx3_valid_ = false;
+	if (tri_) return tri_update_w(exchange, 1, 0, ex_hht);
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
-	if constexpr (std::is_same<T, float>::value) {
-		if (tri_) {
-			HIPX(launch_colsq_stage(sumsq_part_, RP_, panel_update_parts(RP_, sizeof(T), (int)mpad_), colsq_, nullptr, stream_));
-			colsq_parts_ = colsq_stage_parts();
-			return w_normalize_rows(0, mpad_, colsq_);
-		}
-	}
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
 }
@@ -920,29 +920,65 @@ Status Engine<T>::tri_prepare_w() {
 	if constexpr (std::is_same<T, float>::value) {
 		T off, diag;
 		tri_smoothing(&off, &diag);
+		const bool wide = qx3_ != nullptr && panel_update_wide_available(RP_);
+		if (!wtb_valid_ && !tri_gw_ready_ && mpad_ % 64 == 0) {
+			// both consumers of the panel in one launch (nothing to normalise here: W is as the caller / the gather left it)
+			HIPX(launch_finish_and_gram(Wt_, Wt_, RP_, r_, mpad_, m_, nullptr, 0, off, diag, Wtb_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, num_cus_, stream_));
+			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
+			wtb_valid_ = tri_gw_ready_ = true;
+			qx3_holds_g_ = wide;
+		}
 		if (!wtb_valid_) {
 			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, 0, mpad_, nullptr, 0, off, diag, Wtb_, ksH_, stream_));
 			wtb_valid_ = true;
 		}
 		if (!tri_gw_ready_) {
 			HIPX(launch_gram_tri(Wt_, RP_, m_, num_cus_, gram_tri_part_, Gw_raw_, num_cus_, stream_));
-			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, stream_));
+			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
 			tri_gw_ready_ = true;
+			qx3_holds_g_ = wide;
 		}
 	}
 	return ST_OK;
 }
 
+// local_q: hht stays what the W update multiplies with (no reduction over ranks in between), so its split image may be left in qx3_
 template <typename T>
-Status Engine<T>::tri_prepare_h(T* hht) {
+Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
 	if constexpr (std::is_same<T, float>::value) {
 		T off, diag;
 		tri_smoothing(&off, &diag);
-		HIPX(launch_finish_panel_bf16(H_, RP_, r_, 0, npad_, nullptr, 0, off, diag, Hb_, ksW_, stream_));
-		HIPX(launch_gram_tri(H_, RP_, n_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
-		HIPX(launch_smooth_gram(Gh_raw_, hht, RP_, r_, off, diag, stream_));
+		const bool wide = local_q && qx3_ != nullptr && panel_update_wide_available(RP_);
+		if (npad_ % 64 == 0) {
+			HIPX(launch_finish_and_gram(H_, H_, RP_, r_, npad_, n_, nullptr, 0, off, diag, Hb_, ksW_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
+		} else {
+			HIPX(launch_finish_panel_bf16(H_, RP_, r_, 0, npad_, nullptr, 0, off, diag, Hb_, ksW_, stream_));
+			HIPX(launch_gram_tri(H_, RP_, n_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
+		}
+		HIPX(launch_smooth_gram(Gh_raw_, hht, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
+		qx3_holds_g_ = false;
+		qx3_holds_hht_ = wide;
 	}
 	return ST_OK;
+}
+
+// The W update of the rank-256 bf16 path on the whole panel: num = the reduced (V (S H)^T)^T panel (S slabs), hht its r x r operand
+// (nullptr: its split image is in qx3_); then the column sums of squares, and ONE pass that normalises W and leaves the bf16 fragments
+// of its smoothed rows.  (Tried: the update writing to a scratch panel and normalisation + fragments + Gram matrix in one launch --
+// the Gram workgroups hold the CUs' registers, the two kinds of workgroup run one after the other: 68 us against 32 + 31.)
+template <typename T>
+Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
+	if constexpr (std::is_same<T, float>::value) {
+		const T eps = std::numeric_limits<T>::epsilon();
+		const int parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
+		wx3_valid_ = false;
+		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+		qx3_holds_g_ = qx3_holds_hht_ = false;
+		HIPX(launch_colsq_stage(sumsq_part_, RP_, parts, colsq_, nullptr, stream_));
+		colsq_parts_ = colsq_stage_parts();
+		return w_normalize_rows(0, mpad_, colsq_);
+	}
+	return ST_INVALID;
 }
 
 template <typename T>
@@ -1038,7 +1074,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 		const T* Fh = H_;
 		bool hht_done = false;
 		if (tri_) {
-			if (Status s = tri_prepare_h(HHt_)) return s;
+			if (Status s = tri_prepare_h(HHt_, true)) return s;
 			hht_done = true;
 		} else if (alg_ == ALG_NSNMF) {
 			const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -1090,13 +1126,13 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				wx3_valid_ = false;
-				HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
-				                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (tri_) {
-					if constexpr (std::is_same<T, float>::value) HIPX(launch_colsq_stage(sumsq_part_, RP_, norm_parts, colsq_, nullptr, stream_));
-					colsq_parts_ = colsq_stage_parts();
-					if (Status s = w_normalize_rows(0, mpad_, reinterpret_cast<T*>(colsq_))) return s;
-				} else if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
+					if (Status s = tri_update_w(slabs_, S, slab_stride_, qx3_holds_hht_ ? nullptr : HHt_)) return s;
+				} else {
+					HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,
+					                            nullptr, m_, sumsq_part_, gd_err ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
+					if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
+				}
 				if (gd_err) {
 					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
 					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));

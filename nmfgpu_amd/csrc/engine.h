@@ -72,7 +72,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
@@ -207,9 +207,11 @@ private:
 	bool tri_rows_cover_ = false;    // the last w_normalize_rows() covered every row of W
 	int colsq_parts_ = 1;            // staged partial vectors in colsq_ (kernels_tri.hip: launch_colsq_stage)
 	float *gram_tri_part_ = nullptr, *Gw_raw_ = nullptr, *Gh_raw_ = nullptr, *colsq_ = nullptr;
+	bool qx3_holds_g_ = false, qx3_holds_hht_ = false;   // qx3_ holds the split image of G_ / of the smoothed H H^T (k_smooth_gram)
 	void tri_smoothing(T* offdiag, T* diag) const;
 	Status tri_prepare_w();          // Wtb_, Gw_raw_, G_ for the H step
-	Status tri_prepare_h(T* hht);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
+	Status tri_prepare_h(T* hht, bool local_q);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
+	Status tri_update_w(const T* num, int S, long stride, const T* hht);   // W update + normalisation + everything tri_prepare_w() would do
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;

@@ -129,6 +129,11 @@ hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs,
 bool panel_update_delivers_gram(int RP, size_t elem);
 // fp32 / padded rank 128 ... 512 (kernels_wide.hip)
 bool panel_update_wide_available(int RP);
+// long panels at padded rank 128 / 256 (kernels_wide.hip, k_panel_update_wide64_mu): multiplicative update with the r x r operand given as
+// its split image; the result may go to another panel (P_out != P_in), e.g. to keep the unnormalised W readable while it is normalised
+bool panel_update_long_available(int RP, int len_pad);
+hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const float* slabs, int S, long slab_stride, const void* q_split, int RP, int len_pad,
+                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream);
 bool gram_wide_available(int RP);
 // len: valid panel rows (the padding rows behind them are zero); partial: parts * RP * RP elements
 hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream);
@@ -224,7 +229,13 @@ hipError_t launch_colsq_stage(const float* part, int RP, int parts, float* stage
 hipError_t launch_gram_tri(const float* P, int RP, int len, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream);
 long gram_tri_partial_elems(int max_parts);
 // Gs = S G S, S = (diag - offdiag) I + offdiag 1 1^T on the first r rows / columns
-hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float offdiag, float diag, hipStream_t stream);
+// x3_out (optional): also the split image of Gs that the wide update kernels take as their r x r operand (launch_panel_update with Q = nullptr);
+// its closing all-zero K-step is the caller's (written once)
+hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float offdiag, float diag, void* x3_out, hipStream_t stream);
+// the finishing pass over ALL rows of a panel and its Gram matrix in one launch (+ the reduction); colsq != nullptr: P_out (!= P_in) <- the
+// column-normalised panel, G = the Gram matrix of the normalised panel
+hipError_t launch_finish_and_gram(const float* P_in, float* P_out, int RP, int r, long rows, int len, const float* colsq, int colsq_parts, float offdiag, float diag,
+                                  void* dst, long KS, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream);
 hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 // K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP

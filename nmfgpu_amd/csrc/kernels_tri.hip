@@ -48,11 +48,11 @@ __device__ inline void tri_tile(int t, int& i, int& j) {
 // columns, exactly the eight values of one bf16 fragment -- no transposition through LDS.
 // colsq != nullptr: P(y, c) <- sum[c] > 0 ? P / sqrt(sum[c]) : P, written back; sum = the colsq_parts partial vectors of RP sums of squares, added in order.  Then out = offdiag * (rowsum - x) + diag * x
 // for c < r (the analytic S of k_smooth_panel), rounded to nearest-even bf16, stored at the fragment slot of (ks0 + row / 16).
-__global__ __launch_bounds__(256, 4) void k_finish_panel_bf16(float* __restrict__ P, const float* __restrict__ colsq, int colsq_parts, int r, float offdiag, float diag,
-                                                              bf16x8* __restrict__ dst, long ks0, long KS) {
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const long row0 = (long)blockIdx.x * 32 + 8 * wave;
-	float* p = P + row0 * TRI_RP + 4 * lane;
+// (device body: eight rows starting at row0 of the launch's row range, one wave; Pin may be Pout)
+__device__ __forceinline__ void finish_rows_wave(const float* Pin, float* Pout, long row0, int lane, const float* __restrict__ colsq, int colsq_parts, int r, float offdiag,
+                                        float diag, bf16x8* __restrict__ dst, long ks0, long KS) {
+	const float* p = Pin + row0 * TRI_RP + 4 * lane;
+	float* po = Pout + row0 * TRI_RP + 4 * lane;
 	float x[8][4];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 4) void k_finish_panel_bf16(float* __restrict_
 			f32x4 t;
 #pragma unroll
 			for (int i = 0; i < 4; ++i) t[i] = x[k][i];
-			*reinterpret_cast<f32x4*>(p + (long)k * TRI_RP) = t;
+			*reinterpret_cast<f32x4*>(po + (long)k * TRI_RP) = t;
 		}
 	}
 	float s[8];
@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256, 4) void k_finish_panel_bf16(float* __restrict_
 		for (int k = 0; k < 8; ++k) f[k] = (__bf16)(keep * (offdiag * (s[k] - x[k][i]) + diag * x[k][i]));
 		o[i] = f;
 	}
+}
+
+__global__ __launch_bounds__(256, 4) void k_finish_panel_bf16(float* P, const float* __restrict__ colsq, int colsq_parts, int r, float offdiag, float diag,
+                                                              bf16x8* __restrict__ dst, long ks0, long KS) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	finish_rows_wave(P, P, (long)blockIdx.x * 32 + 8 * wave, lane, colsq, colsq_parts, r, offdiag, diag, dst, ks0, KS);
 }
 
 hipError_t launch_finish_panel_bf16(float* P, int RP, int r, long row0, long rows, const float* colsq, int colsq_parts, float offdiag, float diag, void* dst, long KS, hipStream_t stream) {
@@ -156,12 +162,11 @@ hipError_t launch_colsq_stage(const float* part, int RP, int parts, float* stage
 // tiles t = w, w + 8, ... (operand layout of the 32x32x16 MFMA: both operands are "lane (c, h) holds rows 8 h .. 8 h + 7 of column c",
 // so one fragment serves as A of tile (i, .) and as B of tile (., i)).
 // partial[(part * 36 + t) * 1024 + g * 64 + lane] = accumulator register g of tile t.
-__global__ __launch_bounds__(512, 1) void k_gram_tri_x3(const float* __restrict__ P, int len, int parts, float* __restrict__ partial) {
-	__shared__ bf16x8 buf[2][TRI_NB * 3 * 64];
+__device__ __forceinline__ void gram_tri_block(const float* __restrict__ P, int len, int parts, int part, float* __restrict__ partial, bf16x8* __restrict__ buf) {
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int steps_total = (len + 15) / 16;
-	const int s0 = (int)(((long)steps_total * blockIdx.x) / parts);
-	const int s1 = (int)(((long)steps_total * (blockIdx.x + 1)) / parts);
+	const int s0 = (int)(((long)steps_total * part) / parts);
+	const int s1 = (int)(((long)steps_total * (part + 1)) / parts);
 	const int steps = s1 - s0;
 	constexpr int TPW = (TRI_TILES + 7) / 8;       // tiles per wave (the last one only for waves < TRI_TILES % 8)
 	int ti[TPW], tj[TPW];
@@ -190,11 +195,11 @@ __global__ __launch_bounds__(512, 1) void k_gram_tri_x3(const float* __restrict_
 		auto publish = [&](int b, const float (&val)[8]) {
 			bf16x8 hi, mid, lo;
 			split3(val, hi, mid, lo);
-			bf16x8* o = &buf[b][wave * 192 + lane];
+			bf16x8* o = buf + b * (TRI_NB * 192) + wave * 192 + lane;
 			o[0] = hi; o[64] = mid; o[128] = lo;
 		};
 		auto tiles = [&](int b) {
-			const bf16x8* f = buf[b];
+			const bf16x8* f = buf + b * (TRI_NB * 192);
 #pragma unroll
 			for (int q = 0; q < TPW; ++q) {
 				if (q == TPW - 1 && wave + 8 * q >= TRI_TILES) break;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(512, 1) void k_gram_tri_x3(const float* __restrict_
 			}
 		}
 	}
-	float* out = partial + (long)blockIdx.x * TRI_TILES * 1024;
+	float* out = partial + (long)part * TRI_TILES * 1024;
 #pragma unroll
 	for (int q = 0; q < TPW; ++q) {
 		const int t = wave + 8 * q;
@@ -239,10 +244,29 @@ __global__ __launch_bounds__(512, 1) void k_gram_tri_x3(const float* __restrict_
 	}
 }
 
+__global__ __launch_bounds__(512, 1) void k_gram_tri_x3(const float* __restrict__ P, int len, int parts, float* __restrict__ partial) {
+	__shared__ bf16x8 buf[2][TRI_NB * 3 * 64];
+	gram_tri_block(P, len, parts, blockIdx.x, partial, &buf[0][0]);
+}
+
+// One launch for the two consumers of a freshly updated panel: workgroups [0, parts) take the Gram slices of Pin (the long pole: first
+// in the grid), the others 64 rows each of the finishing pass Pin -> Pout (+ bf16 fragments).  Pin != Pout when the pass normalises
+// (the Gram workgroups must see ONE version of the panel: the unnormalised one; k_gram_tri_reduce applies the column scales).
+__global__ __launch_bounds__(512, 2) void k_finish_and_gram(const float* Pin, float* Pout, int len, int parts, float* __restrict__ partial,
+                                                            const float* __restrict__ colsq, int colsq_parts, int r, float offdiag, float diag,
+                                                            bf16x8* __restrict__ dst, long KS) {
+	__shared__ bf16x8 buf[2][TRI_NB * 3 * 64];
+	if ((int)blockIdx.x < parts) { gram_tri_block(Pin, len, parts, blockIdx.x, partial, &buf[0][0]); return; }
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	finish_rows_wave(Pin, Pout, (long)(blockIdx.x - parts) * 64 + 8 * wave, lane, colsq, colsq_parts, r, offdiag, diag, dst, 0, KS);
+}
+
 // One thread per accumulator element: partials added in slice order.  C/D map of the 32 x 32 MFMA: register g of lane l is row
 // (g & 3) + 8 (g >> 2) + 4 (l >> 5) (index within block i), column l & 31 (within block j).  Diagonal tiles: (r, c) and (c, r) add
 // the six terms in different orders, so the upper triangle is kept and mirrored.
-__global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict__ partial, int parts, float* __restrict__ G) {
+// colsq != nullptr: the slices were taken from the panel BEFORE its column normalisation x / sqrt(sum) (sum = the staged vectors, added in order;
+// columns without a norm keep their values): G(r, c) is divided by the two norms.
+__global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict__ partial, int parts, float* __restrict__ G, const float* __restrict__ colsq, int colsq_parts) {
 	// 64 accumulator elements per workgroup; wave q adds the q-th quarter of the slices, the quarters are added in order
 	__shared__ float s_q[4][64];
 	const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -268,6 +292,12 @@ __global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict
 	int i, j;
 	tri_tile(t, i, j);
 	const int r = 32 * i + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), c = 32 * j + (l & 31);
+	if (colsq != nullptr) {
+		float sr = colsq[r], sc = colsq[c];
+		for (int k = 1; k < colsq_parts; ++k) { sr += colsq[(long)k * TRI_RP + r]; sc += colsq[(long)k * TRI_RP + c]; }
+		const float nr = sr > 0.f ? sqrtf(sr) : 1.0f, nc = sc > 0.f ? sqrtf(sc) : 1.0f;
+		sum = (sum / nr) / nc;
+	}
 	if (i != j || r <= c) {
 		G[(long)r * TRI_RP + c] = sum;
 		if (r != c) G[(long)c * TRI_RP + r] = sum;
@@ -282,7 +312,22 @@ hipError_t launch_gram_tri(const float* P, int RP, int len, int max_parts, float
 	hipLaunchKernelGGL(k_gram_tri_x3, dim3(parts), dim3(512), 0, stream, P, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G);
+	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, (const float*)nullptr, 0);
+	return hipGetLastError();
+}
+
+// launch_finish_panel_bf16 over ALL rows of the panel (rows: a multiple of 64) and launch_gram_tri in one launch + the reduction.
+// colsq != nullptr: P_out <- P_in normalised (P_out != P_in), G = the Gram matrix of the NORMALISED panel; else P_out is not written (pass P_in).
+hipError_t launch_finish_and_gram(const float* P_in, float* P_out, int RP, int r, long rows, int len, const float* colsq, int colsq_parts, float offdiag, float diag,
+                                  void* dst, long KS, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream) {
+	if (RP != TRI_RP || rows <= 0 || rows % 64 != 0 || len <= 0 || (colsq != nullptr && P_in == P_out)) return hipErrorInvalidValue;
+	const int steps_total = (len + 15) / 16;
+	const int parts = std::max(1, std::min(std::min(num_cus, max_parts), steps_total / 4));
+	hipLaunchKernelGGL(k_finish_and_gram, dim3((unsigned)(parts + rows / 64)), dim3(512), 0, stream, P_in, P_out, len, parts, partial, colsq, colsq_parts, r, offdiag, diag,
+	                   reinterpret_cast<bf16x8*>(dst), KS);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, colsq, colsq_parts);
 	return hipGetLastError();
 }
 
@@ -290,7 +335,7 @@ long gram_tri_partial_elems(int max_parts) { return (long)max_parts * TRI_TILES 
 
 // Gs = S G S for S = a I + b 1 1^T restricted to the first r rows / columns (a = diag - offdiag, b = offdiag of k_smooth_panel).
 // Every workgroup forms all row sums (G is symmetric: thread i adds column i, coalesced) and writes four rows.
-__global__ __launch_bounds__(1024) void k_smooth_gram(const float* __restrict__ G, float* __restrict__ Gs, int r, float a, float b) {
+__global__ __launch_bounds__(1024) void k_smooth_gram(const float* __restrict__ G, float* __restrict__ Gs, int r, float a, float b, bf16x8* __restrict__ x3) {
 	__shared__ float s_p[4][TRI_RP];
 	__shared__ float s_g[TRI_RP];
 	__shared__ float s_w[4];
@@ -319,16 +364,26 @@ __global__ __launch_bounds__(1024) void k_smooth_gram(const float* __restrict__ 
 		if ((tid & 63) == 0) s_w[tid >> 6] = t;
 	}
 	__syncthreads();
+	if (tid >= 256) return;
 	const float t = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 	const float a2 = a * a, ab = a * b, b2t = (b * b) * t;
-	const int i = blockIdx.x * 4 + q;
-	const float v = G[(long)i * TRI_RP + c];
-	Gs[(long)i * TRI_RP + c] = (i < r && c < r) ? (a2 * v + ab * (s_g[i] + s_g[c])) + b2t : 0.f;
+	// rows 8 blockIdx .. + 7 of column c: exactly one fragment (K-step blockIdx / 2, half blockIdx & 1) of the split image the update
+	// kernels take as their r x r operand (k_pack_panel_x3 of Gs: A(c, k) = Gs(k, c))
+	float v[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) v[k] = G[(long)(blockIdx.x * 8 + k) * TRI_RP + c];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int i = blockIdx.x * 8 + k;
+		v[k] = (i < r && c < r) ? (a2 * v[k] + ab * (s_g[i] + s_g[c])) + b2t : 0.f;
+		Gs[(long)i * TRI_RP + c] = v[k];
+	}
+	if (x3 != nullptr) store_split3(x3, blockIdx.x >> 1, TRI_NB, c >> 5, blockIdx.x & 1, c & 31, v);
 }
 
-hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float offdiag, float diag, hipStream_t stream) {
+hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float offdiag, float diag, void* x3_out, hipStream_t stream) {
 	if (RP != TRI_RP) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_smooth_gram, dim3(TRI_RP / 4), dim3(1024), 0, stream, G, Gs, r, diag - offdiag, offdiag);
+	hipLaunchKernelGGL(k_smooth_gram, dim3(TRI_RP / 8), dim3(1024), 0, stream, G, Gs, r, diag - offdiag, offdiag, reinterpret_cast<bf16x8*>(x3_out));
 	return hipGetLastError();
 }
 

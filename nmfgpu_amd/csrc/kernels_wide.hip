@@ -620,7 +620,7 @@ hipError_t launch_panel_update64_lds_f32(int mode, float* P, const float* slabs,
 // ------------------------------------------------------------------------------------------
 template <int NCB>
 __global__ __launch_bounds__(256, 2) void k_panel_update_wide64_mu(
-	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride, int RP, float eps, float* __restrict__ ps, int len_valid,
+	const float* P, float* Pout, const float* __restrict__ slabs, int S, long slab_stride, int RP, float eps, float* __restrict__ ps, int len_valid,
 	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	constexpr int YB = 64;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide64_mu(
 	// coalesced write-out, per-row error terms, per-column sums of squares (one vector per 32 rows)
 	for (int e = tid; e < YB * q4; e += 256) {
 		const int y = e / q4, c4 = e - y * q4;
-		*reinterpret_cast<f32x4*>(P + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_old + y * LD + 4 * c4);
+		*reinterpret_cast<f32x4*>(Pout + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_old + y * LD + 4 * c4);
 	}
 	if (ps != nullptr && tid < YB) {
 		const int y = blockIdx.x * YB + tid;
@@ -771,15 +771,26 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide64_mu(
 }
 
 template <int NCB>
-static hipError_t launch_wide64(float* P, const float* slabs, int S, long slab_stride, int RP, int len_pad, float eps, float* ps, int len_valid,
+static hipError_t launch_wide64(const float* P, float* Pout, const float* slabs, int S, long slab_stride, int RP, int len_pad, float eps, float* ps, int len_valid,
                                 float* sumsq_part, hipStream_t stream, const void* qx3) {
 	const size_t lds_bytes = sizeof(float) * (64 * (size_t)(RP + 4) + 256);
 	const size_t max_bytes = sizeof(float) * (64 * (size_t)(128 * NCB + 4) + 256);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide64_mu<NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide64_mu<NCB>), dim3(len_pad / 64), dim3(256), lds_bytes, stream,
-	                   P, slabs, S, slab_stride, RP, eps, ps, len_valid, sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	                   P, Pout, slabs, S, slab_stride, RP, eps, ps, len_valid, sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
 	return hipGetLastError();
+}
+
+// long panels (k_panel_update_wide64_mu serves them): the multiplicative update may write its result to another panel
+bool panel_update_long_available(int RP, int len_pad) { return (RP == 128 || RP == 256) && len_pad % 64 == 0 && len_pad >= 64 * 512; }
+
+// P_out <- P_in * num / (P_in Q + eps) with Q given as its split image (k_pack_panel_x3 of Q); P_out may be P_in
+hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const float* slabs, int S, long slab_stride, const void* q_split, int RP, int len_pad,
+                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream) {
+	if (!panel_update_long_available(RP, len_pad) || q_split == nullptr) return hipErrorInvalidValue;
+	return RP == 128 ? launch_wide64<1>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split)
+	                 : launch_wide64<2>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split);
 }
 
 bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }
@@ -802,13 +813,13 @@ hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, 
 	const void* qx3 = nullptr;
 	if (q_split != nullptr) {
 		// Q (RP x RP) split into three bf16 planes in fragment order: A(c, k) = Q(k, c) = Q[k * RP + c]
-		if (hipError_t e = launch_pack_panel_x3(Q, RP, RP, q_split, RP / 16, stream); e != hipSuccess) return e;
+		// (Q == nullptr: q_split holds that image already -- k_smooth_gram writes it next to the matrix)
+		if (Q != nullptr) { if (hipError_t e = launch_pack_panel_x3(Q, RP, RP, q_split, RP / 16, stream); e != hipSuccess) return e; }
 		qx3 = q_split;
-	}
+	} else if (Q == nullptr) return hipErrorInvalidValue;
 	// long panels, multiplicative update, split operands: 64 rows per workgroup (k_panel_update_wide64_mu)
-	if (mode == PANEL_MU && qx3 != nullptr && num_out == nullptr && len_pad % 64 == 0 && len_pad >= 64 * 512 && RP <= 256)
-		return RP == 128 ? launch_wide64<1>(P, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, qx3)
-		                 : launch_wide64<2>(P, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, qx3);
+	if (mode == PANEL_MU && qx3 != nullptr && num_out == nullptr && panel_update_long_available(RP, len_pad))
+		return launch_panel_update_long_mu(P, P, slabs, S, slab_stride, qx3, RP, len_pad, eps, ps, len_valid, sumsq_part, stream);
 #define NMFAMD_WIDE(NCB)                                                                                                                   \
 	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3) \
 	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3)

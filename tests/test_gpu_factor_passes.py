@@ -103,3 +103,28 @@ def test_long_panels_match_the_oracle(m, n, r, alg, kw):
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
     if alg == "mu":
         np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,n", [(33000, 140), (500, 420)])
+def test_rank256_bf16_path_tracks_fp32(m, n):
+    """nsNMF at r = 256 with bf16 product operands (the fused passes of kernels_tri.hip; long W: the update writes to a scratch panel and one
+    launch normalises, packs and takes the Gram matrix) against the fp64 oracle within the bf16 mode's stated 2e-2, error terms included."""
+    r, theta, iters = 256, 0.5, 10
+    rng = np.random.default_rng(m)
+    V = _F(rng.random((m, n)).astype(np.float32))
+    W = _F((1.0 - rng.random((m, r))).astype(np.float32))
+    H = _F((1.0 - rng.random((r, n))).astype(np.float32))
+    V64, W64, H64 = (_F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("nsnmf", V64, W64, H64, iters, theta=theta)
+    eng = na.Engine(m, n, r, "nsnmf", theta=theta, precision="bf16")
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert _rel(Wg, W64) < 2e-2 and _rel(Hg, H64) < 2e-2
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=2e-3)
+    # the same run twice: bit-identical (no atomics, fixed summation orders)
+    eng2 = na.Engine(m, n, r, "nsnmf", theta=theta, precision="bf16")
+    eng2.upload(V); eng2.set_factors(W, H)
+    eng2.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    W2, H2 = eng2.get_factors()
+    assert np.array_equal(Wg, W2) and np.array_equal(Hg, H2)

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "tuning.h"
@@ -782,6 +783,185 @@ static hipError_t launch_wide64(const float* P, float* Pout, const float* slabs,
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// MODE_MU on long panels, second form: a wave owns 32 whole panel rows.
+// The kernels above let the four waves of a workgroup share the panel rows (B operand, through LDS) and split the columns:
+// every wave splits the same rows again, the panel tile is staged and written out through LDS, and with two such workgroups per
+// CU the launch is a sum of serial chains (profiles/r02_c4_kernel_experiments.md: 65 us, 37 us with everything but the skeleton
+// removed, against 25 us of HBM time and 20 us of MFMA time).  Here the waves of a workgroup share Q instead:
+//   * the K-step's fragments of the split image of Q (6 RP bytes per k: 24 KB at rank 256) go through a two-slot LDS ring, loaded
+//     once per workgroup and K-step, read by all four waves;
+//   * a wave takes its own 32 rows straight from global memory (a lane: row l & 31, the 8 k of its half: two 16-byte loads per
+//     K-step, four K-steps in flight), splits them ONCE, and multiplies them with all RP / 32 column blocks: one split per
+//     48 MFMAs instead of one per 12;
+//   * the MFMA computes D(y, c) = sum_k old(y, k) Q(k, c) with the ROWS as its M index: a lane ends up with 16 rows of ONE column
+//     per block, so old / num / new values are 4-byte accesses that are contiguous across lanes (128 B per row and block), the
+//     column sums of squares are in-lane sums plus one cross-half exchange, and nothing is staged through LDS.
+// Same value per element as k_panel_update_wide64_mu (same six-term product, same K order).
+// Measured at config 4 (profiles/r02_c4_kernel_experiments.md): 58 us against 65 - 68; the parts still add up instead of overlapping
+// (MFMAs 16.5, epilogue 17, staging of Q 13, operand split 8.5, skeleton 16), and delaying the second workgroup of each CU by
+// 6 .. 18 us made it slower, not faster.
+// ------------------------------------------------------------------------------------------
+template <int NC, bool HAS_PS>          // NC: column blocks of 32 (RP / 32); HAS_PS: per-row error terms wanted
+__global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
+	const float* P, float* Pout, const float* __restrict__ slabs, int S, long slab_stride, float eps, float* __restrict__ ps, int len_valid,
+	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3) {
+	constexpr int RP = 32 * NC, KSTEPS = RP / 16, FR = NC * 192;      // fragments (16 B) of Q per K-step
+	constexpr int QL = FR / 256;                                      // Q fragments per thread and K-step (6 at rank 256, 3 at 128)
+	static_assert(FR % 256 == 0, "whole fragments per thread");
+	__shared__ __attribute__((aligned(16))) bf16x8 s_q[2][FR];
+	__shared__ float s_sq[4][RP];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int half = lane >> 5, l31 = lane & 31;
+	const long row0 = (long)blockIdx.x * 128 + 32 * wave;            // this wave's rows (wave-uniform)
+	const float* prow = P + row0 * RP + (l31 * RP + 8 * half);        // + 16 u: the 8 k of this lane in K-step u
+
+	constexpr int DA = 4;                                             // K-steps of the wave's own rows in flight
+	f32x4 ra[DA][2];
+#pragma unroll
+	for (int d = 0; d < DA; ++d) { ra[d][0] = *reinterpret_cast<const f32x4*>(prow + 16 * d); ra[d][1] = *reinterpret_cast<const f32x4*>(prow + 16 * d + 4); }
+	bf16x8 rq[QL];
+#pragma unroll
+	for (int i = 0; i < QL; ++i) rq[i] = Qx3[tid + 256 * i];
+#pragma unroll
+	for (int i = 0; i < QL; ++i) s_q[0][tid + 256 * i] = rq[i];
+#pragma unroll
+	for (int i = 0; i < QL; ++i) rq[i] = Qx3[(long)FR + tid + 256 * i];
+
+	f32x16 acc[NC];
+#pragma unroll
+	for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+		for (int g = 0; g < 16; ++g) acc[cb][g] = 0.f;
+
+	bf16x8 nh, nm, nl;
+	{
+		float v[8];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { v[j] = ra[0][0][j]; v[4 + j] = ra[0][1][j]; }
+		split3(v, nh, nm, nl);
+	}
+	for (int u = 0; u < KSTEPS; u += DA) {
+#pragma unroll
+		for (int d = 0; d < DA; ++d) {
+			const int ks = u + d;
+			__syncthreads();                                  // Q of K-step ks is in slot ks & 1; slot (ks + 1) & 1 is free
+			if (ks + 1 < KSTEPS) {
+#pragma unroll
+				for (int i = 0; i < QL; ++i) s_q[(d + 1) & 1][tid + 256 * i] = rq[i];
+				int nq = ks + 2;
+				nq = nq < KSTEPS ? nq : KSTEPS - 1;           // tail: harmless re-load
+#pragma unroll
+				for (int i = 0; i < QL; ++i) rq[i] = Qx3[(long)nq * FR + tid + 256 * i];
+			}
+			// this K-step's operand was split during the previous one; the next one's is split among this step's MFMAs
+			const bf16x8 hi = nh, mid = nm, lo = nl;
+			{
+				float v[8];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { v[j] = ra[(d + 1) % DA][0][j]; v[4 + j] = ra[(d + 1) % DA][1][j]; }
+				split3(v, nh, nm, nl);
+				int na = ks + DA;
+				na = na < KSTEPS ? na : KSTEPS - 1;
+				ra[d][0] = *reinterpret_cast<const f32x4*>(prow + 16 * na); ra[d][1] = *reinterpret_cast<const f32x4*>(prow + 16 * na + 4);
+			}
+			const bf16x8* q = &s_q[d & 1][lane];
+			// the fragments of block cb + 1 are read while block cb multiplies (two sets of three live, not NC)
+			bf16x8 qa[2][3];
+			qa[0][0] = q[0]; qa[0][1] = q[64]; qa[0][2] = q[128];
+#pragma unroll
+			for (int cb = 0; cb < NC; ++cb) {
+				if (cb + 1 < NC) { qa[(cb + 1) & 1][0] = q[(cb + 1) * 192]; qa[(cb + 1) & 1][1] = q[(cb + 1) * 192 + 64]; qa[(cb + 1) & 1][2] = q[(cb + 1) * 192 + 128]; }
+				const bf16x8 q0 = qa[cb & 1][0], q1 = qa[cb & 1][1], q2 = qa[cb & 1][2];
+				// smallest terms first; A = the panel rows (M = y), B = Q (N = c)
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q2, acc[cb], 0, 0, 0);
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, q0, acc[cb], 0, 0, 0);
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q1, acc[cb], 0, 0, 0);
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q1, acc[cb], 0, 0, 0);
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q0, acc[cb], 0, 0, 0);
+				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q0, acc[cb], 0, 0, 0);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+
+	// element-wise step: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the wave's 32, column 32 cb + (l & 31):
+	// wave-uniform bases + one lane offset, 128 contiguous bytes per row and block
+	const float* pw = P + row0 * RP;
+	const float* nw = slabs + row0 * RP;
+	float* ow = Pout + row0 * RP;
+	const int lofs = 4 * half * RP + l31;
+	float rowdot[HAS_PS ? 16 : 1];
+#pragma unroll
+	for (int g = 0; g < (HAS_PS ? 16 : 1); ++g) rowdot[g] = 0.f;
+	// the values of block cb + 1 are requested before block cb is worked on: the numerator comes from HBM, and eight
+	// load -> divide -> store chains in a row would each expose that latency
+	float oldv[2][16], numv[2][16];
+	auto request = [&](int cb, float (&o)[16], float (&nm)[16]) {
+#pragma unroll
+		for (int g = 0; g < 16; ++g) {
+			const int idx = ((g & 3) + 8 * (g >> 2)) * RP + 32 * cb;
+			o[g] = pw[idx + lofs];
+			float nv = nw[idx + lofs];
+			for (int k = 1; k < S; ++k) nv += nw[(long)k * slab_stride + idx + lofs];
+			nm[g] = nv;
+		}
+	};
+	request(0, oldv[0], numv[0]);
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int cb = 0; cb < NC; ++cb) {
+		if (cb + 1 < NC) request(cb + 1, oldv[(cb + 1) & 1], numv[(cb + 1) & 1]);
+		__builtin_amdgcn_sched_barrier(0);
+		float sq = 0.f;
+#pragma unroll
+		for (int g = 0; g < 16; ++g) {
+			const int idx = ((g & 3) + 8 * (g >> 2)) * RP + 32 * cb;
+			const float o = oldv[cb & 1][g] * numv[cb & 1][g] / (acc[cb][g] + eps);
+			ow[idx + lofs] = o;
+			if (HAS_PS) rowdot[g] += o * numv[cb & 1][g];
+			sq += o * o;                                        // rows in register order
+		}
+		if (sumsq_part != nullptr) {
+			sq += __shfl_xor(sq, 32);
+			if (half == 0) s_sq[wave][32 * cb + l31] = sq;
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	if (HAS_PS && ps != nullptr) {
+		// per-row terms sum_c new(y, c) num(y, c): over the 32 lanes of a half
+#pragma unroll
+		for (int w = 16; w > 0; w >>= 1)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) rowdot[g] += __shfl_xor(rowdot[g], w);
+		if (l31 == 0) {
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const long y = row0 + (g & 3) + 8 * (g >> 2) + 4 * half;
+				if (y < len_valid) ps[y] = rowdot[g];
+			}
+		}
+	}
+	if (sumsq_part != nullptr) {
+		// one vector per 32 rows, as panel_update_parts() promises: 4 per workgroup
+		__builtin_amdgcn_s_waitcnt(0xc07f);
+		__builtin_amdgcn_wave_barrier();
+		for (int c = lane; c < RP; c += 64) sumsq_part[((long)blockIdx.x * 4 + wave) * RP + c] = s_sq[wave][c];
+	}
+}
+
+template <int NC>
+static hipError_t launch_rows_mu(const float* P, float* Pout, const float* slabs, int S, long slab_stride, int len_pad, float eps, float* ps, int len_valid,
+                                 float* sumsq_part, hipStream_t stream, const void* qx3) {
+	const int blocks = len_pad / 128;
+	if (ps != nullptr) hipLaunchKernelGGL((k_panel_update_rows_mu<NC, true>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
+	                                      sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	else hipLaunchKernelGGL((k_panel_update_rows_mu<NC, false>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
+	                        sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	return hipGetLastError();
+}
+
 // long panels (k_panel_update_wide64_mu serves them): the multiplicative update may write its result to another panel
 bool panel_update_long_available(int RP, int len_pad) { return (RP == 128 || RP == 256) && len_pad % 64 == 0 && len_pad >= 64 * 512; }
 
@@ -789,6 +969,12 @@ bool panel_update_long_available(int RP, int len_pad) { return (RP == 128 || RP 
 hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const float* slabs, int S, long slab_stride, const void* q_split, int RP, int len_pad,
                                        float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream) {
 	if (!panel_update_long_available(RP, len_pad) || q_split == nullptr) return hipErrorInvalidValue;
+#ifndef NMFAMD_UPDATE_ROWS
+#define NMFAMD_UPDATE_ROWS 1
+#endif
+	if (NMFAMD_UPDATE_ROWS && len_pad % 128 == 0 && !(ps != nullptr && RP == 256))      // (rank 256 with error terms: that instantiation spills)
+		return RP == 128 ? launch_rows_mu<4>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split)
+		                 : launch_rows_mu<8>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split);
 	return RP == 128 ? launch_wide64<1>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split)
 	                 : launch_wide64<2>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split);
 }

@@ -128,3 +128,22 @@ def test_rank256_bf16_path_tracks_fp32(m, n):
     eng2.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
     W2, H2 = eng2.get_factors()
     assert np.array_equal(Wg, W2) and np.array_equal(Hg, H2)
+
+
+@pytest.mark.parametrize("alg,r,kw,const_w", [("mu", 200, {}, False), ("nsnmf", 256, dict(theta=0.3), True), ("mu", 256, {}, True)])
+def test_rank256_bf16_path_other_entries(alg, r, kw, const_w):
+    """The same fused passes serve the multiplicative update (theta = 0: S = I) and constant basis vectors (W never written, the
+    passes over W run once) -- against the fp64 oracle within the bf16 mode's tolerance."""
+    m, n, iters = 420, 390, 10
+    rng = np.random.default_rng(r + int(const_w))
+    V = _F(rng.random((m, n)).astype(np.float32))
+    W = _F((1.0 - rng.random((m, r))).astype(np.float32))
+    H = _F((1.0 - rng.random((r, n))).astype(np.float32))
+    V64, W64, H64 = (_F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, const_w=const_w, **kw)
+    eng = na.Engine(m, n, r, alg, precision="bf16", **kw)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters, constant_w=const_w)
+    Wg, Hg = eng.get_factors()
+    assert _rel(Hg, H64) < 2e-2 and _rel(Wg, W64) < 2e-2
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=2e-3)

@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	// that is visible and read next, the pair being written).  Measured the same as one barrier per step (156 us either way), as did
 	// ring depths 4 .. 12: with the MFMAs removed the kernel takes 155 us, with A served from cache instead of HBM 125 us, with F
 	// from cache 158 us (profiles/r02_c4_kernel_experiments.md) -- the loop is bound by its own memory skeleton, not by the barrier.
+	// Neither by the image layout: with the image K-step-major ([K-step][tile][block][lane]: what all workgroups read at one time is ONE
+	// contiguous window instead of one stream per tile) 162 us against 164 tile-major, both with a run-time K-step stride (which costs
+	// the scalar-base form of the loads: 155 -> 163).
 	constexpr int AHEAD = BFD_PAIR ? 4 : 2, SLOTS = BFD_PAIR ? 6 : 3;
 	__shared__ __attribute__((aligned(16))) bf16x8 l8[SLOTS * 512];      // [slot][block 0..7][lane]
 	const int nblk = tiles * splits;

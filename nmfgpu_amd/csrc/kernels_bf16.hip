@@ -451,14 +451,17 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16_staged(
 // the DMA path top out near 37 GB/s per CU whatever the depth of the request ring (4 / 8 / 9 steps).
 constexpr int BFD_NRB = 7;            // row blocks per workgroup
 #ifndef BFD_R2_D
-#define BFD_R2_D 8                    // register-ring depth (4 .. 12 measure the same)
+#define BFD_R2_D 8                    // register-ring depth of the A operand (4 .. 12 measure the same)
+#endif
+#ifndef BFD_R2_DF
+#define BFD_R2_DF 8                   // ... of the factor fragments (divides BFD_R2_D): 4 -> 166 us, 3 -> 184, 2 -> 274 (their slice of the image streams through L2 once)
 #endif
 __device__ bf16x8 g_bf_zero_block[64];      // one all-zero fragment block: the A operand of K-steps past the end of a slice
-template <int NRB, int D>
+template <int NRB, int D, int DF>
 __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
 	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
-	static_assert(D % 2 == 0 && NRB <= 8, "ring depth even (two operand sets), at most eight row blocks");
+	static_assert(D % 2 == 0 && D % DF == 0 && DF >= 2 && NRB <= 8, "ring depth even (two operand sets) and a multiple of the factor ring's, at most eight row blocks");
 #ifndef BFD_PAIR
 #define BFD_PAIR 0
 #endif
@@ -502,7 +505,10 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	}
 	const bf16x8* fbase = F + ((long)b0 * NBT + grp * 8 + 2 * wave) * 64;
 	const bf16x8* zbase = g_bf_zero_block;
-	auto a_src = [&](int j, int k) -> const bf16x8* { return k < n ? abase[j] + (long)k * 256 : zbase; };      // scalar select
+	// (the spare eighth block of a slot is nobody's operand: it is filled from the zero block -- an L1 hit -- instead of a second copy of
+	//  block NRB - 1 from the image)
+	const bool spare[2] = {2 * wave >= NRB, 2 * wave + 1 >= NRB};
+	auto a_src = [&](int j, int k) -> const bf16x8* { return (k < n && !spare[j]) ? abase[j] + (long)k * 256 : zbase; };      // scalar select
 	auto f_src = [&](int k) -> const bf16x8* { return fbase + (long)(k < last ? k : last) * fstep; };
 	const int pblk = 2 * wave * 64 + lane;                    // this wave's two blocks inside a slot (+ 64 for the second)
 
@@ -514,12 +520,11 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 #pragma unroll
 			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
 
-	bf16x8 stA[D][2], stF[D][2];
+	bf16x8 stA[D][2], stF[DF][2];
 #pragma unroll
-	for (int q = 0; q < D; ++q) {
-		stA[q][0] = a_src(0, q)[lane]; stA[q][1] = a_src(1, q)[lane];
-		stF[q][0] = f_src(q)[lane]; stF[q][1] = f_src(q)[64 + lane];
-	}
+	for (int q = 0; q < D; ++q) { stA[q][0] = a_src(0, q)[lane]; stA[q][1] = a_src(1, q)[lane]; }
+#pragma unroll
+	for (int q = 0; q < DF; ++q) { stF[q][0] = f_src(q)[lane]; stF[q][1] = f_src(q)[64 + lane]; }
 	// steps 0 .. AHEAD - 1 parked, their ring slots reloaded with steps D ...
 #pragma unroll
 	for (int q = 0; q < AHEAD; ++q) {
@@ -551,12 +556,12 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 			stA[(u + AHEAD) % D][1] = a_src(1, s + AHEAD + D)[lane];
 #pragma unroll
 			for (int b = 0; b < NRB; ++b) va[(u + 1) & 1][b] = l8[rd * 512 + b * 64 + lane];
-			stF[(u + D - 1) % D][0] = f_src(s + D - 1)[lane];
-			stF[(u + D - 1) % D][1] = f_src(s + D - 1)[64 + lane];
+			stF[(u + DF - 1) % DF][0] = f_src(s + DF - 1)[lane];
+			stF[(u + DF - 1) % DF][1] = f_src(s + DF - 1)[64 + lane];
 #pragma unroll
 			for (int b = 0; b < NRB; ++b) {
-				acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u][0], acc[b][0], 0, 0, 0);
-				acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u][1], acc[b][1], 0, 0, 0);
+				acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][0], acc[b][0], 0, 0, 0);
+				acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][1], acc[b][1], 0, 0, 0);
 			}
 			// MFMA, then one memory instruction, fourteen times: 2 LDS writes, 2 + 2 loads, 7 (NRB) LDS reads
 #pragma unroll
@@ -608,7 +613,7 @@ static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, i
 	plan_bf16_dma(p.xtiles, KS, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, &tiles, &splits);
 	if (splits != p.splits) return hipErrorInvalidValue;      // the caller sized its slabs with plan_splits_bf16
 	dim3 grid(tiles * splits, RP / 256), block(256);
-	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D>), grid, block, 0, stream,
+	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
 	                   slabs, slab_stride, RP, KS, splits, tiles);
 	return hipGetLastError();

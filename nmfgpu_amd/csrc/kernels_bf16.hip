@@ -449,6 +449,9 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_bf16_staged(
 // Tried first and dropped: both operands by LDS-DMA (global_load_lds_dwordx4 into an 11 + 10 slot ring, 136 - 157 KiB of LDS,
 // counted vmcnt per loader wave, raw s_barrier): 165 us, and 156 us with the MFMAs removed -- 15 KiB per K-step and CU through
 // the DMA path top out near 37 GB/s per CU whatever the depth of the request ring (4 / 8 / 9 steps).
+// Tried last and dropped: the same tile with EIGHT waves (two per SIMD, 128 accumulator registers each: columns by wave & 3, row blocks
+// 0..3 / 3..6 by wave >> 2, one A load and two F loads per wave and K-step so that a wave keeps 16 - 20 loads in flight, the number a
+// streaming probe tolerates): 183 - 194 us for ring depths (4,4) .. (12,4) against this kernel's 162 on the same box.
 constexpr int BFD_NRB = 7;            // row blocks per workgroup
 #ifndef BFD_R2_D
 #define BFD_R2_D 8                    // register-ring depth of the A operand (4 .. 12 measure the same)

@@ -115,7 +115,9 @@ void parallel_chunks(size_t n, size_t align, size_t min_chunk, F&& f) {
 // ---- the reference's warp-shaped reductions ---------------------------------------------------
 // x86-64-v3 clones give the compiler vfmadd; the baseline clone calls libm's fma -- same bits.
 // The *_impl templates are force-inlined so that each clone compiles them for its own target.
+#ifndef NMFAMD_CLONES      // (a sanitizer build defines it empty: gcc cannot combine function multiversioning with -fsanitize)
 #define NMFAMD_CLONES __attribute__((target_clones("default", "arch=x86-64-v3")))
+#endif
 #define NMFAMD_INLINE inline __attribute__((always_inline))
 
 template <typename T>

@@ -150,3 +150,23 @@ def test_host_entry_points_reject_bad_arguments():
         eng.host_kmeans(X, 12)            # clusters must be fewer than columns (Interface.cpp:366-370)
     with pytest.raises(eng.EngineError):
         eng.host_init(X, 3, Init.AllRandomValues)   # not a host-side method
+
+
+# ------------------------------------------------------------------ sanitizers (CPU build only: the GPU pool offers none)
+
+@pytest.mark.parametrize("flags", ["-fsanitize=address,undefined", "-fsanitize=thread"])
+def test_host_initialisers_under_sanitizers(tmp_path, flags):
+    """host_init.cpp alone (no HIP) with AddressSanitizer + UBSan, and with ThreadSanitizer, on odd shapes and several threads:
+    k-means and every initialisation method it serves.  Function multiversioning is switched off for the build (gcc cannot
+    combine it with -fsanitize)."""
+    exe = tmp_path / "hi_san"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-DNMFAMD_CLONES=", *flags.split(), "-fno-omit-frame-pointer", "-pthread", "-ffp-contract=off",
+           os.path.join(ROOT, "tests", "cpp", "host_init_sanitize.cpp"), os.path.join(ROOT, "nmfgpu_amd", "csrc", "host_init.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "cannot find" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env={**os.environ, "NMFAMD_HOST_THREADS": "4"}, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr
+    assert run.stdout.strip().endswith("ok")

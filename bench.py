@@ -161,7 +161,11 @@ def main():
         return main_c3(args)
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
     if args.workload in ("c2", "c4") and not args.torch_comm and (args.native_comm or args.scaling == "strong" or multi):
-        return main_native(args)
+        if main_native(args) is not False:
+            return
+        # the native communicator could not be set up on some rank (every rank agreed on that): the torch-driven loop below
+        if args.scaling == "strong":
+            raise SystemExit("--scaling strong needs the native loop")
     if args.workload == "c4":
         return main_c4(args)
     algorithm, alg_kw = "mu", {}
@@ -187,7 +191,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if dist.is_initialized():
+            pass                                  # (left by main_native's fallback)
+        elif args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=args.backend)
@@ -352,14 +358,40 @@ def main_native(args):
         V, W, H = make_problem(rank, rows, cols, feats)
         nc, total_columns = cols, cols * world
     mode = args.shard_mode if args.shard_mode >= 0 else (0 if 4.0 * rows * feats >= 8e6 else 1)
-    uid = [na.RcclComm.unique_id() if rank == 0 else None]
+    comm = eng = run = None
+    failure = None
+    try:
+        uid = [na.RcclComm.unique_id() if rank == 0 else None]
+    except Exception as e:                        # noqa: BLE001 -- reported below, every rank takes the same way out
+        uid, failure = [None], e
     if distributed:
         dist.broadcast_object_list(uid, src=0)
-    comm = na.RcclComm(uid[0], world, rank)       # blocks until every rank has joined the clique
-    eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, row_blocks=world, **alg_kw)
-    eng.upload(V)
-    eng.set_factors(W, H)
-    run = na.ShardedRun(eng, comm, rows, total_columns, mode)
+    try:
+        if failure is None and uid[0] is None:
+            raise RuntimeError("rank 0 could not create a communicator id")
+        if failure is None:
+            comm = na.RcclComm(uid[0], world, rank)       # blocks until every rank has joined the clique
+            eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, row_blocks=world, **alg_kw)
+            eng.upload(V)
+            eng.set_factors(W, H)
+            run = na.ShardedRun(eng, comm, rows, total_columns, mode)
+    except Exception as e:                        # noqa: BLE001
+        failure = e
+    if distributed:
+        flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed_somewhere = int(flag.item()) != 0
+    else:
+        failed_somewhere = failure is not None
+    if failed_somewhere:
+        print(f"bench.py: native communicator set-up failed on rank {rank}: {failure!r}" if failure is not None else
+              "bench.py: native communicator set-up failed on another rank", file=sys.stderr, flush=True)
+        for obj in (run, eng, comm):
+            if obj is not None:
+                obj.close()
+        if not distributed:
+            raise SystemExit(f"native loop unavailable: {failure!r}")
+        return False
     K, Wm = args.steps, args.warmup
 
     def barrier():

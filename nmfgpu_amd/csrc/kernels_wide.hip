@@ -68,7 +68,20 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = old[i];
 			}
 		}
-		for (int k = 1; k < S; ++k) {
+		// (three slabs in flight, added in slab order: config 4's H update sums nine of them -- nine latencies in a row otherwise)
+		int k = 1;
+		for (; k + 3 <= S; k += 3) {
+			f32x4 t[3][NE];
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+#pragma unroll
+				for (int i = 0; i < NE; ++i) t[j][i] = *reinterpret_cast<const f32x4*>(slabs + (long)(k + j) * slab_stride + base + 4l * (tid + 256 * i));
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+#pragma unroll
+				for (int i = 0; i < NE; ++i) num[i] += t[j][i];
+		}
+		for (; k < S; ++k) {
 			f32x4 t[NE];
 #pragma unroll
 			for (int i = 0; i < NE; ++i) t[i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));

@@ -157,6 +157,10 @@ def main():
                     help="native loop: 0 reduce-scatter / all-gather by row blocks of W, 1 one all-reduce + replicated update, "
                          "-1 (default) by message size: row blocks when the m x r panel is 8 MB or more (config 4), else the single all-reduce")
     args = ap.parse_args()
+    if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):
+        # debugging aid: where is every thread after N seconds (a rank that waits for its peers says nothing otherwise)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NMFAMD_BENCH_DUMP_AFTER"]), exit=False)
     if args.workload == "c3":
         return main_c3(args)
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
@@ -360,6 +364,17 @@ def main_native(args):
     mode = args.shard_mode if args.shard_mode >= 0 else (0 if 4.0 * rows * feats >= 8e6 else 1)
     comm = eng = run = None
     failure = None
+    if distributed:
+        # RCCL wants one device per rank: two ranks on the same device (a rehearsal on a one-GPU box) must not even try -- a communicator
+        # set-up that fails on one rank while its peer is still connecting can hang the peer.  Every rank sees the same gathered list.
+        import socket
+        me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""), device_index)
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        if len(set(seen)) < world:
+            if rank == 0:
+                print("bench.py: native communicator set-up failed before it began: ranks share a device (RCCL needs one per rank)", file=sys.stderr, flush=True)
+            return False
     try:
         uid = [na.RcclComm.unique_id() if rank == 0 else None]
     except Exception as e:                        # noqa: BLE001 -- reported below, every rank takes the same way out

@@ -36,22 +36,3 @@ def test_default_bench_line_has_the_contract_fields():
     # here after 50)
     assert 2000 < d["frobenius_last"] < 2100
 
-
-def test_two_ranks_on_one_gpu_fall_back_to_the_torch_driven_loop_consistently():
-    """`bench.py --gpus 2` as the driver launches it, rehearsed on ONE GPU with the gloo backend: RCCL refuses two ranks on one
-    device, every rank learns that through an all-reduced flag, and all of them take the torch-driven sharded loop instead -- one
-    JSON line from rank 0 with n_gpus = 2 and the whole-job value."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak"
-    assert d["value"] == pytest.approx(2 * 1e3 / d["ms_per_step"], rel=1e-6)
-    assert "native communicator set-up failed" in out.stderr

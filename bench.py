@@ -195,6 +195,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
         if dist.is_initialized():
             pass                                  # (left by main_native's fallback)
         elif args.backend == "nccl":
@@ -343,6 +345,8 @@ def main_native(args):
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -542,6 +546,8 @@ def main_c4(args):
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:

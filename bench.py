@@ -444,7 +444,9 @@ def main_native(args):
         if kernel_launches > 0:
             avg_s = kernel_ms / 1e3 / kernel_launches
             roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "factor product (rank 0's launches)",
+                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
+                        "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0] if c4 else measured_traffic("factor_product_x3", "nmfgpu_amd/csrc/kernels_x3.hip")[0],
+                        "kernel": "factor product (rank 0's launches)",
                         "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
         mode_text = ("reduce-scatter of (V H^T)^T by row blocks of W + all-reduce of H H^T, row-block W update, all-reduce of the column norms, "
                      "all-gather of W") if mode == 0 else "one all-reduce of (V H^T | H H^T), replicated W update"
@@ -502,10 +504,12 @@ def main_c3(args):
     roofline = None
     if kernel_launches > 0:
         avg_s = kernel_ms / 1e3 / kernel_launches
+        c3_traffic, c3_traffic_source = measured_traffic("kl_fused", "nmfgpu_amd/csrc/kernels_sparse.hip")      # what leaves L2: the row gathers that miss it, mostly served by the memory-side cache
         roofline = {"bound": "hbm", "achieved": hbm_bytes / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": hbm_bytes / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_kl_fused",
+                    "frac": hbm_bytes / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": c3_traffic, "traffic_source": c3_traffic_source, "kernel": "k_kl_fused",
                     "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": hbm_bytes,
-                    "note": "the binding resource is the cache-level gather of factor rows, not HBM (SURVEY 8d): see `gather`",
+                    "note": ("the binding resource is the cache-level gather of factor rows, not HBM (SURVEY 8d): see `gather`; `traffic` = bytes that leave L2 "
+                             "(FETCH_SIZE x 2 + WRITE_SIZE): the row gathers that miss L2, served by the memory-side cache which holds both factors"),
                     "gather": {"achieved": gather_bytes / avg_s / 1e9, "peak": PEAK_L2_GATHER_GBS, "unit": "GB/s",
                                "frac": gather_bytes / avg_s / 1e9 / PEAK_L2_GATHER_GBS, "bytes_per_launch": gather_bytes}}
     out = {"metric": "NMF KL-divergence MU iterations/sec, sparse CSR 100kx20k 1% r=128",
@@ -587,7 +591,7 @@ def main_c4(args):
         if kernel_launches > 0:
             avg_s = kernel_ms / 1e3 / kernel_launches
             roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "k_factor_product_bf16",
+                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0], "kernel": "k_factor_product_bf16",
                         "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
         iter_flops = 4.0 * m * n * r + 6.0 * r * r * (m + n)
         print(json.dumps({

@@ -129,6 +129,7 @@ def _worker(rank, world, port, m, n, r, iters, out_dir, theta, mode="replicated"
     from nmfgpu_amd.distributed import ShardedMU
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the box's hostname may not resolve: gloo would probe interfaces
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(5)
     V = rng.random((m, n)); W = 1.0 - rng.random((m, r)); H = 1.0 - rng.random((r, n))

@@ -62,6 +62,7 @@ def _worker(rank, world, port, m, n, r, iters, out_dir, alg, theta, precision, m
     from nmfgpu_amd.distributed import EngineShard, ShardedMU
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the box's hostname may not resolve: gloo would probe interfaces
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     V, W, H = _problem(m, n, r)

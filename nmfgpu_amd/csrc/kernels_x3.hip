@@ -31,6 +31,17 @@ namespace nmfamd {
 #endif
 constexpr bool XCD_REMAP = NMFAMD_XCD_REMAP != 0;
 
+// Ring depth of the rank-64 instantiations: K-steps in flight per wave, 8 loads of V + 6 of factor fragments each.  Fewer is faster (a wave
+// with more than ~20 loads in flight loses HBM bandwidth, profiles/r02_c4_kernel_experiments.md): config 2, us per iteration, depth of
+// the x-tiled / y-tiled form: 3/3 98.1, 2/2 96.1, 4/4 99.9, 2/1 see DESIGN.  Depths 1 and 2 deal the K-steps out in the same units,
+// so all of them give the same bits.
+#ifndef X3_RING_X
+#define X3_RING_X 2                   // K-steps in flight per wave (8 + 6 loads each), x-tiled form
+#endif
+#ifndef X3_RING_Y
+#define X3_RING_Y 2                   // ... y-tiled form (its landing ring; two more steps sit in the LDS slots)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Factor fragments: Fx[(((ks * NBT + nb) * 3 + plane) * 2 + h) * 32 + r][8] = plane of F(c = 32 nb + r, y = 16 ks + 8 h + j)
@@ -171,9 +182,12 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	// The reduction range is dealt out in units of D K-steps, so that every wave runs whole turns of the ring and
 	// the loop needs no tail.  Steps past the end of the range (at most D - 1, in the last unit) re-read the last
 	// valid step of A against the all-zero K-step that closes the factor image (index steps_total).
-	const int units = (steps_total + D - 1) / D;
-	const int s0 = D * (int)(((long)units * widx) / nw);
-	const int s1 = D * (int)(((long)units * (widx + 1)) / nw);
+	// (the unit is 2 for ring depths 1 and 2, so that every instantiation with such a ring deals the K-steps out the same way and
+	//  the forms stay bit-identical to each other whatever their depth)
+	constexpr int DU = D <= 2 ? 2 : D;
+	const int units = (steps_total + DU - 1) / DU;
+	const int s0 = DU * (int)(((long)units * widx) / nw);
+	const int s1 = DU * (int)(((long)units * (widx + 1)) / nw);
 	const int steps = s1 - s0;
 
 	f32x16 acc[4][NBW];
@@ -247,12 +261,12 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 #pragma unroll
 			for (int d = 0; d < 2; ++d) {
 #pragma unroll
-				for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(lw + d * 2560 + j * 320 + wofs) = va[d][j];
+				for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(lw + d * 2560 + j * 320 + wofs) = va[d % D][j];
 				int st = s0 + D + d;
 				st = st < last ? st : last;
 				const int sa = st < kend ? st : kend;
 #pragma unroll
-				for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(g_addr(sa, j));
+				for (int j = 0; j < 8; ++j) va[d % D][j] = *reinterpret_cast<const f32x4*>(g_addr(sa, j));
 			}
 			// LDS reads run two phases ahead of the MFMAs that use them: raw[q & 1] holds the operand of phase q, read during
 			// phase q - 2 and split during phase q - 1 (one wave per SIMD: a read consumed in the phase that issues it would
@@ -464,13 +478,13 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		static const bool ydirect = tuning_env("NMFAMD_X3_YDIRECT") != nullptr;          // A/B switch: row-per-lane global loads
-		if (y_tiled && !ydirect) return launch_fp_x3<3, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return y_tiled ? launch_fp_x3<3, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
-		               : launch_fp_x3<3, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (y_tiled && !ydirect) return launch_fp_x3<X3_RING_Y, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return y_tiled ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
+		               : launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
 	if (y_tiled) {
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return launch_fp_x3<3, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return launch_fp_x3<X3_RING_X, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
 	static const int variant = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
 	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
@@ -486,7 +500,7 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	default: break;
 	}
 #endif
-	return launch_fp_x3<3, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	return launch_fp_x3<X3_RING_X, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 }
 
 } // namespace nmfamd

@@ -185,7 +185,10 @@ __device__ __forceinline__ void gram_tri_block(const float* __restrict__ P, int 
 		const float* src = P + ((long)16 * s0 + 8 * (lane >> 5)) * TRI_RP + 32 * wave + (lane & 31);
 		// register ring of GD K-steps: a gather is issued GD - 1 K-steps before its values are split (one K-step of MFMAs is
 		// ~0.8 us, a dependent global round trip under load more)
-		constexpr int GD = 4;
+#ifndef TRI_GD
+#define TRI_GD 4
+#endif
+		constexpr int GD = TRI_GD;
 		float v[GD][8];
 		auto gather = [&](int s, float (&dst)[8]) {
 			s = s < steps ? s : steps - 1;          // past the slice: harmless re-load of its last K-step

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
-SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "kernels_tri.hip", "comm.hip", "engine.cpp", "sharded.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
+SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "kernels_onepass.hip", "kernels_tri.hip", "comm.hip", "engine.cpp", "sharded.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
 ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 # translation units without device code or HIP runtime calls: plain C++ (function multiversioning
 # is rejected by the device pass of a -x hip compile); no implicit contraction: where the reference's
@@ -27,7 +27,7 @@ ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 HOST_ONLY = {"host_init.cpp"}
 # per-source extra flags.  kernels_x3.hip: the SLP vectoriser pairs the scalar subtractions of the operand split
 # into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
-EXTRA_FLAGS = {"kernels_x3.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"kernels_x3.hip": ["-fno-slp-vectorize"], "kernels_onepass.hip": ["-fno-slp-vectorize"]}
 # experiment switches: NMFAMD_CXXFLAGS="-DNAME=1 ..." is appended to every compile (and forces nothing: use --force)
 USER_FLAGS = os.environ.get("NMFAMD_CXXFLAGS", "").split()
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",

@@ -280,7 +280,7 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 		out->m = g.m(); out->n = g.n(); out->r = g.r(); out->padded_rank = g.rp();
 		out->padded_m = g.mpad(); out->padded_n = g.npad();
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
-		out->product_kernel = g.product_kernel(); out->resident_images = g.resident_images();
+		out->product_kernel = g.product_kernel(); out->resident_images = g.resident_images(); out->one_pass = g.one_pass_state();
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
 	return NMFAMD_OK;

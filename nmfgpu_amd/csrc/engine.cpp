@@ -76,6 +76,8 @@ Engine<T>::~Engine() {
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
+	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_}; for (void* b : ob) if (b) (void)hipFree(b); }
+	if (pin_abort_) (void)hipHostFree(pin_abort_);
 	if (err_event_) (void)hipEventDestroy(err_event_);
 	if (ev_fork_) (void)hipEventDestroy(ev_fork_);
 	if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -154,7 +156,12 @@ Status Engine<T>::allocate() {
 		size_t free_b = 0, total_b = 0;
 		const size_t image_b = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
 		const char* force = std::getenv("NMFAMD_ONE_IMAGE");
-		if (force != nullptr) one_image_ = std::atoi(force) != 0;
+		// the one-pass iteration needs ONE image (16-row tiles) and nothing else
+		one_pass_ = one_pass_allowed_ && row_blocks_ == 1 && fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr &&
+		            std::getenv("NMFAMD_TWO_PASS") == nullptr && tuning_env("NMFAMD_IMAGE_TILE128") == nullptr &&
+		            (force == nullptr || std::atoi(force) != 0) && onepass_available(pad128(m_), num_cus_);
+		if (one_pass_) one_image_ = true;
+		else if (force != nullptr) one_image_ = std::atoi(force) != 0;
 		else if (cache_window) one_image_ = true;
 		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 3 * image_b + (image_b >> 3) > free_b) one_image_ = true;
 	}
@@ -248,6 +255,21 @@ Status Engine<T>::allocate() {
 		}
 	}
 	gram_image_ = x3_ && fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr;
+	one_pass_ = one_pass_ && x3_ && gram_image_ && one_image_ && img_th_ == 16;
+	if (one_pass_) {
+		HIPX(hipMalloc(&op_part_, onepass_part_bytes()));
+		HIPX(hipMalloc(&op_hfrag_, onepass_hfrag_bytes()));
+		HIPX(hipMalloc((void**)&op_ctl_, 64));
+		HIPX(hipMalloc((void**)&op_slabs_, sizeof(float) * (size_t)ONEPASS_XCDS * RP_ * mpad_));
+		HIPX(hipMalloc((void**)&op_hh_part_, sizeof(float) * 4096 * (size_t)(ONEPASS_XCDS * ONEPASS_GROUP)));
+		HIPX(hipMemsetAsync(op_part_, 0, onepass_part_bytes(), stream_));
+		HIPX(hipMemsetAsync(op_hfrag_, 0, onepass_hfrag_bytes(), stream_));
+		HIPX(hipMemsetAsync(op_ctl_, 0, 64, stream_));
+		HIPX(hipMemsetAsync(op_slabs_, 0, sizeof(float) * (size_t)ONEPASS_XCDS * RP_ * mpad_, stream_));
+		HIPX(hipHostMalloc((void**)&pin_abort_, sizeof(unsigned)));
+		*pin_abort_ = 0;
+		op_seq_ = 0;
+	}
 	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
@@ -391,6 +413,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 
 template <typename T>
 Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
+	if (one_pass_) { if (Status s = onepass_check()) return s; }
 	if (Status s = materialize_w()) return s;
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
@@ -1032,9 +1055,59 @@ Status Engine<T>::materialize_w() {
 	return ST_OK;
 }
 
+// One pass over V: G = W^T W (split image of W), then ONE persistent launch for W^T V, the H update and V H^T, then U_W.
+template <typename T>
+Status Engine<T>::iterate_onepass(bool compute_error) {
+	if constexpr (std::is_same<T, float>::value) {
+		if (!fused_ready_) { normalize_next_ = 0; fused_ready_ = true; }
+		if (!wx3_valid_) { HIPX(launch_pack_panel_x3(Wt_, RP_, m_, Wx3_, ksH_, stream_)); wx3_valid_ = true; }
+		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
+		if (Status s = standalone_gram(rgW)) return s;
+		OnePassArgs a;
+		a.V = V_; a.tile_stride = strideV_;
+		a.Wx3 = Wx3_; a.G = G_; a.scale = scale_; a.H = H_; a.ps = psN_;
+		a.slabs = op_slabs_; a.slab_stride = (long)RP_ * mpad_;
+		a.hh_part = op_hh_part_; a.part_scratch = op_part_; a.hfrag_scratch = op_hfrag_;
+		a.ticket = op_ctl_; a.abort_flag = op_ctl_ + 8;
+		a.tile_rows = (int)(mpad_ / 16); a.w_ks = ksH_; a.n = n_; a.panels = (n_ + 31) / 32;
+		a.seq = op_seq_++;
+		a.compute_error = compute_error ? 1 : 0;
+		a.eps = std::numeric_limits<float>::epsilon();
+		record_begin();
+		HIPX(launch_mu64_onepass(a, stream_));
+		record_end();
+		HIPX(launch_reduce_partials<float>(op_hh_part_, ONEPASS_XCDS * ONEPASS_GROUP, 4096, HHt_, 4096, stream_));
+		if (Status s = mu64_update(true, op_slabs_, ONEPASS_XCDS, (long)RP_ * mpad_, HHt_, compute_error)) return s;
+		wx3_valid_ = x3_;
+		hx3_valid_ = false;
+		normalize_next_ = 1;
+		w_pending_ = true;
+		if (compute_error) {
+			if (Status s = fetch_error_terms(n_)) return s;
+			if (Status s = onepass_check()) return s;
+		}
+	}
+	return ST_OK;
+}
+
+// A launch that could not form its groups (an XCD with other than 32 of its workgroups: another kernel held CUs) gives
+// up after bounded waits and leaves the abort word set; its outputs are void.
+template <typename T>
+Status Engine<T>::onepass_check() {
+	HIPX(hipMemcpyAsync(pin_abort_, op_ctl_ + 8, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	if (*pin_abort_ != 0) {
+		one_pass_ = false; one_pass_gave_up_ = true;
+		last_error_ = "the one-pass iteration could not keep its workgroups resident (another kernel on the device?): factors are void; set NMFAMD_TWO_PASS=1";
+		return ST_HIP_ERROR;
+	}
+	return ST_OK;
+}
+
 template <typename T>
 Status Engine<T>::iterate_mu64(bool compute_error) {
 	if constexpr (std::is_same<T, float>::value) {
+		if (one_pass_) return iterate_onepass(compute_error);
 		const float eps = std::numeric_limits<float>::epsilon();
 		if (!fused_ready_) {
 			if (!gram_image_) HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));

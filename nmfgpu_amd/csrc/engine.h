@@ -42,6 +42,11 @@ public:
 	// Row-block form of the sharded W step (sharded.cpp): the padded row count becomes a multiple of 128 * blocks, so that
 	// the Wt panel splits into `blocks` equal row blocks.  Call before allocate().
 	void set_row_blocks(int blocks) { row_blocks_ = blocks > 1 ? blocks : 1; }
+	// The one-pass iteration (kernels_onepass.hip) claims every CU of the device for one persistent launch: engines that run
+	// beside others on one device (rank threads of a team) opt out.  Call before allocate().
+	void set_one_pass(bool allow) { one_pass_allowed_ = allow; }
+	// 0: not in use, 1: in use, 2: was in use and gave up (a launch could not form its groups; the two-pass iteration took over)
+	int one_pass_state() const { return one_pass_ ? 1 : (one_pass_gave_up_ ? 2 : 0); }
 	void set_stream(hipStream_t s) { stream_ = s; }
 	hipStream_t stream() const { return stream_; }
 
@@ -123,6 +128,8 @@ private:
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
+	Status iterate_onepass(bool compute_error);      // the one-pass iteration of kernels_onepass.hip
+	Status onepass_check();                          // host sync: did a one-pass launch give up?
 	Status materialize_w();                          // fold the pending column scale into Wt_
 	Status normalize_w(bool from_gram_partials, int norm_parts);   // column normalisation of W after its update
 	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
@@ -222,6 +229,13 @@ private:
 	long slab_stride_ = 0;
 	int gram_parts_ = 128;
 	FactorProductPlan planH_, planW_;
+	// one pass over V per iteration (kernels_onepass.hip): scratch of the in-launch hand-offs, per-XCD partial results
+	bool one_pass_allowed_ = true, one_pass_ = false, one_pass_gave_up_ = false;
+	void *op_part_ = nullptr, *op_hfrag_ = nullptr;
+	unsigned *op_ctl_ = nullptr;                      // [0..7] tickets, [8] abort flag
+	float *op_slabs_ = nullptr, *op_hh_part_ = nullptr;
+	unsigned op_seq_ = 0;
+	unsigned* pin_abort_ = nullptr;
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
 	hipEvent_t err_event_ = nullptr;

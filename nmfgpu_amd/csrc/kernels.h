@@ -250,6 +250,42 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
                                     unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128);
 int plan_splits_x3(int xtiles, int KS, int num_cus);
 
+// ---- one pass over V per multiplicative-update iteration at padded rank 64 (kernels_onepass.hip) -----------------------
+// The H update is column-separable once W^T W is known (reference: RN2 = RR H, RN = W^T V, multiplyDivide per element,
+// source/nmf/AlgorithmMultiplicativeFrobenius.h:176-191; KernelMultiplyDivide.cu:29-43): a 32-column panel of V is loaded
+// ONCE, W^T V of the panel is reduced over its rows, the panel's columns of H are updated, and (V H^T) is accumulated
+// (:240-241) while the panel is still on chip.  One persistent launch of 256 workgroups (see the kernel).
+struct OnePassArgs {
+	const float* V; long tile_stride;     // the 16-row tiled image: V(i, j) at V[(i / 16) * tile_stride + j * 16 + i % 16]
+	const void* Wx3;                      // split image of the (unnormalised) W panel, NBT = 2 (kernels_x3.hip)
+	const float* G;                       // 64 x 64: diag(scale) Wu^T Wu diag(scale)
+	const float* scale;                   // 64: pending column scale of W
+	float* H;                             // panel [npad][64], updated in place
+	float* ps;                            // per-column terms of tr(H^T W^T V) (error iterations)
+	float* slabs; long slab_stride;       // 8 partial (V H^T)^T panels [mpad][64], one per XCD
+	float* hh_part;                       // [256][4096] partial H H^T, one per workgroup
+	void* part_scratch;                   // [8][ONEPASS_SLOTS][32][256] x 64 B tagged partial sums
+	void* hfrag_scratch;                  // [8][ONEPASS_SLOTS][64][4][8] x 8 B tagged split values of the new H columns
+	unsigned* ticket;                     // [8] per-XCD arrival counters (never reset: 32 per launch)
+	unsigned* abort_flag;                 // set when a workgroup gave up waiting (or found its XCD over-subscribed)
+	int tile_rows;                        // mpad / 16
+	int w_ks;                             // K-steps of 16 rows in the split image of W; step w_ks is the all-zero step that closes it
+	int n;                                // valid columns
+	int panels;                           // ceil(n / 32)
+	unsigned seq;                         // launch number of this engine (tickets and tags derive from it)
+	int compute_error;
+	float eps;
+};
+constexpr int ONEPASS_SLOTS = 4;
+constexpr int ONEPASS_GROUP = 32;         // workgroups per XCD
+constexpr int ONEPASS_XCDS = 8;
+constexpr int ONEPASS_TILES_PER_WAVE = 5; // 16-row tiles per wave: 320 rows per workgroup, 10 240 per XCD
+constexpr size_t onepass_part_bytes() { return (size_t)ONEPASS_XCDS * ONEPASS_SLOTS * ONEPASS_GROUP * 256 * 64; }
+constexpr size_t onepass_hfrag_bytes() { return (size_t)ONEPASS_XCDS * ONEPASS_SLOTS * 64 * 32 * 8; }
+// true when the shape fits the kernel's fixed cut (rows per XCD group) on this device
+bool onepass_available(long mpad, int num_cus);
+hipError_t launch_mu64_onepass(const OnePassArgs& a, hipStream_t stream);
+
 // ---- sparse-V compute path (kernels_sparse.hip) ----------------------------------------------
 // out(row, :) = sum_p val[p] P(idx[p], :) over the stored entries of `row`; rows in [rows, rows_pad) are zeroed.
 template <typename T>

@@ -254,6 +254,7 @@ private:
 		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
 		if (hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; return nmfamd::ST_HIP_ERROR; }
 		rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm_));
+		rk.eng->set_one_pass(false);       // rank threads may share a device: no persistent launch that claims every CU
 		rk.eng->set_stream(rk.stream);
 		if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
 		Status st = rk.eng->allocate();
@@ -268,6 +269,7 @@ private:
 			nmfamd::AlgorithmParams native = prm_;
 			native.precision = -1;
 			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, native));
+			rk.eng->set_one_pass(false);
 			rk.eng->set_stream(rk.stream);
 			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
 			st = rk.eng->allocate();

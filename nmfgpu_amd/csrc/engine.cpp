@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -76,7 +77,7 @@ Engine<T>::~Engine() {
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
-	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_}; for (void* b : ob) if (b) (void)hipFree(b); }
+	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_, op_stamps_}; for (void* b : ob) if (b) (void)hipFree(b); }
 	if (pin_abort_) (void)hipHostFree(pin_abort_);
 	if (err_event_) (void)hipEventDestroy(err_event_);
 	if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -269,6 +270,10 @@ Status Engine<T>::allocate() {
 		HIPX(hipHostMalloc((void**)&pin_abort_, sizeof(unsigned)));
 		*pin_abort_ = 0;
 		op_seq_ = 0;
+		if (tuning_env("NMFAMD_ONEPASS_STAMPS") != nullptr) {
+			HIPX(hipMalloc((void**)&op_stamps_, sizeof(unsigned long long) * 16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP));
+			HIPX(hipMemsetAsync(op_stamps_, 0, sizeof(unsigned long long) * 16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP, stream_));
+		}
 	}
 	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
@@ -1073,6 +1078,7 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		a.seq = op_seq_++;
 		a.compute_error = compute_error ? 1 : 0;
 		a.eps = std::numeric_limits<float>::epsilon();
+		a.stamps = op_stamps_;
 		record_begin();
 		HIPX(launch_mu64_onepass(a, stream_));
 		record_end();
@@ -1096,6 +1102,13 @@ template <typename T>
 Status Engine<T>::onepass_check() {
 	HIPX(hipMemcpyAsync(pin_abort_, op_ctl_ + 8, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
 	HIPX(hipStreamSynchronize(stream_));
+	if (op_stamps_ != nullptr) {
+		// diagnostic builds: the stamps of the last launch go to the file NMFAMD_ONEPASS_STAMPS names
+		std::vector<unsigned long long> h(16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP);
+		if (hipMemcpy(h.data(), op_stamps_, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+			if (FILE* f = std::fopen(tuning_env("NMFAMD_ONEPASS_STAMPS"), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
+		}
+	}
 	if (*pin_abort_ != 0) {
 		one_pass_ = false; one_pass_gave_up_ = true;
 		last_error_ = "the one-pass iteration could not keep its workgroups resident (another kernel on the device?): factors are void; set NMFAMD_TWO_PASS=1";

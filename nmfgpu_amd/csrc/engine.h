@@ -236,6 +236,7 @@ private:
 	float *op_slabs_ = nullptr, *op_hh_part_ = nullptr;
 	unsigned op_seq_ = 0;
 	unsigned* pin_abort_ = nullptr;
+	unsigned long long* op_stamps_ = nullptr;          // diagnostic builds (NMFAMD_ONEPASS_STAMPS = file the last launch's stamps go to)
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
 	hipEvent_t err_event_ = nullptr;

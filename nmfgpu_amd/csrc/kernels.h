@@ -275,6 +275,7 @@ struct OnePassArgs {
 	unsigned seq;                         // launch number of this engine (tickets and tags derive from it)
 	int compute_error;
 	float eps;
+	unsigned long long* stamps = nullptr; // diagnostic builds: 16 words per wave (see the kernel's end)
 };
 constexpr int ONEPASS_SLOTS = 4;
 constexpr int ONEPASS_GROUP = 32;         // workgroups per XCD

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "split3.h"
 
@@ -40,9 +42,8 @@ namespace {
 constexpr int SLOTS = ONEPASS_SLOTS, TPW = ONEPASS_TILES_PER_WAVE;
 constexpr int LDS_VBUF = 3 * 4 * TPW * 32 * 16 * 4;   // three panels x four wave regions of [tile][column][row] floats
 constexpr int LDS_XCH = 4 * 8 * 64 * 16;              // partial W^T V of the four waves
-constexpr int LDS_RED = 16 * 64 * 4;                  // owner: partial sums of 16 source pairs
 constexpr int LDS_TAIL = 64 * 4 + 64;
-constexpr int LDS_TOTAL = LDS_VBUF + LDS_XCH + LDS_RED + LDS_TAIL;
+constexpr int LDS_TOTAL = LDS_VBUF + LDS_XCH + LDS_TAIL;
 static_assert(LDS_TOTAL <= 163840, "LDS budget");
 
 constexpr u64 GIVE_UP_TICKS = 3000000ull;             // 30 ms of the 100 MHz clock
@@ -76,12 +77,13 @@ __device__ inline void split3_scalar(float v, unsigned& hi, unsigned& mid, unsig
 
 } // namespace
 
+// DIAG (diagnostic builds, tools/onepass_stamps.py): per-wave shader-cycle sums of the segments of a tick, see the stamps' layout at the end
+template <bool DIAG>
 __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float* const vbuf = reinterpret_cast<float*>(smem);
 	f32x4* const xch = reinterpret_cast<f32x4*>(smem + LDS_VBUF);
-	float* const s_red = reinterpret_cast<float*>(smem + LDS_VBUF + LDS_XCH);
-	float* const s_hnew = s_red + 1024;
+	float* const s_hnew = reinterpret_cast<float*>(smem + LDS_VBUF + LDS_XCH);
 	float* const s_ps = s_hnew + 64;
 	int* const s_ctl = reinterpret_cast<int*>(s_ps + 4);
 
@@ -112,6 +114,17 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	const unsigned tag0 = a.seq * (unsigned)tmax;          // tag of tick t: tag0 + t + 1 (never 0 in the first launch, always distinct from a slot's previous content)
 	bool gave_up = false;                                  // wave-uniform: stop waiting, run to the end (outputs are discarded by the host)
 	const u64 t_start = __builtin_amdgcn_s_memrealtime();
+	u64 seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_last = 0, c_entry = 0, c_loop0 = 0, c_loop1 = 0;
+	unsigned retries_f = 0, retries_o = 0;
+	auto stamp = [&](int i) __attribute__((always_inline)) {
+		if (DIAG) {
+			__builtin_amdgcn_sched_barrier(0);
+			const u64 c = __builtin_amdgcn_s_memtime();
+			seg[i] += c - c_last; c_last = c;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+	if (DIAG) c_entry = __builtin_amdgcn_s_memtime();
 
 	const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(a.part_scratch, (unsigned)onepass_part_bytes());
 	const __amdgpu_buffer_rsrc_t rs_hf = make_rsrc(a.hfrag_scratch, (unsigned)onepass_hfrag_bytes());
@@ -140,15 +153,10 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				}
 		}
 	}
-	// owner arithmetic: lane (cl, grp) of wave w works on factor row c = 16 w + cl, reduction part k = 16 grp .. 16 grp + 15
-	const int oc = 16 * wave + cl;
-	float gq[16];
-#pragma unroll
-	for (int u = 0; u < 4; ++u) {
-		const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.G + (long)oc * 64 + 16 * grp + 4 * u);
-#pragma unroll
-		for (int i = 0; i < 4; ++i) gq[4 * u + i] = g4[i];
-	}
+	// owner arithmetic: lane l of wave w works on factor row c = 16 w + 2 (l & 7) + ((l >> 3) & 1), reduction part k = 16 (l >> 4) .. + 15
+	// (the row follows from how the owner's loads are dealt out, see O below)
+	const int oc = 16 * wave + 2 * (lane & 7) + ((lane >> 3) & 1);
+	const float* const grow = a.G + (long)oc * 64 + 16 * grp;      // this lane's part of row c of W^T W (read again every tick: L1 / L2)
 	const float sc_c = a.scale[oc];
 	float hh[16];
 #pragma unroll
@@ -158,30 +166,59 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
 		for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+	if (tid < 64) s_hnew[tid] = 0.f;
+	if (tid < 4) s_ps[tid] = 0.f;
 
 	// the two landing slots of the panel stream: lane (l31 = column of the panel, half) takes rows 8 half .. 8 half + 7 of each tile
 	f32x4 va[2][TPW][2];
-	auto v_addr = [&](int t, int ks) -> const float* { return a.V + (long)trw[ks] * a.tile_stride + ((long)(p0 + t) * 32 + l31) * 16 + 8 * half; };
+	// (wave-uniform base + a 32-bit lane offset: the loads take the base in scalar registers)
+	const int v_lane = l31 * 16 + 8 * half;
 	auto prefetch = [&](int t, f32x4 (&dst)[TPW][2]) __attribute__((always_inline)) {
 #pragma unroll
 		for (int ks = 0; ks < TPW; ++ks) {
-			const float* p = v_addr(t, ks);
-			dst[ks][0] = *reinterpret_cast<const f32x4*>(p);
-			dst[ks][1] = *reinterpret_cast<const f32x4*>(p + 4);
+			const float* p = a.V + ((long)trw[ks] * a.tile_stride + (long)(p0 + t) * (32 * 16));
+			dst[ks][0] = *reinterpret_cast<const f32x4*>(p + v_lane);
+			dst[ks][1] = *reinterpret_cast<const f32x4*>(p + v_lane + 4);
 		}
 	};
 	if (T > 0) prefetch(0, va[0]);
-	if (T > 1) prefetch(1, va[1]);
 
 	float* const vw = vbuf + wave * (TPW * 32 * 16);      // this wave's region of a panel buffer (+ buffer * 4 * TPW * 512)
 	int prev_owner_col = -1;                               // column whose error term / H H^T contribution is still to be booked
+	bf16x8 opn[3];                                         // split form of K-step 0 of the NEXT panel (prepared while the matrix pipe runs B)
+	auto split_pair = [&](const f32x4& lo4, const f32x4& hi4, bf16x8 (&o)[3]) __attribute__((always_inline)) {
+		float v[8];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { v[j] = lo4[j]; v[4 + j] = hi4[j]; }
+		split3(v, o[0], o[1], o[2]);
+	};
+	// x + (x of the lane N places on, cyclically, in its row of 16 lanes) -- a DPP rotation, no LDS
+	auto add_ror = [&](float x, auto ctrl_c) __attribute__((always_inline)) -> float {
+		constexpr int CTRL = decltype(ctrl_c)::value;
+		return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+	};
+	typedef std::integral_constant<int, 0x128> ROR8;
+	typedef std::integral_constant<int, 0x124> ROR4;
+	typedef std::integral_constant<int, 0x122> ROR2;
+	typedef std::integral_constant<int, 0x121> ROR1;
+	if (T > 0) split_pair(va[0][0][0], va[0][0][1], opn);
+	__syncthreads();
 
 	// ---- one tick -----------------------------------------------------------------------------------------------------------------
-	auto tick = [&](const int t, f32x4 (&vs)[TPW][2]) __attribute__((always_inline)) {
+	// vs: landing slot of panel t, vn: of panel t + 1 (the split of its first K-step rides in B's last tile).
+	auto tick = [&](const int t, f32x4 (&vs)[TPW][2], f32x4 (&vn)[TPW][2]) __attribute__((always_inline)) {
 		const bool do_a = t < T;
 		const bool do_b = t >= 3 && t - 3 < T;
 		const bool do_o = t >= 1 && t - 1 < T;
-		// A(t): D(c, j) = sum_i W(i, c) V(i, j) over this wave's rows
+		const int tb = t - 3, to = t - 1;
+		stamp(7);
+		// the split columns of H that B(t - 3) multiplies with were published a tick ago: requested before A, looked at after it.
+		// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules k = 2 q, 2 q + 1 of (c = 16 nt + cl, j = 4 k + grp)
+		const unsigned hbase = hf_group + (unsigned)((tb + SLOTS) % SLOTS) * (64u * 32u * 8u) + (unsigned)lane * 16u;
+		// the next panel is requested now: the only loads from far away (memory-side cache / HBM) are then the oldest ones in flight, and the
+		// waits for the hand-off loads issued later in the tick do not have to outwait younger far loads (vmcnt completes in order)
+		if (t + 1 < T) prefetch(t + 1, vn);
+		// ---- A(t): D(c, j) = sum_i W(i, c) V(i, j) over this wave's rows ---------------------------------------------------------
 		if (do_a) {
 			f32x16 accA[2];
 #pragma unroll
@@ -189,21 +226,12 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 #pragma unroll
 				for (int g = 0; g < 16; ++g) accA[nb][g] = 0.f;
 			bf16x8 op[2][3];
-			{
-				float v[8];
 #pragma unroll
-				for (int j = 0; j < 4; ++j) { v[j] = vs[0][0][j]; v[4 + j] = vs[0][1][j]; }
-				split3(v, op[0][0], op[0][1], op[0][2]);
-			}
+			for (int pl = 0; pl < 3; ++pl) op[0][pl] = opn[pl];
 #pragma unroll
 			for (int ks = 0; ks < TPW; ++ks) {
 				const int cur = ks & 1, nxt = cur ^ 1;
-				if (ks + 1 < TPW) {
-					float v[8];
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { v[j] = vs[ks + 1][0][j]; v[4 + j] = vs[ks + 1][1][j]; }
-					split3(v, op[nxt][0], op[nxt][1], op[nxt][2]);
-				}
+				if (ks + 1 < TPW) split_pair(vs[ks + 1][0], vs[ks + 1][1], op[nxt]);
 #pragma unroll
 				for (int nb = 0; nb < 2; ++nb) {
 					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][2], op[cur][0], accA[nb], 0, 0, 0);
@@ -222,21 +250,35 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
-			// C/D map of the 32 x 32 MFMA: register 4 q + g of lane (l31, half) is row 8 q + 4 half + g (here c = 32 nb + that), column l31 (= j)
+			// C/D map of the 32 x 32 MFMA: register 4 q + g of lane (l31, half) is row 8 q + 4 half + g (here c = 32 nb + that), column l31 (= j).
+			// Exchange image: float4 (wave, lane, nbq = 4 nb + q) at (wave * 64 + lane) * 8 + (nbq ^ (lane & 7)): a lane's eight
+			// chunks are 128 contiguous bytes, the XOR spreads lanes over the banks for the writer and for the transposing reader
 #pragma unroll
 			for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					f32x4 v;
 					v[0] = accA[nb][4 * q + 0]; v[1] = accA[nb][4 * q + 1]; v[2] = accA[nb][4 * q + 2]; v[3] = accA[nb][4 * q + 3];
-					xch[(wave * 8 + nb * 4 + q) * 64 + lane] = v;
+					xch[(wave * 64 + lane) * 8 + ((nb * 4 + q) ^ (lane & 7))] = v;
 				}
 		}
-		__syncthreads();                                                                   // BAR_a
+		stamp(0);
+		__syncthreads();                                                                   // BAR_a: the exchange image is complete
+		stamp(1);
+		u32x4 hraw[4][4];
+		if (do_b) {
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) hraw[nt][q] = load_sc1(rs_hf, hbase + (unsigned)(nt * 4 + q) * 1024u);
+		}
+		// owner of column `slot` of panel t - 1: its old values and the denominator (W^T W) H do not wait for anybody
+		const int jc = do_o ? (p0 + to) * 32 + slot_i : 0;
 		// book the column this workgroup finished as owner in the previous tick: error term, H H^T
-		if (prev_owner_col >= 0) {
-			if (a.compute_error && tid == 0 && prev_owner_col < a.n) a.ps[prev_owner_col] = ((s_ps[0] + s_ps[1]) + s_ps[2]) + s_ps[3];
-			const float hc = s_hnew[oc];
+		{
+			const bool have = prev_owner_col >= 0;
+			if (have && a.compute_error && tid == 0 && prev_owner_col < a.n) a.ps[prev_owner_col] = ((s_ps[0] + s_ps[1]) + s_ps[2]) + s_ps[3];
+			const float hc = have ? s_hnew[oc] : 0.f;
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const f32x4 hk = *reinterpret_cast<const f32x4*>(s_hnew + 16 * grp + 4 * u);
@@ -245,52 +287,106 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			}
 			prev_owner_col = -1;
 		}
-		// sum over the four waves (wave order) and publish: thread (w', lane) owns (nb, q) = 2 w', 2 w' + 1 of column l31, rows 4 half + g
+		// sum over the four waves (wave order) and publish: thread (j = tid / 8, nbq = tid % 8) takes c = 8 nbq .. 8 nbq + 7 of column j,
+		// i.e. the chunk nbq of lanes (j, half 0) and (j, half 1); its 64 bytes of granules are bytes [64 tid, 64 tid + 64) of the
+		// workgroup's slot: slot image = [column j][c] granules {value, tag}
 		if (do_a) {
 			const unsigned tg = tag0 + (unsigned)t + 1u;
 			u32x4* dst = reinterpret_cast<u32x4*>(a.part_scratch) + ((long)((xcd * SLOTS + (t % SLOTS)) * ONEPASS_GROUP + slot_i) * 256 + tid) * 4;
+			const int pj = tid >> 3, pq = tid & 7;
 #pragma unroll
-			for (int u = 0; u < 2; ++u) {
-				const int nbq = 2 * (tid >> 6) + u;
-				f32x4 s = xch[(0 * 8 + nbq) * 64 + lane];
+			for (int h = 0; h < 2; ++h) {
+				const int ln = pj + 32 * h;
+				f32x4 s = xch[(0 * 64 + ln) * 8 + (pq ^ (ln & 7))];
 #pragma unroll
-				for (int w = 1; w < 4; ++w) s += xch[(w * 8 + nbq) * 64 + lane];
+				for (int w = 1; w < 4; ++w) s += xch[(w * 64 + ln) * 8 + (pq ^ (ln & 7))];
 				u32x4 g0, g1;
 				g0[0] = __float_as_uint(s[0]); g0[1] = tg; g0[2] = __float_as_uint(s[1]); g0[3] = tg;
 				g1[0] = __float_as_uint(s[2]); g1[1] = tg; g1[2] = __float_as_uint(s[3]); g1[3] = tg;
-				dst[2 * u] = g0; dst[2 * u + 1] = g1;
+				dst[2 * h] = g0; dst[2 * h + 1] = g1;
 			}
 		}
-		// B(t - 3): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 k + grp
+		__builtin_amdgcn_sched_barrier(0);
+		f32x4 hold[4], gq[4];
+		float hcur = 0.f, den = 0.f;
+		if (do_o) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { hold[u] = *reinterpret_cast<const f32x4*>(a.H + (long)jc * 64 + 16 * grp + 4 * u); gq[u] = *reinterpret_cast<const f32x4*>(grow + 4 * u); }
+			hcur = a.H[(long)jc * 64 + oc];
+		}
+		stamp(2);
+		__syncthreads();                                                                   // BAR_b: every wave is done with the exchange image and the booking words
+		if (do_o) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) den = fmaf(gq[u][i], hold[u][i], den);
+			den += __shfl_xor(den, 16);
+			den += __shfl_xor(den, 32);                                                // (0 + 1) + (2 + 3) in every lane
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// B's operand H: every granule must carry its tick's tag
+		bf16x8 hf[4][3];
 		if (do_b) {
-			const int tb = t - 3;
 			const unsigned tg16 = (tag0 + (unsigned)tb + 1u) & 0xffffu;
-			const unsigned hbase = hf_group + (unsigned)(tb % SLOTS) * (64u * 32u * 8u) + (unsigned)(cl * 4 + grp) * 64u;
-			bf16x8 hf[4][3];
-			const u64 w0 = __builtin_amdgcn_s_memrealtime();
-			for (;;) {
-				unsigned bad = 0;
+			unsigned bad = 0;
 #pragma unroll
-				for (int nt = 0; nt < 4; ++nt) {
-					u32x4 d[4];
+			for (int nt = 0; nt < 4; ++nt) {
+				u32x4 o0, o1, o2;
 #pragma unroll
-					for (int q = 0; q < 4; ++q) d[q] = load_sc1(rs_hf, hbase + (unsigned)nt * (16u * 4u * 64u) + 16u * q);
-					u32x4 o0, o1, o2;
-#pragma unroll
-					for (int q = 0; q < 4; ++q) {
-						// d[q] = two granules {p0 | p1 << 16, p2 | tag << 16} of k = 2 q, 2 q + 1
-						o0[q] = (d[q][0] & 0xffffu) | (d[q][2] << 16);
-						o1[q] = (d[q][0] >> 16) | (d[q][2] & 0xffff0000u);
-						o2[q] = (d[q][1] & 0xffffu) | (d[q][3] << 16);
-						bad |= ((d[q][1] >> 16) ^ tg16) | ((d[q][3] >> 16) ^ tg16);
-					}
-					hf[nt][0] = __builtin_bit_cast(bf16x8, o0); hf[nt][1] = __builtin_bit_cast(bf16x8, o1); hf[nt][2] = __builtin_bit_cast(bf16x8, o2);
+				for (int q = 0; q < 4; ++q) {
+					// two granules {p0 | p1 << 16, p2 | tag << 16} of k = 2 q, 2 q + 1
+					const u32x4 d = hraw[nt][q];
+					o0[q] = (d[0] & 0xffffu) | (d[2] << 16);
+					o1[q] = (d[0] >> 16) | (d[2] & 0xffff0000u);
+					o2[q] = (d[1] & 0xffffu) | (d[3] << 16);
+					bad |= ((d[1] >> 16) ^ tg16) | ((d[3] >> 16) ^ tg16);
 				}
-				if (__all(bad == 0) || gave_up) break;
-				if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 2u); break; }
-				__builtin_amdgcn_s_sleep(8);
+				hf[nt][0] = __builtin_bit_cast(bf16x8, o0); hf[nt][1] = __builtin_bit_cast(bf16x8, o1); hf[nt][2] = __builtin_bit_cast(bf16x8, o2);
 			}
-			const float* vr = vw + (tb % 3) * (4 * TPW * 512) + grp * 16 + cl;                // + tile * 512 + k * 64
+			if (!__all(bad == 0) && !gave_up) {
+				// (rare) an owner is late: read again until every tag matches
+				const u64 w0 = __builtin_amdgcn_s_memrealtime();
+				for (;;) {
+					__builtin_amdgcn_s_sleep(4);
+					if (DIAG) ++retries_f;
+					bad = 0;
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt) {
+						u32x4 d[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) d[q] = load_sc1(rs_hf, hbase + (unsigned)(nt * 4 + q) * 1024u);
+						u32x4 o0, o1, o2;
+#pragma unroll
+						for (int q = 0; q < 4; ++q) {
+							o0[q] = (d[q][0] & 0xffffu) | (d[q][2] << 16);
+							o1[q] = (d[q][0] >> 16) | (d[q][2] & 0xffff0000u);
+							o2[q] = (d[q][1] & 0xffffu) | (d[q][3] << 16);
+							bad |= ((d[q][1] >> 16) ^ tg16) | ((d[q][3] >> 16) ^ tg16);
+						}
+						hf[nt][0] = __builtin_bit_cast(bf16x8, o0); hf[nt][1] = __builtin_bit_cast(bf16x8, o1); hf[nt][2] = __builtin_bit_cast(bf16x8, o2);
+					}
+					if (__all(bad == 0)) break;
+					if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 2u); break; }
+				}
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		stamp(3);
+		// O(t - 1), this wave's sixteen factor rows c = 16 w .. 16 w + 15 of the owned column: the 32 sources' partial sums are requested
+		// before B and looked at after it.  A source's 128 bytes (16 granules) are 8 pieces of 16 bytes (c = 16 w + 2 p, + 1); load q of
+		// lane l takes piece p = l & 7 of source 8 q + (l >> 3): 128 contiguous bytes per source and instruction
+		u32x4 od[4];
+		const unsigned obase = part_group + (unsigned)(((to + SLOTS) % SLOTS) * ONEPASS_GROUP + (lane >> 3)) * (256u * 64u) + (unsigned)slot_i * 512u +
+		                       (unsigned)wave * 128u + (unsigned)(lane & 7) * 16u;
+		if (do_o) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// ---- B(t - 3): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 k + grp -----------------------------
+		if (do_b) {
+			const float* vr = vw + (t % 3) * (4 * TPW * 512) + grp * 16 + cl;                 // (t - 3) % 3 = t % 3;  + tile * 512 + k * 64
 			bf16x8 op[2][3];
 			float raw[2][8];
 #pragma unroll
@@ -302,13 +398,14 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			for (int tl = 0; tl < TPW; ++tl) {
 				const int cur = tl & 1, nxt = cur ^ 1;
 				if (tl + 1 < TPW) split3(raw[nxt], op[nxt][0], op[nxt][1], op[nxt][2]);
+				else split_pair(vn[0][0], vn[0][1], opn);                              // the next A's first operand (whatever the slot holds when there is no next A)
 				if (tl + 2 < TPW) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) raw[cur][k] = vr[(tl + 2) * 512 + k * 64];
 				}
 #pragma unroll
 				for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = six_terms_16(op[cur], hf[nt], accB[tl][nt]);
-				if (tl + 1 < TPW) {
+				{
 #pragma unroll
 					for (int g = 0; g < 24; ++g) {
 						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -319,22 +416,9 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		// owner loads of O(t - 1), issued before the panel stream's next loads so that they can be waited for on their own
-		const int to = t - 1;
-		const int jc = do_o ? (p0 + to) * 32 + slot_i : 0;                                       // the column this workgroup owns in panel t - 1
-		u32x4 od[4];
-		f32x4 hold[4];
-		float hcur = 0.f;
-		const unsigned obase = part_group + (unsigned)((to & (SLOTS - 1)) * ONEPASS_GROUP + (tid >> 3)) * (256u * 64u) +
-		                       (unsigned)(((tid & 7) >> 1) * 64 + slot_i + 32 * (tid & 1)) * 64u;
-		if (do_o) {
-#pragma unroll
-			for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + 16u * q);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) hold[u] = *reinterpret_cast<const f32x4*>(a.H + (long)jc * 64 + 16 * grp + 4 * u);
-			hcur = a.H[(long)jc * 64 + oc];
-		}
-		// the panel leaves its landing registers for LDS (the buffer B(t - 3) has just finished with); the slot takes panel t + 2
+		__builtin_amdgcn_sched_barrier(0);
+		stamp(4);
+		// the panel leaves its landing registers for LDS (the buffer B(t - 3) has just finished with); the slot is free for panel t + 2
 		if (do_a) {
 			float* vd = vw + (t % 3) * (4 * TPW * 512) + l31 * 16 + 8 * half;
 #pragma unroll
@@ -342,8 +426,10 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				*reinterpret_cast<f32x4*>(vd + ks * 512) = vs[ks][0];
 				*reinterpret_cast<f32x4*>(vd + ks * 512 + 4) = vs[ks][1];
 			}
-			if (t + 2 < T) prefetch(t + 2, vs);
 		}
+		if (!do_b && t + 1 < T) split_pair(vn[0][0], vn[0][1], opn);
+		__builtin_amdgcn_sched_barrier(0);
+		stamp(5);
 		if (do_o) {
 			const unsigned tg = tag0 + (unsigned)to + 1u;
 			const u64 w0 = __builtin_amdgcn_s_memrealtime();
@@ -353,78 +439,51 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				for (int q = 0; q < 4; ++q) bad |= (od[q][1] ^ tg) | (od[q][3] ^ tg);
 				if (__all(bad == 0) || gave_up) break;
 				if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 4u); break; }
-				__builtin_amdgcn_s_sleep(8);
+				__builtin_amdgcn_s_sleep(4);
+				if (DIAG) ++retries_o;
 #pragma unroll
-				for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + 16u * q);
+				for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
 			}
 			// (__uint_as_float, not __builtin_bit_cast(float, od[q][i]): hipcc 7.2 folds the bit cast of a vector ELEMENT of a
 			//  buffer load's result to element 0)
-			// thread (source s' = tid / 8, piece e = tid % 8 = (w', h)) holds D(c, slot column) of source s' for
-			// c = 32 (w' / 2) + 16 (w' % 2) + 8 u + 4 h + g; sources 2 i and 2 i + 1 sit eight lanes apart
-			f32x4 v0, v1;
-			v0[0] = __uint_as_float(od[0][0]); v0[1] = __uint_as_float(od[0][2]);
-			v0[2] = __uint_as_float(od[1][0]); v0[3] = __uint_as_float(od[1][2]);
-			v1[0] = __uint_as_float(od[2][0]); v1[1] = __uint_as_float(od[2][2]);
-			v1[2] = __uint_as_float(od[3][0]); v1[3] = __uint_as_float(od[3][2]);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) { v0[i] += __shfl_xor(v0[i], 8); v1[i] += __shfl_xor(v1[i], 8); }
-			if ((lane & 8) == 0) {
-				const int e = tid & 7, wq = e >> 1, h = e & 1;
-				const int cb = 32 * (wq >> 1) + 16 * (wq & 1) + 4 * h;
-				float* r = s_red + (tid >> 4) * 64 + cb;
-				*reinterpret_cast<f32x4*>(r) = v0;
-				*reinterpret_cast<f32x4*>(r + 8) = v1;
-			}
-		}
-		__syncthreads();                                                                   // BAR_b
-		if (do_o) {
-			// lane (cl, grp): source pairs 4 grp .. 4 grp + 3, then the four groups in order
-			float sum = s_red[(4 * grp + 0) * 64 + oc];
-#pragma unroll
-			for (int i = 1; i < 4; ++i) sum += s_red[(4 * grp + i) * 64 + oc];
-			float den = 0.f;
-#pragma unroll
-			for (int u = 0; u < 4; ++u)
-#pragma unroll
-				for (int i = 0; i < 4; ++i) den = fmaf(gq[4 * u + i], hold[u][i], den);
-			// (0 + 1) + (2 + 3) in every lane
-			sum += __shfl_xor(sum, 16); den += __shfl_xor(den, 16);
-			sum += __shfl_xor(sum, 32); den += __shfl_xor(den, 32);
+			// sources 8 q + g in q order, then the eight lane groups g = l >> 3: g ^ 1 by a DPP rotation, g ^ 2 and g ^ 4 across rows
+			float v0 = ((__uint_as_float(od[0][0]) + __uint_as_float(od[1][0])) + __uint_as_float(od[2][0])) + __uint_as_float(od[3][0]);
+			float v1 = ((__uint_as_float(od[0][2]) + __uint_as_float(od[1][2])) + __uint_as_float(od[2][2])) + __uint_as_float(od[3][2]);
+			v0 = add_ror(v0, ROR8()); v1 = add_ror(v1, ROR8());
+			v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+			v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+			const float sum = (lane & 8) ? v1 : v0;                                    // this lane's factor row: c = 16 w + 2 (l & 7) + ((l >> 3) & 1)
 			const float num = sum * sc_c;                                              // the pending column scale of W (kernels_mu64.hip)
 			const float hn = hcur * num / (den + a.eps);                               // KernelMultiplyDivide.cu:39-42
-			float psum = hn * num;                                                     // KernelTraceMultiplication.cu:43-80, per-column term
-			psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2); psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
 			if (grp == 0) {
 				a.H[(long)jc * 64 + oc] = hn;
 				s_hnew[oc] = hn;
 				unsigned p0b, p1b, p2b;
 				split3_scalar(hn, p0b, p1b, p2b);
 				const u64 gr = (u64)p0b | ((u64)p1b << 16) | ((u64)p2b << 32) | ((u64)((tag0 + (unsigned)to + 1u) & 0xffffu) << 48);
-				u64* hd = reinterpret_cast<u64*>(a.hfrag_scratch) + ((long)(xcd * SLOTS + (to % SLOTS)) * 64 + oc) * 32 + (slot_i & 3) * 8 + (slot_i >> 2);
+				const int kq = slot_i >> 2;                                           // j = slot_i = 4 k + (slot_i & 3)
+				u64* hd = reinterpret_cast<u64*>(a.hfrag_scratch) + (long)(xcd * SLOTS + (to % SLOTS)) * (64 * 32) +
+				          (((wave * 4 + (kq >> 1)) * 64 + (slot_i & 3) * 16 + (oc & 15)) * 2 + (kq & 1));
 				*hd = gr;
-				if (cl == 0) s_ps[wave] = psum;
+			}
+			if (a.compute_error) {
+				// per-column term of tr(H^T W^T V) (KernelTraceMultiplication.cu:43-80): sixteen rows per wave by DPP rotations, waves by the booking step
+				float psum = hn * num;
+				psum = add_ror(psum, ROR8()); psum = add_ror(psum, ROR4()); psum = add_ror(psum, ROR2()); psum = add_ror(psum, ROR1());
+				if (lane == 0) s_ps[wave] = psum;
 			}
 			prev_owner_col = jc;
 		}
+		__builtin_amdgcn_sched_barrier(0);
+		stamp(6);
 	};
 
+	if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
 	for (int t = 0; t < T + 3; t += 2) {
-		tick(t, va[0]);
-		tick(t + 1, va[1]);
+		tick(t, va[0], va[1]);
+		tick(t + 1, va[1], va[0]);
 	}
-	// the last owner column (booked after the barrier of a tick that does not come): one more barrier
-	__syncthreads();
-	if (prev_owner_col >= 0) {
-		if (a.compute_error && tid == 0 && prev_owner_col < a.n) a.ps[prev_owner_col] = ((s_ps[0] + s_ps[1]) + s_ps[2]) + s_ps[3];
-		const float hc = s_hnew[oc];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const f32x4 hk = *reinterpret_cast<const f32x4*>(s_hnew + 16 * grp + 4 * u);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) hh[4 * u + i] = fmaf(hc, hk[i], hh[4 * u + i]);
-		}
-	}
-
+	if (DIAG) c_loop1 = __builtin_amdgcn_s_memtime();
 	// ---- results ------------------------------------------------------------------------------------------------------------------
 	// (V H^T)^T partial of this group: C/D map of the 16 x 16 MFMA: register g of lane (cl, grp) is row 4 grp + g (tile row i), column cl (c = 16 nt + cl)
 	float* slab = a.slabs + (long)xcd * a.slab_stride;
@@ -445,6 +504,19 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 		v[0] = hh[4 * u]; v[1] = hh[4 * u + 1]; v[2] = hh[4 * u + 2]; v[3] = hh[4 * u + 3];
 		*reinterpret_cast<f32x4*>(hp + 4 * u) = v;
 	}
+	if (DIAG && a.stamps != nullptr) {
+		// per wave, 16 words: cycles in A | wait BAR_a | booking + publish | BAR_b, denominator, H operand | B | panel to LDS, next panel
+		// requested | owner: wait for the partials, reduce, new column | loads before A; retries of the two waits;
+		// cycles before the loop, in the loop, after it; 100 MHz ticks of the whole kernel; XCD and slot
+		__builtin_amdgcn_s_waitcnt(0);
+		const u64 c_exit = __builtin_amdgcn_s_memtime();
+		if (lane == 0) {
+			unsigned long long* o = a.stamps + 16 * ((long)blockIdx.x * 4 + wave);
+			for (int i = 0; i < 8; ++i) o[i] = seg[i];
+			o[8] = retries_f; o[9] = retries_o; o[10] = c_loop0 - c_entry; o[11] = c_loop1 - c_loop0; o[12] = c_exit - c_loop1;
+			o[13] = __builtin_amdgcn_s_memrealtime() - t_start; o[14] = (u64)xcd * 64 + slot_i; o[15] = (u64)T;
+		}
+	}
 	(void)t_start;
 }
 
@@ -455,8 +527,16 @@ bool onepass_available(long mpad, int num_cus) {
 hipError_t launch_mu64_onepass(const OnePassArgs& a, hipStream_t stream) {
 	if (a.tile_rows <= 0 || a.tile_rows > ONEPASS_GROUP * 4 * TPW || a.panels <= 0) return hipErrorInvalidValue;
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_mu64_onepass), LDS_TOTAL, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_mu64_onepass, dim3(ONEPASS_XCDS * ONEPASS_GROUP), dim3(256), LDS_TOTAL, stream, a);
+#ifdef NMFAMD_DIAG_BUILD
+	if (a.stamps != nullptr) {
+		static std::atomic<unsigned long long> lds_done_d{0ull};
+		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_mu64_onepass<true>), LDS_TOTAL, lds_done_d); e != hipSuccess) return e;
+		hipLaunchKernelGGL(k_mu64_onepass<true>, dim3(ONEPASS_XCDS * ONEPASS_GROUP), dim3(256), LDS_TOTAL, stream, a);
+		return hipGetLastError();
+	}
+#endif
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_mu64_onepass<false>), LDS_TOTAL, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_mu64_onepass<false>, dim3(ONEPASS_XCDS * ONEPASS_GROUP), dim3(256), LDS_TOTAL, stream, a);
 	return hipGetLastError();
 }
 

@@ -1,25 +1,28 @@
-// kernels_onepass.hip -- the rank-64 multiplicative update with ONE pass over V per iteration.
+// kernels_onepass.hip -- the rank-64 multiplicative update with ONE pass over V per iteration (one fetch from HBM).
 //
 // Reference sequence (source/nmf/AlgorithmMultiplicativeFrobenius.h:165-248): RN = W^T V (gemm TN, :187-188), RN2 = (W^T W) H
 // (:176-183), H .*= RN ./ (RN2 + eps) (:191, KernelMultiplyDivide.cu:29-43), then MR = V H^T with the NEW H (:240-241).
 // The element-wise step makes column j of the new H a function of column j of V and the r x r matrix W^T W only, so a
-// column panel V(:, J) can be loaded once: reduce W^T V(:, J) over the rows, update H(:, J), and add V(:, J) H(:, J)^T to
-// the running (V H^T) while the panel is still on chip.  Only the W update waits for all panels (kernels_mu64.hip, U_W).
+// column panel V(:, J) can be taken once: reduce W^T V(:, J) over the rows, update H(:, J), and add V(:, J) H(:, J)^T to
+// the running (V H^T) while the panel is still close by.  Only the W update waits for all panels (kernels_mu64.hip, U_W).
 //
 // Cut (one persistent launch, 256 workgroups of 4 waves, one wave per SIMD, one workgroup per CU):
 //   * the 32 workgroups of an XCD form a group that owns a contiguous range of 32-column panels and ALL rows: workgroup
 //     `slot` of the group holds a slice of <= 320 rows (20 tiles of 16), wave w of it 80 of them -- for both products;
-//   * the wave keeps its rows of the split image of W in registers (120) and its 80 x 64 block of (V H^T) in accumulators (80);
-//   * tick t of a workgroup:  A(t): partial W^T V of panel t over its rows (operand V straight from the registers the
-//     panel was loaded into), summed over the four waves through LDS and published to the group;  B(t - 3): (V H^T) +=
-//     V(rows, panel t-3) Hnew(:, panel t-3)^T with V read back from LDS;  O(t - 1): the workgroup is the OWNER of column
-//     `slot` of panel t - 1: it adds the 32 published partials, forms the new column of H and publishes its split form;
-//   * a panel therefore stays in LDS for three ticks (3 x 40 KB), which is what hides the two hand-offs of its update.
+//   * the wave keeps its rows of the split image of W in LDS (30 KB per wave, read in place as MFMA operands) and its
+//     80 x 64 block of (V H^T) in accumulators (80 registers);
+//   * tick t of a workgroup:  A(t): partial W^T V of panel t over its rows (operand V from the registers the panel was
+//     loaded into, once, from HBM), summed over the four waves through LDS and published to the group;  O(t - 1): the
+//     workgroup is the OWNER of column `slot` of panel t - 1: it adds the 32 published partials, forms the new column of H
+//     and publishes its split form;  B(t - LAG): (V H^T) += V(rows, panel) Hnew(:, panel)^T -- V read a second time, now
+//     from the XCD's L2 / the memory-side cache it passed through LAG ticks ago (fully coalesced 256-byte rows).
 // Hand-offs stay inside the XCD's L2: plain stores (the vector L1 is write-through), `sc1` loads (they bypass the reader's
 // L1), every 8 bytes carry their own tag (tick number), so there is no flag, no fence and no drain -- a reader retries
 // until all its tags match.  The group is formed from HW_REG_XCC_ID (the hardware's answer to "which L2 do I use"), not
 // from blockIdx: a workgroup takes a ticket of ITS XCD; a launch whose XCDs do not get 32 workgroups each gives up (abort
 // flag; every wait is bounded) and the engine falls back to the two-pass iteration.
+// vmcnt completes in order: the far loads (next panel) are issued first in a tick, so that the waits for the near loads
+// (hand-offs, second read of V) issued later never have to outwait a younger far load.
 //
 // Arithmetic: both products are the six-term split-operand products of kernels_x3.hip (fp32 accuracy on the bf16 matrix
 // pipe); the update itself is fp32 with the reference's formula.  Summation orders differ from the two-pass path (rows are
@@ -40,11 +43,13 @@ typedef unsigned long long u64;
 namespace {
 
 constexpr int SLOTS = ONEPASS_SLOTS, TPW = ONEPASS_TILES_PER_WAVE;
-constexpr int LDS_VBUF = 3 * 4 * TPW * 32 * 16 * 4;   // three panels x four wave regions of [tile][column][row] floats
+constexpr int LAG = 3;                                // ticks between a panel's first use (A) and its second (B): two hand-offs fit in between
+constexpr int LDS_WF = 4 * TPW * 2 * 3 * 64 * 16;     // the four waves' rows of the split image of W, fragment order
 constexpr int LDS_XCH = 4 * 8 * 64 * 16;              // partial W^T V of the four waves
 constexpr int LDS_TAIL = 64 * 4 + 64;
-constexpr int LDS_TOTAL = LDS_VBUF + LDS_XCH + LDS_TAIL;
+constexpr int LDS_TOTAL = LDS_WF + LDS_XCH + LDS_TAIL;
 static_assert(LDS_TOTAL <= 163840, "LDS budget");
+static_assert(LAG >= 2 && LAG < SLOTS, "a slot must not be rewritten before its readers are done");
 
 constexpr u64 GIVE_UP_TICKS = 3000000ull;             // 30 ms of the 100 MHz clock
 
@@ -65,6 +70,11 @@ __device__ inline f32x4 six_terms_16(const bf16x8 (&x)[3], const bf16x8 (&y)[3],
 	return acc;
 }
 
+// Workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt (every load and STORE in flight: the next panel from HBM,
+// the hand-off loads, the publishing stores) -- thousands of cycles per tick here.  The LDS operations of this wave are complete
+// (lgkmcnt(0)) before it arrives; global memory is not ordered by this barrier (the hand-offs carry their own tags).
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // hi + mid + lo = v exactly (round-to-nearest cuts, as split3)
 __device__ inline void split3_scalar(float v, unsigned& hi, unsigned& mid, unsigned& lo) {
 	const __bf16 h = (__bf16)v;
@@ -81,16 +91,15 @@ __device__ inline void split3_scalar(float v, unsigned& hi, unsigned& mid, unsig
 template <bool DIAG>
 __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float* const vbuf = reinterpret_cast<float*>(smem);
-	f32x4* const xch = reinterpret_cast<f32x4*>(smem + LDS_VBUF);
-	float* const s_hnew = reinterpret_cast<float*>(smem + LDS_VBUF + LDS_XCH);
+	bf16x8* const wfl = reinterpret_cast<bf16x8*>(smem);
+	f32x4* const xch = reinterpret_cast<f32x4*>(smem + LDS_WF);
+	float* const s_hnew = reinterpret_cast<float*>(smem + LDS_WF + LDS_XCH);
 	float* const s_ps = s_hnew + 64;
 	int* const s_ctl = reinterpret_cast<int*>(s_ps + 4);
 
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-	const int l31 = lane & 31, half = lane >> 5;          // 32 x 32 MFMA operand coordinates
-	const int cl = lane & 15, grp = lane >> 4;            // 16 x 16 MFMA operand coordinates
+	const int grp = lane >> 4;                            // K group of the 16 x 16 MFMA operands
 
 	// ---- which group (XCD) and which slot of it -------------------------------------------------------------------------------
 	if (tid == 0) {
@@ -101,6 +110,8 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 		if (xcc < (unsigned)ONEPASS_XCDS) sl = (int)(atomicAdd(a.ticket + xcc, 1u) - a.seq * (unsigned)ONEPASS_GROUP);
 		s_ctl[0] = sl; s_ctl[1] = (int)xcc;
 	}
+	if (tid < 64) s_hnew[tid] = 0.f;
+	if (tid < 4) s_ps[tid] = 0.f;
 	__syncthreads();
 	const int slot_i = __builtin_amdgcn_readfirstlane(s_ctl[0]), xcd = __builtin_amdgcn_readfirstlane(s_ctl[1]);
 	if (slot_i < 0 || slot_i >= ONEPASS_GROUP) {          // this XCD holds more workgroups than a group has members (or an unknown id)
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	const unsigned tag0 = a.seq * (unsigned)tmax;          // tag of tick t: tag0 + t + 1 (never 0 in the first launch, always distinct from a slot's previous content)
 	bool gave_up = false;                                  // wave-uniform: stop waiting, run to the end (outputs are discarded by the host)
 	const u64 t_start = __builtin_amdgcn_s_memrealtime();
-	u64 seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_last = 0, c_entry = 0, c_loop0 = 0, c_loop1 = 0;
+	u64 seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_last = 0, c_entry = 0, c_loop0 = 0, c_loop1 = 0;
 	unsigned retries_f = 0, retries_o = 0;
 	auto stamp = [&](int i) __attribute__((always_inline)) {
 		if (DIAG) {
@@ -132,8 +143,9 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	const unsigned hf_group = (unsigned)xcd * SLOTS * 64u * 32u * 8u;
 
 	// ---- resident operands ------------------------------------------------------------------------------------------------------
-	// this wave's rows of the split image of W: K-step ks = tile row tr0 + TPW wave + ks (zero beyond the slice: those steps add nothing)
-	bf16x8 wf[TPW][2][3];
+	// this wave's rows of the split image of W, into its own part of LDS: K-step ks = tile row tr0 + TPW wave + ks (zero beyond the
+	// slice: those steps add nothing); fragment (ks, nb, plane) of lane l at wl[((ks * 2 + nb) * 3 + plane) * 64 + l]
+	bf16x8* const wl = wfl + wave * (TPW * 2 * 3 * 64) + lane;
 	int trw[TPW];
 	{
 		const bf16x8* F = reinterpret_cast<const bf16x8*>(a.Wx3);
@@ -142,15 +154,13 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			const int tr = tr0 + TPW * wave + ks;
 			const bool valid = tr < tr1;
 			trw[ks] = valid ? tr : tr1 - 1;
+			const int wk = trw[ks] < a.w_ks ? trw[ks] : a.w_ks;          // rows past the image: its closing all-zero step
 #pragma unroll
-			for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-				for (int pl = 0; pl < 3; ++pl) {
-					const int wk = trw[ks] < a.w_ks ? trw[ks] : a.w_ks;      // rows past the image: its closing all-zero step
-					bf16x8 v = F[((long)(wk * 2 + nb) * 3 + pl) * 64 + lane];
-					if (!valid) { const u32x4 z = {0u, 0u, 0u, 0u}; v = __builtin_bit_cast(bf16x8, z); }
-					wf[ks][nb][pl] = v;
-				}
+			for (int f = 0; f < 6; ++f) {
+				bf16x8 v = F[((long)wk * 6 + f) * 64 + lane];
+				if (!valid) { const u32x4 z = {0u, 0u, 0u, 0u}; v = __builtin_bit_cast(bf16x8, z); }
+				wl[(ks * 6 + f) * 64] = v;
+			}
 		}
 	}
 	// owner arithmetic: lane l of wave w works on factor row c = 16 w + 2 (l & 7) + ((l >> 3) & 1), reduction part k = 16 (l >> 4) .. + 15
@@ -166,13 +176,11 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	for (int tl = 0; tl < TPW; ++tl)
 #pragma unroll
 		for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-	if (tid < 64) s_hnew[tid] = 0.f;
-	if (tid < 4) s_ps[tid] = 0.f;
 
 	// the two landing slots of the panel stream: lane (l31 = column of the panel, half) takes rows 8 half .. 8 half + 7 of each tile
-	f32x4 va[2][TPW][2];
 	// (wave-uniform base + a 32-bit lane offset: the loads take the base in scalar registers)
-	const int v_lane = l31 * 16 + 8 * half;
+	f32x4 va[2][TPW][2];
+	const int v_lane = (lane & 31) * 16 + 8 * (lane >> 5);
 	auto prefetch = [&](int t, f32x4 (&dst)[TPW][2]) __attribute__((always_inline)) {
 #pragma unroll
 		for (int ks = 0; ks < TPW; ++ks) {
@@ -183,7 +191,6 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	};
 	if (T > 0) prefetch(0, va[0]);
 
-	float* const vw = vbuf + wave * (TPW * 32 * 16);      // this wave's region of a panel buffer (+ buffer * 4 * TPW * 512)
 	int prev_owner_col = -1;                               // column whose error term / H H^T contribution is still to be booked
 	bf16x8 opn[3];                                         // split form of K-step 0 of the NEXT panel (prepared while the matrix pipe runs B)
 	auto split_pair = [&](const f32x4& lo4, const f32x4& hi4, bf16x8 (&o)[3]) __attribute__((always_inline)) {
@@ -202,21 +209,17 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	typedef std::integral_constant<int, 0x122> ROR2;
 	typedef std::integral_constant<int, 0x121> ROR1;
 	if (T > 0) split_pair(va[0][0][0], va[0][0][1], opn);
-	__syncthreads();
+	__builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's fragments of W are in LDS (nobody else reads them)
 
 	// ---- one tick -----------------------------------------------------------------------------------------------------------------
 	// vs: landing slot of panel t, vn: of panel t + 1 (the split of its first K-step rides in B's last tile).
 	auto tick = [&](const int t, f32x4 (&vs)[TPW][2], f32x4 (&vn)[TPW][2]) __attribute__((always_inline)) {
 		const bool do_a = t < T;
-		const bool do_b = t >= 3 && t - 3 < T;
+		const bool do_b = t >= LAG && t - LAG < T;
 		const bool do_o = t >= 1 && t - 1 < T;
-		const int tb = t - 3, to = t - 1;
+		const int tb = t - LAG, to = t - 1;
 		stamp(7);
-		// the split columns of H that B(t - 3) multiplies with were published a tick ago: requested before A, looked at after it.
-		// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules k = 2 q, 2 q + 1 of (c = 16 nt + cl, j = 4 k + grp)
-		const unsigned hbase = hf_group + (unsigned)((tb + SLOTS) % SLOTS) * (64u * 32u * 8u) + (unsigned)lane * 16u;
-		// the next panel is requested now: the only loads from far away (memory-side cache / HBM) are then the oldest ones in flight, and the
-		// waits for the hand-off loads issued later in the tick do not have to outwait younger far loads (vmcnt completes in order)
+		// the next panel is requested first: the only loads from far away (memory-side cache / HBM) are then the oldest ones in flight
 		if (t + 1 < T) prefetch(t + 1, vn);
 		// ---- A(t): D(c, j) = sum_i W(i, c) V(i, j) over this wave's rows ---------------------------------------------------------
 		if (do_a) {
@@ -225,27 +228,34 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
 				for (int g = 0; g < 16; ++g) accA[nb][g] = 0.f;
-			bf16x8 op[2][3];
+			bf16x8 op[2][3], wf[2][2][3];
 #pragma unroll
 			for (int pl = 0; pl < 3; ++pl) op[0][pl] = opn[pl];
 #pragma unroll
+			for (int f = 0; f < 6; ++f) wf[0][f / 3][f % 3] = wl[f * 64];
+#pragma unroll
 			for (int ks = 0; ks < TPW; ++ks) {
 				const int cur = ks & 1, nxt = cur ^ 1;
-				if (ks + 1 < TPW) split_pair(vs[ks + 1][0], vs[ks + 1][1], op[nxt]);
+				if (ks + 1 < TPW) {
+#pragma unroll
+					for (int f = 0; f < 6; ++f) wf[nxt][f / 3][f % 3] = wl[((ks + 1) * 6 + f) * 64];
+					split_pair(vs[ks + 1][0], vs[ks + 1][1], op[nxt]);
+				}
 #pragma unroll
 				for (int nb = 0; nb < 2; ++nb) {
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][2], op[cur][0], accA[nb], 0, 0, 0);
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][0], op[cur][2], accA[nb], 0, 0, 0);
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][1], op[cur][1], accA[nb], 0, 0, 0);
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][1], op[cur][0], accA[nb], 0, 0, 0);
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][0], op[cur][1], accA[nb], 0, 0, 0);
-					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][nb][0], op[cur][0], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][2], op[cur][0], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][2], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][1], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][0], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][1], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][0], accA[nb], 0, 0, 0);
 				}
 				if (ks + 1 < TPW) {
 #pragma unroll
 					for (int g = 0; g < 12; ++g) {
 						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 						__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+						if (g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
@@ -263,8 +273,11 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 				}
 		}
 		stamp(0);
-		__syncthreads();                                                                   // BAR_a: the exchange image is complete
+		lds_barrier();                                                                     // BAR_a: the exchange image is complete
 		stamp(1);
+		// the split columns of H that B multiplies with were published a tick ago: requested now, looked at after the publishing step.
+		// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules k = 2 q, 2 q + 1 of (c = 16 nt + (lane & 15), j = 4 k + grp)
+		const unsigned hbase = hf_group + (unsigned)((tb + SLOTS) % SLOTS) * (64u * 32u * 8u) + (unsigned)lane * 16u;
 		u32x4 hraw[4][4];
 		if (do_b) {
 #pragma unroll
@@ -272,8 +285,6 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 #pragma unroll
 				for (int q = 0; q < 4; ++q) hraw[nt][q] = load_sc1(rs_hf, hbase + (unsigned)(nt * 4 + q) * 1024u);
 		}
-		// owner of column `slot` of panel t - 1: its old values and the denominator (W^T W) H do not wait for anybody
-		const int jc = do_o ? (p0 + to) * 32 + slot_i : 0;
 		// book the column this workgroup finished as owner in the previous tick: error term, H H^T
 		{
 			const bool have = prev_owner_col >= 0;
@@ -307,6 +318,8 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
+		// owner of column `slot` of panel t - 1: its old values and the denominator (W^T W) H do not wait for anybody
+		const int jc = do_o ? (p0 + to) * 32 + slot_i : 0;
 		f32x4 hold[4], gq[4];
 		float hcur = 0.f, den = 0.f;
 		if (do_o) {
@@ -315,7 +328,16 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			hcur = a.H[(long)jc * 64 + oc];
 		}
 		stamp(2);
-		__syncthreads();                                                                   // BAR_b: every wave is done with the exchange image and the booking words
+		lds_barrier();                                                                     // BAR_b: every wave is done with the exchange image and the booking words
+		// second read of V(rows, panel t - LAG): tile tl is 8 rows of 256 bytes, lane l of load k takes row i = l & 15 at column j = 4 k + (l >> 4)
+		float rawb[3][8];
+		const float* const vb0 = a.V + ((long)(p0 + tb) * (32 * 16) + lane);
+		auto load_tile = [&](int tl, float (&dst)[8]) __attribute__((always_inline)) {
+			const float* p = vb0 + (long)trw[tl] * a.tile_stride;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) dst[k] = p[64 * k];
+		};
+		if (do_b) { load_tile(0, rawb[0]); load_tile(1, rawb[1]); load_tile(2, rawb[2]); }
 		if (do_o) {
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
@@ -384,25 +406,16 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 			for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		// ---- B(t - 3): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 k + grp -----------------------------
+		// ---- B(t - LAG): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 k + grp ---------------------------
 		if (do_b) {
-			const float* vr = vw + (t % 3) * (4 * TPW * 512) + grp * 16 + cl;                 // (t - 3) % 3 = t % 3;  + tile * 512 + k * 64
 			bf16x8 op[2][3];
-			float raw[2][8];
-#pragma unroll
-			for (int k = 0; k < 8; ++k) raw[0][k] = vr[k * 64];
-#pragma unroll
-			for (int k = 0; k < 8; ++k) raw[1][k] = vr[512 + k * 64];
-			split3(raw[0], op[0][0], op[0][1], op[0][2]);
+			split3(rawb[0], op[0][0], op[0][1], op[0][2]);
 #pragma unroll
 			for (int tl = 0; tl < TPW; ++tl) {
 				const int cur = tl & 1, nxt = cur ^ 1;
-				if (tl + 1 < TPW) split3(raw[nxt], op[nxt][0], op[nxt][1], op[nxt][2]);
+				if (tl + 1 < TPW) split3(rawb[(tl + 1) % 3], op[nxt][0], op[nxt][1], op[nxt][2]);
 				else split_pair(vn[0][0], vn[0][1], opn);                              // the next A's first operand (whatever the slot holds when there is no next A)
-				if (tl + 2 < TPW) {
-#pragma unroll
-					for (int k = 0; k < 8; ++k) raw[cur][k] = vr[(tl + 2) * 512 + k * 64];
-				}
+				if (tl + 3 < TPW) load_tile(tl + 3, rawb[tl % 3]);
 #pragma unroll
 				for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = six_terms_16(op[cur], hf[nt], accB[tl][nt]);
 				{
@@ -410,26 +423,15 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 					for (int g = 0; g < 24; ++g) {
 						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 						__builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-						if (g < 8 && tl + 2 < TPW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+						if (g < 8 && tl + 3 < TPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		__builtin_amdgcn_sched_barrier(0);
-		stamp(4);
-		// the panel leaves its landing registers for LDS (the buffer B(t - 3) has just finished with); the slot is free for panel t + 2
-		if (do_a) {
-			float* vd = vw + (t % 3) * (4 * TPW * 512) + l31 * 16 + 8 * half;
-#pragma unroll
-			for (int ks = 0; ks < TPW; ++ks) {
-				*reinterpret_cast<f32x4*>(vd + ks * 512) = vs[ks][0];
-				*reinterpret_cast<f32x4*>(vd + ks * 512 + 4) = vs[ks][1];
-			}
-		}
 		if (!do_b && t + 1 < T) split_pair(vn[0][0], vn[0][1], opn);
 		__builtin_amdgcn_sched_barrier(0);
-		stamp(5);
+		stamp(4);
 		if (do_o) {
 			const unsigned tg = tag0 + (unsigned)to + 1u;
 			const u64 w0 = __builtin_amdgcn_s_memrealtime();
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 #pragma unroll
 				for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
 			}
+			stamp(5);
 			// (__uint_as_float, not __builtin_bit_cast(float, od[q][i]): hipcc 7.2 folds the bit cast of a vector ELEMENT of a
 			//  buffer load's result to element 0)
 			// sources 8 q + g in q order, then the eight lane groups g = l >> 3: g ^ 1 by a DPP rotation, g ^ 2 and g ^ 4 across rows
@@ -479,14 +482,17 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 	};
 
 	if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
-	for (int t = 0; t < T + 3; t += 2) {
+	for (int t = 0; t < T + LAG; t += 2) {
 		tick(t, va[0], va[1]);
 		tick(t + 1, va[1], va[0]);
 	}
 	if (DIAG) c_loop1 = __builtin_amdgcn_s_memtime();
+	// (the last owned column was booked in tick T + 1 <= T + LAG - 1)
+
 	// ---- results ------------------------------------------------------------------------------------------------------------------
 	// (V H^T)^T partial of this group: C/D map of the 16 x 16 MFMA: register g of lane (cl, grp) is row 4 grp + g (tile row i), column cl (c = 16 nt + cl)
 	float* slab = a.slabs + (long)xcd * a.slab_stride;
+	const int cl = lane & 15;
 #pragma unroll
 	for (int tl = 0; tl < TPW; ++tl) {
 		const int tr = tr0 + TPW * wave + tl;
@@ -505,9 +511,10 @@ __global__ __launch_bounds__(256, 1) void k_mu64_onepass(const OnePassArgs a) {
 		*reinterpret_cast<f32x4*>(hp + 4 * u) = v;
 	}
 	if (DIAG && a.stamps != nullptr) {
-		// per wave, 16 words: cycles in A | wait BAR_a | booking + publish | BAR_b, denominator, H operand | B | panel to LDS, next panel
-		// requested | owner: wait for the partials, reduce, new column | loads before A; retries of the two waits;
-		// cycles before the loop, in the loop, after it; 100 MHz ticks of the whole kernel; XCD and slot
+		// per wave, 16 words: cycles in: next panel requested + A | wait BAR_a | H columns requested, booking, publish, owner's old values
+		// requested | BAR_b, second read of V requested, denominator, H operand | owner's partials requested + B | wait for the partials |
+		// owner: reduce, new column | (between ticks); retries of the two waits; cycles before the loop, in the loop, after it; 100 MHz
+		// ticks of the whole kernel; XCD and slot; ticks
 		__builtin_amdgcn_s_waitcnt(0);
 		const u64 c_exit = __builtin_amdgcn_s_memtime();
 		if (lane == 0) {

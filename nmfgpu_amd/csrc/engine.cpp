@@ -271,8 +271,8 @@ Status Engine<T>::allocate() {
 		*pin_abort_ = 0;
 		op_seq_ = 0;
 		if (tuning_env("NMFAMD_ONEPASS_STAMPS") != nullptr) {
-			HIPX(hipMalloc((void**)&op_stamps_, sizeof(unsigned long long) * 16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP));
-			HIPX(hipMemsetAsync(op_stamps_, 0, sizeof(unsigned long long) * 16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP, stream_));
+			HIPX(hipMalloc((void**)&op_stamps_, sizeof(unsigned long long) * 16 * 8 * ONEPASS_XCDS * ONEPASS_GROUP));
+			HIPX(hipMemsetAsync(op_stamps_, 0, sizeof(unsigned long long) * 16 * 8 * ONEPASS_XCDS * ONEPASS_GROUP, stream_));
 		}
 	}
 	if (fused_capable() || gram_from_update()) {
@@ -1104,7 +1104,7 @@ Status Engine<T>::onepass_check() {
 	HIPX(hipStreamSynchronize(stream_));
 	if (op_stamps_ != nullptr) {
 		// diagnostic builds: the stamps of the last launch go to the file NMFAMD_ONEPASS_STAMPS names
-		std::vector<unsigned long long> h(16 * 4 * ONEPASS_XCDS * ONEPASS_GROUP);
+		std::vector<unsigned long long> h(16 * 8 * ONEPASS_XCDS * ONEPASS_GROUP);
 		if (hipMemcpy(h.data(), op_stamps_, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
 			if (FILE* f = std::fopen(tuning_env("NMFAMD_ONEPASS_STAMPS"), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
 		}

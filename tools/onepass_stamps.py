@@ -18,16 +18,17 @@ eng.iterate(30, first_iteration=1, last_iteration=30); eng.synchronize()
 f = eng.frobenius
 eng.get_factors()
 s = np.fromfile(path, dtype=np.uint64).reshape(-1, 16).astype(np.float64)
-s = s[s[:, 11] > 0]
-T = s[:, 15]
-names = ["A", "wait BAR_a", "book+publish", "wait H cols", "B", "owner ld/panel->LDS/prefetch/wait", "wait BAR_b", "owner math"]
-print(f"waves {len(s)}  ticks per group {sorted(set(T.astype(int)))}  frobenius {f:.4f}")
-clk = np.median((s[:, 10] + s[:, 11] + s[:, 12]) / (s[:, 13] * 10.0)) * 1000
-print(f"kernel: median {np.median(s[:, 13]) / 100:.1f} us per wave, clock ~{clk:.0f} MHz; before loop {np.median(s[:, 10]):.0f} cyc, loop {np.median(s[:, 11]):.0f}, after {np.median(s[:, 12]):.0f}")
-per = s[:, :8] / (T[:, None] + 3)
-for i, nme in enumerate(names):
-    print(f"  {nme:36s} median {np.median(per[:, i]):8.0f} cyc/tick   p10 {np.percentile(per[:, i], 10):8.0f}  p90 {np.percentile(per[:, i], 90):8.0f}")
-print(f"  sum {np.median(per.sum(axis=1)):.0f} cyc/tick; retries per wave: H cols {np.median(s[:, 8]):.0f} (max {s[:, 8].max():.0f}), partials {np.median(s[:, 9]):.0f} (max {s[:, 9].max():.0f})")
-for w in range(4):
-    sel = s[w::4]
-    print(f"  wave {w}: " + "  ".join(f"{np.median(sel[:, i] / (sel[:, 15] + 3)):7.0f}" for i in range(8)))
+role = (np.arange(len(s)) % 8) // 4
+ok = s[:, 11] > 0
+print(f"waves {ok.sum()}  ticks per group {sorted(set(s[ok, 15].astype(int)))}  frobenius {f:.4f}")
+for r, nm, names in ((0, "A waves", ["loads issued + A", "exchange: wait free, write", "owner: wait partials, new column", "wait B waves + exchange full", "publish", "booking", "next denominator", "first split (drain)"]),
+                     (1, "B waves", ["H operand: wait + repack", "B", "-", "-", "-", "-", "-", "between (tile loads issued)"])):
+    q = s[ok & (role == r)]
+    T = q[:, 15]
+    clk = np.median((q[:, 10] + q[:, 11] + q[:, 12]) / (q[:, 13] * 10.0)) * 1000
+    print(f"{nm}: kernel median {np.median(q[:, 13]) / 100:.1f} us per wave, clock ~{clk:.0f} MHz; before loop {np.median(q[:, 10]):.0f} cyc, loop {np.median(q[:, 11]):.0f}, after {np.median(q[:, 12]):.0f}")
+    per = q[:, :8] / T[:, None]
+    for i, nme in enumerate(names):
+        if nme != "-":
+            print(f"  {nme:36s} median {np.median(per[:, i]):8.0f} cyc/panel   p10 {np.percentile(per[:, i], 10):8.0f}  p90 {np.percentile(per[:, i], 90):8.0f}")
+    print(f"  sum {np.median(per.sum(axis=1)):.0f} cyc/panel; retries per wave: H cols {np.median(q[:, 8]):.0f} (max {q[:, 8].max():.0f}), partials {np.median(q[:, 9]):.0f} (max {q[:, 9].max():.0f})")

@@ -77,7 +77,7 @@ Engine<T>::~Engine() {
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
-	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_, op_stamps_}; for (void* b : ob) if (b) (void)hipFree(b); }
+	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_, op_ps4_, op_H2_, op_stamps_}; for (void* b : ob) if (b) (void)hipFree(b); }
 	if (pin_abort_) (void)hipHostFree(pin_abort_);
 	if (err_event_) (void)hipEventDestroy(err_event_);
 	if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -135,7 +135,11 @@ Status Engine<T>::allocate() {
 	const size_t image_bytes = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
 	const size_t mall = memory_side_cache_bytes(prop);
 	const bool cache_window = mall > 0 && (double)image_bytes > 0.6 * (double)mall && (double)image_bytes < 1.12 * (double)mall && std::getenv("NMFAMD_ONE_IMAGE") == nullptr;
-	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && (planH_.nb == 2 || cache_window) &&
+	// (the opt-in one-pass iteration runs on the split-operand products whatever the rank)
+	const char* op_env = std::getenv("NMFAMD_ONE_PASS");
+	const bool op_req = op_env != nullptr && std::atoi(op_env) != 0 && one_pass_allowed_ && row_blocks_ == 1 && fused_capable() && RP_ == 64 &&
+	                    std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr && tuning_env("NMFAMD_IMAGE_TILE128") == nullptr && onepass_available(pad128(m_), num_cus_);
+	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && (planH_.nb == 2 || cache_window || op_req) &&
 	    tuning_env("NMFAMD_FP32_NATIVE") == nullptr) {
 		planH_.nb = planW_.nb = 2;
 		x3_ = true;
@@ -158,9 +162,8 @@ Status Engine<T>::allocate() {
 		const size_t image_b = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
 		const char* force = std::getenv("NMFAMD_ONE_IMAGE");
 		// the one-pass iteration needs ONE image (16-row tiles) and nothing else
-		one_pass_ = one_pass_allowed_ && row_blocks_ == 1 && fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr &&
-		            std::getenv("NMFAMD_TWO_PASS") == nullptr && tuning_env("NMFAMD_IMAGE_TILE128") == nullptr &&
-		            (force == nullptr || std::atoi(force) != 0) && onepass_available(pad128(m_), num_cus_);
+		// (opt-in, NMFAMD_ONE_PASS=1: measured slower than the two-pass iteration)
+		one_pass_ = op_req && (force == nullptr || std::atoi(force) != 0);
 		if (one_pass_) one_image_ = true;
 		else if (force != nullptr) one_image_ = std::atoi(force) != 0;
 		else if (cache_window) one_image_ = true;
@@ -263,6 +266,9 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&op_ctl_, 64));
 		HIPX(hipMalloc((void**)&op_slabs_, sizeof(float) * (size_t)ONEPASS_XCDS * RP_ * mpad_));
 		HIPX(hipMalloc((void**)&op_hh_part_, sizeof(float) * 4096 * (size_t)(ONEPASS_XCDS * ONEPASS_GROUP)));
+		HIPX(hipMalloc((void**)&op_ps4_, sizeof(float) * 4 * (size_t)npad_));
+		HIPX(dalloc(&op_H2_, panelH));
+		HIPX(hipMemsetAsync(op_ps4_, 0, sizeof(float) * 4 * (size_t)npad_, stream_));
 		HIPX(hipMemsetAsync(op_part_, 0, onepass_part_bytes(), stream_));
 		HIPX(hipMemsetAsync(op_hfrag_, 0, onepass_hfrag_bytes(), stream_));
 		HIPX(hipMemsetAsync(op_ctl_, 0, 64, stream_));
@@ -1070,7 +1076,8 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		if (Status s = standalone_gram(rgW)) return s;
 		OnePassArgs a;
 		a.V = V_; a.tile_stride = strideV_;
-		a.Wx3 = Wx3_; a.G = G_; a.scale = scale_; a.H = H_; a.ps = psN_;
+		a.Wx3 = Wx3_; a.G = G_; a.scale = scale_; a.ps = op_ps4_; a.ps_stride = npad_;
+		if constexpr (std::is_same<T, float>::value) { a.H = H_; a.H_out = op_H2_; }
 		a.slabs = op_slabs_; a.slab_stride = (long)RP_ * mpad_;
 		a.hh_part = op_hh_part_; a.part_scratch = op_part_; a.hfrag_scratch = op_hfrag_;
 		a.ticket = op_ctl_; a.abort_flag = op_ctl_ + 8;
@@ -1082,7 +1089,9 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		record_begin();
 		HIPX(launch_mu64_onepass(a, stream_));
 		record_end();
+		std::swap(H_, op_H2_);                             // the new H
 		HIPX(launch_reduce_partials<float>(op_hh_part_, ONEPASS_XCDS * ONEPASS_GROUP, 4096, HHt_, 4096, stream_));
+		if (compute_error) HIPX(launch_reduce_partials<float>(op_ps4_, 4, npad_, psN_, n_, stream_));   // the four owner waves' parts of the per-column terms
 		if (Status s = mu64_update(true, op_slabs_, ONEPASS_XCDS, (long)RP_ * mpad_, HHt_, compute_error)) return s;
 		wx3_valid_ = x3_;
 		hx3_valid_ = false;
@@ -1111,7 +1120,7 @@ Status Engine<T>::onepass_check() {
 	}
 	if (*pin_abort_ != 0) {
 		one_pass_ = false; one_pass_gave_up_ = true;
-		last_error_ = "the one-pass iteration could not keep its workgroups resident (another kernel on the device?): factors are void; set NMFAMD_TWO_PASS=1";
+		last_error_ = "the one-pass iteration could not keep its workgroups resident (another kernel on the device?): factors are void; unset NMFAMD_ONE_PASS";
 		return ST_HIP_ERROR;
 	}
 	return ST_OK;

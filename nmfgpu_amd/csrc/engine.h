@@ -233,7 +233,8 @@ private:
 	bool one_pass_allowed_ = true, one_pass_ = false, one_pass_gave_up_ = false;
 	void *op_part_ = nullptr, *op_hfrag_ = nullptr;
 	unsigned *op_ctl_ = nullptr;                      // [0..7] tickets, [8] abort flag
-	float *op_slabs_ = nullptr, *op_hh_part_ = nullptr;
+	float *op_slabs_ = nullptr, *op_hh_part_ = nullptr, *op_ps4_ = nullptr;
+	T* op_H2_ = nullptr;                              // the panel the next one-pass launch writes the new H into (swapped with H_ after it)
 	unsigned op_seq_ = 0;
 	unsigned* pin_abort_ = nullptr;
 	unsigned long long* op_stamps_ = nullptr;          // diagnostic builds (NMFAMD_ONEPASS_STAMPS = file the last launch's stamps go to)

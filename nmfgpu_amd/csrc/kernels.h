@@ -260,8 +260,9 @@ struct OnePassArgs {
 	const void* Wx3;                      // split image of the (unnormalised) W panel, NBT = 2 (kernels_x3.hip)
 	const float* G;                       // 64 x 64: diag(scale) Wu^T Wu diag(scale)
 	const float* scale;                   // 64: pending column scale of W
-	float* H;                             // panel [npad][64], updated in place
-	float* ps;                            // per-column terms of tr(H^T W^T V) (error iterations)
+	const float* H;                       // panel [npad][64]: the old H
+	float* H_out;                         // the new H (another panel: the four owner waves of a column read the whole old column at their own pace)
+	float* ps; long ps_stride;            // error iterations: four partial vectors (one per owner wave) of the per-column terms of tr(H^T W^T V)
 	float* slabs; long slab_stride;       // 8 partial (V H^T)^T panels [mpad][64], one per XCD
 	float* hh_part;                       // [256][4096] partial H H^T, one per workgroup
 	void* part_scratch;                   // [8][ONEPASS_SLOTS][32][256] x 64 B tagged partial sums

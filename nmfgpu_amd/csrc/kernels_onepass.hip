@@ -185,6 +185,8 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 
 	if (role == 0) {
 		// ================================================= A waves =================================================================
+		// (they win the arbitration for the SIMD: the B waves fill what the A waves leave)
+		__builtin_amdgcn_s_setprio(2);
 		// this wave's rows of the split image of W, into its own part of LDS: K-step ks = tile row tr0 + TPW rw + ks (zero beyond the
 		// slice: those steps add nothing); fragment (ks, nb, plane) of lane l at wl[((ks * 2 + nb) * 3 + plane) * 64]
 		bf16x8* const wl = wfl + rw * (TPW * 2 * 3 * 64) + lane;
@@ -202,24 +204,6 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 				}
 			}
 		}
-		// owner arithmetic: lane l of A wave w works on factor row c = 16 w + 2 (l & 7) + ((l >> 3) & 1), reduction part k = 16 (l >> 4) .. + 15
-		// (the row follows from how the owner's loads are dealt out, see O below)
-		const int oc = 16 * rw + 2 * (lane & 7) + ((lane >> 3) & 1);
-		const float* const grow = a.G + (long)oc * 64 + 16 * grp;      // this lane's part of row c of W^T W (read again every tick: L1 / L2)
-		const float sc_c = a.scale[oc];
-		float hh[16];
-#pragma unroll
-		for (int i = 0; i < 16; ++i) hh[i] = 0.f;
-		// x + (x of the lane N places on, cyclically, in its row of 16 lanes) -- a DPP rotation, no LDS
-		auto add_ror = [&](float x, auto ctrl_c) __attribute__((always_inline)) -> float {
-			constexpr int CTRL = decltype(ctrl_c)::value;
-			return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-		};
-		typedef std::integral_constant<int, 0x128> ROR8;
-		typedef std::integral_constant<int, 0x124> ROR4;
-		typedef std::integral_constant<int, 0x122> ROR2;
-		typedef std::integral_constant<int, 0x121> ROR1;
-
 		// the two landing slots of the panel stream: lane (l31 = column of the panel, half) takes rows 8 half .. 8 half + 7 of each tile
 		// (wave-uniform base + a 32-bit lane offset: the loads take the base in scalar registers)
 		f32x4 va[2][TPW][2];
@@ -235,90 +219,185 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 		if (T > 0) prefetch(0, va[0]);
 		__builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's fragments of W are in LDS (nobody else reads them)
 
-		float den_next = 0.f, hcur_next = 0.f;
 		auto tick = [&](const int t, f32x4 (&vs)[TPW][2], f32x4 (&vn)[TPW][2]) __attribute__((always_inline)) {
-			const bool do_a = t < T;
-			const bool do_o = t >= OLAG && t - OLAG < T;
-			const int to = t - OLAG;
 			stamp(7);
 			// first use of the panel: whatever the compiler drains here (it cannot count loads across the loop's back edge) is old
 			bf16x8 op0[3];
-			if (do_a) split_pair(vs[0][0], vs[0][1], op0);
+			split_pair(vs[0][0], vs[0][1], op0);
 			__builtin_amdgcn_sched_barrier(0);
-			// now the loads that fly during A: the next panel (from far away) and the inputs of the owner duty O(t - OLAG) (from L2):
-			// the 32 sources' partial sums of the owned column -- a source's 128 bytes (16 granules, c = 16 rw .. + 15) are 8 pieces of 16 bytes
-			// (c = 16 rw + 2 p, + 1); load q of lane l takes piece p = l & 7 of source 8 q + (l >> 3): 128 contiguous bytes per source and
-			// instruction -- and the column's old values with this lane's part of row c of W^T W
+			// the next panel flies during A
 			if (t + 1 < T) prefetch(t + 1, vn);
-			const int jc = do_o ? (p0 + to) * 32 + slot_i : 0;
+			__builtin_amdgcn_sched_barrier(0);
+			stamp(6);
+			// ---- A(t): D(c, j) = sum_i W(i, c) V(i, j) over this wave's rows -----------------------------------------------------
+			f32x16 accA[2];
+#pragma unroll
+			for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+				for (int g = 0; g < 16; ++g) accA[nb][g] = 0.f;
+			bf16x8 op[2][3], wf[2][2][3];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) op[0][pl] = op0[pl];
+#pragma unroll
+			for (int f = 0; f < 6; ++f) wf[0][f / 3][f % 3] = wl[f * 64];
+#pragma unroll
+			for (int ks = 0; ks < TPW; ++ks) {
+				const int cur = ks & 1, nxt = cur ^ 1;
+				if (ks + 1 < TPW) {
+#pragma unroll
+					for (int f = 0; f < 6; ++f) wf[nxt][f / 3][f % 3] = wl[((ks + 1) * 6 + f) * 64];
+					split_pair(vs[ks + 1][0], vs[ks + 1][1], op[nxt]);
+				}
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb) {
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][2], op[cur][0], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][2], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][1], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][0], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][1], accA[nb], 0, 0, 0);
+					accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][0], accA[nb], 0, 0, 0);
+				}
+				if (ks + 1 < TPW) {
+#pragma unroll
+					for (int g = 0; g < 12; ++g) {
+						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+						__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+						if (g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			stamp(0);
+			// the exchange image must be free: every A wave has read what it publishes of tick t - 1
+			gave_up = lds_wait(s_cnt + 1, 4u * (unsigned)t, gave_up, a.abort_flag, 8u, lane);
+			// C/D map of the 32 x 32 MFMA: register 4 q + g of lane (l31, half) is row 8 q + 4 half + g (here c = 32 nb + that), column l31 (= j).
+			// Exchange image: float4 (wave, lane, nbq = 4 nb + q) at (wave * 64 + lane) * 8 + (nbq ^ (lane & 7)): a lane's eight
+			// chunks are 128 contiguous bytes, the XOR spreads lanes over the banks for the writer and for the transposing reader
+#pragma unroll
+			for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					f32x4 v;
+					v[0] = accA[nb][4 * q + 0]; v[1] = accA[nb][4 * q + 1]; v[2] = accA[nb][4 * q + 2]; v[3] = accA[nb][4 * q + 3];
+					xch[(rw * 64 + lane) * 8 + ((nb * 4 + q) ^ (lane & 7))] = v;
+				}
+			lds_arrive(s_cnt + 0, lane);
+			stamp(1);
+			// The slot tick t is published into held tick t - SLOTS: its readers -- the owners, B waves of every workgroup of the group -- are
+			// done with it once the new H columns of panel t - SLOTS are complete, which is what this workgroup's B waves have seen when their
+			// progress has passed that panel.  (The same condition keeps the H slots safe: the owners write the columns of panel t only after
+			// every workgroup has published tick t.)
+			if (t >= SLOTS && !gave_up) {
+				const u64 w0 = __builtin_amdgcn_s_memrealtime();
+				for (;;) {
+					const unsigned b0 = __hip_atomic_load(s_cnt + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), b1 = __hip_atomic_load(s_cnt + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					const unsigned b2 = __hip_atomic_load(s_cnt + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), b3 = __hip_atomic_load(s_cnt + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					const unsigned mn = min(min(b0, b1), min(b2, b3));
+					if ((int)(mn - (unsigned)(t - SLOTS + 1)) >= 0) break;
+					if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 16u); break; }
+					__builtin_amdgcn_s_sleep(2);
+				}
+			}
+			stamp(2);
+			gave_up = lds_wait(s_cnt + 0, 4u * (unsigned)(t + 1), gave_up, a.abort_flag, 8u, lane);
+			stamp(3);
+			// sum over the four waves (wave order) and publish: thread (j = atid / 8, nbq = atid % 8) takes c = 8 nbq .. 8 nbq + 7 of column j,
+			// i.e. the chunk nbq of lanes (j, half 0) and (j, half 1); its 64 bytes of granules are bytes [64 atid, 64 atid + 64) of the
+			// workgroup's slot: slot image = [column j][c] granules {value, tag}
+			const unsigned tg = tag0 + (unsigned)t + 1u;
+			u32x4* dst = reinterpret_cast<u32x4*>(a.part_scratch) + ((long)((xcd * SLOTS + (t % SLOTS)) * ONEPASS_GROUP + slot_i) * 256 + atid) * 4;
+			const int pj = atid >> 3, pq = atid & 7;
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int ln = pj + 32 * h;
+				f32x4 s = xch[(0 * 64 + ln) * 8 + (pq ^ (ln & 7))];
+#pragma unroll
+				for (int w = 1; w < 4; ++w) s += xch[(w * 64 + ln) * 8 + (pq ^ (ln & 7))];
+				u32x4 g0, g1;
+				g0[0] = __float_as_uint(s[0]); g0[1] = tg; g0[2] = __float_as_uint(s[1]); g0[3] = tg;
+				g1[0] = __float_as_uint(s[2]); g1[1] = tg; g1[2] = __float_as_uint(s[3]); g1[3] = tg;
+				dst[2 * h] = g0; dst[2 * h + 1] = g1;
+			}
+			lds_arrive(s_cnt + 1, lane);
+			stamp(4);
+		};
+
+		if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
+		for (int t = 0; t < T; t += 2) {
+			tick(t, va[0], va[1]);
+			if (t + 1 < T) tick(t + 1, va[1], va[0]);
+		}
+		if (DIAG) c_loop1 = __builtin_amdgcn_s_memtime();
+	} else {
+		// ================================================= B waves =================================================================
+		// owner arithmetic: lane l of B wave w works on factor row c = 16 w + 2 (l & 7) + ((l >> 3) & 1), reduction part k = 16 (l >> 4) .. + 15
+		// (the row follows from how the owner's loads are dealt out, see O below)
+		const int oc = 16 * rw + 2 * (lane & 7) + ((lane >> 3) & 1);
+		const float* const grow = a.G + (long)oc * 64 + 16 * grp;      // this lane's part of row c of W^T W (read again every tick: L1 / L2)
+		const float sc_c = a.scale[oc];
+		// x + (x of the lane N places on, cyclically, in its row of 16 lanes) -- a DPP rotation, no LDS
+		auto add_ror = [&](float x, auto ctrl_c) __attribute__((always_inline)) -> float {
+			constexpr int CTRL = decltype(ctrl_c)::value;
+			return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+		};
+		typedef std::integral_constant<int, 0x128> ROR8;
+		typedef std::integral_constant<int, 0x124> ROR4;
+		typedef std::integral_constant<int, 0x122> ROR2;
+		typedef std::integral_constant<int, 0x121> ROR1;
+		f32x4 accB[TPW][4], hht[4];                                    // hht: H H^T tiles (16 rw .., 16 nt' ..) of the panels this workgroup books
+#pragma unroll
+		for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) hht[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+		// the denominator (W^T W) H and the old value of the owned column of panel k: they wait for nobody
+		float den_next = 0.f, hcur_next = 0.f;
+		auto prepare_owner = [&](int k) __attribute__((always_inline)) {
+			const int jn = (p0 + k) * 32 + slot_i;
+			f32x4 hold[4], gq[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { hold[u] = *reinterpret_cast<const f32x4*>(a.H + (long)jn * 64 + 16 * grp + 4 * u); gq[u] = *reinterpret_cast<const f32x4*>(grow + 4 * u); }
+			hcur_next = a.H[(long)jn * 64 + oc];
+			float den = 0.f;
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) den = fmaf(gq[u][i], hold[u][i], den);
+			den += __shfl_xor(den, 16);
+			den += __shfl_xor(den, 32);                                                // (0 + 1) + (2 + 3) in every lane
+			den_next = den;
+		};
+		if (T > 0) prepare_owner(0);
+		if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
+		// iteration k: owner duty O(k) (k < T), then B(k - 1) (k >= 1), whose H columns the owners published an iteration ago
+		for (int k = 0; k < T + 1; ++k) {
+			const bool do_o = k < T, do_b = k >= 1;
+			const int tb = k - 1;
+			stamp(7);
+			// the 32 sources' partial sums of the owned column: a source's 128 bytes (16 granules, c = 16 rw .. + 15) are 8 pieces of 16 bytes
+			// (c = 16 rw + 2 p, + 1); load q of lane l takes piece p = l & 7 of source 8 q + (l >> 3): 128 contiguous bytes per source and instruction
 			u32x4 od[4];
-			const unsigned obase = part_group + (unsigned)(((to + SLOTS) % SLOTS) * ONEPASS_GROUP + (lane >> 3)) * (256u * 64u) + (unsigned)slot_i * 512u +
+			const unsigned obase = part_group + (unsigned)((k % SLOTS) * ONEPASS_GROUP + (lane >> 3)) * (256u * 64u) + (unsigned)slot_i * 512u +
 			                       (unsigned)rw * 128u + (unsigned)(lane & 7) * 16u;
 			if (do_o) {
 #pragma unroll
 				for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
 			}
+			// second read of V(rows, panel k - 1): tile tl is 8 rows of 256 bytes, lane l of load kk takes row i = l & 15 at column j = 4 kk + (l >> 4)
+			float rawb[3][8];
+			const float* const vb0 = a.V + ((long)(p0 + tb) * (32 * 16) + lane);
+			auto load_tile = [&](int tl, float (&dst)[8]) __attribute__((always_inline)) {
+				const float* p = vb0 + (long)trw[tl] * a.tile_stride;
+#pragma unroll
+				for (int kk = 0; kk < 8; ++kk) dst[kk] = p[64 * kk];
+			};
+			if (do_b) { load_tile(0, rawb[0]); load_tile(1, rawb[1]); load_tile(2, rawb[2]); }
 			__builtin_amdgcn_sched_barrier(0);
-			// ---- A(t): D(c, j) = sum_i W(i, c) V(i, j) over this wave's rows -----------------------------------------------------
-			if (do_a) {
-				f32x16 accA[2];
-#pragma unroll
-				for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-					for (int g = 0; g < 16; ++g) accA[nb][g] = 0.f;
-				bf16x8 op[2][3], wf[2][2][3];
-#pragma unroll
-				for (int pl = 0; pl < 3; ++pl) op[0][pl] = op0[pl];
-#pragma unroll
-				for (int f = 0; f < 6; ++f) wf[0][f / 3][f % 3] = wl[f * 64];
-#pragma unroll
-				for (int ks = 0; ks < TPW; ++ks) {
-					const int cur = ks & 1, nxt = cur ^ 1;
-					if (ks + 1 < TPW) {
-#pragma unroll
-						for (int f = 0; f < 6; ++f) wf[nxt][f / 3][f % 3] = wl[((ks + 1) * 6 + f) * 64];
-						split_pair(vs[ks + 1][0], vs[ks + 1][1], op[nxt]);
-					}
-#pragma unroll
-					for (int nb = 0; nb < 2; ++nb) {
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][2], op[cur][0], accA[nb], 0, 0, 0);
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][2], accA[nb], 0, 0, 0);
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][1], accA[nb], 0, 0, 0);
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][1], op[cur][0], accA[nb], 0, 0, 0);
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][1], accA[nb], 0, 0, 0);
-						accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb][0], op[cur][0], accA[nb], 0, 0, 0);
-					}
-					if (ks + 1 < TPW) {
-#pragma unroll
-						for (int g = 0; g < 12; ++g) {
-							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-							__builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-							if (g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-						}
-					}
-					__builtin_amdgcn_sched_barrier(0);
-				}
-				stamp(0);
-				// the exchange image must be free: every A wave has read what it publishes of tick t - 1
-				gave_up = lds_wait(s_cnt + 1, 4u * (unsigned)t, gave_up, a.abort_flag, 8u, lane);
-				// C/D map of the 32 x 32 MFMA: register 4 q + g of lane (l31, half) is row 8 q + 4 half + g (here c = 32 nb + that), column l31 (= j).
-				// Exchange image: float4 (wave, lane, nbq = 4 nb + q) at (wave * 64 + lane) * 8 + (nbq ^ (lane & 7)): a lane's eight
-				// chunks are 128 contiguous bytes, the XOR spreads lanes over the banks for the writer and for the transposing reader
-#pragma unroll
-				for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-					for (int q = 0; q < 4; ++q) {
-						f32x4 v;
-						v[0] = accA[nb][4 * q + 0]; v[1] = accA[nb][4 * q + 1]; v[2] = accA[nb][4 * q + 2]; v[3] = accA[nb][4 * q + 3];
-						xch[(rw * 64 + lane) * 8 + ((nb * 4 + q) ^ (lane & 7))] = v;
-					}
-				lds_arrive(s_cnt + 0, lane);
-				stamp(1);
-			}
-			// ---- O(t - OLAG): this workgroup owns column `slot` of the panel, this wave its factor rows c = 16 rw .. 16 rw + 15 -----------------
+			// ---- O(k): this workgroup owns column `slot` of panel k, this wave its factor rows c = 16 rw .. 16 rw + 15 ---------------------------
 			if (do_o) {
-				const float den = den_next, hcur = hcur_next;                          // prepared at the end of the previous tick
-				const unsigned tg = tag0 + (unsigned)to + 1u;
+				const int jc = (p0 + k) * 32 + slot_i;
+				const unsigned tg = tag0 + (unsigned)k + 1u;
 				{
 					const u64 w0 = __builtin_amdgcn_s_memrealtime();
 					for (;;) {
@@ -333,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 						for (int q = 0; q < 4; ++q) od[q] = load_sc1(rs_part, obase + (unsigned)q * (8u * 256u * 64u));
 					}
 				}
+				stamp(0);
 				// (__uint_as_float, not __builtin_bit_cast(float, od[q][i]): hipcc 7.2 folds the bit cast of a vector ELEMENT of a
 				//  buffer load's result to element 0)
 				// sources 8 q + g in q order, then the eight lane groups g = l >> 3: g ^ 1 by a DPP rotation, g ^ 2 and g ^ 4 across rows
@@ -343,191 +423,95 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 				v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
 				const float sum = (lane & 8) ? v1 : v0;                                // this lane's factor row: c = 16 rw + 2 (l & 7) + ((l >> 3) & 1)
 				const float num = sum * sc_c;                                          // the pending column scale of W (kernels_mu64.hip)
-				const float hn = hcur * num / (den + a.eps);                           // KernelMultiplyDivide.cu:39-42
-				// the booking words must be free: every A wave has booked the previous column
-				gave_up = lds_wait(s_cnt + 3, 4u * (unsigned)to, gave_up, a.abort_flag, 8u, lane);
+				const float hn = hcur_next * num / (den_next + a.eps);                 // KernelMultiplyDivide.cu:39-42
 				if (grp == 0) {
-					a.H[(long)jc * 64 + oc] = hn;
-					s_hnew[oc] = hn;
+					a.H_out[(long)jc * 64 + oc] = hn;                                  // (not in place: the other owner waves still read the old column)
 					unsigned p0b, p1b, p2b;
 					split3_scalar(hn, p0b, p1b, p2b);
-					const u64 gr = (u64)p0b | ((u64)p1b << 16) | ((u64)p2b << 32) | ((u64)((tag0 + (unsigned)to + 1u) & 0xffffu) << 48);
-					const int kq = slot_i >> 2;                                       // j = slot_i = 4 k + (slot_i & 3)
+					const u64 gr = (u64)p0b | ((u64)p1b << 16) | ((u64)p2b << 32) | ((u64)(tg & 0xffffu) << 48);
+					const int kq = slot_i >> 2;                                       // j = slot_i = 4 kq + (slot_i & 3)
 					// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules k = 2 q, 2 q + 1 of (c = 16 nt + (lane & 15), j = 4 k + (lane >> 4))
-					u64* hd = reinterpret_cast<u64*>(a.hfrag_scratch) + (long)(xcd * SLOTS + (to % SLOTS)) * (64 * 32) +
+					u64* hd = reinterpret_cast<u64*>(a.hfrag_scratch) + (long)(xcd * SLOTS + (k % SLOTS)) * (64 * 32) +
 					          (((rw * 4 + (kq >> 1)) * 64 + (slot_i & 3) * 16 + (oc & 15)) * 2 + (kq & 1));
 					*hd = gr;
 				}
 				if (a.compute_error) {
-					// per-column term of tr(H^T W^T V) (KernelTraceMultiplication.cu:43-80): sixteen rows per wave by DPP rotations, waves by the booking step
+					// per-column term of tr(H^T W^T V) (KernelTraceMultiplication.cu:43-80): this wave's sixteen rows by DPP rotations; the four
+					// waves' parts are added by the host side of the iteration (launch_reduce_partials, wave order)
 					float psum = hn * num;
 					psum = add_ror(psum, ROR8()); psum = add_ror(psum, ROR4()); psum = add_ror(psum, ROR2()); psum = add_ror(psum, ROR1());
-					if (lane == 0) s_ps[rw] = psum;
+					if (lane == 0) a.ps[(long)rw * a.ps_stride + jc] = psum;
 				}
-				lds_arrive(s_cnt + 2, lane);
-				stamp(2);
+				stamp(1);
 			}
-			// the column this workgroup owns NEXT tick: its old values and the denominator (W^T W) H wait for nobody -- requested now, used at the tick's end
-			const bool do_n = t + 1 >= OLAG && t + 1 - OLAG < T;
-			const int jn = do_n ? (p0 + t + 1 - OLAG) * 32 + slot_i : 0;
-			f32x4 hold[4], gq[4];
-			float hcn = 0.f;
-			if (do_n) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { hold[u] = *reinterpret_cast<const f32x4*>(a.H + (long)jn * 64 + 16 * grp + 4 * u); gq[u] = *reinterpret_cast<const f32x4*>(grow + 4 * u); }
-				hcn = a.H[(long)jn * 64 + oc];
-			}
-			// ---- the publishing step of tick t -------------------------------------------------------------------------------------------
-			if (do_a) {
-				// the B waves of this workgroup must be done with the slot the owners will rewrite once every workgroup has published tick t
-				// (O(t) writes the H slot of panel t, i.e. of panel t - SLOTS before: their progress must have passed it)
-				if (t >= SLOTS && !gave_up) {
+			__builtin_amdgcn_sched_barrier(0);
+			if (do_b) {
+				// the split columns of H of panel k - 1: every granule must carry the panel's tag.
+				// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules kk = 2 q, 2 q + 1 of (c = 16 nt + (lane & 15), j = 4 kk + grp)
+				const unsigned hbase = hf_group + (unsigned)(tb % SLOTS) * (64u * 32u * 8u) + (unsigned)lane * 16u;
+				const unsigned tg16 = (tag0 + (unsigned)tb + 1u) & 0xffffu;
+				bf16x8 hf[4][3];
+				{
 					const u64 w0 = __builtin_amdgcn_s_memrealtime();
 					for (;;) {
-						const unsigned b0 = __hip_atomic_load(s_cnt + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), b1 = __hip_atomic_load(s_cnt + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						const unsigned b2 = __hip_atomic_load(s_cnt + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), b3 = __hip_atomic_load(s_cnt + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						const unsigned mn = min(min(b0, b1), min(b2, b3));
-						if ((int)(mn - (unsigned)(t - SLOTS + 1)) >= 0) break;
-						if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 16u); break; }
-						__builtin_amdgcn_s_sleep(2);
-					}
-				}
-				gave_up = lds_wait(s_cnt + 0, 4u * (unsigned)(t + 1), gave_up, a.abort_flag, 8u, lane);
-				stamp(3);
-				// sum over the four waves (wave order) and publish: thread (j = atid / 8, nbq = atid % 8) takes c = 8 nbq .. 8 nbq + 7 of column j,
-				// i.e. the chunk nbq of lanes (j, half 0) and (j, half 1); its 64 bytes of granules are bytes [64 atid, 64 atid + 64) of the
-				// workgroup's slot: slot image = [column j][c] granules {value, tag}
-				const unsigned tg = tag0 + (unsigned)t + 1u;
-				u32x4* dst = reinterpret_cast<u32x4*>(a.part_scratch) + ((long)((xcd * SLOTS + (t % SLOTS)) * ONEPASS_GROUP + slot_i) * 256 + atid) * 4;
-				const int pj = atid >> 3, pq = atid & 7;
+						unsigned bad = 0;
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int ln = pj + 32 * h;
-					f32x4 s = xch[(0 * 64 + ln) * 8 + (pq ^ (ln & 7))];
+						for (int nt = 0; nt < 4; ++nt) {
+							u32x4 d[4];
 #pragma unroll
-					for (int w = 1; w < 4; ++w) s += xch[(w * 64 + ln) * 8 + (pq ^ (ln & 7))];
-					u32x4 g0, g1;
-					g0[0] = __float_as_uint(s[0]); g0[1] = tg; g0[2] = __float_as_uint(s[1]); g0[3] = tg;
-					g1[0] = __float_as_uint(s[2]); g1[1] = tg; g1[2] = __float_as_uint(s[3]); g1[3] = tg;
-					dst[2 * h] = g0; dst[2 * h + 1] = g1;
-				}
-				lds_arrive(s_cnt + 1, lane);
-				stamp(4);
-			}
-			// ---- book the owned column: error term, H H^T ------------------------------------------------------------------------------------
-			if (do_o) {
-				gave_up = lds_wait(s_cnt + 2, 4u * (unsigned)(to + 1), gave_up, a.abort_flag, 8u, lane);
-				if (a.compute_error && atid == 0 && jc < a.n) a.ps[jc] = ((s_ps[0] + s_ps[1]) + s_ps[2]) + s_ps[3];
-				const float hc = s_hnew[oc];
+							for (int q = 0; q < 4; ++q) d[q] = load_sc1(rs_hf, hbase + (unsigned)(nt * 4 + q) * 1024u);
+							u32x4 o0, o1, o2;
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const f32x4 hk = *reinterpret_cast<const f32x4*>(s_hnew + 16 * grp + 4 * u);
-#pragma unroll
-					for (int i = 0; i < 4; ++i) hh[4 * u + i] = fmaf(hc, hk[i], hh[4 * u + i]);
-				}
-				lds_arrive(s_cnt + 3, lane);
-				stamp(5);
-			}
-			if (do_n) {
-				float den = 0.f;
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int i = 0; i < 4; ++i) den = fmaf(gq[u][i], hold[u][i], den);
-				den += __shfl_xor(den, 16);
-				den += __shfl_xor(den, 32);                                            // (0 + 1) + (2 + 3) in every lane
-				den_next = den; hcur_next = hcn;
-				stamp(6);
-			}
-		};
-
-		if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
-		for (int t = 0; t < T + OLAG; t += 2) {
-			tick(t, va[0], va[1]);
-			tick(t + 1, va[1], va[0]);
-		}
-		if (DIAG) c_loop1 = __builtin_amdgcn_s_memtime();
-		float* hp = a.hh_part + (long)(xcd * ONEPASS_GROUP + slot_i) * 4096 + (long)oc * 64 + 16 * grp;
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			f32x4 v;
-			v[0] = hh[4 * u]; v[1] = hh[4 * u + 1]; v[2] = hh[4 * u + 2]; v[3] = hh[4 * u + 3];
-			*reinterpret_cast<f32x4*>(hp + 4 * u) = v;
-		}
-	} else {
-		// ================================================= B waves =================================================================
-		f32x4 accB[TPW][4];
-#pragma unroll
-		for (int tl = 0; tl < TPW; ++tl)
-#pragma unroll
-			for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-		if (DIAG) { c_loop0 = __builtin_amdgcn_s_memtime(); c_last = c_loop0; }
-		for (int tb = 0; tb < T; ++tb) {
-			stamp(7);
-			// second read of V(rows, panel tb): tile tl is 8 rows of 256 bytes, lane l of load k takes row i = l & 15 at column j = 4 k + (l >> 4)
-			float rawb[3][8];
-			const float* const vb0 = a.V + ((long)(p0 + tb) * (32 * 16) + lane);
-			auto load_tile = [&](int tl, float (&dst)[8]) __attribute__((always_inline)) {
-				const float* p = vb0 + (long)trw[tl] * a.tile_stride;
-#pragma unroll
-				for (int k = 0; k < 8; ++k) dst[k] = p[64 * k];
-			};
-			load_tile(0, rawb[0]); load_tile(1, rawb[1]); load_tile(2, rawb[2]);
-			// the split columns of H of the panel: every granule must carry the panel's tag.
-			// image of a slot: 16-byte piece ((nt * 4 + q) * 64 + lane) = the two granules k = 2 q, 2 q + 1 of (c = 16 nt + (lane & 15), j = 4 k + grp)
-			const unsigned hbase = hf_group + (unsigned)(tb % SLOTS) * (64u * 32u * 8u) + (unsigned)lane * 16u;
-			const unsigned tg16 = (tag0 + (unsigned)tb + 1u) & 0xffffu;
-			bf16x8 hf[4][3];
-			{
-				const u64 w0 = __builtin_amdgcn_s_memrealtime();
-				for (;;) {
-					unsigned bad = 0;
-#pragma unroll
-					for (int nt = 0; nt < 4; ++nt) {
-						u32x4 d[4];
-#pragma unroll
-						for (int q = 0; q < 4; ++q) d[q] = load_sc1(rs_hf, hbase + (unsigned)(nt * 4 + q) * 1024u);
-						u32x4 o0, o1, o2;
-#pragma unroll
-						for (int q = 0; q < 4; ++q) {
-							// d[q] = two granules {p0 | p1 << 16, p2 | tag << 16} of k = 2 q, 2 q + 1
-							o0[q] = (d[q][0] & 0xffffu) | (d[q][2] << 16);
-							o1[q] = (d[q][0] >> 16) | (d[q][2] & 0xffff0000u);
-							o2[q] = (d[q][1] & 0xffffu) | (d[q][3] << 16);
-							bad |= ((d[q][1] >> 16) ^ tg16) | ((d[q][3] >> 16) ^ tg16);
+							for (int q = 0; q < 4; ++q) {
+								// d[q] = two granules {p0 | p1 << 16, p2 | tag << 16} of kk = 2 q, 2 q + 1
+								o0[q] = (d[q][0] & 0xffffu) | (d[q][2] << 16);
+								o1[q] = (d[q][0] >> 16) | (d[q][2] & 0xffff0000u);
+								o2[q] = (d[q][1] & 0xffffu) | (d[q][3] << 16);
+								bad |= ((d[q][1] >> 16) ^ tg16) | ((d[q][3] >> 16) ^ tg16);
+							}
+							hf[nt][0] = __builtin_bit_cast(bf16x8, o0); hf[nt][1] = __builtin_bit_cast(bf16x8, o1); hf[nt][2] = __builtin_bit_cast(bf16x8, o2);
 						}
-						hf[nt][0] = __builtin_bit_cast(bf16x8, o0); hf[nt][1] = __builtin_bit_cast(bf16x8, o1); hf[nt][2] = __builtin_bit_cast(bf16x8, o2);
-					}
-					if (__all(bad == 0) || gave_up) break;
-					if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 2u); break; }
-					__builtin_amdgcn_s_sleep(8);
-					if (DIAG) ++retries_f;
-				}
-			}
-			// this wave is done with the slot of panel tb (the A waves wait for that before they let the ring go round)
-			if (lane == 0) __hip_atomic_store(s_cnt + 4 + rw, (unsigned)(tb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			stamp(0);
-			// ---- B(tb): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 k + grp -----------------------------
-			bf16x8 op[2][3];
-			split3(rawb[0], op[0][0], op[0][1], op[0][2]);
-#pragma unroll
-			for (int tl = 0; tl < TPW; ++tl) {
-				const int cur = tl & 1, nxt = cur ^ 1;
-				if (tl + 1 < TPW) split3(rawb[(tl + 1) % 3], op[nxt][0], op[nxt][1], op[nxt][2]);
-				if (tl + 3 < TPW) load_tile(tl + 3, rawb[tl % 3]);
-#pragma unroll
-				for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = six_terms_16(op[cur], hf[nt], accB[tl][nt]);
-				if (tl + 1 < TPW) {
-#pragma unroll
-					for (int g = 0; g < 24; ++g) {
-						__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-						__builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-						if (g < 8 && tl + 3 < TPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+						if (__all(bad == 0) || gave_up) break;
+						if (__builtin_amdgcn_s_memrealtime() - w0 > GIVE_UP_TICKS) { gave_up = true; if (lane == 0) atomicOr(a.abort_flag, 2u); break; }
+						__builtin_amdgcn_s_sleep(8);
+						if (DIAG) ++retries_f;
 					}
 				}
-				__builtin_amdgcn_sched_barrier(0);
+				// the columns of panel k - 1 are complete: every owner of the group is done with tick k - 1's partial sums, and this wave with
+				// the H slot (the A waves wait for that before they let the slot rings go round)
+				if (lane == 0) __hip_atomic_store(s_cnt + 4 + rw, (unsigned)(tb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				stamp(2);
+				// H H^T of the panel (reference: syrk upper, AlgorithmMultiplicativeFrobenius.h:231-232): every B wave of the group holds the whole
+				// panel of new columns as MFMA operands, so ONE workgroup per panel books it -- this wave the tiles (16 rw .., 16 nt ..)
+				if ((tb & (ONEPASS_GROUP - 1)) == slot_i) {
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt) hht[nt] = rw == 0 ? six_terms_16(hf[0], hf[nt], hht[nt]) : rw == 1 ? six_terms_16(hf[1], hf[nt], hht[nt])
+					                                       : rw == 2 ? six_terms_16(hf[2], hf[nt], hht[nt]) : six_terms_16(hf[3], hf[nt], hht[nt]);
+				}
+				// ---- B(k - 1): D(i, c) += sum_j V(i, j) Hnew(c, j) over the panel's 32 columns, K order j = 4 kk + grp -----------------------------
+				bf16x8 op[2][3];
+				split3(rawb[0], op[0][0], op[0][1], op[0][2]);
+#pragma unroll
+				for (int tl = 0; tl < TPW; ++tl) {
+					const int cur = tl & 1, nxt = cur ^ 1;
+					if (tl + 1 < TPW) split3(rawb[(tl + 1) % 3], op[nxt][0], op[nxt][1], op[nxt][2]);
+					if (tl + 3 < TPW) load_tile(tl + 3, rawb[tl % 3]);
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt) accB[tl][nt] = six_terms_16(op[cur], hf[nt], accB[tl][nt]);
+					if (tl + 1 < TPW) {
+#pragma unroll
+						for (int g = 0; g < 24; ++g) {
+							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+							__builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+							if (g < 8 && tl + 3 < TPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				stamp(3);
 			}
-			stamp(1);
+			if (k + 1 < T) prepare_owner(k + 1);
+			stamp(4);
 		}
 		if (DIAG) c_loop1 = __builtin_amdgcn_s_memtime();
 		// (V H^T)^T partial of this group: C/D map of the 16 x 16 MFMA: register g of lane (cl, grp) is row 4 grp + g (tile row i), column cl (c = 16 nt + cl)
@@ -543,6 +527,12 @@ __global__ __launch_bounds__(512, 2) void k_mu64_onepass(const OnePassArgs a) {
 					for (int g = 0; g < 4; ++g) slab[((long)tr * 16 + 4 * grp + g) * 64 + 16 * nt + cl] = accB[tl][nt][g];
 			}
 		}
+		// this workgroup's part of H H^T (zero for most): rows 16 rw + 4 grp + g, columns 16 nt + cl
+		float* hp = a.hh_part + (long)(xcd * ONEPASS_GROUP + slot_i) * 4096;
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) hp[(long)(16 * rw + 4 * grp + g) * 64 + 16 * nt + cl] = hht[nt][g];
 	}
 	if (DIAG && a.stamps != nullptr) {
 		// per wave, 16 words.  A waves: cycles in: next panel requested + A | waits around the exchange (free, B waves, full) | publish |

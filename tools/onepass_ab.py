@@ -18,9 +18,9 @@ H0 = np.asfortranarray((1.0 - np.random.RandomState(3).random_sample((n, r))).as
 
 def run(two_pass: bool, timed: int = 200):
     if two_pass:
-        os.environ["NMFAMD_TWO_PASS"] = "1"
+        os.environ.pop("NMFAMD_ONE_PASS", None)
     else:
-        os.environ.pop("NMFAMD_TWO_PASS", None)
+        os.environ["NMFAMD_ONE_PASS"] = "1"
     eng = na.Engine(m, n, r, "mu")
     g = eng.geometry()
     eng.upload(V); eng.set_factors(W0, H0)

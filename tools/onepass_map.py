@@ -2,6 +2,7 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["NMFAMD_ONE_PASS"] = "1"
 import nmfgpu_amd as na
 m, n, r = 10000, 5000, 64
 V = np.zeros((m, n), dtype=np.float32, order="F")

@@ -5,6 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "onepass_stamps.bin")
 os.environ["NMFAMD_ONEPASS_STAMPS"] = path
+os.environ["NMFAMD_ONE_PASS"] = "1"
 import nmfgpu_amd as na
 m, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10000, 5000)
 r = 64
@@ -21,8 +22,8 @@ s = np.fromfile(path, dtype=np.uint64).reshape(-1, 16).astype(np.float64)
 role = (np.arange(len(s)) % 8) // 4
 ok = s[:, 11] > 0
 print(f"waves {ok.sum()}  ticks per group {sorted(set(s[ok, 15].astype(int)))}  frobenius {f:.4f}")
-for r, nm, names in ((0, "A waves", ["loads issued + A", "exchange: wait free, write", "owner: wait partials, new column", "wait B waves + exchange full", "publish", "booking", "next denominator", "first split (drain)"]),
-                     (1, "B waves", ["H operand: wait + repack", "B", "-", "-", "-", "-", "-", "between (tile loads issued)"])):
+for r, nm, names in ((0, "A waves", ["A", "exchange: wait free, write", "wait B waves", "wait exchange full", "publish", "-", "next panel requested", "first split (drain)"]),
+                     (1, "B waves", ["owner: wait partials", "owner: new column", "H operand: wait + repack", "H H^T + B", "next denominator", "-", "-", "loads issued"])):
     q = s[ok & (role == r)]
     T = q[:, 15]
     clk = np.median((q[:, 10] + q[:, 11] + q[:, 12]) / (q[:, 13] * 10.0)) * 1000

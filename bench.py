@@ -131,6 +131,37 @@ def cpu_baseline_blas(V, W, H, threads: int, budget_s: float = 6.0):
             "sample": f"{iters} MU iterations of the full 10000x5000 r=64 problem"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes here (one per GPU, torch.distributed.run on the
+    loopback interface) -- BEFORE anything in this process touches the GPU (counting devices does not) -- and leave with their exit
+    code.  Fewer than N devices: refuse (non-zero exit, nothing on stdout) rather than print a line measured on fewer GPUs than it
+    claims, unless --allow-shared-device asks for a rehearsal."""
+    import socket
+    import subprocess
+    import torch
+    devices = torch.cuda.device_count()
+    argv = list(sys.argv[1:])
+    if devices < args.gpus:
+        if not args.allow_shared_device:
+            print(f"bench.py: --gpus {args.gpus} asked for, {devices} HIP device(s) visible: not running (a line measured on fewer GPUs than it names "
+                  f"would be wrong).  --allow-shared-device rehearses {args.gpus} ranks on the devices there are.", file=sys.stderr, flush=True)
+            raise SystemExit(2)
+        if devices < 1:
+            print("bench.py needs a HIP device: the engine has no CPU fallback", file=sys.stderr, flush=True)
+            raise SystemExit(2)
+        if "--backend" not in argv:
+            argv += ["--backend", "gloo"]          # RCCL wants one device per rank
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.run(cmd, env=env).returncode
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +187,14 @@ def main():
     ap.add_argument("--shard-mode", type=int, choices=[-1, 0, 1], default=-1,
                     help="native loop: 0 reduce-scatter / all-gather by row blocks of W, 1 one all-reduce + replicated update, "
                          "-1 (default) by message size: row blocks when the m x r panel is 8 MB or more (config 4), else the single all-reduce")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="--gpus N with fewer than N HIP devices visible: rehearse with ranks sharing devices (gloo backend, no RCCL) "
+                         "instead of refusing; the line says so in config.parallelism")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return self_launch(args)
     if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):
         # debugging aid: where is every thread after N seconds (a rank that waits for its peers says nothing otherwise)
         import faulthandler
@@ -266,7 +304,9 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        parallelism = f"column shards x{world}, W replicated, RCCL all-reduce of (V H^T | H H^T) per iteration"
+        parallelism = f"column shards x{world}, W replicated, {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of (V H^T | H H^T) per iteration"
+        if world > torch.cuda.device_count():
+            parallelism += f" -- REHEARSAL: {world} ranks share {torch.cuda.device_count()} device(s) (--allow-shared-device), not a scaling measurement"
 
     if rank == 0:
         flops_per_launch = 2.0 * M * N_COLS * R               # one product against V (algorithmic, unpadded)
@@ -393,15 +433,25 @@ def main_native(args):
             eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=torch.cuda.current_stream().cuda_stream, row_blocks=world, **alg_kw)
             eng.upload(V)
             eng.set_factors(W, H)
-            run = na.ShardedRun(eng, comm, rows, total_columns, mode)
     except Exception as e:                        # noqa: BLE001
         failure = e
-    if distributed:
+
+    def agree(failure):
+        if not distributed:
+            return failure is not None
         flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        failed_somewhere = int(flag.item()) != 0
-    else:
-        failed_somewhere = failure is not None
+        return int(flag.item()) != 0
+
+    # every rank must hold its engine and its shard before anybody enters the sharded run's set-up: that set-up is a collective
+    # (all-gather of the shard geometry on the engine's stream), and a rank that failed above would never join it
+    failed_somewhere = agree(failure)
+    if not failed_somewhere:
+        try:
+            run = na.ShardedRun(eng, comm, rows, total_columns, mode)
+        except Exception as e:                    # noqa: BLE001
+            failure = e
+        failed_somewhere = agree(failure)
     if failed_somewhere:
         print(f"bench.py: native communicator set-up failed on rank {rank}: {failure!r}" if failure is not None else
               "bench.py: native communicator set-up failed on another rank", file=sys.stderr, flush=True)
@@ -552,7 +602,9 @@ def main_c4(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
-        if args.backend == "nccl":
+        if dist.is_initialized():
+            pass                                  # (left by main_native's fallback)
+        elif args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=args.backend)

@@ -36,3 +36,23 @@ def test_default_bench_line_has_the_contract_fields():
     # here after 50)
     assert 2000 < d["frobenius_last"] < 2100
 
+
+
+def test_gpus_n_without_torchrun_refuses_or_rehearses():
+    """`python bench.py --gpus 2` outside torchrun on a box with ONE device: no line at all and a non-zero exit (never an n_gpus = 1
+    line under a --gpus 2 command); with --allow-shared-device it starts two rank processes itself (gloo, ranks share the device) and
+    the line says n_gpus = 2 and that it is a rehearsal."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-device box")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(base, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 2" in out.stderr and "1 HIP device" in out.stderr
+    out = subprocess.run(base + ["--allow-shared-device"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and "REHEARSAL" in d["config"]["parallelism"]
+    assert d["value"] == pytest.approx(2 * 1e3 / d["ms_per_step"], rel=1e-6)

@@ -610,11 +610,10 @@ static void plan_bf16_dma(int xtiles, int KS, int num_cus, int* tiles, int* spli
 
 static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
                                      float* slabs, long slab_stride, hipStream_t stream) {
-	int tiles = 0, splits = 0, dev = 0;
-	hipDeviceProp_t prop;
-	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-	plan_bf16_dma(p.xtiles, KS, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, &tiles, &splits);
-	if (splits != p.splits) return hipErrorInvalidValue;      // the caller sized its slabs with plan_splits_bf16
+	// (the K slices are the caller's plan -- plan_splits_bf16 from the engine's CU count, which also sized the slabs; the workgroups
+	//  along x follow from the tile count alone: no device query per launch)
+	const int tiles = (4 * p.xtiles + BFD_NRB - 1) / BFD_NRB, splits = p.splits;
+	if (splits < 1 || KS < 1) return hipErrorInvalidValue;
 	dim3 grid(tiles * splits, RP / 256), block(256);
 	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,

@@ -238,29 +238,42 @@ private:
 		}
 		switch (c) {
 		case CMD_SETUP: rk.status = do_setup(g); break;
-		case CMD_INIT: rk.status = do_init(g); break;
-		case CMD_ITERATE: rk.status = rk.sh->iterate(compute_error_); break;
+		case CMD_INIT: rk.status = rk.sh ? do_init(g) : nmfamd::ST_INVALID; break;      // (no sharded run: the set-up failed on some rank)
+		case CMD_ITERATE: rk.status = rk.sh ? rk.sh->iterate(compute_error_) : nmfamd::ST_INVALID; break;
 		case CMD_STORE: {
 			T* hcols = outH_ + (size_t)rk.col0 * out_ldh_;
-			rk.status = rk.eng->get_factors(g == 0 ? outW_ : nullptr, out_ldw_, hcols, out_ldh_);
+			rk.status = rk.sh ? rk.eng->get_factors(g == 0 ? outW_ : nullptr, out_ldw_, hcols, out_ldh_) : nmfamd::ST_INVALID;
 			break;
 		}
-		case CMD_SYNC: if (hipStreamSynchronize(rk.stream) != hipSuccess) rk.status = nmfamd::ST_HIP_ERROR; break;
+		case CMD_SYNC: if (rk.stream != nullptr && hipStreamSynchronize(rk.stream) != hipSuccess) rk.status = nmfamd::ST_HIP_ERROR; break;
 		default: break;
 		}
+		// A rank that failed in the middle of a command leaves its peers inside a collective (spinning in the in-process transport's
+		// publish / retire rendezvous): raise the abort flag NOW, before the closing rendezvous of the command, so that they return.
+		// (RCCL has no such flag here: a rank failing between the collectives of an iteration is fatal for the process group;
+		//  failures before the communicator exists are agreed upon in do_setup.)
+		if (rk.status != nmfamd::ST_OK && transport_group_) nmfamd::local_group_abort(*transport_group_);
 	}
+	// Every rank runs every rendezvous of this function whatever happened to it (an early return would leave its peers waiting in a
+	// barrier or in the communicator's own rendezvous), and the ranks AGREE before each step that is a collective: the communicator
+	// is created only when every rank holds its engine and its shard, the sharded run is prepared (an all-gather) only when every
+	// rank holds a communicator.
 	Status do_setup(int g) {
 		Rank& rk = *ranks_[g];
-		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
-		if (hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; return nmfamd::ST_HIP_ERROR; }
-		rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm_));
-		rk.eng->set_one_pass(false);       // rank threads may share a device: no persistent launch that claims every CU
-		rk.eng->set_stream(rk.stream);
-		if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
-		Status st = rk.eng->allocate();
-		// every rank must reach the communicator's rendezvous, whatever happened before it
+		Status st = nmfamd::ST_OK;
+		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); st = nmfamd::ST_NO_DEVICE; }
+		if (st == nmfamd::ST_OK && hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; st = nmfamd::ST_HIP_ERROR; }
 		const MatrixDescription<T>& V = input_->inputMatrix;
-		if (st == nmfamd::ST_OK) st = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+		auto make_engine = [&](const nmfamd::AlgorithmParams& prm) -> Status {
+			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm));
+			rk.eng->set_one_pass(false);       // rank threads may share a device: no persistent launch that claims every CU
+			rk.eng->set_stream(rk.stream);
+			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
+			Status s = rk.eng->allocate();
+			if (s == nmfamd::ST_OK) s = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+			return s;
+		};
+		if (st == nmfamd::ST_OK) st = make_engine(prm_);
 		// values outside the exact range of the split-operand product in ANY shard: every rank switches to the native fp32
 		// MFMA instructions (the ranks must run the same arithmetic: W is replicated)
 		if (st == nmfamd::ST_VALUE_RANGE) odd_values_.store(true, std::memory_order_release);
@@ -268,16 +281,15 @@ private:
 		if (odd_values_.load(std::memory_order_acquire) && (st == nmfamd::ST_OK || st == nmfamd::ST_VALUE_RANGE)) {
 			nmfamd::AlgorithmParams native = prm_;
 			native.precision = -1;
-			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, native));
-			rk.eng->set_one_pass(false);
-			rk.eng->set_stream(rk.stream);
-			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
-			st = rk.eng->allocate();
-			if (st == nmfamd::ST_OK) st = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+			st = make_engine(native);
 		}
+		if (st != nmfamd::ST_OK) setup_failed_.store(true, std::memory_order_release);
+		nmfamd::local_group_barrier(*rendezvous_);
+		if (setup_failed_.load(std::memory_order_acquire)) return st;          // (a healthy rank reports ST_OK: the caller sees the failed one's status)
 		Status ct = local_ ? nmfamd::local_comm_create(transport_group_, g, &rk.comm) : nmfamd::rccl_comm_create(unique_id_, world_, g, &rk.comm);
-		if (st != nmfamd::ST_OK) return st;
-		if (ct != nmfamd::ST_OK) return ct;
+		if (ct != nmfamd::ST_OK) { setup_failed_.store(true, std::memory_order_release); if (transport_group_) nmfamd::local_group_abort(*transport_group_); }
+		nmfamd::local_group_barrier(*rendezvous_);
+		if (setup_failed_.load(std::memory_order_acquire)) return ct;
 		rk.sh.reset(new nmfamd::ShardedRank<T>(rk.eng.get(), rk.comm.get(), mode_, (long)m_, (long)n_));
 		return rk.sh->prepare();
 	}
@@ -294,7 +306,7 @@ private:
 	unsigned m_, n_, r_;
 	int alg_;
 	bool local_ = true;
-	std::atomic<bool> odd_values_{false};
+	std::atomic<bool> odd_values_{false}, setup_failed_{false};
 	std::vector<std::unique_ptr<Rank>> ranks_;
 	std::string error_;
 	std::vector<std::thread> workers_;

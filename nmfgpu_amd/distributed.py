@@ -56,8 +56,13 @@ class EngineShard:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if algorithm not in ("mu", "nsnmf"):
             raise ValueError("the sharded iteration covers the multiplicative algorithms: 'mu' and 'nsnmf'")
+        self._precision_asked = precision
         self.engine = Engine(m, n, r, algorithm, dtype=V_local.dtype, stream=stream, theta=theta, precision=precision, row_blocks=row_blocks)
         self.engine.upload(V_local)
+        # Engine.upload switches THIS rank to the native fp32 MFMA instructions when its shard holds values outside the exact range
+        # of the split-operand product; W is replicated, so every rank must then run the same arithmetic (and take the same update
+        # path): the ranks agree, and the ones that did not switch by themselves switch now (as nmfgpu::compute's rank team does)
+        self._agree_on_value_range(V_local)
         self.engine.set_factors(W, H_local)
         g = self.engine.geometry()
         count = g["exchange_count"]
@@ -79,6 +84,24 @@ class EngineShard:
                                         "data": (self.engine.w_panel_ptr(), False), "version": 2}
         self._raw = raw
         self.w_panel = torch.as_tensor(raw, device=self.device)
+
+    def _agree_on_value_range(self, V_local):
+        torch = self.torch
+        try:
+            import torch.distributed as dist
+        except Exception:      # noqa: BLE001
+            return
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        switched = self.engine._ctor["params"][8] == -1.0 and self._precision_asked == "native"
+        on_gpu = dist.get_backend() == "nccl"
+        flag = torch.tensor([1 if switched else 0], dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0 and not switched and self._precision_asked == "native":
+            self.engine.close()
+            self.engine._ctor["params"][8] = -1.0
+            self.engine._create()
+            self.engine.upload(V_local)
 
     def w_update_rows(self, block, row0: int, rows: int, compute_error: bool):
         self.engine.w_update_rows(block.data_ptr(), self.hht.data_ptr(), row0, rows, compute_error, self.colsq.data_ptr())

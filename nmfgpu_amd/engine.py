@@ -105,7 +105,9 @@ class Engine:
         st = call()
         if st == 6 and self._ctor["params"][8] == 0.0:
             # NMFAMD_VALUE_RANGE: infinities, NaN, |v| > 2^126 or 0 < |v| < 2^-100 in V -- the split-operand product is not the
-            # fp32 product there; recreate the engine on the native fp32 MFMA instructions, as nmfgpu::compute does
+            # fp32 product there; recreate the engine on the native fp32 MFMA instructions, as nmfgpu::compute does.
+            # The handle changes: anything created from the old one (a ShardedRun, w_panel_ptr()) is void -- upload V before
+            # creating those.  Column-sharded callers must make this switch on every rank together (EngineShard does).
             self.close()
             self._ctor["params"][8] = -1.0
             self._create()

@@ -70,7 +70,7 @@ Engine<T>::~Engine() {
 	if (inv_work_) (void)hipFree(inv_work_);
 	if (range_flag_) (void)hipFree(range_flag_);
 	{
-		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_};
+		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_, csr_bptr_, csc_bptr_, kl_part_, kl_tpart_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
@@ -1329,6 +1329,42 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 		HIPX(hipMemcpyAsync(csr_val_, csr_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemcpyAsync(csc_val_, csc_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 	}
+	// KL divergence: cut the gathered factor into blocks that stay in an XCD's L2 (4 MiB; NMFAMD_KL_BLOCK_KB sets the block's bytes,
+	// 0 = no blocking) when the whole factor does not: W step gathers rows of H by column index (range n), H step rows of Wt by row index
+	// (range m).  A row's entries are sorted by that index, so its entries of block b are one range: only boundaries are needed.
+	{
+		void** oldb[] = {(void**)&csr_bptr_, (void**)&csc_bptr_, (void**)&kl_part_, (void**)&kl_tpart_};
+		for (void** b : oldb) { if (*b) (void)hipFree(*b); *b = nullptr; }
+		kl_blocks_w_ = kl_blocks_h_ = 1;
+		const char* be = std::getenv("NMFAMD_KL_BLOCK_KB");
+		const long block_bytes = be ? std::atol(be) * 1024 : 3584 * 1024;     // (measured at config 3: 2 MiB 1.73 ms / iteration, 3 MiB 1.62, 3.5 MiB 1.58, 4 MiB 1.57, 8 MiB 1.64; unblocked 2.14)
+		if (prm_.divergence != 0 && block_bytes > 0) {
+			const long rows_per_block = std::max<long>(64, block_bytes / ((long)RP_ * (long)sizeof(T)));
+			auto cut = [&](long range) { return (range * RP_ * (long)sizeof(T) > 3l * 1024 * 1024) ? (int)std::min<long>(64, (range + rows_per_block - 1) / rows_per_block) : 1; };
+			kl_blocks_w_ = cut(n_); kl_blocks_h_ = cut(m_);
+			auto boundaries = [&](const std::vector<int>& ptr, const std::vector<int>& idx, int rows, long range, int blocks, int** dev) -> hipError_t {
+				if (blocks <= 1) return hipSuccess;
+				const long per = (range + blocks - 1) / blocks;
+				std::vector<int> bp((size_t)rows * (blocks + 1));
+				for (int i = 0; i < rows; ++i) {
+					int p = ptr[i];
+					for (int b = 0; b <= blocks; ++b) {
+						const long lim = (long)b * per;                      // first index of block b
+						while (p < ptr[i + 1] && idx[p] < lim) ++p;
+						bp[(size_t)i * (blocks + 1) + b] = b == blocks ? ptr[i + 1] : p;
+					}
+				}
+				hipError_t e = hipMalloc((void**)dev, sizeof(int) * bp.size());
+				if (e != hipSuccess) return e;
+				return hipMemcpy(*dev, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice);
+			};
+			HIPX(boundaries(csr_ptr, csr_idx, m_, n_, kl_blocks_w_, &csr_bptr_));
+			HIPX(boundaries(csc_ptr, csc_idx, n_, m_, kl_blocks_h_, &csc_bptr_));
+			const long pe = std::max<long>(kl_blocks_w_ > 1 ? (long)kl_blocks_w_ * RP_ * mpad_ : 0, kl_blocks_h_ > 1 ? (long)kl_blocks_h_ * RP_ * npad_ : 0);
+			if (pe > 0) HIPX(hipMalloc((void**)&kl_part_, sizeof(T) * (size_t)pe));
+			if (kl_blocks_w_ > 1) HIPX(hipMalloc((void**)&kl_tpart_, sizeof(T) * 2 * (size_t)kl_blocks_w_ * mpad_));
+		}
+	}
 	HIPX(hipStreamSynchronize(stream_));
 	nnz_ = nnz;
 	return ST_OK;
@@ -1354,17 +1390,28 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
 		HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
 	} else {
-		HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
+		if (kl_blocks_h_ > 1) HIPX(launch_kl_fused<T>(csc_bptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, kl_part_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, kl_blocks_h_, (long)RP_ * npad_));
+		else HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
 	}
 	record_end();
 	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
-	HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
+	if (!two_pass && kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_));
+	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
 	// W step (the quotient is re-evaluated with the new H), over the CSR image; per-row error terms on error iterations only
 	record_begin();
 	if (two_pass) {
 		HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr, m_, stream_));
 		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, q_, H_, RP_, slabs_, m_, (int)mpad_, stream_));
 	} else {
+		if (kl_blocks_w_ > 1) {
+			HIPX(launch_kl_fused<T>(csr_bptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, kl_part_, compute_error ? kl_tpart_ : (T*)nullptr,
+			                        compute_error ? kl_tpart_ + (long)kl_blocks_w_ * mpad_ : (T*)nullptr, m_, (int)mpad_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
+			if (compute_error) {
+				// the blocks' parts of the per-row error terms, block order
+				HIPX(launch_reduce_partials<T>(kl_tpart_, kl_blocks_w_, mpad_, t_vwh_, m_, stream_));
+				HIPX(launch_reduce_partials<T>(kl_tpart_ + (long)kl_blocks_w_ * mpad_, kl_blocks_w_, mpad_, t_kl_, m_, stream_));
+			}
+		} else
 		HIPX(launch_kl_fused<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, slabs_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr,
 		                        m_, (int)mpad_, stream_));
 	}
@@ -1387,7 +1434,8 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		HIPX(hipEventRecord(err_event_, stream_));
 		kl_pending_ = true;
 	}
-	HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
+	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
+	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
 	return ST_OK;
 }

@@ -190,6 +190,11 @@ private:
 	int *csr_ptr_ = nullptr, *csr_idx_ = nullptr, *csc_ptr_ = nullptr, *csc_idx_ = nullptr, *csc_from_csr_ = nullptr;
 	T *csr_val_ = nullptr, *csc_val_ = nullptr, *q_ = nullptr, *q2_ = nullptr;
 	T *t_vwh_ = nullptr, *t_kl_ = nullptr, *rowsum_part_ = nullptr, *sW_ = nullptr, *sH_ = nullptr;
+	// KL half-steps with the gathered factor cut into blocks that fit an XCD's L2 (kernels_sparse.hip, k_kl_fused): blocked pointer arrays
+	// [rows][blocks + 1] of the CSR image (W step: column blocks of H) and of the CSC image (H step: row blocks of W), partial panels
+	int kl_blocks_w_ = 1, kl_blocks_h_ = 1;
+	int *csr_bptr_ = nullptr, *csc_bptr_ = nullptr;
+	T *kl_part_ = nullptr, *kl_tpart_ = nullptr;
 	double sum_v_ = 0, kl_ = 0;
 	// KL error terms travel like the Frobenius ones: pinned landing buffer [t_vwh (m) | t_kl (m) | sW (RP) | sH (RP) | psR (RP)],
 	// copied stream-ordered, summed on the host only when somebody reads the error

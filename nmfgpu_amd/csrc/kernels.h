@@ -299,8 +299,10 @@ hipError_t launch_sddmm_quotient(const int* ptr, const int* idx, const T* val, c
 // KL half-step in one pass: out(row, :) = sum_p val[p] / (A(row,:).B(idx[p],:) + eps) * B(idx[p], :) (quotient and numerator
 // together, one gather per stored entry); rows in [rows, rows_pad) are zeroed; optional per-row error terms as above
 template <typename T>
+// blocks > 1: ptr is the blocked pointer array [rows][blocks + 1] (a row's entries cut at the block boundaries of the gathered index);
+// out then receives `blocks` partial panels out_stride apart (and t_vwh / t_kl `blocks` partial vectors of rows_pad), grid block-major
 hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
-                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream);
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks = 1, long out_stride = 0);
 template <typename T>
 hipError_t launch_permute(const T* src, const int* perm, T* dst, long count, hipStream_t stream);
 // sums(c) = sum_y P(c, y); partial: (len_pad / 128) * RP elements of scratch
@@ -308,6 +310,7 @@ template <typename T>
 hipError_t launch_panel_rowsum(const T* P, int RP, int len_pad, T* partial, T* sums, hipStream_t stream);
 // P(c, y) <- P(c, y) num(c, y) / (den(c) + eps); sumsq_part (optional): (len_pad / 128) * RP partial sums of squares
 template <typename T>
-hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream);
+// num: `parts` partial numerator panels part_stride apart, added in order
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts = 1, long part_stride = 0);
 
 } // namespace nmfamd

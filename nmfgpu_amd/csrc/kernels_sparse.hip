@@ -187,13 +187,24 @@ template hipError_t launch_sddmm_quotient<double>(const int*, const int*, const 
 // One wave per row; a group of 16 lanes owns one entry, each lane RP / 16 contiguous factor rows; two entries per group in
 // flight.  Fixed order: lane segments, butterfly inside the group (dot), per-group running sums, groups 0 .. 3 at the end.
 // TERMS: the per-row error terms t_vwh(row) = sum val * wh, t_kl(row) = sum val * log(val / wh) (W step of error iterations).
+// BLOCKED form (blocks > 1): the gathered index range is cut into `blocks` blocks whose rows of B fit an XCD's L2 (the verdict of round 2:
+// 70 % of the gathered rows missed L2 and came from the memory-side cache at its rate).  The grid runs block-major -- all rows' entries
+// of block 0, then block 1, ... -- so that at any time the workgroups in flight gather from one or two blocks; a row's entries are
+// sorted by index, hence its entries of block b are the range [bptr[row * (blocks + 1) + b], bptr[row * (blocks + 1) + b + 1]).
+// One partial numerator panel (and one vector of error terms) per block, added in block order by the update kernel: deterministic.
 template <typename T, int VEC, bool TERMS>
 __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                                   const T* __restrict__ A, const T* __restrict__ B, T eps,
-                                                  T* __restrict__ out, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows, int rows_pad) {
+                                                  T* __restrict__ out, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows, int rows_pad,
+                                                  int blocks, long out_stride) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int row = blockIdx.x * 4 + wave;
+	const int per_block = (rows_pad + 3) >> 2;            // workgroups per block
+	const int blk = blocks > 1 ? (int)(blockIdx.x / per_block) : 0;
+	const int row = (int)(blockIdx.x - (unsigned)blk * per_block) * 4 + wave;
 	if (row >= rows_pad) return;
+	out += (long)blk * out_stride;
+	if (TERMS) { t_vwh += (long)blk * rows_pad; t_kl += (long)blk * rows_pad; }
+	const int pstride = blocks > 1 ? blocks + 1 : 1;
 	constexpr int RP = 64 * VEC, SEG = 4 * VEC;
 	const int g = lane >> 4, sl = lane & 15;
 	T acc[SEG];
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
 		T a[SEG];
 #pragma unroll
 		for (int e = 0; e < SEG; ++e) a[e] = A[(long)row * RP + sl * SEG + e];
-		const int p_begin = ptr[row], p_end = ptr[row + 1];
+		const int p_begin = ptr[(long)row * pstride + blk], p_end = ptr[(long)row * pstride + blk + 1];
 		for (int p0 = p_begin; p0 < p_end; p0 += 8) {
 			const int pa = p0 + g, pb = p0 + 4 + g;
 			const bool va = pa < p_end, vb = pb < p_end;
@@ -255,12 +266,13 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
 // out: rows_pad x RP numerator panel (rows in [rows, rows_pad) zeroed); t_vwh == nullptr: no per-row error terms
 template <typename T>
 hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
-                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream) {
-	dim3 grid((rows_pad + 3) / 4), block(256);
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks, long out_stride) {
+	if (blocks < 1) return hipErrorInvalidValue;
+	dim3 grid((unsigned)(((rows_pad + 3) / 4) * blocks)), block(256);
 	const bool terms = t_vwh != nullptr && t_kl != nullptr;
 #define NMFAMD_KLF(VEC)                                                                                                                        \
-	if (terms) hipLaunchKernelGGL((k_kl_fused<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad); \
-	else hipLaunchKernelGGL((k_kl_fused<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad);      \
+	if (terms) hipLaunchKernelGGL((k_kl_fused<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride); \
+	else hipLaunchKernelGGL((k_kl_fused<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride);      \
 	break
 	switch (RP / 64) {
 	case 1: NMFAMD_KLF(1);
@@ -271,8 +283,8 @@ hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T
 #undef NMFAMD_KLF
 	return hipGetLastError();
 }
-template hipError_t launch_kl_fused<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, int, hipStream_t);
-template hipError_t launch_kl_fused<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, int, hipStream_t);
+template hipError_t launch_kl_fused<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, int, hipStream_t, int, long);
+template hipError_t launch_kl_fused<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, int, hipStream_t, int, long);
 
 // dst[p] = src[perm[p]]: the quotients in the other storage order
 template <typename T>
@@ -315,29 +327,56 @@ template hipError_t launch_panel_rowsum<double>(const double*, int, int, double*
 
 // KL multiplicative update: P(c, y) <- P(c, y) * num(c, y) / (den(c) + eps), plus the per-workgroup
 // sums of squares of the result (for the column normalisation of W).  One workgroup = 128 panel columns.
+// One workgroup = 128 panel columns; a thread owns four consecutive factor rows c (one 16-byte access) and every (1024 / RP)-th
+// panel column; the `parts` partial numerators (the blocks of the blocked KL step) are added in block order, eight loads in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* __restrict__ num, const T* __restrict__ den, int RP, T eps,
-                                                   T* __restrict__ sumsq_part) {
+                                                   T* __restrict__ sumsq_part, int parts, long part_stride) {
+	typedef T T4 __attribute__((ext_vector_type(4)));
+	__shared__ T s_ss[256 * 4];
 	const long base = (long)blockIdx.x * 128 * RP;
-	for (int c = threadIdx.x; c < RP; c += 256) {
-		const T d = den[c] + eps;
-		T ss = 0;
-		for (int y = 0; y < 128; ++y) {
-			const long e = base + (long)y * RP + c;
-			const T v = P[e] * num[e] / d;
-			P[e] = v;
-			ss += v * v;
+	const int per_row = RP / 4, c4 = threadIdx.x % per_row, yy = threadIdx.x / per_row, ystep = 256 / per_row;
+	T4 d = *reinterpret_cast<const T4*>(den + 4 * c4);
+	d += eps;
+	T4 ss = {0, 0, 0, 0};
+	for (int y = yy; y < 128; y += ystep) {
+		const long e = base + (long)y * RP + 4 * c4;
+		T4 nm = *reinterpret_cast<const T4*>(num + e);
+		int b = 1;
+		for (; b + 8 <= parts; b += 8) {
+			T4 t[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const T4*>(num + (long)(b + u) * part_stride + e);
+#pragma unroll
+			for (int u = 0; u < 8; ++u) nm += t[u];
 		}
-		if (sumsq_part) sumsq_part[(long)blockIdx.x * RP + c] = ss;
+		for (; b < parts; ++b) nm += *reinterpret_cast<const T4*>(num + (long)b * part_stride + e);
+		const T4 p = *reinterpret_cast<const T4*>(P + e);
+		const T4 v = p * nm / d;
+		*reinterpret_cast<T4*>(P + e) = v;
+		ss += v * v;
+	}
+	if (sumsq_part) {
+		// the panel columns of one factor row in ascending order of the thread's start column (fixed order)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) s_ss[threadIdx.x * 4 + i] = ss[i];
+		__syncthreads();
+		if ((int)threadIdx.x < RP) {
+			const int c = threadIdx.x;
+			T acc = 0;
+			for (int g = 0; g < ystep; ++g) acc += s_ss[(g * per_row + c / 4) * 4 + (c & 3)];
+			sumsq_part[(long)blockIdx.x * RP + c] = acc;
+		}
 	}
 }
 
 template <typename T>
-hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream) {
-	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part);
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts, long part_stride) {
+	if (RP % 64 != 0 || RP > 256 || parts < 1) return hipErrorInvalidValue;
+	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part, parts, part_stride);
 	return hipGetLastError();
 }
-template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t);
-template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t);
+template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t, int, long);
+template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t, int, long);
 
 } // namespace nmfamd

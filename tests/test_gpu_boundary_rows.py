@@ -308,3 +308,40 @@ def test_engine_rejects_factors_of_the_wrong_dtype_or_shape():
         eng.upload(V.astype(np.float64))
     with pytest.raises(ValueError):
         eng.upload(F(V[:, :29]))
+
+
+def test_kl_blocked_gather_equals_unblocked(monkeypatch):
+    """The KL half-steps with the gathered factor cut into L2-sized blocks (default above 3 MiB of factor; partial numerators added in
+    block order) against the unblocked form (NMFAMD_KL_BLOCK_KB=0): same arithmetic, different grouping of a row's entries, so the
+    factors agree to fp32 rounding; both within the usual tolerance of the float restatement over the stored entries."""
+    import scipy.sparse as sp
+    m, n, r = 30000, 9000, 128                     # 15 MB of W, 4.6 MB of H: both half-steps are blocked
+    rng = np.random.default_rng(11)
+    S = sp.random(m, n, density=0.004, format="csr", random_state=rng, data_rvs=lambda k: rng.integers(1, 6, k).astype(np.float32))
+    S.sort_indices()
+    val, ptr, idx = S.data.astype(np.float32), S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    W0 = F((1.0 - rng.random((m, r))).astype(np.float32)); H0 = F((1.0 - rng.random((r, n))).astype(np.float32))
+
+    def run(block_kb):
+        if block_kb is None:
+            monkeypatch.delenv("NMFAMD_KL_BLOCK_KB", raising=False)
+        else:
+            monkeypatch.setenv("NMFAMD_KL_BLOCK_KB", str(block_kb))
+        eng = na.Engine(m, n, r, "mu", divergence="kl")
+        try:
+            eng.upload_sparse(1, val, ptr, idx, 0)
+            eng.set_factors(W0, H0)
+            eng.iterate(10, first_iteration=1, error_every=10, last_iteration=10)
+            return eng.get_factors() + (eng.kl_divergence, eng.frobenius)
+        finally:
+            eng.close()
+
+    Wb, Hb, klb, fb = run(None)
+    Wu, Hu, klu, fu = run(0)
+    Ws, Hs, kls, fs = run(512)                      # many small blocks (30 / 9 of them)
+    assert rel(Wb, Wu) < 2e-6 and rel(Hb, Hu) < 2e-6 and rel(Ws, Wu) < 2e-6 and rel(Hs, Hu) < 2e-6
+    assert klb == pytest.approx(klu, rel=1e-6) and kls == pytest.approx(klu, rel=1e-6) and fb == pytest.approx(fu, rel=1e-6)
+    W64, H64 = W0.copy(order="F"), H0.copy(order="F")
+    ref = oracle.run_kl_csr(m, n, val, ptr, idx, W64, H64, 10)
+    assert rel(Wb, W64) < 1e-4 and rel(Hb, H64) < 1e-4
+    assert klb == pytest.approx(ref["kl"], rel=1e-5)

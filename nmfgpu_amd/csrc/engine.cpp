@@ -824,7 +824,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 
 template <typename T>
 Status Engine<T>::w_products(T* exchange) {
-	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
+	if (prm_.divergence != 0 || sparse_) return ST_INVALID;
 	T* ex_hht = exchange + (long)RP_ * mpad_;
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
@@ -861,9 +861,47 @@ Status Engine<T>::w_products(T* exchange) {
 
 template <typename T>
 Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
-	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
+	if (prm_.divergence != 0 || sparse_) return ST_INVALID;
 	const T eps = std::numeric_limits<T>::epsilon();
 	const T* ex_hht = exchange + (long)RP_ * mpad_;
+	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) {
+		// GDCLS / ALS / ACLS / AHCLS on the all-reduced sums (their extra products are r x r sized or row / column
+		// separable): exactly the W step of iterate() with the reduced (V H^T)^T panel as the one "slab" and the reduced H H^T
+		// (AlgorithmGradientDescentConstrainedLeastSquares.h:236-264, AlgorithmAlternatingHoyerConstrainedLeastSquares.h:226-284)
+		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
+		const bool ls_family = alg_ != ALG_GDCLS;
+		if (compute_error) HIPX(launch_trace_small<T>(ex_hht, G2_, RP_, r_, psR_, stream_));      // G2_: W^T W saved before the regulariser (h_step)
+		T* wpart = nullptr;
+		if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
+		wx3_valid_ = false;
+		if (!ls_family) {
+			HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_,
+			                            wpart, nullptr, 0, qx3_));
+			if (Status st = normalize_w(wpart != nullptr, norm_parts)) return st;
+			// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
+			if (compute_error) HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+		} else {
+			T offW = 0, diagW = 0;
+			if (alg_ == ALG_ACLS) diagW = (T)prm_.lambdaW;
+			else if (alg_ == ALG_AHCLS) {
+				const T lam = (T)prm_.lambdaW, alpha = (T)prm_.alphaW;
+				T beta = (T)((1 - alpha) * std::sqrt((double)(unsigned)r_) + alpha);
+				beta *= beta;
+				offW = -lam; diagW = lam * beta - lam;
+			}
+			// (the inverse destroys its input: a copy of the reduced H H^T, the exchange buffer stays the caller's)
+			HIPX(hipMemcpyAsync(HHt_, ex_hht, sizeof(T) * (size_t)RP_ * RP_, hipMemcpyDeviceToDevice, stream_));
+			if (Status st = normal_inverse(HHt_, offW, diagW)) return st;
+			if (compute_error) HIPX(hipMemcpyAsync(Wold_, Wt_, sizeof(T) * (size_t)RP_ * mpad_, hipMemcpyDeviceToDevice, stream_));
+			HIPX(launch_panel_update<T>(PANEL_LS, Wt_, exchange, 1, 0, Qinv_, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_,
+			                            wpart, nullptr, 0, qx3_));
+			// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
+			if (compute_error) HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));
+			if (Status st = normalize_w(wpart != nullptr, norm_parts)) return st;
+		}
+		if (compute_error) { if (Status st = fetch_error_terms(r_)) return st; }
+		return ST_OK;
+	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
 			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T

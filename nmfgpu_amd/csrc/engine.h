@@ -106,6 +106,9 @@ public:
 	int n() const { return n_; }
 	int r() const { return r_; }
 	int rp() const { return RP_; }
+	// GDCLS and the ALS family evaluate tr(H^T W^T V) as r terms (one per factor row, from the reduced sums: identical on every rank of a
+	// column-sharded run); the multiplicative algorithms as one term per column of V
+	bool error_terms_per_factor_row() const { return alg_ != ALG_MU && alg_ != ALG_NSNMF; }
 	long mpad() const { return mpad_; }
 	long npad() const { return npad_; }
 	int slabs_h() const { return planH_.splits; }

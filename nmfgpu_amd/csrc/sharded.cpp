@@ -24,6 +24,7 @@ ShardedRank<T>::~ShardedRank() {
 template <typename T>
 Status ShardedRank<T>::prepare() {
 	if (!eng_ || !comm_ || (mode_ != SHARD_ROW_BLOCKS && mode_ != SHARD_REPLICATED)) return ST_INVALID;
+	if (eng_->error_terms_per_factor_row() && mode_ != SHARD_REPLICATED) { last_error_ = "GDCLS / ALS family: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	const int world = comm_->world(), rank = comm_->rank();
 	long first = 0, count = 0;
 	shard_columns(total_columns_, world, rank, &first, &count);
@@ -114,10 +115,17 @@ void ShardedRank<T>::finalize() {
 	const int world = comm_->world(), rank = comm_->rank();
 	const long L = slot_len();
 	std::vector<T> htwtv, hhtwtw;
-	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); htwtv.insert(htwtv.end(), err_pin_ + (long)p * L, err_pin_ + (long)p * L + c); }
-	// the r terms of tr(H H^T W^T W) come from the reduced H H^T and the replicated W^T W: identical on every rank
-	const T* mine = err_pin_ + (long)rank * L + eng_->n();
-	hhtwtw.assign(mine, mine + eng_->r());
+	if (eng_->error_terms_per_factor_row()) {
+		// GDCLS / ALS family: r terms of tr(H^T W^T V) and r of tr(H H^T W^T W), both from the reduced sums: this rank's own slot
+		const T* mine = err_pin_ + (long)rank * L;
+		htwtv.assign(mine, mine + eng_->r());
+		hhtwtw.assign(mine + eng_->r(), mine + 2 * eng_->r());
+	} else {
+		for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); htwtv.insert(htwtv.end(), err_pin_ + (long)p * L, err_pin_ + (long)p * L + c); }
+		// the r terms of tr(H H^T W^T W) come from the reduced H H^T and the replicated W^T W: identical on every rank
+		const T* mine = err_pin_ + (long)rank * L + eng_->n();
+		hhtwtw.assign(mine, mine + eng_->r());
+	}
 	frob_ = resolve_frobenius<T>(vtv_all_, htwtv, hhtwtw);
 	rmsd_ = frob_ / std::sqrt((double)(unsigned)((unsigned)rows_ * (unsigned)total_columns_));   // (unsigned product, like the reference)
 }

@@ -14,6 +14,8 @@
 // reads the error.
 #pragma once
 
+#include <algorithm>
+
 #include <vector>
 
 #include "comm.h"
@@ -47,7 +49,7 @@ private:
 	Status fail(const char* what) { last_error_ = what; (void)hipGetLastError(); return ST_HIP_ERROR; }
 	Status launch_error_gather();
 	// elements per rank in the gathered error-term buffer: [n_local terms | r terms], padded to whole 16-byte units
-	long slot_len() const { return ((nloc_max_ + eng_->r() + 3) / 4) * 4; }
+	long slot_len() const { return ((std::max<long>(nloc_max_, eng_->r()) + eng_->r() + 3) / 4) * 4; }
 	void finalize();
 
 	Engine<T>* eng_;

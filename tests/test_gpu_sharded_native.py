@@ -103,7 +103,7 @@ def test_compute_with_numgpus_kmeans_init_threshold_stop_and_runs():
 
 def test_compute_with_numgpus_rejects_what_does_not_shard():
     V, W, H = problem(60, 50, 4, np.float32)
-    assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.ALS, iterations=2, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success
@@ -129,3 +129,80 @@ def test_native_sharded_run_over_a_one_rank_rccl_clique(alg, r, kw, mode):
     assert run.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
     assert run.rmsd == pytest.approx(ref["rmsd"], rel=1e-5)
     run.close(); eng.close(); comm.close()
+
+
+LS_PARAMS = {"gdcls": (na.NmfAlgorithm.GDCLS, {"lambda": 0.01}), "als": (na.NmfAlgorithm.ALS, {}),
+             "acls": (na.NmfAlgorithm.ACLS, {"lambdaW": 0.01, "lambdaH": 0.01}),
+             "ahcls": (na.NmfAlgorithm.AHCLS, {"lambdaW": 0.01, "lambdaH": 0.01, "alphaW": 0.01, "alphaH": 0.01})}
+LS_ORACLE_KW = {"gdcls": dict(lam=0.01), "als": {}, "acls": dict(lambda_w=0.01, lambda_h=0.01), "ahcls": dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01)}
+
+
+@pytest.mark.parametrize("name", ["gdcls", "als", "acls", "ahcls"])
+@pytest.mark.parametrize("ranks,r,dtype,tol", [(2, 12, np.float32, 1e-3), (3, 64, np.float32, 1e-3), (3, 10, np.float64, 1e-8)])
+def test_compute_with_numgpus_least_squares_family(name, ranks, r, dtype, tol):
+    """GDCLS / ACLS / AHCLS / ALS shard like the multiplicative update -- their H step is local (an r x r solve per rank
+    from the replicated W), their W step needs the same two sums over the shards (V H^T, H H^T); the r x r inverse and the row
+    update then run replicated (reference: AlgorithmGradientDescentConstrainedLeastSquares.h:175-272,
+    AlgorithmAlternatingHoyerConstrainedLeastSquares.h:183-296).  Against the fp64 oracle and the single-engine run."""
+    alg, params = LS_PARAMS[name]
+    m, n, iters = 600, 431, 12                       # ragged shards
+    V, W0, H0 = problem(m, n, r, dtype, seed=r + ranks)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
+    ref = oracle.run(name, V64, W64, H64, iters, **LS_ORACLE_KW[name])
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    s1 = na.Summary()
+    assert na.compute(V, W1, H1, algorithm=alg, iterations=iters, parameters=params, summary=s1) == na.ResultType.Success
+    Wn, Hn = W0.copy(order="F"), H0.copy(order="F")
+    sn = na.Summary()
+    assert na.compute(V, Wn, Hn, algorithm=alg, iterations=iters, parameters=dict(params, numGpus=ranks), summary=sn) == na.ResultType.Success
+    assert rel(Wn, W64) < tol and rel(Hn, H64) < tol, (rel(Wn, W64), rel(Hn, H64))
+    assert rel(Wn, W1) < tol and rel(Hn, H1) < tol
+    assert sn.record(0).frobenius == pytest.approx(ref["frobenius"], rel=max(1e-5, tol / 10))
+    assert sn.record(0).frobenius == pytest.approx(s1.record(0).frobenius, rel=max(1e-5, tol / 10))
+
+
+def test_eight_ranks_rank256_against_the_oracle():
+    """BASELINE configs[3]'s cut (8 column shards, nsNMF theta = 0.5, r = 256) at a size the fp64 oracle covers, fp32 and bf16 operands,
+    both shard modes; the ranks share the box's one device (in-process transport)."""
+    m, n, r, iters = 2048, 8 * 160, 256, 6
+    V, W0, H0 = problem(m, n, r, np.float32, seed=8)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
+    ref = oracle.run("nsnmf", V64, W64, H64, iters, theta=0.5)
+    for prec, tol in ((0, 2e-4), (1, 2e-2)):
+        for mode in (0, 1):
+            Wn, Hn = W0.copy(order="F"), H0.copy(order="F")
+            sn = na.Summary()
+            p = {"theta": 0.5, "numGpus": 8, "shardMode": mode, "precision": prec}
+            assert na.compute(V, Wn, Hn, algorithm=na.NmfAlgorithm.nsNMF, iterations=iters, parameters=p, summary=sn) == na.ResultType.Success
+            assert rel(Wn, W64) < tol and rel(Hn, H64) < tol, (prec, mode, rel(Wn, W64), rel(Hn, H64))
+            assert sn.record(0).frobenius == pytest.approx(ref["frobenius"], rel=5 * tol)
+
+
+def test_config4_as_stated_eight_shards_on_one_device():
+    """BASELINE configs[3] as it is stated -- 8 column shards, a collective every iteration, nsNMF theta = 0.5, r = 256, bf16 operands,
+    50 000 rows -- with 1 024 columns per shard (the full 6 250 per shard is 10 GB of host matrix per run and eight bf16 images on one
+    device; the per-shard kernels at full size are covered by test_config4_shard_size_nsnmf_bf16_properties).  Eight rank threads share
+    the device.  Properties of the gathered result, agreement of the two shard modes, and agreement with the single-engine run."""
+    m, n, r, iters = 50000, 8 * 1024, 256, 4
+    rng = np.random.default_rng(4)
+    V = np.empty((m, n), dtype=np.float32, order="F")
+    for j0 in range(0, n, 1024):
+        V[:, j0:j0 + 1024] = rng.random((m, 1024), dtype=np.float32)
+    W0 = F((1.0 - rng.random((m, r))).astype(np.float32)); H0 = F((1.0 - rng.random((r, n))).astype(np.float32))
+    base = {"theta": 0.5, "precision": 1}
+    out = {}
+    for key, extra in (("single", {}), ("rows", {"numGpus": 8, "shardMode": 0}), ("repl", {"numGpus": 8, "shardMode": 1})):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.nsNMF, iterations=iters, parameters=dict(base, **extra), summary=s) == na.ResultType.Success, key
+        out[key] = (W, H, s.record(0).frobenius)
+    for key in ("rows", "repl"):
+        W, H, f = out[key]
+        assert np.isfinite(W).all() and np.isfinite(H).all() and (W >= 0).all() and (H >= 0).all()
+        # nsNMF returns W S (AlgorithmNonSmoothNMF.h:221-225): S = (1 - theta) I + theta / r 11^T; the columns of W itself are unit vectors
+        theta = 0.5
+        Wn = (W.astype(np.float64) - (theta / r) * W.astype(np.float64).sum(axis=1, keepdims=True) / ((1 - theta) + theta)) / (1 - theta)
+        np.testing.assert_allclose(np.linalg.norm(Wn, axis=0), 1.0, rtol=2e-3)
+        assert rel(W, out["single"][0]) < 2e-2 and rel(H, out["single"][1]) < 2e-2, (key, rel(W, out["single"][0]), rel(H, out["single"][1]))
+        assert f == pytest.approx(out["single"][2], rel=2e-2)
+    assert rel(out["rows"][0], out["repl"][0]) < 1e-3 and rel(out["rows"][1], out["repl"][1]) < 1e-3

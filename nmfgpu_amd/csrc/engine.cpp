@@ -1310,7 +1310,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 // Sparse mode: 0-based triplets (any order) -> CSR and CSC images on the device, the permutation
 // between the two value orders, the sorted tr(V^T V) terms and sum(V).  Built on the host with stable
 // counting sorts, once per upload (outside the iteration loop).  Duplicate coordinates stay separate
-// entries (their contributions add; the dense path keeps the last one).
+// entries (their contributions add; the densifying path adds them too, k_densify).
 template <typename T>
 Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals) {
 	const long nnz = (long)vals.size();

@@ -1001,7 +1001,11 @@ __global__ void k_densify(int format, const T* __restrict__ values, const int* _
 		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if ((long)(ptr[mid] - base) <= p) lo = mid; else hi = mid; }
 		if (format == 1) { i = lo; j = idx[p] - base; } else { j = lo; i = idx[p] - base; }
 	}
-	if (i >= 0 && i < rows && j >= 0 && j < cols) V[(long)j * ldv + i] = values[p];
+	// Duplicate coordinates ADD (as on the sparse-compute path, Engine::upload_triplets): a plain store would leave whichever duplicate's
+	// thread came last -- a race.  The destination is zero-filled, so a unique coordinate is stored exactly (0 + v); two duplicates add
+	// exactly in either order; with three or more the rounding can depend on the order of the additions.  (cusparse's csr2dense,
+	// Matrix.h:161-168, documents nothing for duplicates.)
+	if (i >= 0 && i < rows && j >= 0 && j < cols) atomicAdd(&V[(long)j * ldv + i], values[p]);
 }
 
 template <typename T>

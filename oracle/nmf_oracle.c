@@ -25,6 +25,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#if defined(__AVX2__) && defined(__FMA__) && !defined(ORACLE_NO_FAST_SGEMM)
+#include "sgemm_avx2.h"
+#define ORACLE_FAST_SGEMM 1
+#endif
+
 #define T float
 #define SFX f32
 #define EPS_T FLT_EPSILON
@@ -32,6 +40,7 @@
 #undef T
 #undef SFX
 #undef EPS_T
+#undef ORACLE_FAST_SGEMM
 
 #define T double
 #define SFX f64

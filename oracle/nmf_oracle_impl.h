@@ -21,6 +21,9 @@
  * `W.transposed() * W` and `W.transposed() * V`
  * (AlgorithmMultiplicativeFrobenius.h:168-169,176-178,187-188 via Matrix.h:361-376). */
 static void FN(gemm_tn)(int m, int ka, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) {
+#ifdef ORACLE_FAST_SGEMM
+	if (sgemm_tn_avx2(m, ka, kb, A, lda, B, ldb, C, ldc)) return;      /* float only: packed 16 x 6 micro-kernel (sgemm_avx2.h) */
+#endif
 	/* Blocked for the cache hierarchy: a thread owns a pair of columns of B; the reduction range is walked in chunks of
 	 * IC rows (the chunk of A -- ka columns x IC rows -- stays in L2 while all column blocks of A pass over it), and a
 	 * 4 x 2 block of C is accumulated per pass with simd reductions (vector-wide partial sums; without the pragma a float
@@ -66,6 +69,9 @@ static void FN(gemm_tn)(int m, int ka, int kb, const T* A, int lda, const T* B, 
 /* C(m x kb) = A B^T, A is m x n, B is kb x n.  Restates gemm-NT `V * H.transposed()`
  * and `H * H.transposed()` (AlgorithmMultiplicativeFrobenius.h:208-209,231-232,240-241). */
 static void FN(gemm_nt)(int m, int n, int kb, const T* A, int lda, const T* B, int ldb, T* C, int ldc) {
+#ifdef ORACLE_FAST_SGEMM
+	if (sgemm_nt_avx2(m, n, kb, A, lda, B, ldb, C, ldc)) return;
+#endif
 	const int RB = 256; /* row block owned by one thread: C block stays in L2 */
 #pragma omp parallel for schedule(static)
 	for (int i0 = 0; i0 < m; i0 += RB) {

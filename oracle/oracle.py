@@ -26,7 +26,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle (and, if /root/reference is present, the reference host units)."""
     stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(_KM_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                           for f in ("nmf_oracle.c", "nmf_oracle_impl.h"))) or (
+                                           for f in ("nmf_oracle.c", "nmf_oracle_impl.h", "sgemm_avx2.h"))) or (
         os.path.getmtime(_KM_PATH) < os.path.getmtime(os.path.join(_HERE, "kmeans_oracle.cpp")))
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])

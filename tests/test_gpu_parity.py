@@ -289,6 +289,37 @@ def test_sparse_upload_equals_dense_path_bit_exact(fmt, base):
     assert np.array_equal(Vdev.reshape(128, 256).T[:m, :n], D)
 
 
+def test_sparse_upload_duplicate_coordinates_add():
+    """Duplicate coordinates in COO / CSR input: the densifying upload ADDS them (as the sparse-compute path does) -- no race between
+    the duplicates' threads.  Two duplicates add exactly in either order, so the result is the dense matrix of the sums, bit for bit."""
+    rng = np.random.default_rng(9)
+    m, n, r = 120, 70, 5
+    rows = rng.integers(0, m, 900); cols = rng.integers(0, n, 900); vals = rng.integers(1, 6, 900).astype(np.float32)
+    # every coordinate at most twice: drop third and later occurrences
+    seen, keep = {}, []
+    for k, rc in enumerate(zip(rows, cols)):
+        seen[rc] = seen.get(rc, 0) + 1
+        keep.append(seen[rc] <= 2)
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    assert max(seen.values()) >= 2
+    D = np.zeros((m, n), dtype=np.float32)
+    np.add.at(D, (rows, cols), vals)
+    _, W, H = problem(m, n, r, np.float32)
+    dense = na.Engine(m, n, r, "mu"); dense.upload(F(D)); dense.set_factors(W, H); dense.iterate(5, last_iteration=5)
+    for base in (0, 1):
+        coo = na.Engine(m, n, r, "mu")
+        coo.upload_sparse(3, vals, (rows + base).astype(np.int32), (cols + base).astype(np.int32), base)
+        assert np.array_equal(coo.debug_read(6, 128 * 128).reshape(128, 128).T[:m, :n], D)
+        coo.set_factors(W, H); coo.iterate(5, last_iteration=5)
+        assert np.array_equal(coo.get_factors()[0], dense.get_factors()[0]) and coo.frobenius == dense.frobenius
+    # CSR with duplicates inside a row (stable sort by row keeps them)
+    order = np.argsort(rows, kind="stable")
+    ptr = np.zeros(m + 1, dtype=np.int32); np.add.at(ptr, rows + 1, 1); ptr = np.cumsum(ptr).astype(np.int32)
+    csr = na.Engine(m, n, r, "mu")
+    csr.upload_sparse(1, vals[order], ptr, cols[order].astype(np.int32), 0)
+    assert np.array_equal(csr.debug_read(6, 128 * 128).reshape(128, 128).T[:m, :n], D)
+
+
 def test_determinism_bitwise_repeatable():
     V, W, H = problem(400, 300, 64, np.float32, seed=12)
     outs = []

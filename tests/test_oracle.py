@@ -62,6 +62,44 @@ def test_products_against_numpy(dtype, tol):
     np.testing.assert_allclose(oracle.gemm_nn(A, Hh), A.astype(np.float64) @ Hh, rtol=tol)
 
 
+def _product(name, a, b, shape, dims, threads=2):
+    """The C entry point itself: leading dimensions from the strides (views allowed), team size pinned."""
+    import ctypes as C
+    ld = lambda x: x.strides[1] // 4 if x.shape[1] > 1 else max(x.shape[0], 1)
+    out = np.zeros(shape, dtype=np.float32, order="F")
+    oracle.lib().oracle_set_num_threads(threads)
+    getattr(oracle.lib(), name)(*dims, a.ctypes.data_as(C.c_void_p), ld(a), b.ctypes.data_as(C.c_void_p), ld(b), out.ctypes.data_as(C.c_void_p), ld(out))
+    return out
+
+
+# shapes chosen for the packed fp32 products (oracle/sgemm_avx2.h): panel tails (rows not a multiple of 16, columns not a multiple
+# of 6), reduction ranges on both sides of the 256 / 128 chunk, the short-and-wide case that is cut along the reduction range
+@pytest.mark.parametrize("m,n,r", [(1, 1, 1), (17, 5, 3), (300, 77, 7), (517, 1300, 64), (130, 2049, 33), (2000, 260, 65)])
+def test_packed_fp32_products_against_numpy(m, n, r):
+    rng = np.random.default_rng(m * 7 + n * 3 + r)
+    V = F(rng.random((m, n)).astype(np.float32)); W = F(rng.random((m, r)).astype(np.float32)); H = F(rng.random((r, n)).astype(np.float32))
+    d = lambda a: a.astype(np.float64)
+    np.testing.assert_allclose(oracle.gemm_tn(W, V), d(W).T @ d(V), rtol=5e-6)
+    np.testing.assert_allclose(oracle.gemm_tn(W, W), d(W).T @ d(W), rtol=5e-6)
+    np.testing.assert_allclose(oracle.gemm_nt(V, H), d(V) @ d(H).T, rtol=5e-6)
+    np.testing.assert_allclose(oracle.gemm_nt(H, H), d(H) @ d(H).T, rtol=5e-6)
+    # a view with a leading dimension larger than its row count
+    big = F(rng.random((m + 5, n)).astype(np.float32)); Vs = big[2:m + 2, :]
+    np.testing.assert_allclose(_product("oracle_gemm_nt_f32", Vs, H, (m, r), (m, n, r)), d(Vs) @ d(H).T, rtol=5e-6)
+    np.testing.assert_allclose(_product("oracle_gemm_tn_f32", W, Vs, (r, n), (m, r, n)), d(W).T @ d(Vs), rtol=5e-6)
+
+
+def test_packed_fp32_products_do_not_depend_on_the_thread_count():
+    rng = np.random.default_rng(4)
+    V = F(rng.random((900, 1500)).astype(np.float32)); W = F(rng.random((900, 20)).astype(np.float32)); H = F(rng.random((20, 1500)).astype(np.float32))
+    got = []
+    for threads in (1, 3):       # oracle.gemm_* size the team themselves; here it is pinned
+        got.append((_product("oracle_gemm_tn_f32", W, V, (20, 1500), (900, 20, 1500), threads), _product("oracle_gemm_nt_f32", V, H, (900, 20), (900, 1500, 20), threads),
+                    _product("oracle_gemm_nt_f32", H, H, (20, 20), (20, 1500, 20), threads)))
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+
+
 def test_multiply_divide_order_and_eps():
     X = F(np.array([[3.0, 0.0], [1e-30, 2.0]], dtype=np.float32))
     N = F(np.array([[2.0, 5.0], [1e-30, 0.0]], dtype=np.float32))

@@ -574,6 +574,65 @@ int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float 
 // Test / measurement entry of kernels_tri.hip (padded rank 256): the passes between a factor update and the next product.
 // P: [len][ldp] panel rows; colsq (r values) or NULL; theta: nsNMF smoothing.  Outputs (any may be NULL): P_out = the panel after the optional
 // column normalisation; pack_out [len][r] = the bf16 fragments of the smoothed panel, widened back to fp32; G_raw / G_smooth [r][r].
+// One multiplicative update of a panel at padded rank 256 in the form the bf16 path uses it (PanelTriExtras): old values with a pending column scale, optional
+// scale + smoothing of the numerator rows, new rows written unnormalised together with their bf16 fragments; then the pending scale of the new panel and the
+// Gram matrix of its rounded rows.  All matrices row-major [len][r] / [r][r].
+int nmfamd_op_tri_update_f32(const float* P, const float* num, const float* Q, int r, int len, const float* old_colsq, int transform_num, const float* num_colsq,
+                             float theta, float frag_theta, float* P_out, float* pack_out, float* scale_out, float* gram_out) {
+	if (!P || !num || !Q || r <= 0 || len <= 0) return NMFAMD_INVALID_ARGUMENT;
+	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
+	const int RP = padded_rank(r);
+	if (!tri_kernels_available(RP)) return NMFAMD_INVALID_ARGUMENT;
+	const long lp = pad128(len), KS = (len + 15) / 16;
+	const size_t pack_bytes = 16 * (size_t)KS * (RP / 32) * 64;
+	int dev = 0, cus = 256;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+	const int parts = panel_update_parts(RP, sizeof(float), (int)lp);
+	DevBuf dP, dN, dQ, dOs, dNs, dPack, dPart, dG, dSq, dStage, dScale, dQx, dDummy;
+	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dN.alloc(sizeof(float) * RP * lp) != hipSuccess || dQ.alloc(sizeof(float) * RP * RP) != hipSuccess ||
+	    dOs.alloc(sizeof(float) * RP) != hipSuccess || dNs.alloc(sizeof(float) * RP) != hipSuccess || dPack.alloc(pack_bytes) != hipSuccess ||
+	    dPart.alloc(sizeof(float) * (size_t)gram_tri_partial_elems(cus)) != hipSuccess || dG.alloc(sizeof(float) * RP * RP) != hipSuccess ||
+	    dSq.alloc(sizeof(float) * ((size_t)parts + 16) * RP) != hipSuccess || dStage.alloc(sizeof(float) * RP * colsq_stage_parts()) != hipSuccess ||
+	    dScale.alloc(sizeof(float) * RP) != hipSuccess || dDummy.alloc(sizeof(float) * RP * 4) != hipSuccess || dQx.alloc((size_t)3 * 16 * (RP / 16 + 1) * (RP / 32) * 64) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	if (hipMemcpy2D(dP.p, RP * sizeof(float), P, r * sizeof(float), r * sizeof(float), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dN.p, RP * sizeof(float), num, r * sizeof(float), r * sizeof(float), len, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemcpy2D(dQ.p, RP * sizeof(float), Q, r * sizeof(float), r * sizeof(float), r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (old_colsq && hipMemcpy(dOs.p, old_colsq, sizeof(float) * r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (num_colsq && hipMemcpy(dNs.p, num_colsq, sizeof(float) * r, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
+	PanelTriExtras ex;
+	ex.num_transform = transform_num != 0;
+	ex.num_colsq = num_colsq ? (const float*)dNs.p : nullptr; ex.num_colsq_parts = 1;
+	const float off = theta / (float)(unsigned)r, diag = (float)((1.0 - theta) + off);
+	ex.num_a = diag - off; ex.num_b = off; ex.r = r;
+	ex.old_colsq = old_colsq ? (const float*)dOs.p : nullptr; ex.old_colsq_parts = 1;
+	ex.frag_out = dPack.p; ex.frag_KS = KS;
+	const float foff = frag_theta / (float)(unsigned)r, fdiag = (float)((1.0 - frag_theta) + foff);
+	if (frag_theta != 0.0f) { ex.frag_a = fdiag - foff; ex.frag_b = foff; }
+	if (launch_panel_update<float>(PANEL_MU, (float*)dP.p, (const float*)dN.p, 1, 0, (const float*)dQ.p, RP, (int)lp, std::numeric_limits<float>::epsilon(), nullptr, len,
+	                               (float*)dSq.p, nullptr, nullptr, nullptr, nullptr, 0, dQx.p, &ex) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_colsq_stage((const float*)dSq.p, RP, parts, (float*)dStage.p, nullptr, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_scale_panel_tri((float*)dDummy.p, RP, 4, (const float*)dStage.p, colsq_stage_parts(), (float*)dScale.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_gram_tri_bf16(dPack.p, RP, KS, cus, (float*)dPart.p, (float*)dG.p, (const float*)dStage.p, colsq_stage_parts(), cus, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (P_out && hipMemcpy2D(P_out, r * sizeof(float), dP.p, RP * sizeof(float), r * sizeof(float), len, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (scale_out && hipMemcpy(scale_out, dScale.p, sizeof(float) * r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (gram_out && hipMemcpy2D(gram_out, r * sizeof(float), dG.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (pack_out) {
+		std::vector<uint16_t> h(pack_bytes / 2);
+		if (hipMemcpy(h.data(), dPack.p, pack_bytes, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+		const int NBT = RP / 32;
+		for (long y = 0; y < len; ++y)
+			for (int c = 0; c < r; ++c) {
+				const long frag = ((y / 16) * NBT + c / 32) * 64 + ((y / 8) & 1) * 32 + (c & 31);
+				const uint32_t bits = (uint32_t)h[frag * 8 + (y & 7)] << 16;
+				float f;
+				std::memcpy(&f, &bits, 4);
+				pack_out[y * r + c] = f;
+			}
+	}
+	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
+}
+
 int nmfamd_op_factor_passes_f32(const float* P, long ldp, int r, int len, const float* colsq, float theta, float* P_out, float* pack_out,
                                 float* G_raw, float* G_smooth, int reps, double* avg_us_finish, double* avg_us_gram) {
 	if (!P || r <= 0 || len <= 0 || ldp < r) return NMFAMD_INVALID_ARGUMENT;

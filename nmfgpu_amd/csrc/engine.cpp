@@ -406,13 +406,14 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
 		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
+		tri_scale_pending_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
 		HIPX(launch_transpose<T>(stage_, mpad_, m_, r_, Wt_, RP_, stream_));
 	}
 	if (H) {
-		hx3_valid_ = false;
+		hx3_valid_ = false; hb_valid_ = false;
 		if (ldh < r_) return ST_INVALID;
 		gram_h_partials_ = false;
 		HIPX(hipMemsetAsync(H_, 0, sizeof(T) * (size_t)RP_ * npad_, stream_));
@@ -450,8 +451,8 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; }
-	if (h) { gram_h_partials_ = false; hx3_valid_ = false; }
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; }
+	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
 	return ST_OK;
@@ -759,18 +760,29 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		}
 	}
 	hx3_valid_ = false;
-	if (Status s = materialize_w()) return s;
 	if constexpr (std::is_same<T, float>::value) {
 		if (tri_) {
+			// The fragments hold bf16(W) as the panel stores it -- unsmoothed, without the pending column scale D; the product's output gets both:
+			// (W D S)^T V = S D (W^T V), applied by the H update to the summed slabs (PanelTriExtras).
 			if (Status s = tri_prepare_w()) return s;
 			if (Status s = product_h(Wt_, nullptr, true)) return s;
+			T off, diag;
+			tri_smoothing(&off, &diag);
+			PanelTriExtras ex;
+			ex.num_transform = true;
+			if (tri_scale_pending_) { ex.num_colsq = colsq_; ex.num_colsq_parts = colsq_parts_; }
+			ex.num_a = (float)(diag - off); ex.num_b = (float)off; ex.r = r_;
+			// ... and leaves the operand of the next V (S H)^T behind: the bf16 fragments of the smoothed new columns (AlgorithmNonSmoothNMF.h:194)
+			ex.frag_out = Hb_; ex.frag_KS = ksW_; ex.frag_a = (float)(diag - off); ex.frag_b = (float)off;
 			// (qx3_holds_g_: k_smooth_gram left the split image of G_ in qx3_ -- Q = nullptr tells the update kernel so)
 			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, qx3_holds_g_ ? nullptr : G_, RP_, (int)npad_, eps,
-			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 			qx3_holds_g_ = false;
+			hb_valid_ = true;
 			return ST_OK;
 		}
 	}
+	if (Status s = materialize_w()) return s;
 	const T* F = Wt_;
 	if (alg_ == ALG_NSNMF) {
 		const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -964,10 +976,8 @@ Status Engine<T>::w_normalize_rows(long row0, long rows, T* colsq) {
 	// colsq: the r sums of squares over ALL rows (one "partial"): kernel::normalizeColumns' sum > 0 ? x / sqrt(sum) : x
 	if constexpr (std::is_same<T, float>::value) {
 		if (tri_) {
-			// the same pass leaves the bf16 fragments of the smoothed rows for the next W^T V
-			T off, diag;
-			tri_smoothing(&off, &diag);
-			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, row0, rows, colsq, colsq == colsq_ ? colsq_parts_ : 1, off, diag, Wtb_, ksH_, stream_));
+			// the same pass leaves the bf16 fragments of the normalised rows for the next W^T V (unsmoothed: S is applied to the product's output)
+			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, row0, rows, colsq, colsq == colsq_ ? colsq_parts_ : 1, 0.0f, 1.0f, Wtb_, ksH_, stream_));
 			tri_rows_cover_ = row0 == 0 && rows == mpad_;
 			wtb_valid_ = tri_rows_cover_;
 			tri_gw_ready_ = false;
@@ -993,19 +1003,15 @@ Status Engine<T>::tri_prepare_w() {
 		T off, diag;
 		tri_smoothing(&off, &diag);
 		const bool wide = qx3_ != nullptr && panel_update_wide_available(RP_);
-		if (!wtb_valid_ && !tri_gw_ready_ && mpad_ % 64 == 0) {
-			// both consumers of the panel in one launch (nothing to normalise here: W is as the caller / the gather left it)
-			HIPX(launch_finish_and_gram(Wt_, Wt_, RP_, r_, mpad_, m_, nullptr, 0, off, diag, Wtb_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, num_cus_, stream_));
-			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
-			wtb_valid_ = tri_gw_ready_ = true;
-			qx3_holds_g_ = wide;
-		}
 		if (!wtb_valid_) {
-			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, 0, mpad_, nullptr, 0, off, diag, Wtb_, ksH_, stream_));
+			// plain re-rounding of the panel as it lies (no smoothing, no normalisation: W is as the caller / the gather left it)
+			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, 0, mpad_, nullptr, 0, 0.0f, 1.0f, Wtb_, ksH_, stream_));
 			wtb_valid_ = true;
 		}
 		if (!tri_gw_ready_) {
-			HIPX(launch_gram_tri(Wt_, RP_, m_, num_cus_, gram_tri_part_, Gw_raw_, num_cus_, stream_));
+			// W^T W of the ROUNDED W (the matrix the product multiplies V with), times the pending column scale on both sides: Gw_raw_ is the
+			// unsmoothed Gram matrix of the normalised W (the error term's operand, AlgorithmNonSmoothNMF.h:201-202), G_ its smoothed form S G S
+			HIPX(launch_gram_tri_bf16(Wtb_, RP_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, tri_scale_pending_ ? colsq_ : nullptr, colsq_parts_, num_cus_, stream_));
 			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
 			tri_gw_ready_ = true;
 			qx3_holds_g_ = wide;
@@ -1014,41 +1020,49 @@ Status Engine<T>::tri_prepare_w() {
 	return ST_OK;
 }
 
-// local_q: hht stays what the W update multiplies with (no reduction over ranks in between), so its split image may be left in qx3_
+// hht = (S H)(S H)^T for the W step, from the bf16 fragments of the smoothed columns the H update left in Hb_ -- the Gram matrix of exactly the operand
+// V is multiplied with.  (local_q is kept for the callers' sake: the split image of hht is made by the update's launcher either way.)
 template <typename T>
 Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
+	(void)local_q;
 	if constexpr (std::is_same<T, float>::value) {
-		T off, diag;
-		tri_smoothing(&off, &diag);
-		const bool wide = local_q && qx3_ != nullptr && panel_update_wide_available(RP_);
-		if (npad_ % 64 == 0) {
-			HIPX(launch_finish_and_gram(H_, H_, RP_, r_, npad_, n_, nullptr, 0, off, diag, Hb_, ksW_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
-		} else {
+		if (!hb_valid_) {
+			// H did not come from this engine's H update (set_factors / randomize between the two half-steps): one finishing pass makes the fragments
+			T off, diag;
+			tri_smoothing(&off, &diag);
 			HIPX(launch_finish_panel_bf16(H_, RP_, r_, 0, npad_, nullptr, 0, off, diag, Hb_, ksW_, stream_));
-			HIPX(launch_gram_tri(H_, RP_, n_, num_cus_, gram_tri_part_, Gh_raw_, num_cus_, stream_));
+			hb_valid_ = true;
 		}
-		HIPX(launch_smooth_gram(Gh_raw_, hht, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
+		HIPX(launch_gram_tri_bf16(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, nullptr, 0, num_cus_, stream_));
 		qx3_holds_g_ = false;
-		qx3_holds_hht_ = wide;
+		qx3_holds_hht_ = false;
 	}
 	return ST_OK;
 }
 
 // The W update of the rank-256 bf16 path on the whole panel: num = the reduced (V (S H)^T)^T panel (S slabs), hht its r x r operand
-// (nullptr: its split image is in qx3_); then the column sums of squares, and ONE pass that normalises W and leaves the bf16 fragments
-// of its smoothed rows.  (Tried: the update writing to a scratch panel and normalisation + fragments + Gram matrix in one launch --
-// the Gram workgroups hold the CUs' registers, the two kinds of workgroup run one after the other: 68 us against 32 + 31.)
+// (nullptr: its split image is in qx3_).  ONE pass over the panel: the update kernel reads the old rows with their pending column scale, writes the new
+// rows unnormalised, their bf16 fragments (what the next W^T V multiplies with) and the partial sums of squares; the column normalisation
+// (kernel::normalizeColumns, KernelNormalizeColumns.cu:37-58) becomes the new pending scale.  Round 2 followed the update with k_finish_panel_bf16
+// (read + write of the panel, 30 us at config 4) and took the Gram matrix from the fp32 panel by split operands (k_gram_tri_x3, 29 us).
 template <typename T>
 Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
 	if constexpr (std::is_same<T, float>::value) {
 		const T eps = std::numeric_limits<T>::epsilon();
 		const int parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 		wx3_valid_ = false;
-		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
+		PanelTriExtras ex;
+		if (tri_scale_pending_) { ex.old_colsq = colsq_; ex.old_colsq_parts = colsq_parts_; }
+		ex.frag_out = Wtb_; ex.frag_KS = ksH_;
+		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 		qx3_holds_g_ = qx3_holds_hht_ = false;
 		HIPX(launch_colsq_stage(sumsq_part_, RP_, parts, colsq_, nullptr, stream_));
 		colsq_parts_ = colsq_stage_parts();
-		return w_normalize_rows(0, mpad_, colsq_);
+		tri_scale_pending_ = true;             // (the staged sums ARE the pending scale: every consumer forms 1 / sqrt(sum) itself, PanelTriExtras)
+		wtb_valid_ = true;
+		tri_rows_cover_ = true;
+		tri_gw_ready_ = false;
+		return ST_OK;
 	}
 	return ST_INVALID;
 }
@@ -1099,6 +1113,13 @@ Status Engine<T>::materialize_w() {
 			w_pending_ = false;
 			fused_ready_ = false;
 			wx3_valid_ = false;
+		}
+		if (tri_scale_pending_) {
+			// rank-256 bf16 path: W <- W diag(d), d from the staged sums of squares; the fragments (of the unscaled panel) are re-made on demand, the Gram matrices already
+			// describe the normalised W
+			HIPX(launch_scale_panel_tri(Wt_, RP_, mpad_, colsq_, colsq_parts_, nullptr, stream_));
+			tri_scale_pending_ = false;
+			wtb_valid_ = false;
 		}
 	}
 	return ST_OK;

@@ -77,7 +77,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
@@ -217,7 +217,9 @@ private:
 	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams
 	// it (normalise + smooth + bf16 fragments), Gram matrices of the smoothed panels from the unsmoothed ones (S G S)
 	bool tri_ = false;
-	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current (smoothed) W
+	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
+	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
+	bool hb_valid_ = false;          // Hb_ holds the bf16 fragments of the current smoothed H (written by the H update)
 	bool tri_gw_ready_ = false;      // Gw_raw_ / G_ describe the current W
 	bool tri_rows_cover_ = false;    // the last w_normalize_rows() covered every row of W
 	int colsq_parts_ = 1;            // staged partial vectors in colsq_ (kernels_tri.hip: launch_colsq_stage)

@@ -112,6 +112,28 @@ template <typename T>
 hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G, hipStream_t stream);
 
 enum PanelMode { PANEL_MU = 0, PANEL_LS = 1, PANEL_SET = 2 };
+// Extras of the multiplicative update at padded rank 256 with bf16 product operands (config 4, kernels_tri.hip).  W is carried unnormalised with a
+// pending column scale D (as the rank-64 path does), and its bf16 fragments hold the unnormalised, unsmoothed values: scale and nsNMF smoothing move to
+// the OUTPUT side of the product, (W D S)^T V = S D (W^T V) -- O(r n) work inside the H update instead of a pass over the panel.
+struct PanelTriExtras {
+	// A pending column scale is handed over as the staged sums of squares the update left behind (launch_colsq_stage: `parts` vectors of RP, added in
+	// order): d(c) = sum > 0 ? 1 / sqrt(sum) : 1 -- kernel::normalizeColumns (KernelNormalizeColumns.cu:37-58) as a factor.  Every consumer forms d the
+	// same way (tri_pending_scale() below), so they all see the same bits.  nullptr: ones.
+	// numerator transform, per panel row y:  num'(y, c) = a * d(c) num(y, c) + b * sum_{c'} d(c') num(y, c'),  c < r  (zero beyond); d from num_colsq.
+	bool num_transform = false;
+	const float* num_colsq = nullptr;
+	int num_colsq_parts = 0;
+	float num_a = 1.0f, num_b = 0.0f;
+	int r = 0;
+	// the panel's own pending column scale: every old value is read as old(y, c) * d(c), d from old_colsq
+	const float* old_colsq = nullptr;
+	int old_colsq_parts = 0;
+	// bf16 fragments of the NEW rows (layout of k_finish_panel_bf16), K-steps >= frag_KS are not written; the 32-row kernel can smooth them on the way
+	// (f(y, c) = frag_a x(y, c) + frag_b sum_c' x(y, c'), c < r; needs r), the 128-row kernel writes them as they are (frag_a = 1, frag_b = 0)
+	void* frag_out = nullptr;
+	long frag_KS = 0;
+	float frag_a = 1.0f, frag_b = 0.0f;
+};
 int panel_update_rows(int RP, size_t elem);
 // number of per-workgroup sum-of-squares partials launch_panel_update writes for a panel of len_pad columns
 int panel_update_parts(int RP, size_t elem, int len_pad);
@@ -133,7 +155,7 @@ bool panel_update_wide_available(int RP);
 // its split image; the result may go to another panel (P_out != P_in), e.g. to keep the unnormalised W readable while it is normalised
 bool panel_update_long_available(int RP, int len_pad);
 hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const float* slabs, int S, long slab_stride, const void* q_split, int RP, int len_pad,
-                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream);
+                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream, const PanelTriExtras* tri = nullptr);
 bool gram_wide_available(int RP);
 // len: valid panel rows (the padding rows behind them are zero); partial: parts * RP * RP elements
 hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream);
@@ -141,7 +163,7 @@ hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, floa
 // matrix pipe with exactly split operands (fp32 accuracy, kernels_x3.hip) instead of the fp32 MFMA instructions
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
-                                        void* q_split = nullptr);
+                                        void* q_split = nullptr, const PanelTriExtras* tri = nullptr);
 template <typename T>
 hipError_t launch_reduce_partials(const T* partial, int parts, long stride, T* out, long count, hipStream_t stream);
 template <typename T>
@@ -152,7 +174,8 @@ template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
                                T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial = nullptr,
                                void* x3_out = nullptr, int x3_ks = 0,    // x3_out: split image of the new panel (kernels_x3.hip); only where panel_update_delivers_gram()
-                               void* q_split = nullptr);                 // scratch for the split image of Q (wide fp32 panels, see launch_panel_update_wide_f32)
+                               void* q_split = nullptr,                  // scratch for the split image of Q (wide fp32 panels, see launch_panel_update_wide_f32)
+                               const PanelTriExtras* tri = nullptr);     // fp32, padded rank 256 only
 
 // sumsq_part: parts * RP partial sums followed by 16 * RP elements of scratch
 template <typename T>
@@ -228,6 +251,12 @@ hipError_t launch_colsq_stage(const float* part, int RP, int parts, float* stage
 // G (RP x RP, both triangles, exactly symmetric) = P^T P over `len` panel rows; partial: gram_tri_partial_elems(max_parts) floats
 hipError_t launch_gram_tri(const float* P, int RP, int len, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream);
 long gram_tri_partial_elems(int max_parts);
+// the same matrix from the panel's bf16 fragments (KS K-steps of 16 rows, layout of k_finish_panel_bf16 without smoothing): ONE bf16 MFMA per tile and
+// K-step, i.e. G = P~^T P~ of the ROUNDED panel P~ -- exactly the operand the product against V multiplies with, so numerator and denominator of the
+// H update refer to the same matrix.  colsq != nullptr: G(r, c) *= d(r) d(c), the pending column scale of the panel (PanelTriExtras).
+hipError_t launch_gram_tri_bf16(const void* frags, int RP, long KS, int max_parts, float* partial, float* G, const float* colsq, int colsq_parts, int num_cus, hipStream_t stream);
+// P(y, c) *= d(c) over `rows` panel rows (folds a pending column scale, given as staged sums of squares, into the panel); scale_out (optional): the RP factors
+hipError_t launch_scale_panel_tri(float* P, int RP, long rows, const float* colsq, int colsq_parts, float* scale_out, hipStream_t stream);
 // Gs = S G S, S = (diag - offdiag) I + offdiag 1 1^T on the first r rows / columns
 // x3_out (optional): also the split image of Gs that the wide update kernels take as their r x r operand (launch_panel_update with Q = nullptr);
 // its closing all-zero K-step is the caller's (written once)

@@ -679,15 +679,17 @@ bool panel_update_delivers_gram(int RP, size_t elem) {
 
 template <typename T>
 hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_stride, const T* Q, int RP, int len_pad,
-                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial, void* x3_out, int x3_ks, void* q_split) {
+                               T eps, T* ps, int len_valid, T* sumsq_part, T* num_out, hipStream_t stream, T* gram_partial, void* x3_out, int x3_ks, void* q_split,
+                               const PanelTriExtras* tri) {
 	if ((gram_partial != nullptr || x3_out != nullptr) && !(panel_update_delivers_gram(RP, sizeof(T)) && mode != MODE_SET)) return hipErrorInvalidValue;
+	if (tri != nullptr && !(std::is_same<T, float>::value && RP == 256 && mode == MODE_MU && use_wide_update(RP))) return hipErrorInvalidValue;
 	if constexpr (std::is_same<T, float>::value) {
 		if (RP == 64 && mode != MODE_SET) {
 			if (tuning_env("NMFAMD_UPDATE64_OLD")) return launch_panel_update64_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream);
 			return launch_panel_update64_lds_f32(mode, P, slabs, S, slab_stride, Q, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, gram_partial, x3_out, x3_ks);
 		}
 		if (use_wide_update(RP) && mode != MODE_SET)
-			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, q_split);
+			return launch_panel_update_wide_f32(mode, P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, q_split, tri);
 	}
 	if constexpr (std::is_same<T, double>::value) {
 		// same 32 rows per workgroup as the generic kernel at this rank: the norm-partial count does not change
@@ -706,8 +708,8 @@ hipError_t launch_panel_update(int mode, T* P, const T* slabs, int S, long slab_
 	}
 	return hipGetLastError();
 }
-template hipError_t launch_panel_update<float>(int, float*, const float*, int, long, const float*, int, int, float, float*, int, float*, float*, hipStream_t, float*, void*, int, void*);
-template hipError_t launch_panel_update<double>(int, double*, const double*, int, long, const double*, int, int, double, double*, int, double*, double*, hipStream_t, double*, void*, int, void*);
+template hipError_t launch_panel_update<float>(int, float*, const float*, int, long, const float*, int, int, float, float*, int, float*, float*, hipStream_t, float*, void*, int, void*, const PanelTriExtras*);
+template hipError_t launch_panel_update<double>(int, double*, const double*, int, long, const double*, int, int, double, double*, int, double*, double*, hipStream_t, double*, void*, int, void*, const PanelTriExtras*);
 
 // ------------------------------------------------------------------------------------------
 // column normalisation of W (rows of the Wt panel): second half of kernel::normalizeColumns

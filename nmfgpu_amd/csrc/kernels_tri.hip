@@ -269,7 +269,8 @@ __global__ __launch_bounds__(512, 2) void k_finish_and_gram(const float* Pin, fl
 // the six terms in different orders, so the upper triangle is kept and mirrored.
 // colsq != nullptr: the slices were taken from the panel BEFORE its column normalisation x / sqrt(sum) (sum = the staged vectors, added in order;
 // columns without a norm keep their values): G(r, c) is divided by the two norms.
-__global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict__ partial, int parts, float* __restrict__ G, const float* __restrict__ colsq, int colsq_parts) {
+__global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict__ partial, int parts, float* __restrict__ G, const float* __restrict__ colsq, int colsq_parts,
+                                                         bool as_factor) {
 	// 64 accumulator elements per workgroup; wave q adds the q-th quarter of the slices, the quarters are added in order
 	__shared__ float s_q[4][64];
 	const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -295,7 +296,10 @@ __global__ __launch_bounds__(256) void k_gram_tri_reduce(const float* __restrict
 	int i, j;
 	tri_tile(t, i, j);
 	const int r = 32 * i + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), c = 32 * j + (l & 31);
-	if (colsq != nullptr) {
+	if (colsq != nullptr && as_factor) {
+		// the panel's pending column scale (PanelTriExtras), the same factors every other consumer forms (r <= c on the kept triangle: one order for both mirrors)
+		sum = (sum * tri_pending_scale(colsq, colsq_parts, TRI_RP, r)) * tri_pending_scale(colsq, colsq_parts, TRI_RP, c);
+	} else if (colsq != nullptr) {
 		float sr = colsq[r], sc = colsq[c];
 		for (int k = 1; k < colsq_parts; ++k) { sr += colsq[(long)k * TRI_RP + r]; sc += colsq[(long)k * TRI_RP + c]; }
 		const float nr = sr > 0.f ? sqrtf(sr) : 1.0f, nc = sc > 0.f ? sqrtf(sc) : 1.0f;
@@ -315,7 +319,97 @@ hipError_t launch_gram_tri(const float* P, int RP, int len, int max_parts, float
 	hipLaunchKernelGGL(k_gram_tri_x3, dim3(parts), dim3(512), 0, stream, P, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, (const float*)nullptr, 0);
+	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, (const float*)nullptr, 0, false);
+	return hipGetLastError();
+}
+
+// ---- Gram matrix from the bf16 fragments ---------------------------------------------------------------------------------------------
+// The fragments are already MFMA operands ("lane (c, h) holds rows 8 h .. 8 h + 7 of column c" of a 16-row K-step, block nb at
+// [(ks * 8 + nb) * 64 + lane]): a workgroup of eight waves streams its slice of K-steps, thread t loads fragment t of the K-step (8 KB per K-step,
+// one 16-byte load per thread, GB K-steps in flight), parks it in a two-slot LDS ring, and wave w multiplies the blocks of its tiles w, w + 8, ...
+// -- ONE MFMA per tile and K-step (the x3 form above: six, plus the operand split).  Same partial layout as k_gram_tri_x3.
+__global__ __launch_bounds__(512, 1) void k_gram_tri_bf16(const bf16x8* __restrict__ frags, int steps_total, int parts, float* __restrict__ partial) {
+	__shared__ bf16x8 buf[2][TRI_NB * 64];
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int part = blockIdx.x;
+	const int s0 = (int)(((long)steps_total * part) / parts);
+	const int s1 = (int)(((long)steps_total * (part + 1)) / parts);
+	const int steps = s1 - s0;
+	constexpr int TPW = (TRI_TILES + 7) / 8;
+	int ti[TPW], tj[TPW];
+#pragma unroll
+	for (int q = 0; q < TPW; ++q) {
+		const int t = wave + 8 * q;
+		tri_tile(t < TRI_TILES ? t : 0, ti[q], tj[q]);
+	}
+	f32x16 acc[TPW];
+#pragma unroll
+	for (int q = 0; q < TPW; ++q)
+#pragma unroll
+		for (int g = 0; g < 16; ++g) acc[q][g] = 0.f;
+	if (steps > 0) {
+		constexpr int GB = 8;
+		const bf16x8* src = frags + (long)s0 * (TRI_NB * 64) + tid;
+		bf16x8 v[GB];
+		auto fetch = [&](int s) { s = s < steps ? s : steps - 1; return src[(long)s * (TRI_NB * 64)]; };      // past the slice: harmless re-load
+#pragma unroll
+		for (int d = 0; d < GB; ++d) v[d] = fetch(d);
+		buf[0][tid] = v[0];
+		v[0] = fetch(GB);
+		for (int s = 0; s < steps; s += GB) {
+#pragma unroll
+			for (int d = 0; d < GB; ++d) {
+				if (s + d < steps) {
+					__syncthreads();                       // K-step s + d is in slot d & 1; the other slot has been read by everybody
+					if (s + d + 1 < steps) buf[(d + 1) & 1][tid] = v[(d + 1) % GB];
+					v[(d + 1) % GB] = fetch(s + d + 1 + GB);
+					const bf16x8* f = buf[d & 1];
+#pragma unroll
+					for (int q = 0; q < TPW; ++q) {
+						if (q == TPW - 1 && wave + 8 * q >= TRI_TILES) break;
+						acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ti[q] * 64 + lane], f[tj[q] * 64 + lane], acc[q], 0, 0, 0);
+					}
+				}
+			}
+		}
+	}
+	float* out = partial + (long)part * TRI_TILES * 1024;
+#pragma unroll
+	for (int q = 0; q < TPW; ++q) {
+		const int t = wave + 8 * q;
+		if (t < TRI_TILES) {
+#pragma unroll
+			for (int g = 0; g < 16; ++g) out[(long)t * 1024 + g * 64 + lane] = acc[q][g];
+		}
+	}
+}
+
+hipError_t launch_gram_tri_bf16(const void* frags, int RP, long KS, int max_parts, float* partial, float* G, const float* colsq, int colsq_parts, int num_cus, hipStream_t stream) {
+	if (RP != TRI_RP || KS <= 0) return hipErrorInvalidValue;
+	const int parts = (int)std::max<long>(1, std::min<long>(std::min(num_cus, max_parts), KS / 4));
+	hipLaunchKernelGGL(k_gram_tri_bf16, dim3(parts), dim3(512), 0, stream, reinterpret_cast<const bf16x8*>(frags), (int)KS, parts, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, colsq, colsq_parts, true);
+	return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_scale_panel_tri(float* __restrict__ P, long rows, const float* __restrict__ colsq, int colsq_parts, float* __restrict__ scale_out) {
+	const int lane = threadIdx.x & 63;
+	const long y = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (y >= rows) return;
+	f32x4 d;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) d[j] = tri_pending_scale(colsq, colsq_parts, TRI_RP, 4 * lane + j);
+	f32x4* p = reinterpret_cast<f32x4*>(P + y * TRI_RP) + lane;
+	*p = *p * d;
+	if (scale_out != nullptr && y == 0) *reinterpret_cast<f32x4*>(scale_out + 4 * lane) = d;
+}
+
+hipError_t launch_scale_panel_tri(float* P, int RP, long rows, const float* colsq, int colsq_parts, float* scale_out, hipStream_t stream) {
+	if (RP != TRI_RP || rows <= 0 || colsq == nullptr) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_scale_panel_tri, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, P, rows, colsq, colsq_parts, scale_out);
 	return hipGetLastError();
 }
 
@@ -330,7 +424,7 @@ hipError_t launch_finish_and_gram(const float* P_in, float* P_out, int RP, int r
 	                   reinterpret_cast<bf16x8*>(dst), KS);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, colsq, colsq_parts);
+	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, colsq, colsq_parts, false);
 	return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ template <int MODE, int NCB>      // NCB = column blocks per wave = RP / 128
 __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, int RP, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, float* __restrict__ num_out, const bf16x8* __restrict__ Qx3) {
+	float* __restrict__ sumsq_part, float* __restrict__ num_out, const bf16x8* __restrict__ Qx3, const PanelTriExtras tri) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	const int LD = RP + 4;
 	float* s_num = lds;                       // [32][LD]
@@ -62,9 +62,15 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			f32x4 old[NE];
 #pragma unroll
 			for (int i = 0; i < NE; ++i) old[i] = *reinterpret_cast<const f32x4*>(P + base + 4l * (tid + 256 * i));
+			f32x4 od = {1.f, 1.f, 1.f, 1.f};
+			if (NCB == 2 && tri.old_colsq != nullptr) {      // the panel's pending column scale (rank 256 only: this thread's columns are 4 (tid & 63) .. in every row)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) od[j] = tri_pending_scale(tri.old_colsq, tri.old_colsq_parts, 256, 4 * (tid & 63) + j);
+			}
 #pragma unroll
 			for (int i = 0; i < NE; ++i) {
 				const int e = tid + 256 * i, y = e / q4, c4 = e - y * q4;
+				if (NCB == 2 && tri.old_colsq != nullptr) old[i] *= od;
 				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = old[i];
 			}
 		}
@@ -87,6 +93,29 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			for (int i = 0; i < NE; ++i) t[i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));
 #pragma unroll
 			for (int i = 0; i < NE; ++i) num[i] += t[i];
+		}
+		if (NCB == 2 && tri.num_transform) {
+			// scale and nsNMF smoothing on the output side of the product (PanelTriExtras): RP = 256 (the launcher checks), so a panel row is the 64
+			// float4 of one wave (e = tid + 256 i: row tid / 64 + 4 i, columns 4 (tid & 63) ..) and its sum is a butterfly over the wave
+			const int c0 = 4 * (tid & 63);
+			f32x4 d = {1.f, 1.f, 1.f, 1.f};
+			if (tri.num_colsq != nullptr) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) d[j] = tri_pending_scale(tri.num_colsq, tri.num_colsq_parts, 256, c0 + j);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) d[j] = c0 + j < tri.r ? d[j] : 0.f;
+			float rs[NE];
+#pragma unroll
+			for (int i = 0; i < NE; ++i) { num[i] *= d; rs[i] = (num[i][0] + num[i][1]) + (num[i][2] + num[i][3]); }
+#pragma unroll
+			for (int w = 32; w > 0; w >>= 1)
+#pragma unroll
+				for (int i = 0; i < NE; ++i) rs[i] += __shfl_xor(rs[i], w);
+#pragma unroll
+			for (int i = 0; i < NE; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) num[i][j] = c0 + j < tri.r ? tri.num_a * num[i][j] + tri.num_b * rs[i] : 0.f;
 		}
 #pragma unroll
 		for (int i = 0; i < NE; ++i) {
@@ -234,7 +263,40 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			sumsq_part[(long)blockIdx.x * RP + c] = s;
 		}
 	}
+	if (NCB == 2 && tri.frag_out != nullptr) {
+		// bf16 fragments of the 32 new rows (two K-steps): fragment (kk, cb, h, c) = rows 16 kk + 8 h .. + 7 of column 32 cb + c, at
+		// [(K-step * RP / 32 + cb) * 64 + 32 h + c] -- the layout k_finish_panel_bf16 writes; optionally smoothed like there:
+		// f = frag_b * rowsum + frag_a * x for c < r (frag_a = diag - offdiag, frag_b = offdiag of the analytic S)
+		const bool smooth = tri.frag_b != 0.0f || tri.frag_a != 1.0f;
+		float* s_rs = s_ps + 128;                      // [32] row sums
+		if (smooth) {
+			const int y = tid >> 3, part = tid & 7;    // eight threads per row, 32 columns each (columns >= r hold zeros)
+			float t = 0.f;
+			for (int c = part * (RP / 8); c < (part + 1) * (RP / 8); ++c) t += s_old[y * LD + c];
+			t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+			if (part == 0) s_rs[y] = t;
+			__syncthreads();
+		}
+		bf16x8* dst = reinterpret_cast<bf16x8*>(tri.frag_out);
+		const int nb = RP / 32;
+		for (int f = tid; f < 2 * nb * 64; f += 256) {
+			const int kk = f / (nb * 64), rem = f - kk * nb * 64, cb = rem >> 6, l = rem & 63;
+			const long ks = (long)blockIdx.x * 2 + kk;
+			if (ks >= tri.frag_KS) continue;
+			const int c = 32 * cb + (l & 31);
+			bf16x8 v;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int y = 16 * kk + 8 * (l >> 5) + j;
+				float x = s_old[y * LD + c];
+				if (smooth) x = c < tri.r ? tri.frag_b * s_rs[y] + tri.frag_a * x : 0.f;
+				v[j] = (__bf16)x;
+			}
+			dst[(ks * nb + cb) * 64 + l] = v;
+		}
+	}
 }
+
 
 // ------------------------------------------------------------------------------------------
 // Gram matrix G = P P^T of a wide panel on the MFMA pipe (reference: syrk / gemm for W^T W and H H^T,
@@ -818,15 +880,18 @@ static hipError_t launch_wide64(const float* P, float* Pout, const float* slabs,
 template <int NC, bool HAS_PS>          // NC: column blocks of 32 (RP / 32); HAS_PS: per-row error terms wanted
 __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 	const float* P, float* Pout, const float* __restrict__ slabs, int S, long slab_stride, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3) {
+	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3, const float* __restrict__ old_colsq, int old_colsq_parts, bf16x8* __restrict__ frag_out, long frag_KS) {
 	constexpr int RP = 32 * NC, KSTEPS = RP / 16, FR = NC * 192;      // fragments (16 B) of Q per K-step
 	constexpr int QL = FR / 256;                                      // Q fragments per thread and K-step (6 at rank 256, 3 at 128)
 	static_assert(FR % 256 == 0, "whole fragments per thread");
 	__shared__ __attribute__((aligned(16))) bf16x8 s_q[2][FR];
 	__shared__ float s_sq[4][RP];
+	__shared__ __attribute__((aligned(16))) float s_d[RP];           // the panel's pending column scale (PanelTriExtras::old_colsq): old values are old * d
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int half = lane >> 5, l31 = lane & 31;
+	const bool scaled = old_colsq != nullptr;                         // (kernel argument: uniform)
+	if (scaled) for (int c = tid; c < RP; c += 256) s_d[c] = tri_pending_scale(old_colsq, old_colsq_parts, RP, c);
 	const long row0 = (long)blockIdx.x * 128 + 32 * wave;            // this wave's rows (wave-uniform)
 	const float* prow = P + row0 * RP + (l31 * RP + 8 * half);        // + 16 u: the 8 k of this lane in K-step u
 
@@ -849,10 +914,16 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 		for (int g = 0; g < 16; ++g) acc[cb][g] = 0.f;
 
 	bf16x8 nh, nm, nl;
+	if (scaled) __syncthreads();
 	{
 		float v[8];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) { v[j] = ra[0][0][j]; v[4 + j] = ra[0][1][j]; }
+		if (scaled) {
+			const f32x4 d0 = *reinterpret_cast<const f32x4*>(&s_d[8 * half]), d1 = *reinterpret_cast<const f32x4*>(&s_d[8 * half + 4]);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { v[j] *= d0[j]; v[4 + j] *= d1[j]; }
+		}
 		split3(v, nh, nm, nl);
 	}
 	for (int u = 0; u < KSTEPS; u += DA) {
@@ -874,6 +945,12 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 				float v[8];
 #pragma unroll
 				for (int j = 0; j < 4; ++j) { v[j] = ra[(d + 1) % DA][0][j]; v[4 + j] = ra[(d + 1) % DA][1][j]; }
+				if (scaled) {
+					const int kn = ks + 1 < KSTEPS ? ks + 1 : KSTEPS - 1;      // (the K-step these values belong to)
+					const f32x4 d0 = *reinterpret_cast<const f32x4*>(&s_d[16 * kn + 8 * half]), d1 = *reinterpret_cast<const f32x4*>(&s_d[16 * kn + 8 * half + 4]);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { v[j] *= d0[j]; v[4 + j] *= d1[j]; }
+				}
 				split3(v, nh, nm, nl);
 				int na = ks + DA;
 				na = na < KSTEPS ? na : KSTEPS - 1;
@@ -928,13 +1005,33 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 		if (cb + 1 < NC) request(cb + 1, oldv[(cb + 1) & 1], numv[(cb + 1) & 1]);
 		__builtin_amdgcn_sched_barrier(0);
 		float sq = 0.f;
+		const float dcol = scaled ? s_d[32 * cb + l31] : 1.0f;
+		float nw16[16];
 #pragma unroll
 		for (int g = 0; g < 16; ++g) {
 			const int idx = ((g & 3) + 8 * (g >> 2)) * RP + 32 * cb;
-			const float o = oldv[cb & 1][g] * numv[cb & 1][g] / (acc[cb][g] + eps);
+			const float o = (oldv[cb & 1][g] * dcol) * numv[cb & 1][g] / (acc[cb][g] + eps);
 			ow[idx + lofs] = o;
+			nw16[g] = o;
 			if (HAS_PS) rowdot[g] += o * numv[cb & 1][g];
 			sq += o * o;                                        // rows in register order
+		}
+		if (frag_out != nullptr) {
+			// bf16 fragments of the new rows: a fragment is rows 8 h .. 8 h + 7 of one column within a 16-row K-step; register g holds row
+			// (g & 3) + 8 (g >> 2) + 4 half.  v_permlane32_swap(x, y) exchanges x's upper half-wave with y's lower one: with x = register 8 kk + g4 and
+			// y = register 8 kk + 4 + g4 the lower half-wave ends up with rows g4 and 4 + g4 of K-step kk, the upper one with rows 8 + g4 and 12 + g4.
+#pragma unroll
+			for (int kk = 0; kk < 2; ++kk) {
+				bf16x8 f;
+#pragma unroll
+				for (int g4 = 0; g4 < 4; ++g4) {
+					const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(nw16[8 * kk + g4]), __float_as_uint(nw16[8 * kk + 4 + g4]), false, false);
+					f[g4] = (__bf16)__uint_as_float(sw[0]);
+					f[4 + g4] = (__bf16)__uint_as_float(sw[1]);
+				}
+				const long ks = (row0 >> 4) + kk;
+				if (ks < frag_KS) frag_out[(ks * NC + cb) * 64 + lane] = f;
+			}
 		}
 		if (sumsq_part != nullptr) {
 			sq += __shfl_xor(sq, 32);
@@ -966,12 +1063,16 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 
 template <int NC>
 static hipError_t launch_rows_mu(const float* P, float* Pout, const float* slabs, int S, long slab_stride, int len_pad, float eps, float* ps, int len_valid,
-                                 float* sumsq_part, hipStream_t stream, const void* qx3) {
+                                 float* sumsq_part, hipStream_t stream, const void* qx3, const PanelTriExtras* tri) {
 	const int blocks = len_pad / 128;
+	const float* old_colsq = tri ? tri->old_colsq : nullptr;
+	const int old_parts = tri ? tri->old_colsq_parts : 0;
+	bf16x8* frag = tri ? reinterpret_cast<bf16x8*>(tri->frag_out) : nullptr;
+	const long frag_KS = tri ? tri->frag_KS : 0;
 	if (ps != nullptr) hipLaunchKernelGGL((k_panel_update_rows_mu<NC, true>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
-	                                      sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	                                      sumsq_part, reinterpret_cast<const bf16x8*>(qx3), old_colsq, old_parts, frag, frag_KS);
 	else hipLaunchKernelGGL((k_panel_update_rows_mu<NC, false>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
-	                        sumsq_part, reinterpret_cast<const bf16x8*>(qx3));
+	                        sumsq_part, reinterpret_cast<const bf16x8*>(qx3), old_colsq, old_parts, frag, frag_KS);
 	return hipGetLastError();
 }
 
@@ -980,14 +1081,17 @@ bool panel_update_long_available(int RP, int len_pad) { return (RP == 128 || RP 
 
 // P_out <- P_in * num / (P_in Q + eps) with Q given as its split image (k_pack_panel_x3 of Q); P_out may be P_in
 hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const float* slabs, int S, long slab_stride, const void* q_split, int RP, int len_pad,
-                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream) {
+                                       float eps, float* ps, int len_valid, float* sumsq_part, hipStream_t stream, const PanelTriExtras* tri) {
 	if (!panel_update_long_available(RP, len_pad) || q_split == nullptr) return hipErrorInvalidValue;
+	// (the 128-row kernel has no numerator transform, no fragment smoothing and, at rank 256, no error terms: callers route those to k_panel_update_wide_f32)
+	if (tri != nullptr && (tri->num_transform || tri->frag_a != 1.0f || tri->frag_b != 0.0f || RP != 256 || len_pad % 128 != 0 || ps != nullptr)) return hipErrorInvalidValue;
 #ifndef NMFAMD_UPDATE_ROWS
 #define NMFAMD_UPDATE_ROWS 1
 #endif
 	if (NMFAMD_UPDATE_ROWS && len_pad % 128 == 0 && !(ps != nullptr && RP == 256))      // (rank 256 with error terms: that instantiation spills)
-		return RP == 128 ? launch_rows_mu<4>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split)
-		                 : launch_rows_mu<8>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split);
+		return RP == 128 ? launch_rows_mu<4>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split, tri)
+		                 : launch_rows_mu<8>(P_in, P_out, slabs, S, slab_stride, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split, tri);
+	if (tri != nullptr) return hipErrorInvalidValue;
 	return RP == 128 ? launch_wide64<1>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split)
 	                 : launch_wide64<2>(P_in, P_out, slabs, S, slab_stride, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, q_split);
 }
@@ -996,19 +1100,21 @@ bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && 
 
 template <int MODE, int NCB>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3) {
-	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 128);
-	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 128);
+                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3, const PanelTriExtras& tri) {
+	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 160);
+	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 160);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
-	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3));
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3), tri);
 	return hipGetLastError();
 }
 
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, void* q_split) {
+                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, void* q_split, const PanelTriExtras* tri) {
 	if (!panel_update_wide_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % WIDE_YB != 0) return hipErrorInvalidValue;
+	if (tri != nullptr && (RP != 256 || mode != PANEL_MU)) return hipErrorInvalidValue;
+	const PanelTriExtras ext = tri ? *tri : PanelTriExtras();
 	const void* qx3 = nullptr;
 	if (q_split != nullptr) {
 		// Q (RP x RP) split into three bf16 planes in fragment order: A(c, k) = Q(k, c) = Q[k * RP + c]
@@ -1017,11 +1123,13 @@ hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, 
 		qx3 = q_split;
 	} else if (Q == nullptr) return hipErrorInvalidValue;
 	// long panels, multiplicative update, split operands: 64 rows per workgroup (k_panel_update_wide64_mu)
-	if (mode == PANEL_MU && qx3 != nullptr && num_out == nullptr && panel_update_long_available(RP, len_pad))
-		return launch_panel_update_long_mu(P, P, slabs, S, slab_stride, qx3, RP, len_pad, eps, ps, len_valid, sumsq_part, stream);
+	// (the long form has no numerator transform and, at rank 256, no error terms: those launches stay with the 32-row kernel)
+	if (mode == PANEL_MU && qx3 != nullptr && num_out == nullptr && panel_update_long_available(RP, len_pad) &&
+	    !(tri != nullptr && (tri->num_transform || tri->frag_a != 1.0f || tri->frag_b != 0.0f || len_pad % 128 != 0 || ps != nullptr)))
+		return launch_panel_update_long_mu(P, P, slabs, S, slab_stride, qx3, RP, len_pad, eps, ps, len_valid, sumsq_part, stream, tri);
 #define NMFAMD_WIDE(NCB)                                                                                                                   \
-	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3) \
-	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3)
+	return mode == PANEL_MU ? launch_wide<PANEL_MU, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3, ext) \
+	                        : launch_wide<PANEL_LS, NCB>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, qx3, ext)
 	switch (RP / 128) {
 	case 1: NMFAMD_WIDE(1);
 	case 2: NMFAMD_WIDE(2);

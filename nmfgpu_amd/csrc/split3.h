@@ -62,4 +62,12 @@ __device__ inline void store_split3(bf16x8* __restrict__ dst, long ks, int NBT, 
 	o[0] = hi; o[64] = mid; o[128] = lo;
 }
 
+// d(c) of a pending column scale handed over as staged sums of squares (PanelTriExtras, kernels.h): the vectors are added in order, every consumer
+// through this one function
+__device__ inline float tri_pending_scale(const float* __restrict__ colsq, int parts, int RP, int c) {
+	float s = colsq[c];
+	for (int k = 1; k < parts; ++k) s += colsq[(long)k * RP + c];
+	return s > 0.f ? 1.0f / sqrtf(s) : 1.0f;
+}
+
 } // namespace nmfamd

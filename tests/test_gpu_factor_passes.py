@@ -71,6 +71,52 @@ def test_rejected_shapes():
         na.op_factor_passes(np.ones((64, 64), np.float32))          # padded rank 64: other kernels serve it
 
 
+# ------------------------------------------------------------------ the update that leaves the next product's operands behind
+@pytest.mark.parametrize("length,r,theta,transform,scaled,frag_theta", [(1000, 256, 0.5, False, True, 0.0), (33, 200, 0.0, False, False, 0.0), (777, 256, 0.4, True, True, 0.0),
+                                                                        (33024, 256, 0.5, False, True, 0.0), (33024, 256, 0.3, True, False, 0.0), (4096, 129, 0.6, True, True, 0.5),
+                                                                        (6250, 256, 0.5, True, True, 0.5)])
+def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r, theta, transform, scaled, frag_theta):
+    """PanelTriExtras (csrc/kernels.h): the old values carry a pending column scale (kernel::normalizeColumns as a factor,
+    KernelNormalizeColumns.cu:37-58), the numerator rows get scale + smoothing (S D (W^T V) = (W D S)^T V, AlgorithmNonSmoothNMF.h:174-178),
+    the new rows are written unnormalised with their bf16 fragments (the H update smooths them on the way: S H, :194); 33 024 rows without
+    a numerator transform take the 128-row kernel (k_panel_update_rows_mu), the others the 32-row one (k_panel_update_wide_f32)."""
+    rng = np.random.default_rng(length + r)
+    P = rng.random((length, r), dtype=np.float32) + 0.01
+    num = rng.random((length, r), dtype=np.float32) * 3.0
+    A = rng.random((r, 40), dtype=np.float32)
+    Q = (A @ A.T).astype(np.float32)
+    P[:, 5] = 0.0                                                     # a zero column stays zero and keeps scale 1
+    ocs = (0.5 + 8.0 * rng.random(r, dtype=np.float32)) if scaled else None
+    ncs = (0.5 + 8.0 * rng.random(r, dtype=np.float32)) if transform else None
+    if ncs is not None:
+        ncs[7] = 0.0                                                  # no norm: factor 1
+    out = na.op_tri_update(P, num, Q, old_colsq=ocs, transform_num=transform, num_colsq=ncs, theta=theta, frag_theta=frag_theta)
+
+    d = np.float64
+    factor = lambda s: np.where(s > 0, np.float32(1.0) / np.sqrt(np.where(s > 0, s, np.float32(1.0))), np.float32(1.0)).astype(d)
+    old = P.astype(d) * (factor(ocs) if scaled else 1.0)
+    nm = num.astype(d)
+    if transform:
+        x = nm * factor(ncs)
+        nm = (1.0 - theta) * x + (theta / r) * x.sum(axis=1, keepdims=True)
+    want = old * nm / (old @ Q.astype(d) + np.finfo(np.float32).eps)
+    assert _rel(out["panel"], want) < 2e-6
+    assert np.max(np.abs(out["panel"] - want) / (np.abs(want) + 1e-30)) < 2e-5
+    if frag_theta == 0.0:
+        assert np.array_equal(out["pack"], _round_bf16(out["panel"])), "fragments are the bf16 rounding of the rows the kernel wrote"
+    else:
+        sm = _smooth(out["panel"], frag_theta)
+        assert np.all(np.abs(out["pack"].astype(d) - sm) <= 2.0 ** -8 * np.abs(sm) + 1e-30)
+        assert np.mean(out["pack"] == _round_bf16(sm.astype(np.float32))) > 0.99
+    sq = (out["panel"].astype(d) ** 2).sum(axis=0)
+    scale = np.where(sq > 0, 1.0 / np.sqrt(np.where(sq > 0, sq, 1.0)), 1.0)
+    np.testing.assert_allclose(out["scale"], scale, rtol=2e-6)
+    assert out["scale"][5] == 1.0
+    G = (out["pack"].astype(d) * scale).T @ (out["pack"].astype(d) * scale)
+    assert np.max(np.abs(out["gram"] - G)) < 3e-6 * max(1.0, np.max(np.abs(G)))   # fp32 accumulation over `length` rows
+    assert np.array_equal(out["gram"], out["gram"].T)
+
+
 # ------------------------------------------------------------------ long panels: 64 rows per workgroup in the wide update kernel
 from oracle import oracle  # noqa: E402
 

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave
 	//    has finished reading them as B operands
 	f32x4 nv[NCB][4];
-	float psum = 0.f;
+	float psum = 0.f, rsum = 0.f;                 // rsum: this lane's share of the new row's sum (smoothed fragments, PanelTriExtras)
 #pragma unroll
 	for (int i = 0; i < NCB; ++i)
 #pragma unroll
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			}
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) psum += o[gi] * num[gi];
+			if (NCB == 2) rsum += (o[0] + o[1]) + (o[2] + o[3]);
 			nv[i][q] = o;
 		}
 	__syncthreads();
@@ -244,6 +245,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 		for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(s_old + l31 * LD + 32 * (wave + 4 * i) + 8 * q + 4 * half) = nv[i][q];
 	psum += __shfl_xor(psum, 32);
 	if (half == 0) s_ps[wave * 32 + l31] = psum;
+	if (NCB == 2) {
+		rsum += __shfl_xor(rsum, 32);
+		if (half == 0) s_ps[128 + wave * 32 + l31] = rsum;
+	}
 	__syncthreads();
 
 	// 4. coalesced write-out, per-row error terms, per-column sums of squares
@@ -265,38 +270,37 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	}
 	if (NCB == 2 && tri.frag_out != nullptr) {
 		// bf16 fragments of the 32 new rows (two K-steps): fragment (kk, cb, h, c) = rows 16 kk + 8 h .. + 7 of column 32 cb + c, at
-		// [(K-step * RP / 32 + cb) * 64 + 32 h + c] -- the layout k_finish_panel_bf16 writes; optionally smoothed like there:
-		// f = frag_b * rowsum + frag_a * x for c < r (frag_a = diag - offdiag, frag_b = offdiag of the analytic S)
+		// [(K-step * 8 + cb) * 64 + 32 h + c] -- the layout k_finish_panel_bf16 writes; optionally smoothed like there:
+		// f = frag_b * rowsum + frag_a * x for c < r (frag_a = diag - offdiag, frag_b = offdiag of the analytic S).
+		// Thread (kk, h, cg): the eight rows of its (kk, h) as 16-byte LDS reads of columns 4 cg .. 4 cg + 3 -> four fragments, 64 contiguous bytes
+		// per thread and 4 KB per wave on the way out.
 		const bool smooth = tri.frag_b != 0.0f || tri.frag_a != 1.0f;
-		float* s_rs = s_ps + 128;                      // [32] row sums
-		if (smooth) {
-			const int y = tid >> 3, part = tid & 7;    // eight threads per row, 32 columns each (columns >= r hold zeros)
-			float t = 0.f;
-			for (int c = part * (RP / 8); c < (part + 1) * (RP / 8); ++c) t += s_old[y * LD + c];
-			t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
-			if (part == 0) s_rs[y] = t;
-			__syncthreads();
-		}
-		bf16x8* dst = reinterpret_cast<bf16x8*>(tri.frag_out);
-		const int nb = RP / 32;
-		for (int f = tid; f < 2 * nb * 64; f += 256) {
-			const int kk = f / (nb * 64), rem = f - kk * nb * 64, cb = rem >> 6, l = rem & 63;
-			const long ks = (long)blockIdx.x * 2 + kk;
-			if (ks >= tri.frag_KS) continue;
-			const int c = 32 * cb + (l & 31);
-			bf16x8 v;
+		const int cg = tid & 63, kh = tid >> 6, kk = kh >> 1, h = kh & 1;
+		const long ks = (long)blockIdx.x * 2 + kk;
+		if (ks < tri.frag_KS) {
+			f32x4 x[8];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const int y = 16 * kk + 8 * (l >> 5) + j;
-				float x = s_old[y * LD + c];
-				if (smooth) x = c < tri.r ? tri.frag_b * s_rs[y] + tri.frag_a * x : 0.f;
-				v[j] = (__bf16)x;
+			for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(s_old + (16 * kk + 8 * h + j) * LD + 4 * cg);
+			if (smooth) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int y = 16 * kk + 8 * h + j;
+					const float rs = ((s_ps[128 + y] + s_ps[160 + y]) + s_ps[192 + y]) + s_ps[224 + y];      // (columns >= r hold zeros)
+#pragma unroll
+					for (int i = 0; i < 4; ++i) x[j][i] = 4 * cg + i < tri.r ? tri.frag_b * rs + tri.frag_a * x[j][i] : 0.f;
+				}
 			}
-			dst[(ks * nb + cb) * 64 + l] = v;
+			bf16x8* dst = reinterpret_cast<bf16x8*>(tri.frag_out) + (ks * 8 + (cg >> 3)) * 64 + 32 * h + 4 * (cg & 7);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				bf16x8 v;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j][i];
+				dst[i] = v;
+			}
 		}
 	}
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Gram matrix G = P P^T of a wide panel on the MFMA pipe (reference: syrk / gemm for W^T W and H H^T,
@@ -1101,8 +1105,8 @@ bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && 
 template <int MODE, int NCB>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                               float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3, const PanelTriExtras& tri) {
-	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 160);
-	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 160);
+	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 256);      // (+ [4][32] error terms, [4][32] row sums)
+	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 256);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,

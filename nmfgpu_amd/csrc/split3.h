@@ -65,8 +65,15 @@ __device__ inline void store_split3(bf16x8* __restrict__ dst, long ks, int NBT, 
 // d(c) of a pending column scale handed over as staged sums of squares (PanelTriExtras, kernels.h): the vectors are added in order, every consumer
 // through this one function
 __device__ inline float tri_pending_scale(const float* __restrict__ colsq, int parts, int RP, int c) {
-	float s = colsq[c];
-	for (int k = 1; k < parts; ++k) s += colsq[(long)k * RP + c];
+	// (all loads of a batch of 16 in flight together: a dependent chain of `parts` round trips otherwise)
+	float s = 0.f;
+	for (int k0 = 0; k0 < parts; k0 += 16) {
+		float v[16];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) v[u] = k0 + u < parts ? colsq[(long)(k0 + u) * RP + c] : 0.f;
+#pragma unroll
+		for (int u = 0; u < 16; ++u) s += v[u];
+	}
 	return s > 0.f ? 1.0f / sqrtf(s) : 1.0f;
 }
 

@@ -262,12 +262,13 @@ def _config2(dtype=np.float32):
 @pytest.mark.parametrize("alg,kw", [
     ("ahcls", dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01)),
     ("gdcls", dict(lam=0.01)),
+    ("als", {}),
 ])
 def test_config5_full_size_20_iterations_against_fp64_and_fp32_restatements(alg, kw):
-    """BASELINE configs[4] at full size, 20 iterations.  Yardstick: the reference's own arithmetic restated in fp32
-    (Householder QR + apply + triangular solve in float, oracle.run on float32 data) is some distance d32 from the fp64
-    trajectory; the HIP path (fp64 Gauss-Jordan inverse, fp32 apply) must stay within max(1e-3, 2 d32) of fp64.
-    cond(W^T W + reg) of the final normal matrix is part of the message."""
+    """BASELINE configs[4] at full size, 20 iterations: the HIP path (fp64 Gauss-Jordan inverse, split-operand fp32 apply) stays within a FLAT 2e-4
+    of the fp64 trajectory -- the tolerance of every fp32 engine test -- and no further from it than 1.25 x the reference's own arithmetic restated
+    in fp32 (Householder QR + apply + triangular solve in float, oracle.run on float32 data).  Measured (tools/ls_family_drift.py, round 3):
+    2.7e-5 ... 4.9e-5 for the HIP path against 3.9e-5 ... 7.6e-5 for the float restatement, cond(W^T W + reg) 36 ... 130 (part of the message)."""
     V, W, H = _config2()
     iters = 20
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
@@ -283,8 +284,8 @@ def test_config5_full_size_20_iterations_against_fp64_and_fp32_restatements(alg,
     lam = kw.get("lambda_h", kw.get("lam", 0.0))
     cond = np.linalg.cond(G + lam * np.eye(64))
     dg = max(rel(Wg, W64), rel(Hg, H64))
-    assert dg < max(1e-3, 2.0 * d32), f"gpu {dg:.3e} vs fp32 restatement {d32:.3e}, cond(W^T W + reg) = {cond:.3e}"
-    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(1e-4, 10 * abs(ref32["frobenius"] - ref["frobenius"]) / ref["frobenius"]))
+    assert dg < 2e-4 and dg < 1.25 * d32, f"gpu {dg:.3e} vs fp32 restatement {d32:.3e}, cond(W^T W + reg) = {cond:.3e}"
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
     assert (Wg >= 0).all() and (Hg >= 0).all()
 
 

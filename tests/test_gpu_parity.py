@@ -482,8 +482,9 @@ def test_config2_full_size_mu_matches_oracle_and_invariants():
 
 
 @pytest.mark.parametrize("alg,kw,tol", [
-    ("ahcls", dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01), 5e-3),
-    ("gdcls", dict(lam=0.01), 5e-3),
+    ("ahcls", dict(lambda_w=0.01, lambda_h=0.01, alpha_w=0.01, alpha_h=0.01), 2e-4),     # (measured 4e-5 / 2e-5, tools/ls_family_drift.py)
+    ("gdcls", dict(lam=0.01), 2e-4),
+    ("acls", dict(lambda_w=0.01, lambda_h=0.01), 2e-4),
     ("nsnmf", dict(theta=0.5), 2e-4),
 ])
 def test_config5_full_size_algorithm_dispatch(alg, kw, tol):
@@ -497,7 +498,7 @@ def test_config5_full_size_algorithm_dispatch(alg, kw, tol):
     eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
     Wg, Hg = eng.get_factors()
     assert rel(Wg, W64) < tol and rel(Hg, H64) < tol
-    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=10 * tol)
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
 
 
 def test_factor_product_160_row_tiles_bit_exact(monkeypatch):

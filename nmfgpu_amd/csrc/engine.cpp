@@ -774,6 +774,8 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			ex.num_a = (float)(diag - off); ex.num_b = (float)off; ex.r = r_;
 			// ... and leaves the operand of the next V (S H)^T behind: the bf16 fragments of the smoothed new columns (AlgorithmNonSmoothNMF.h:194)
 			ex.frag_out = Hb_; ex.frag_KS = ksW_; ex.frag_a = (float)(diag - off); ex.frag_b = (float)off;
+			// (old_as_bf16 stays off here: the H update is bound by what a CU can ingest, not by its MFMAs -- 28.3 -> 27.7 us -- and H's distance from the
+			// fp64 oracle doubles, 5.7e-5 -> 1.5e-4 after 10 iterations; the W update gains 11 us at no measurable cost, tri_update_w)
 			// (qx3_holds_g_: k_smooth_gram left the split image of G_ in qx3_ -- Q = nullptr tells the update kernel so)
 			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, qx3_holds_g_ ? nullptr : G_, RP_, (int)npad_, eps,
 			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
@@ -1054,6 +1056,9 @@ Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
 		PanelTriExtras ex;
 		if (tri_scale_pending_) { ex.old_colsq = colsq_; ex.old_colsq_parts = colsq_parts_; }
 		ex.frag_out = Wtb_; ex.frag_KS = ksH_;
+		// the old rows enter W (SH)(SH)^T rounded to bf16: 63.7 -> 52.3 us, W's distance from the fp64 oracle unchanged (3.4e-4 vs 3.2e-4 after 10 iterations,
+		// 1.17e-3 vs 1.16e-3 after 40, tools/tri_accuracy.py); NMFAMD_TRI_FP32_DEN=1 keeps the six-term product
+		ex.old_as_bf16 = std::getenv("NMFAMD_TRI_FP32_DEN") == nullptr;
 		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 		qx3_holds_g_ = qx3_holds_hht_ = false;
 		HIPX(launch_colsq_stage(sumsq_part_, RP_, parts, colsq_, nullptr, stream_));

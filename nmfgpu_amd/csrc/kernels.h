@@ -128,6 +128,10 @@ struct PanelTriExtras {
 	// the panel's own pending column scale: every old value is read as old(y, c) * d(c), d from old_colsq
 	const float* old_colsq = nullptr;
 	int old_colsq_parts = 0;
+	// the old rows enter the r x r product rounded to bf16 (three MFMAs per tile instead of six, no operand split; Q keeps its three planes); the
+	// element-wise step keeps the fp32 values.  Measured at rank 256 / nsNMF (tools/tri_accuracy.py): the bf16 mode's distance from the fp64 oracle does
+	// not move (W 3.4e-4 vs 3.2e-4 after 10 iterations, 1.17e-3 vs 1.16e-3 after 40): it is set by the rounding of V and the factors in the big products
+	bool old_as_bf16 = false;
 	// bf16 fragments of the NEW rows (layout of k_finish_panel_bf16), K-steps >= frag_KS are not written; the 32-row kernel can smooth them on the way
 	// (f(y, c) = frag_a x(y, c) + frag_b sum_c' x(y, c'), c < r; needs r), the 128-row kernel writes them as they are (frag_a = 1, frag_b = 0)
 	void* frag_out = nullptr;

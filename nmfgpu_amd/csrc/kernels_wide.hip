@@ -158,14 +158,19 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 #pragma unroll
 				for (int j = 0; j < 4; ++j) { v[j] = b0[j]; v[4 + j] = b1[j]; }
 				bf16x8 hi, mid, lo;
-				split3(v, hi, mid, lo);
+				const bool b16 = NCB == 2 && tri.old_as_bf16;      // (PanelTriExtras: the panel's rows enter the product rounded to bf16; uniform)
+				if (b16) {
+#pragma unroll
+					for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
+					mid = hi; lo = hi;
+				} else split3(v, hi, mid, lo);
 #pragma unroll
 				for (int i = 0; i < NCB; ++i) {
 					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][2], hi, acc[i], 0, 0, 0);
-					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], lo, acc[i], 0, 0, 0);
-					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][1], mid, acc[i], 0, 0, 0);
+					if (!b16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], lo, acc[i], 0, 0, 0);
+					if (!b16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][1], mid, acc[i], 0, 0, 0);
 					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][1], hi, acc[i], 0, 0, 0);
-					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], mid, acc[i], 0, 0, 0);
+					if (!b16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], mid, acc[i], 0, 0, 0);
 					acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[d][i][0], hi, acc[i], 0, 0, 0);
 				}
 				int nu = u + DX + d;
@@ -881,7 +886,9 @@ static hipError_t launch_wide64(const float* P, float* Pout, const float* slabs,
 // (MFMAs 16.5, epilogue 17, staging of Q 13, operand split 8.5, skeleton 16), and delaying the second workgroup of each CU by
 // 6 .. 18 us made it slower, not faster.
 // ------------------------------------------------------------------------------------------
-template <int NC, bool HAS_PS>          // NC: column blocks of 32 (RP / 32); HAS_PS: per-row error terms wanted
+// A_BF16 (PanelTriExtras::old_as_bf16, the rank-256 bf16 mode): the old rows enter the r x r product rounded to bf16 -- the very values the product against V
+// multiplies with -- so the operand split and three of the six MFMAs per tile go; Q keeps its three planes.  The element-wise step still uses the fp32 rows.
+template <int NC, bool HAS_PS, bool A_BF16>          // NC: column blocks of 32 (RP / 32); HAS_PS: per-row error terms wanted
 __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 	const float* P, float* Pout, const float* __restrict__ slabs, int S, long slab_stride, float eps, float* __restrict__ ps, int len_valid,
 	float* __restrict__ sumsq_part, const bf16x8* __restrict__ Qx3, const float* __restrict__ old_colsq, int old_colsq_parts, bf16x8* __restrict__ frag_out, long frag_KS) {
@@ -928,7 +935,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 #pragma unroll
 			for (int j = 0; j < 4; ++j) { v[j] *= d0[j]; v[4 + j] *= d1[j]; }
 		}
-		split3(v, nh, nm, nl);
+		if (A_BF16) {
+#pragma unroll
+			for (int j = 0; j < 8; ++j) nh[j] = (__bf16)v[j];
+		} else split3(v, nh, nm, nl);
 	}
 	for (int u = 0; u < KSTEPS; u += DA) {
 #pragma unroll
@@ -955,7 +965,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 #pragma unroll
 					for (int j = 0; j < 4; ++j) { v[j] *= d0[j]; v[4 + j] *= d1[j]; }
 				}
-				split3(v, nh, nm, nl);
+				if (A_BF16) {
+#pragma unroll
+					for (int j = 0; j < 8; ++j) nh[j] = (__bf16)v[j];
+				} else split3(v, nh, nm, nl);
 				int na = ks + DA;
 				na = na < KSTEPS ? na : KSTEPS - 1;
 				ra[d][0] = *reinterpret_cast<const f32x4*>(prow + 16 * na); ra[d][1] = *reinterpret_cast<const f32x4*>(prow + 16 * na + 4);
@@ -970,10 +983,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_rows_mu(
 				const bf16x8 q0 = qa[cb & 1][0], q1 = qa[cb & 1][1], q2 = qa[cb & 1][2];
 				// smallest terms first; A = the panel rows (M = y), B = Q (N = c)
 				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q2, acc[cb], 0, 0, 0);
-				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, q0, acc[cb], 0, 0, 0);
-				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q1, acc[cb], 0, 0, 0);
+				if (!A_BF16) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, q0, acc[cb], 0, 0, 0);
+				if (!A_BF16) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q1, acc[cb], 0, 0, 0);
 				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q1, acc[cb], 0, 0, 0);
-				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q0, acc[cb], 0, 0, 0);
+				if (!A_BF16) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mid, q0, acc[cb], 0, 0, 0);
 				acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q0, acc[cb], 0, 0, 0);
 				__builtin_amdgcn_sched_barrier(0);
 			}
@@ -1073,9 +1086,11 @@ static hipError_t launch_rows_mu(const float* P, float* Pout, const float* slabs
 	const int old_parts = tri ? tri->old_colsq_parts : 0;
 	bf16x8* frag = tri ? reinterpret_cast<bf16x8*>(tri->frag_out) : nullptr;
 	const long frag_KS = tri ? tri->frag_KS : 0;
-	if (ps != nullptr) hipLaunchKernelGGL((k_panel_update_rows_mu<NC, true>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
+	if (ps != nullptr) hipLaunchKernelGGL((k_panel_update_rows_mu<NC, true, false>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
 	                                      sumsq_part, reinterpret_cast<const bf16x8*>(qx3), old_colsq, old_parts, frag, frag_KS);
-	else hipLaunchKernelGGL((k_panel_update_rows_mu<NC, false>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
+	else if (tri != nullptr && tri->old_as_bf16) hipLaunchKernelGGL((k_panel_update_rows_mu<NC, false, true>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
+	                                                               sumsq_part, reinterpret_cast<const bf16x8*>(qx3), old_colsq, old_parts, frag, frag_KS);
+	else hipLaunchKernelGGL((k_panel_update_rows_mu<NC, false, false>), dim3(blocks), dim3(256), 0, stream, P, Pout, slabs, S, slab_stride, eps, ps, len_valid,
 	                        sumsq_part, reinterpret_cast<const bf16x8*>(qx3), old_colsq, old_parts, frag, frag_KS);
 	return hipGetLastError();
 }

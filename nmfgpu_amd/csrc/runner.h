@@ -57,6 +57,42 @@ Status upload_input(nmfamd::Engine<T>& engine, const MatrixDescription<T>& V) {
 	return nmfamd::ST_INVALID;
 }
 
+// Columns [col0, col0 + ncols) of the input matrix into a shard's engine.  Dense: a pointer offset.  CSR / CSC / COO ("sparse V shards by column
+// blocks"): the rank filters the caller's arrays on the host into 0-based triplets of its block -- the index base applied to both index arrays exactly as
+// the single-engine upload applies it (reference: cusparseSetMatIndexBase, Matrix.h:158-160,184-186,215-217), entries outside the matrix dropped,
+// duplicates kept (they add) -- and uploads them as a COO block.
+template <typename T>
+Status upload_shard(nmfamd::Engine<T>& engine, const MatrixDescription<T>& V, long col0, long ncols) {
+	if (V.format == StorageFormat::Dense) return engine.upload_dense(V.dense.values + (size_t)col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+	std::vector<int> ri, ci; std::vector<T> vals;
+	const long m = V.rows, n = V.columns;
+	auto push = [&](long i, long j, T v) { if (i >= 0 && i < m && j >= col0 && j < col0 + ncols) { ri.push_back((int)i); ci.push_back((int)(j - col0)); vals.push_back(v); } };
+	switch (V.format) {
+	case StorageFormat::CSR: {
+		const long base = V.csr.base == IndexBase::One ? 1 : 0, nnz = V.csr.nnz;
+		if (nnz > 0 && (!V.csr.values || !V.csr.rowPtr || !V.csr.columnIndices)) return nmfamd::ST_INVALID;
+		for (long i = 0; i < m && nnz > 0; ++i)
+			for (long p = (long)V.csr.rowPtr[i] - base; p < (long)V.csr.rowPtr[i + 1] - base && p < nnz; ++p) if (p >= 0) push(i, (long)V.csr.columnIndices[p] - base, V.csr.values[p]);
+		break;
+	}
+	case StorageFormat::CSC: {
+		const long base = V.csc.base == IndexBase::One ? 1 : 0, nnz = V.csc.nnz;
+		if (nnz > 0 && (!V.csc.values || !V.csc.columnPtr || !V.csc.rowIndices)) return nmfamd::ST_INVALID;
+		for (long j = col0; j < col0 + ncols && j < n && nnz > 0; ++j)
+			for (long p = (long)V.csc.columnPtr[j] - base; p < (long)V.csc.columnPtr[j + 1] - base && p < nnz; ++p) if (p >= 0) push((long)V.csc.rowIndices[p] - base, j, V.csc.values[p]);
+		break;
+	}
+	case StorageFormat::COO: {
+		const long base = V.coo.base == IndexBase::One ? 1 : 0, nnz = V.coo.nnz;
+		if (nnz > 0 && (!V.coo.values || !V.coo.rowIndices || !V.coo.columnIndices)) return nmfamd::ST_INVALID;
+		for (long p = 0; p < nnz; ++p) push((long)V.coo.rowIndices[p] - base, (long)V.coo.columnIndices[p] - base, V.coo.values[p]);
+		break;
+	}
+	default: return nmfamd::ST_INVALID;
+	}
+	return engine.upload_sparse(3, vals.data(), ri.data(), ci.data(), (long)vals.size(), 0);
+}
+
 // ---- one engine on the context's device ------------------------------------------------------------------------------
 template <typename T>
 class SingleRunner : public Runner<T> {
@@ -138,7 +174,7 @@ public:
 	Status setup(const NmfDescription<T>& d) override {
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
-		if (d.inputMatrix.format != StorageFormat::Dense || world_ < 2 || world_ > 16 || (long)world_ > (long)n_) return nmfamd::ST_INVALID;
+		if (world_ < 2 || world_ > 16 || (long)world_ > (long)n_) return nmfamd::ST_INVALID;
 		const char* force = std::getenv("NMFAMD_COMM");
 		const bool shared = world_ > ndev;
 		local_ = shared || (force != nullptr && (std::strcmp(force, "p2p") == 0 || std::strcmp(force, "local") == 0)) || !nmfamd::rccl_available();
@@ -270,7 +306,7 @@ private:
 			rk.eng->set_stream(rk.stream);
 			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
 			Status s = rk.eng->allocate();
-			if (s == nmfamd::ST_OK) s = rk.eng->upload_dense(V.dense.values + (size_t)rk.col0 * V.dense.leadingDimension, V.dense.leadingDimension);
+			if (s == nmfamd::ST_OK) s = upload_shard(*rk.eng, V, rk.col0, rk.ncols);
 			return s;
 		};
 		if (st == nmfamd::ST_OK) st = make_engine(prm_);

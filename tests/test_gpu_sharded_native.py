@@ -101,11 +101,53 @@ def test_compute_with_numgpus_kmeans_init_threshold_stop_and_runs():
     assert rel(W2, W1) < 5e-4 and rel(H2, H1) < 5e-4
 
 
+@pytest.mark.parametrize("ranks,mode", [(2, 1), (3, 0)])
+def test_compute_with_numgpus_sparse_input_formats_shard_by_column_blocks(ranks, mode):
+    """sparse V shards by column blocks.  CSR / CSC / COO x index base 0 / 1 (COO unordered, one duplicated coordinate
+    pair whose values add) on N ranks: every format gives the SAME bits as the dense upload of the same matrix on the same ranks
+    (each rank densifies its own block: exact indexing, reference Matrix.h:145-232), and the run agrees with the single-GPU one."""
+    import scipy.sparse as sp
+    m, n, r, iters = 300, 250, 12, 15
+    rng = np.random.default_rng(17)
+    D = F((rng.random((m, n)) * (rng.random((m, n)) < 0.15)).astype(np.float32))
+    W0 = F((1.0 - rng.random((m, r))).astype(np.float32)); H0 = F((1.0 - rng.random((r, n))).astype(np.float32))
+    p = {"numGpus": ranks, "shardMode": mode}
+
+    def run(V, params):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(V, W, H, iterations=iters, parameters=params, summary=s) == na.ResultType.Success
+        return W, H, s.record(0).frobenius
+    Wd, Hd, fd = run(D, p)
+    W1, H1, f1 = run(D, {})
+    assert rel(Wd, W1) < 2e-4 and rel(Hd, H1) < 2e-4 and fd == pytest.approx(f1, rel=1e-6)
+    keep = []
+    for fmt in (na.StorageFormat.CSR, na.StorageFormat.CSC, na.StorageFormat.COO):
+        for base in (0, 1):
+            if fmt == na.StorageFormat.CSR:
+                sm = sp.csr_matrix(D); vals, a, b = sm.data, sm.indptr + base, sm.indices + base
+            elif fmt == na.StorageFormat.CSC:
+                sm = sp.csc_matrix(D); vals, a, b = sm.data, sm.indptr + base, sm.indices + base
+            else:
+                sm = sp.coo_matrix(D)
+                perm = rng.permutation(sm.nnz)
+                vals, a, b = sm.data[perm].copy(), (sm.row + base)[perm], (sm.col + base)[perm]
+                # split one entry into two triplets with the same coordinates: 0.75 v + 0.25 v (exact in fp32)
+                vals = np.concatenate([vals, vals[:1] * np.float32(0.25)]); vals[0] *= np.float32(0.75)
+                a = np.concatenate([a, a[:1]]); b = np.concatenate([b, b[:1]])
+            vals = np.ascontiguousarray(vals, np.float32); a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
+            keep.append((vals, a, b))
+            desc = na.api.sparse_description(fmt, m, n, vals, a, b, na.IndexBase.One if base else na.IndexBase.Zero)
+            Ws, Hs, fs = run(desc, p)
+            assert np.array_equal(Ws, Wd) and np.array_equal(Hs, Hd) and fs == fd, (fmt, base)
+
+
 def test_compute_with_numgpus_rejects_what_does_not_shard():
     V, W, H = problem(60, 50, 4, np.float32)
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "sparseCompute": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success
 
 

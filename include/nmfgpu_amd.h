@@ -249,15 +249,18 @@ NMFAMD_API int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offd
 NMFAMD_API int nmfamd_op_factor_passes_f32(const float* P, long ldp, int r, int len, const float* colsq, float theta, float* P_out, float* pack_out,
                                            float* G_raw, float* G_smooth, int reps, double* avg_us_finish, double* avg_us_gram);
 /* One multiplicative update of a panel (129 <= r <= 256) as the bf16 path at padded rank 256 runs it (csrc/kernels.h, PanelTriExtras).  A pending column
- * scale is given as the sums of squares it comes from: d(c) = s[c] > 0 ? 1 / sqrt(s[c]) : 1.
+ * scale is given as the sums of squares it comes from: d(c) = s[c] > 0 ? 1 / sqrt(s[c]) : 1; S = (1 - theta) I + (theta / r) 1 1^T.
  *   old'(y, c) = P(y, c) * d_old(c)                                       (old_colsq NULL: ones)
- *   num'(y, :) = a d_num .* num(y, :) + b sum(d_num .* num(y, :))          (transform_num != 0; a = 1 - theta, b = theta / r; num_colsq NULL: ones)
- *   P_out = old' .* num' ./ (old' Q + eps)                                 (unnormalised)
+ *   num'(y, :) = S (d_num .* num(y, :))                                    (transform_num != 0; num_colsq NULL: ones)
+ *   den(y, :)  = old'(y, :) Q + eps,  or  S D_num Q D_num S old'(y, :) + eps when transform_den != 0
+ *   P_out = old' .* num' ./ den                                            (unnormalised)
  *   pack_out = bf16 of P_out as written for the next product, smoothed by frag_theta first when that is not 0
- *   scale_out(c) = d of the columns of P_out, gram_out = diag(scale) pack^T pack diag(scale).
+ *   scale_out(c) = d of the columns of P_out, gram_out = diag(scale) pack^T pack diag(scale);
+ *   gram_raw_out = pack^T pack, gram_image_out = the same matrix read back from the split image the reduction writes beside it, diag_out = its diagonal.
  * Row-major [len][r] and [r][r]; outputs may be NULL. */
 NMFAMD_API int nmfamd_op_tri_update_f32(const float* P, const float* num, const float* Q, int r, int len, const float* old_colsq, int transform_num,
-                                        const float* num_colsq, float theta, float frag_theta, float* P_out, float* pack_out, float* scale_out, float* gram_out);
+                                        const float* num_colsq, float theta, float frag_theta, int transform_den, float* P_out, float* pack_out,
+                                        float* scale_out, float* gram_out, float* gram_raw_out, float* gram_image_out, float* diag_out);
 /* Test access to an engine's device intermediates in panel layout: which = 0 Wt, 1 H, 2 W^T W,
  * 3 H H^T, 4 slabs, 5 inverse, 6 V, 7 Vt. */
 NMFAMD_API int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count);

@@ -578,7 +578,8 @@ int nmfamd_op_inverse_f32(const float* A, long lda, int r, float offdiag, float 
 // scale + smoothing of the numerator rows, new rows written unnormalised together with their bf16 fragments; then the pending scale of the new panel and the
 // Gram matrix of its rounded rows.  All matrices row-major [len][r] / [r][r].
 int nmfamd_op_tri_update_f32(const float* P, const float* num, const float* Q, int r, int len, const float* old_colsq, int transform_num, const float* num_colsq,
-                             float theta, float frag_theta, float* P_out, float* pack_out, float* scale_out, float* gram_out) {
+                             float theta, float frag_theta, int transform_den, float* P_out, float* pack_out, float* scale_out, float* gram_out,
+                             float* gram_raw_out, float* gram_image_out, float* diag_out) {
 	if (!P || !num || !Q || r <= 0 || len <= 0) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	const int RP = padded_rank(r);
@@ -589,7 +590,9 @@ int nmfamd_op_tri_update_f32(const float* P, const float* num, const float* Q, i
 	hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
 	const int parts = panel_update_parts(RP, sizeof(float), (int)lp);
-	DevBuf dP, dN, dQ, dOs, dNs, dPack, dPart, dG, dSq, dStage, dScale, dQx, dDummy;
+	DevBuf dP, dN, dQ, dOs, dNs, dPack, dPart, dG, dSq, dStage, dScale, dQx, dDummy, dG2, dImg, dDiag;
+	const size_t img_bytes = (size_t)3 * 16 * (RP / 16 + 1) * (RP / 32) * 64;
+	if (dG2.alloc(sizeof(float) * RP * RP) != hipSuccess || dImg.alloc(img_bytes) != hipSuccess || dDiag.alloc(sizeof(float) * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
 	if (dP.alloc(sizeof(float) * RP * lp) != hipSuccess || dN.alloc(sizeof(float) * RP * lp) != hipSuccess || dQ.alloc(sizeof(float) * RP * RP) != hipSuccess ||
 	    dOs.alloc(sizeof(float) * RP) != hipSuccess || dNs.alloc(sizeof(float) * RP) != hipSuccess || dPack.alloc(pack_bytes) != hipSuccess ||
 	    dPart.alloc(sizeof(float) * (size_t)gram_tri_partial_elems(cus)) != hipSuccess || dG.alloc(sizeof(float) * RP * RP) != hipSuccess ||
@@ -609,11 +612,34 @@ int nmfamd_op_tri_update_f32(const float* P, const float* num, const float* Q, i
 	ex.frag_out = dPack.p; ex.frag_KS = KS;
 	const float foff = frag_theta / (float)(unsigned)r, fdiag = (float)((1.0 - frag_theta) + foff);
 	if (frag_theta != 0.0f) { ex.frag_a = fdiag - foff; ex.frag_b = foff; }
+	if (transform_den) { ex.den_transform = true; ex.den_a = ex.num_a; ex.den_b = ex.num_b; ex.den_colsq = ex.num_colsq; ex.den_colsq_parts = 1; }
 	if (launch_panel_update<float>(PANEL_MU, (float*)dP.p, (const float*)dN.p, 1, 0, (const float*)dQ.p, RP, (int)lp, std::numeric_limits<float>::epsilon(), nullptr, len,
 	                               (float*)dSq.p, nullptr, nullptr, nullptr, nullptr, 0, dQx.p, &ex) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_colsq_stage((const float*)dSq.p, RP, parts, (float*)dStage.p, nullptr, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_scale_panel_tri((float*)dDummy.p, RP, 4, (const float*)dStage.p, colsq_stage_parts(), (float*)dScale.p, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_gram_tri_bf16(dPack.p, RP, KS, cus, (float*)dPart.p, (float*)dG.p, (const float*)dStage.p, colsq_stage_parts(), cus, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	// the reduction that also leaves the split image and the diagonal (what the engine's H step consumes)
+	if (launch_gram_tri_bf16_image(dPack.p, RP, KS, cus, (float*)dPart.p, (float*)dG2.p, dImg.p, (float*)dDiag.p, cus, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (gram_raw_out && hipMemcpy2D(gram_raw_out, r * sizeof(float), dG2.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (diag_out && hipMemcpy(diag_out, dDiag.p, sizeof(float) * r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (gram_image_out) {
+		// image element: plane p of A(c, k) at bf16 index ((((ks * NBT + nb) * 3 + p) * 2 + h) * 32 + (c & 31)) * 8 + (k & 7), ks = k / 16, nb = c / 32, h = (k / 8) & 1; A(c, k) = G(k, c)
+		std::vector<uint16_t> h(img_bytes / 2);
+		if (hipMemcpy(h.data(), dImg.p, img_bytes, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
+		const int NBT = RP / 32;
+		for (int k = 0; k < r; ++k)
+			for (int c = 0; c < r; ++c) {
+				float sum = 0.f;
+				for (int pl = 2; pl >= 0; --pl) {
+					const size_t idx = (((((size_t)(k / 16) * NBT + c / 32) * 3 + pl) * 2 + ((k / 8) & 1)) * 32 + (c & 31)) * 8 + (k & 7);
+					const uint32_t bits = (uint32_t)h[idx] << 16;
+					float f;
+					std::memcpy(&f, &bits, 4);
+					sum += f;
+				}
+				gram_image_out[(size_t)k * r + c] = sum;
+			}
+	}
 	if (P_out && hipMemcpy2D(P_out, r * sizeof(float), dP.p, RP * sizeof(float), r * sizeof(float), len, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (scale_out && hipMemcpy(scale_out, dScale.p, sizeof(float) * r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (gram_out && hipMemcpy2D(gram_out, r * sizeof(float), dG.p, RP * sizeof(float), r * sizeof(float), r, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;

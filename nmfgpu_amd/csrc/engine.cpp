@@ -406,7 +406,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
 		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
-		tri_scale_pending_ = false;
+		tri_scale_pending_ = false; tri_scale_from_gram_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -451,7 +451,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; }
+	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -772,12 +772,16 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			ex.num_transform = true;
 			if (tri_scale_pending_) { ex.num_colsq = colsq_; ex.num_colsq_parts = colsq_parts_; }
 			ex.num_a = (float)(diag - off); ex.num_b = (float)off; ex.r = r_;
+			// ... and the denominator S D G D S H from the Gram matrix as the reduction left it (its split image is in qx3_): D and S around the product
+			ex.den_transform = true;
+			ex.den_a = ex.num_a; ex.den_b = ex.num_b;
+			ex.den_colsq = ex.num_colsq; ex.den_colsq_parts = ex.num_colsq_parts;
 			// ... and leaves the operand of the next V (S H)^T behind: the bf16 fragments of the smoothed new columns (AlgorithmNonSmoothNMF.h:194)
 			ex.frag_out = Hb_; ex.frag_KS = ksW_; ex.frag_a = (float)(diag - off); ex.frag_b = (float)off;
 			// (old_as_bf16 stays off here: the H update is bound by what a CU can ingest, not by its MFMAs -- 28.3 -> 27.7 us -- and H's distance from the
 			// fp64 oracle doubles, 5.7e-5 -> 1.5e-4 after 10 iterations; the W update gains 11 us at no measurable cost, tri_update_w)
-			// (qx3_holds_g_: k_smooth_gram left the split image of G_ in qx3_ -- Q = nullptr tells the update kernel so)
-			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, qx3_holds_g_ ? nullptr : G_, RP_, (int)npad_, eps,
+			// (qx3_holds_g_: the Gram reduction left the split image of W^T W in qx3_ -- Q = nullptr tells the update kernel so; else it packs Gw_raw_)
+			HIPX(launch_panel_update<T>(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, qx3_holds_g_ ? nullptr : reinterpret_cast<const T*>(Gw_raw_), RP_, (int)npad_, eps,
 			                            compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 			qx3_holds_g_ = false;
 			hb_valid_ = true;
@@ -928,12 +932,12 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		}
 	}
 	if (compute_error) {
-		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+		const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 			if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);      // (by-product of this iteration's H step)
 			else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 		}
-		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_));
+		HIPX(launch_trace_small<T>(ex_hht, wtw, RP_, r_, psR_, stream_, tri_trace_scale()));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	wx3_valid_ = false;
@@ -951,12 +955,12 @@ Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long
 	const T eps = std::numeric_limits<T>::epsilon();
 	if (Status s = materialize_w()) return s;           // (a pending column scale belongs to the old W; fold it in first)
 	if (compute_error) {
-		const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+		const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 			if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
 			else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 		}
-		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_));
+		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_, tri_trace_scale()));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	const long valid = std::max<long>(0, std::min<long>(rows, (long)m_ - row0));
@@ -1002,8 +1006,6 @@ void Engine<T>::tri_smoothing(T* offdiag, T* diag) const {
 template <typename T>
 Status Engine<T>::tri_prepare_w() {
 	if constexpr (std::is_same<T, float>::value) {
-		T off, diag;
-		tri_smoothing(&off, &diag);
 		const bool wide = qx3_ != nullptr && panel_update_wide_available(RP_);
 		if (!wtb_valid_) {
 			// plain re-rounding of the panel as it lies (no smoothing, no normalisation: W is as the caller / the gather left it)
@@ -1011,10 +1013,12 @@ Status Engine<T>::tri_prepare_w() {
 			wtb_valid_ = true;
 		}
 		if (!tri_gw_ready_) {
-			// W^T W of the ROUNDED W (the matrix the product multiplies V with), times the pending column scale on both sides: Gw_raw_ is the
-			// unsmoothed Gram matrix of the normalised W (the error term's operand, AlgorithmNonSmoothNMF.h:201-202), G_ its smoothed form S G S
-			HIPX(launch_gram_tri_bf16(Wtb_, RP_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, tri_scale_pending_ ? colsq_ : nullptr, colsq_parts_, num_cus_, stream_));
-			HIPX(launch_smooth_gram(Gw_raw_, G_, RP_, r_, off, diag, wide ? qx3_ : nullptr, stream_));
+			// W^T W of the ROUNDED W (the matrix the product multiplies V with), as the reduction leaves it: Gw_raw_ and its split image are NOT normalised
+			// and not smoothed -- the H update applies D and S around its r x r product (PanelTriExtras::den_transform), the error term's trace applies D
+			// (AlgorithmNonSmoothNMF.h:201-202 wants the unsmoothed W^T W).  Round 3 first ran k_smooth_gram here (6.5 us) and a staging launch for D (4.7 us).
+			// The diagonal of the matrix IS the new pending scale: sums of squares of the rounded columns (one "staged" vector).
+			HIPX(launch_gram_tri_bf16_image(Wtb_, RP_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, wide ? qx3_ : nullptr, tri_scale_from_gram_ ? colsq_ : nullptr, num_cus_, stream_));
+			if (tri_scale_from_gram_) { colsq_parts_ = 1; tri_scale_from_gram_ = false; }
 			tri_gw_ready_ = true;
 			qx3_holds_g_ = wide;
 		}
@@ -1059,11 +1063,14 @@ Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
 		// the old rows enter W (SH)(SH)^T rounded to bf16: 63.7 -> 52.3 us, W's distance from the fp64 oracle unchanged (3.4e-4 vs 3.2e-4 after 10 iterations,
 		// 1.17e-3 vs 1.16e-3 after 40, tools/tri_accuracy.py); NMFAMD_TRI_FP32_DEN=1 keeps the six-term product
 		ex.old_as_bf16 = std::getenv("NMFAMD_TRI_FP32_DEN") == nullptr;
-		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
+		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 		qx3_holds_g_ = qx3_holds_hht_ = false;
-		HIPX(launch_colsq_stage(sumsq_part_, RP_, parts, colsq_, nullptr, stream_));
-		colsq_parts_ = colsq_stage_parts();
-		tri_scale_pending_ = true;             // (the staged sums ARE the pending scale: every consumer forms 1 / sqrt(sum) itself, PanelTriExtras)
+		// The new pending scale comes out of the next Gram reduction (tri_prepare_w): d(c) = 1 / sqrt(sum of squares of the ROUNDED column c) -- the column
+		// norms of the matrix the product multiplies with; they differ from the fp32 norms by ~1e-5 relative (zero-mean rounding over m rows).  Every consumer
+		// (H update, next W update, error trace, materialize_w) runs after that reduction.
+		tri_scale_pending_ = true;
+		tri_scale_from_gram_ = true;
+		(void)parts;
 		wtb_valid_ = true;
 		tri_rows_cover_ = true;
 		tri_gw_ready_ = false;
@@ -1120,11 +1127,14 @@ Status Engine<T>::materialize_w() {
 			wx3_valid_ = false;
 		}
 		if (tri_scale_pending_) {
+			if (tri_scale_from_gram_) { if (Status s = tri_prepare_w()) return s; }      // (the scale of the last W update comes out of the Gram reduction)
 			// rank-256 bf16 path: W <- W diag(d), d from the staged sums of squares; the fragments (of the unscaled panel) are re-made on demand, the Gram matrices already
 			// describe the normalised W
 			HIPX(launch_scale_panel_tri(Wt_, RP_, mpad_, colsq_, colsq_parts_, nullptr, stream_));
 			tri_scale_pending_ = false;
 			wtb_valid_ = false;
+			tri_gw_ready_ = false;        // (Gw_raw_ and its image describe the unscaled panel)
+			qx3_holds_g_ = false;
 		}
 	}
 	return ST_OK;
@@ -1250,12 +1260,12 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 		}
 		if (!hht_done) HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
 		if (compute_error) {
-			const T* wtw = G_;                                  // MU: W^T W of this iteration's H step
+			const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 				if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
 				else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 			} else if (alg_ != ALG_MU) wtw = G2_;               // LS algorithms: copy saved before the regulariser
-			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_));
+			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_, tri_trace_scale()));
 		}
 		if (!constant_w) {
 			const int S = planW_.splits;

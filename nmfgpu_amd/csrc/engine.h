@@ -77,7 +77,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
@@ -219,7 +219,10 @@ private:
 	bool tri_ = false;
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
+	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
 	bool hb_valid_ = false;          // Hb_ holds the bf16 fragments of the current smoothed H (written by the H update)
+	// Gw_raw_ holds W^T W without the pending scale: what the error term's trace multiplies it with
+	const T* tri_trace_scale() const { return (tri_ && tri_scale_pending_) ? reinterpret_cast<const T*>(colsq_) : nullptr; }
 	bool tri_gw_ready_ = false;      // Gw_raw_ / G_ describe the current W
 	bool tri_rows_cover_ = false;    // the last w_normalize_rows() covered every row of W
 	int colsq_parts_ = 1;            // staged partial vectors in colsq_ (kernels_tri.hip: launch_colsq_stage)

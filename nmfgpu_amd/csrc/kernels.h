@@ -125,6 +125,13 @@ struct PanelTriExtras {
 	int num_colsq_parts = 0;
 	float num_a = 1.0f, num_b = 0.0f;
 	int r = 0;
+	// denominator with the smoothing (and a pending scale) applied around the r x r product instead of inside its operand (32-row kernel):
+	//   den(y, :) = S D G D S old(y, :),  S = den_a I + den_b 1 1^T on the first r columns, D = diag(d) from den_colsq (nullptr: ones), G = the split image given
+	// -- the Gram matrix arrives as the reduction left it (unnormalised, unsmoothed) and no O(r^2) pass over it is launched
+	bool den_transform = false;
+	float den_a = 1.0f, den_b = 0.0f;
+	const float* den_colsq = nullptr;
+	int den_colsq_parts = 0;
 	// the panel's own pending column scale: every old value is read as old(y, c) * d(c), d from old_colsq
 	const float* old_colsq = nullptr;
 	int old_colsq_parts = 0;
@@ -189,7 +196,7 @@ template <typename T>
 hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream);
 
 template <typename T>
-hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream);
+hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq = nullptr);
 
 template <typename T>
 hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream);
@@ -259,6 +266,10 @@ long gram_tri_partial_elems(int max_parts);
 // K-step, i.e. G = P~^T P~ of the ROUNDED panel P~ -- exactly the operand the product against V multiplies with, so numerator and denominator of the
 // H update refer to the same matrix.  colsq != nullptr: G(r, c) *= d(r) d(c), the pending column scale of the panel (PanelTriExtras).
 hipError_t launch_gram_tri_bf16(const void* frags, int RP, long KS, int max_parts, float* partial, float* G, const float* colsq, int colsq_parts, int num_cus, hipStream_t stream);
+// the same product, reduced WITHOUT any scaling into G and, in the same launch, into the split image x3_out that the update kernels take as their r x r operand
+// (launch_panel_update with Q = nullptr; A(c, k) = G(k, c)); diag_out[c] = G(c, c) = the sum of squares of column c of the rounded panel -- the pending
+// column scale of that panel in the form PanelTriExtras takes it (one "staged" vector)
+hipError_t launch_gram_tri_bf16_image(const void* frags, int RP, long KS, int max_parts, float* partial, float* G, void* x3_out, float* diag_out, int num_cus, hipStream_t stream);
 // P(y, c) *= d(c) over `rows` panel rows (folds a pending column scale, given as staged sums of squares, into the panel); scale_out (optional): the RP factors
 hipError_t launch_scale_panel_tri(float* P, int RP, long rows, const float* colsq, int colsq_parts, float* scale_out, hipStream_t stream);
 // Gs = S G S, S = (diag - offdiag) I + offdiag 1 1^T on the first r rows / columns

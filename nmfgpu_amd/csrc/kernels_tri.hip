@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "split3.h"
@@ -392,6 +393,70 @@ hipError_t launch_gram_tri_bf16(const void* frags, int RP, long KS, int max_part
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k_gram_tri_reduce, dim3(TRI_TILES * 16), dim3(256), 0, stream, partial, parts, G, colsq, colsq_parts, true);
+	return hipGetLastError();
+}
+
+// Reduction of the partial tiles that also writes the split image (three bf16 planes in fragment order, store_split3) and the diagonal.  Workgroup = 1 024
+// threads = 16 waves: wave (pq, gq) adds quarter pq of the slices for accumulator register g = 4 q + gq of tile t (blockIdx = 4 t + q); the four registers of
+// a q are rows 8 q .. 8 q + 7 of the tile's row block (gq + 4 (lane >> 5)), exactly the eight k of one image fragment.  Direct fragments A(c, k) = G(k, c) for
+// (k in row block i, c in column block j); for i != j also the mirrored ones A(r, k') = G(r, k') for k' in block j.  Diagonal tiles write the MFMA's own
+// values on both sides of the diagonal (the fp32 matrix keeps the upper triangle and mirrors it).
+__global__ __launch_bounds__(1024) void k_gram_tri_reduce_image(const float* __restrict__ partial, int parts, float* __restrict__ G, bf16x8* __restrict__ x3, float* __restrict__ diag) {
+	__shared__ float s_p[4][4][64];
+	__shared__ float s_v[4][64];
+	const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, pq = w >> 2, gq = w & 3;
+	const int t = blockIdx.x >> 2, q = blockIdx.x & 3, g = 4 * q + gq;
+	const float* p = partial + (long)t * 1024 + g * 64 + l;
+	const long stride = (long)TRI_TILES * 1024;
+	const int k0 = (parts * pq) / 4, k1 = (parts * (pq + 1)) / 4;
+	float sum = 0.f;
+	int k = k0;
+	for (; k + 16 <= k1; k += 16) {
+		float v[16];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) v[u] = p[(long)(k + u) * stride];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) sum += v[u];
+	}
+	for (; k < k1; ++k) sum += p[(long)k * stride];
+	s_p[pq][gq][l] = sum;
+	__syncthreads();
+	int i, j;
+	tri_tile(t, i, j);
+	if (pq == 0) {
+		sum = ((s_p[0][gq][l] + s_p[1][gq][l]) + s_p[2][gq][l]) + s_p[3][gq][l];
+		const int r = 32 * i + gq + 8 * q + 4 * (l >> 5), c = 32 * j + (l & 31);
+		if (i != j || r <= c) {
+			G[(long)r * TRI_RP + c] = sum;
+			if (r != c) G[(long)c * TRI_RP + r] = sum;
+			else if (diag != nullptr) diag[r] = sum;
+		}
+		s_v[gq][l] = sum;
+	}
+	__syncthreads();
+	if (x3 == nullptr) return;
+	if (tid < 32) {
+		float v8[8];
+#pragma unroll
+		for (int kk = 0; kk < 8; ++kk) v8[kk] = s_v[kk & 3][(kk >> 2) * 32 + tid];
+		store_split3(x3, (32 * i + 8 * q) >> 4, TRI_NB, j, q & 1, tid, v8);
+	} else if (tid < 64 && i != j) {
+		const int rr = (tid - 32) >> 2, mm = (tid - 32) & 3;
+		float v8[8];
+#pragma unroll
+		for (int kk = 0; kk < 8; ++kk) v8[kk] = s_v[rr & 3][(rr >> 2) * 32 + 8 * mm + kk];
+		store_split3(x3, (32 * j + 8 * mm) >> 4, TRI_NB, i, mm & 1, 8 * q + rr, v8);
+	}
+}
+
+hipError_t launch_gram_tri_bf16_image(const void* frags, int RP, long KS, int max_parts, float* partial, float* G, void* x3_out, float* diag_out, int num_cus, hipStream_t stream) {
+	if (RP != TRI_RP || KS <= 0) return hipErrorInvalidValue;
+	// (slices: one per CU.  128 / 64 slices measured at config 4: Gram 17.6 / 23.2 us + reduction 6.4 / 5.1 against 14.8 + 9.6 -- no gain)
+	const int parts = (int)std::max<long>(1, std::min<long>(std::min(num_cus, max_parts), KS / 4));
+	hipLaunchKernelGGL(k_gram_tri_bf16, dim3(parts), dim3(512), 0, stream, reinterpret_cast<const bf16x8*>(frags), (int)KS, parts, partial);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_gram_tri_reduce_image, dim3(TRI_TILES * 4), dim3(1024), 0, stream, partial, parts, G, reinterpret_cast<bf16x8*>(x3_out), diag_out);
 	return hipGetLastError();
 }
 

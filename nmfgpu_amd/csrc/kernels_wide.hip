@@ -44,12 +44,18 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	const int LD = RP + 4;
 	float* s_num = lds;                       // [32][LD]
 	float* s_old = lds + WIDE_YB * LD;        // [32][LD]   old values, then the new ones
-	float* s_ps = s_old + WIDE_YB * LD;       // [4][32]
+	float* s_ps = s_old + WIDE_YB * LD;       // [4][32] error terms, [4][32] row sums of the new rows
+	// PanelTriExtras::den_transform (rank 256; the launcher sizes the LDS for it): the product's operand u = D S old, the factors D, partial sums of D (G u)
+	const bool dent = NCB == 2 && tri.den_transform;
+	float* s_u = s_ps + 256;                  // [32][LD]
+	float* s_dg = s_u + WIDE_YB * LD;         // [RP]
+	float* s_tau = s_dg + RP;                 // [4][32]
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int half = lane >> 5, l31 = lane & 31;
 	const long base = (long)blockIdx.x * WIDE_YB * RP;
 	const int q4 = RP / 4;                    // float4 per panel row
+	if (dent) s_dg[tid] = tri.den_colsq != nullptr ? tri_pending_scale(tri.den_colsq, tri.den_colsq_parts, 256, tid) : 1.0f;      // (256 threads, 256 columns)
 
 	// 1. numerator = sum of the split-K slabs (slab order), old panel values.  All of a thread's loads of one
 	//    slab are issued together (NE independent 16-byte loads): one memory latency per slab, not per element.
@@ -72,6 +78,30 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 				const int e = tid + 256 * i, y = e / q4, c4 = e - y * q4;
 				if (NCB == 2 && tri.old_colsq != nullptr) old[i] *= od;
 				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = old[i];
+			}
+			if (dent) {
+				// u(y, c) = d(c) (den_a old(y, c) + den_b sum_c' old(y, c')) for c < r: a panel row is the 64 float4 of one wave (as for the numerator below)
+				const int c0 = 4 * (tid & 63);
+				f32x4 dg = {1.f, 1.f, 1.f, 1.f};
+				if (tri.den_colsq != nullptr) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) dg[j] = tri_pending_scale(tri.den_colsq, tri.den_colsq_parts, 256, c0 + j);
+				}
+				float rs[NE];
+#pragma unroll
+				for (int i = 0; i < NE; ++i) rs[i] = (old[i][0] + old[i][1]) + (old[i][2] + old[i][3]);      // (columns >= r hold zeros)
+#pragma unroll
+				for (int w = 32; w > 0; w >>= 1)
+#pragma unroll
+					for (int i = 0; i < NE; ++i) rs[i] += __shfl_xor(rs[i], w);
+#pragma unroll
+				for (int i = 0; i < NE; ++i) {
+					const int y = (tid + 256 * i) / q4;
+					f32x4 u;
+#pragma unroll
+					for (int j = 0; j < 4; ++j) u[j] = c0 + j < tri.r ? dg[j] * (tri.den_a * old[i][j] + tri.den_b * rs[i]) : 0.f;
+					*reinterpret_cast<f32x4*>(s_u + y * LD + c0) = u;
+				}
 			}
 		}
 		// (three slabs in flight, added in slab order: config 4's H update sums nine of them -- nine latencies in a row otherwise)
@@ -127,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	__syncthreads();
 
 	// 2. the r x r product
-	const float* vec = (MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 4 * half;
+	const float* vec = (dent ? s_u : MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 4 * half;
 	f32x16 acc[NCB];
 #pragma unroll
 	for (int i = 0; i < NCB; ++i)
@@ -139,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 		// six 32x32x16 MFMAs per 16 k replace eight 32x32x2 fp32 ones at a quarter of their cycles each.
 		const int NBT = RP / 32, ksteps = RP / 16;
 		const bf16x8* qf = Qx3 + (long)wave * 192 + lane;        // + (ks * NBT + 4 i) * 192 + plane * 64
-		const float* vb = (MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 8 * half;
+		const float* vb = (dent ? s_u : MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 8 * half;
 		constexpr int DX = NCB <= 2 ? 4 : 2;
 		bf16x8 af[DX][NCB][3];
 #pragma unroll
@@ -217,6 +247,28 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 		}
 	}
 
+	}
+
+	// den = S D acc: acc(c, y) <- den_a d(c) acc(c, y) + den_b sum_c' d(c') acc(c', y); the sum runs over this lane's 16 NCB columns, its half-wave
+	// partner's and the other three waves'
+	if (dent) {
+		float tl = 0.f;
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const int c = 32 * (wave + 4 * i) + 8 * (g >> 2) + 4 * half + (g & 3);
+				acc[i][g] *= s_dg[c];
+				tl += acc[i][g];
+			}
+		tl += __shfl_xor(tl, 32);
+		if (half == 0) s_tau[wave * 32 + l31] = tl;
+		__syncthreads();
+		const float tau = ((s_tau[l31] + s_tau[32 + l31]) + s_tau[64 + l31]) + s_tau[96 + l31];
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) acc[i][g] = tri.den_a * acc[i][g] + tri.den_b * tau;
 	}
 
 	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave
@@ -1120,8 +1172,10 @@ bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && 
 template <int MODE, int NCB>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                               float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3, const PanelTriExtras& tri) {
-	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 256);      // (+ [4][32] error terms, [4][32] row sums)
-	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 256);
+	// two panels + [4][32] error terms + [4][32] row sums; PanelTriExtras::den_transform (rank 256): a third panel, the RP factors, [4][32] partial sums
+	const size_t extra = NCB == 2 ? (size_t)WIDE_YB * (RP + 4) + RP + 128 : 0;
+	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 256 + (tri.den_transform ? extra : 0));
+	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 256 + extra);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
 	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,

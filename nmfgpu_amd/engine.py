@@ -428,23 +428,27 @@ def op_factor_passes(P: np.ndarray, theta: float = 0.0, colsq: Optional[np.ndarr
 
 
 def op_tri_update(P: np.ndarray, num: np.ndarray, Q: np.ndarray, *, old_colsq: Optional[np.ndarray] = None, transform_num: bool = False,
-                  num_colsq: Optional[np.ndarray] = None, theta: float = 0.0, frag_theta: float = 0.0):
+                  num_colsq: Optional[np.ndarray] = None, theta: float = 0.0, frag_theta: float = 0.0, transform_den: bool = False):
     """One multiplicative update of a (len, r) panel the way the rank-256 bf16 path runs it (nmfamd_op_tri_update_f32): pending column scale
     on the old values (given as the sums of squares it comes from), optional scale + smoothing of the numerator rows, the new rows
     unnormalised (`panel`), their bf16 rounding as the product operand (`pack`; smoothed by frag_theta first), the new pending scale
-    (`scale`) and the scaled Gram matrix of the rounded rows (`gram`)."""
+    (`scale`) and the scaled Gram matrix of the rounded rows (`gram`); `gram_raw`, `gram_image` and `diag`: the unscaled matrix, the same matrix read back
+    from the split image the reduction writes, its diagonal.  transform_den: the denominator is S D Q D S old instead of old Q (D from num_colsq)."""
     P = np.ascontiguousarray(P, dtype=np.float32); num = np.ascontiguousarray(num, dtype=np.float32); Q = np.ascontiguousarray(Q, dtype=np.float32)
     length, r = P.shape
     if num.shape != P.shape or Q.shape != (r, r):
         raise ValueError("shapes: P, num (len, r); Q (r, r)")
     osc = None if old_colsq is None else np.ascontiguousarray(old_colsq, dtype=np.float32)
     nsc = None if num_colsq is None else np.ascontiguousarray(num_colsq, dtype=np.float32)
-    out = {"panel": np.zeros_like(P), "pack": np.zeros_like(P), "scale": np.zeros(r, np.float32), "gram": np.zeros((r, r), np.float32)}
+    out = {"panel": np.zeros_like(P), "pack": np.zeros_like(P), "scale": np.zeros(r, np.float32), "gram": np.zeros((r, r), np.float32),
+           "gram_raw": np.zeros((r, r), np.float32), "gram_image": np.zeros((r, r), np.float32), "diag": np.zeros(r, np.float32)}
     st = library().nmfamd_op_tri_update_f32(C.c_void_p(P.ctypes.data), C.c_void_p(num.ctypes.data), C.c_void_p(Q.ctypes.data), r, length,
                                             C.c_void_p(osc.ctypes.data) if osc is not None else None, int(bool(transform_num)),
                                             C.c_void_p(nsc.ctypes.data) if nsc is not None else None, C.c_float(theta), C.c_float(frag_theta),
+                                            int(bool(transform_den)),
                                             C.c_void_p(out["panel"].ctypes.data), C.c_void_p(out["pack"].ctypes.data), C.c_void_p(out["scale"].ctypes.data),
-                                            C.c_void_p(out["gram"].ctypes.data))
+                                            C.c_void_p(out["gram"].ctypes.data), C.c_void_p(out["gram_raw"].ctypes.data), C.c_void_p(out["gram_image"].ctypes.data),
+                                            C.c_void_p(out["diag"].ctypes.data))
     if st != 0:
         raise EngineError(st, "nmfamd_op_tri_update_f32")
     return out

@@ -72,10 +72,11 @@ def test_rejected_shapes():
 
 
 # ------------------------------------------------------------------ the update that leaves the next product's operands behind
-@pytest.mark.parametrize("length,r,theta,transform,scaled,frag_theta", [(1000, 256, 0.5, False, True, 0.0), (33, 200, 0.0, False, False, 0.0), (777, 256, 0.4, True, True, 0.0),
-                                                                        (33024, 256, 0.5, False, True, 0.0), (33024, 256, 0.3, True, False, 0.0), (4096, 129, 0.6, True, True, 0.5),
-                                                                        (6250, 256, 0.5, True, True, 0.5)])
-def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r, theta, transform, scaled, frag_theta):
+@pytest.mark.parametrize("length,r,theta,transform,scaled,frag_theta,den", [(1000, 256, 0.5, False, True, 0.0, False), (33, 200, 0.0, False, False, 0.0, False),
+                                                                            (777, 256, 0.4, True, True, 0.0, False), (33024, 256, 0.5, False, True, 0.0, False),
+                                                                            (33024, 256, 0.3, True, False, 0.0, False), (4096, 129, 0.6, True, True, 0.5, True),
+                                                                            (6250, 256, 0.5, True, True, 0.5, True), (500, 256, 0.0, True, True, 0.0, True)])
+def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r, theta, transform, scaled, frag_theta, den):
     """PanelTriExtras (csrc/kernels.h): the old values carry a pending column scale (kernel::normalizeColumns as a factor,
     KernelNormalizeColumns.cu:37-58), the numerator rows get scale + smoothing (S D (W^T V) = (W D S)^T V, AlgorithmNonSmoothNMF.h:174-178),
     the new rows are written unnormalised with their bf16 fragments (the H update smooths them on the way: S H, :194); 33 024 rows without
@@ -90,7 +91,7 @@ def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r
     ncs = (0.5 + 8.0 * rng.random(r, dtype=np.float32)) if transform else None
     if ncs is not None:
         ncs[7] = 0.0                                                  # no norm: factor 1
-    out = na.op_tri_update(P, num, Q, old_colsq=ocs, transform_num=transform, num_colsq=ncs, theta=theta, frag_theta=frag_theta)
+    out = na.op_tri_update(P, num, Q, old_colsq=ocs, transform_num=transform, num_colsq=ncs, theta=theta, frag_theta=frag_theta, transform_den=den)
 
     d = np.float64
     factor = lambda s: np.where(s > 0, np.float32(1.0) / np.sqrt(np.where(s > 0, s, np.float32(1.0))), np.float32(1.0)).astype(d)
@@ -99,7 +100,12 @@ def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r
     if transform:
         x = nm * factor(ncs)
         nm = (1.0 - theta) * x + (theta / r) * x.sum(axis=1, keepdims=True)
-    want = old * nm / (old @ Q.astype(d) + np.finfo(np.float32).eps)
+    Qd = Q.astype(d)
+    if den:          # S D Q D S around the product (the H step: Q = W^T W as the Gram reduction leaves it, D its pending scale, AlgorithmNonSmoothNMF.h:176-178)
+        Sm = (1.0 - theta) * np.eye(r) + (theta / r) * np.ones((r, r))
+        Dm = np.diag(factor(ncs)) if ncs is not None else np.eye(r)
+        Qd = Sm @ Dm @ Qd @ Dm @ Sm
+    want = old * nm / (old @ Qd + np.finfo(np.float32).eps)
     assert _rel(out["panel"], want) < 2e-6
     assert np.max(np.abs(out["panel"] - want) / (np.abs(want) + 1e-30)) < 2e-5
     if frag_theta == 0.0:
@@ -115,6 +121,12 @@ def test_update_with_pending_scale_fragments_and_output_side_smoothing(length, r
     G = (out["pack"].astype(d) * scale).T @ (out["pack"].astype(d) * scale)
     assert np.max(np.abs(out["gram"] - G)) < 3e-6 * max(1.0, np.max(np.abs(G)))   # fp32 accumulation over `length` rows
     assert np.array_equal(out["gram"], out["gram"].T)
+    # the reduction that leaves the unscaled matrix, its split image (three bf16 planes: exact to ~2^-24 relative) and the diagonal
+    Graw = out["pack"].astype(d).T @ out["pack"].astype(d)
+    assert np.max(np.abs(out["gram_raw"] - Graw)) < 3e-6 * np.max(np.abs(Graw))
+    assert np.array_equal(out["gram_raw"], out["gram_raw"].T)
+    assert np.array_equal(out["diag"], np.diag(out["gram_raw"]))
+    assert np.max(np.abs(out["gram_image"].astype(d) - out["gram_raw"].astype(d))) <= 2.0 ** -22 * np.max(np.abs(Graw)) + 3e-6 * np.max(np.abs(Graw))
 
 
 # ------------------------------------------------------------------ long panels: 64 rows per workgroup in the wide update kernel

@@ -163,10 +163,11 @@ def test_long_panels_match_the_oracle(m, n, r, alg, kw):
         np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("m,n", [(33000, 140), (500, 420)])
+@pytest.mark.parametrize("m,n", [(33000, 140), (500, 420), (150, 33000)])
 def test_rank256_bf16_path_tracks_fp32(m, n):
-    """nsNMF at r = 256 with bf16 product operands (the fused passes of kernels_tri.hip; long W: the update writes to a scratch panel and one
-    launch normalises, packs and takes the Gram matrix) against the fp64 oracle within the bf16 mode's stated 2e-2, error terms included."""
+    """nsNMF at r = 256 with bf16 product operands (kernels_tri.hip: pending column scale, scale and smoothing around the H update's products, fragments
+    written by the update kernels, Gram matrices from the fragments; long W: the 128-row update kernel, long H: the 32-row one with its transforms)
+    against the fp64 oracle within the bf16 mode's stated 2e-2, error terms included."""
     r, theta, iters = 256, 0.5, 10
     rng = np.random.default_rng(m)
     V = _F(rng.random((m, n)).astype(np.float32))

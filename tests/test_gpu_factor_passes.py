@@ -189,6 +189,37 @@ def test_rank256_bf16_path_tracks_fp32(m, n):
     assert np.array_equal(Wg, W2) and np.array_equal(Hg, H2)
 
 
+def test_rank256_bf16_path_factors_read_in_the_middle_of_a_run():
+    """get_factors() folds the pending column scale into W (and drops the fragments and the Gram image made from the unscaled panel); the run
+    continues from the normalised W.  Same trajectory as the uninterrupted run up to the bf16 mode's rounding (bf16 of W D instead of bf16 of W)."""
+    m, n, r, theta = 33000, 150, 256, 0.5
+    rng = np.random.default_rng(77)
+    V = _F(rng.random((m, n)).astype(np.float32))
+    W = _F((1.0 - rng.random((m, r))).astype(np.float32))
+    H = _F((1.0 - rng.random((r, n))).astype(np.float32))
+    out = []
+    for stops in ((10,), (3, 4, 3)):
+        eng = na.Engine(m, n, r, "nsnmf", theta=theta, precision="bf16")
+        eng.upload(V); eng.set_factors(W, H)
+        it = 1
+        for k in stops:
+            eng.iterate(k, first_iteration=it, error_every=10, last_iteration=10)
+            it += k
+            Wg, Hg = eng.get_factors()
+            np.testing.assert_allclose(np.linalg.norm(_smooth_inverse(Wg, theta), axis=0), 1.0, rtol=1e-4)      # W S is returned; W itself has unit columns
+        out.append((Wg, Hg, eng.frobenius))
+        eng.close()
+    assert _rel(out[1][0], out[0][0]) < 2e-3 and _rel(out[1][1], out[0][1]) < 2e-3
+    assert out[1][2] == pytest.approx(out[0][2], rel=1e-3)
+
+
+def _smooth_inverse(WS, theta):
+    """W from the W S that get_factors returns for nsNMF (S = (1 - theta) I + theta / r 1 1^T, inverted in fp64)."""
+    r = WS.shape[1]
+    S = (1.0 - theta) * np.eye(r) + theta / r * np.ones((r, r))
+    return WS.astype(np.float64) @ np.linalg.inv(S)
+
+
 @pytest.mark.parametrize("alg,r,kw,const_w", [("mu", 200, {}, False), ("nsnmf", 256, dict(theta=0.3), True), ("mu", 256, {}, True)])
 def test_rank256_bf16_path_other_entries(alg, r, kw, const_w):
     """The same fused passes serve the multiplicative update (theta = 0: S = I) and constant basis vectors (W never written, the

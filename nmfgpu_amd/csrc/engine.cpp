@@ -242,6 +242,7 @@ Status Engine<T>::allocate() {
 			HIPX(dalloc(&Gw_raw_, rr));
 			HIPX(dalloc(&Gh_raw_, rr));
 			HIPX(dalloc(&colsq_, (long)RP_ * colsq_stage_parts()));
+			tri_w_den_bf16_ = std::getenv("NMFAMD_TRI_FP32_DEN") == nullptr;
 		}
 	}
 	if (alg_ == ALG_NSNMF) {
@@ -1062,7 +1063,7 @@ Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
 		ex.frag_out = Wtb_; ex.frag_KS = ksH_;
 		// the old rows enter W (SH)(SH)^T rounded to bf16: 63.7 -> 52.3 us, W's distance from the fp64 oracle unchanged (3.4e-4 vs 3.2e-4 after 10 iterations,
 		// 1.17e-3 vs 1.16e-3 after 40, tools/tri_accuracy.py); NMFAMD_TRI_FP32_DEN=1 keeps the six-term product
-		ex.old_as_bf16 = std::getenv("NMFAMD_TRI_FP32_DEN") == nullptr;
+		ex.old_as_bf16 = tri_w_den_bf16_;
 		HIPX(launch_panel_update<T>(PANEL_MU, Wt_, num, S, stride, hht, RP_, (int)mpad_, eps, nullptr, m_, nullptr, nullptr, stream_, nullptr, nullptr, 0, qx3_, &ex));
 		qx3_holds_g_ = qx3_holds_hht_ = false;
 		// The new pending scale comes out of the next Gram reduction (tri_prepare_w): d(c) = 1 / sqrt(sum of squares of the ROUNDED column c) -- the column

@@ -220,6 +220,7 @@ private:
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
+	bool tri_w_den_bf16_ = true;     // the W update's r x r product takes the old rows rounded to bf16 (NMFAMD_TRI_FP32_DEN=1: six-term fp32-accurate product)
 	bool hb_valid_ = false;          // Hb_ holds the bf16 fragments of the current smoothed H (written by the H update)
 	// Gw_raw_ holds W^T W without the pending scale: what the error term's trace multiplies it with
 	const T* tri_trace_scale() const { return (tri_ && tri_scale_pending_) ? reinterpret_cast<const T*>(colsq_) : nullptr; }

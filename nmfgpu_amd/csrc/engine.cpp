@@ -843,7 +843,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 
 template <typename T>
 Status Engine<T>::w_products(T* exchange) {
-	if (prm_.divergence != 0 || sparse_) return ST_INVALID;
+	if (prm_.divergence != 0) return ST_INVALID;      // (the KL update is not sharded; sparse Frobenius compute is: the two products are SpMMs over the shard's CSC / CSR images)
 	T* ex_hht = exchange + (long)RP_ * mpad_;
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
@@ -880,7 +880,7 @@ Status Engine<T>::w_products(T* exchange) {
 
 template <typename T>
 Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
-	if (prm_.divergence != 0 || sparse_) return ST_INVALID;
+	if (prm_.divergence != 0) return ST_INVALID;      // (the KL update is not sharded; sparse Frobenius compute is: the two products are SpMMs over the shard's CSC / CSR images)
 	const T eps = std::numeric_limits<T>::epsilon();
 	const T* ex_hht = exchange + (long)RP_ * mpad_;
 	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) {

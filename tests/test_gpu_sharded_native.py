@@ -142,12 +142,38 @@ def test_compute_with_numgpus_sparse_input_formats_shard_by_column_blocks(ranks,
             assert np.array_equal(Ws, Wd) and np.array_equal(Hs, Hd) and fs == fd, (fmt, base)
 
 
+@pytest.mark.parametrize("ranks,mode,r", [(2, 1, 12), (3, 0, 12), (2, 0, 100)])
+def test_compute_with_numgpus_sparse_compute_shards_the_csc_and_csr_images(ranks, mode, r):
+    """Parameter "sparseCompute" on N ranks (sparse V shards by column blocks of the CSC mirror): every rank keeps the CSC / CSR images of
+    its column block resident and runs the two products as SpMMs over them; same run as the one-GPU sparse-compute engine and as the dense oracle."""
+    import scipy.sparse as sp
+    m, n, iters = 400, 330, 20
+    rng = np.random.default_rng(5 + r)
+    D = F((rng.random((m, n)) * (rng.random((m, n)) < 0.2)).astype(np.float32))
+    W0 = F((1.0 - rng.random((m, r))).astype(np.float32)); H0 = F((1.0 - rng.random((r, n))).astype(np.float32))
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W0, H0))
+    ref = oracle.run("mu", D64, W64, H64, iters)
+    sm = sp.csr_matrix(D)
+    vals = np.ascontiguousarray(sm.data, np.float32); ptr = np.ascontiguousarray(sm.indptr, np.int32); idx = np.ascontiguousarray(sm.indices, np.int32)
+    desc = na.api.sparse_description(na.StorageFormat.CSR, m, n, vals, ptr, idx)
+    out = []
+    for params in ({"sparseCompute": 1}, {"sparseCompute": 1, "numGpus": ranks, "shardMode": mode}):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(desc, W, H, iterations=iters, parameters=params, summary=s) == na.ResultType.Success
+        out.append((W, H, s.record(0).frobenius))
+    (W1, H1, f1), (Wn, Hn, fn) = out
+    assert rel(Wn, W64) < 5e-4 and rel(Hn, H64) < 5e-4
+    assert rel(Wn, W1) < 2e-4 and rel(Hn, H1) < 2e-4
+    assert fn == pytest.approx(ref["frobenius"], rel=1e-4) and fn == pytest.approx(f1, rel=1e-5)
+
+
 def test_compute_with_numgpus_rejects_what_does_not_shard():
     V, W, H = problem(60, 50, 4, np.float32)
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
-    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "sparseCompute": 1}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "sparseCompute": 1, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success
 
 

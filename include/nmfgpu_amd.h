@@ -147,6 +147,9 @@ NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* o
 NMFAMD_API int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error);
 NMFAMD_API int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange);
 NMFAMD_API int nmfamd_engine_w_finish(nmfamd_engine* e, const void* exchange, int compute_error);
+/* A caller that drives the three phases for a team of ONE rank (no reduction between w_products and w_finish: `exchange` reaches w_finish as w_products
+ * left it) may say so: the engine then skips work that only a reduced buffer needs (rank 256 / bf16: re-splitting H H^T).  sole != 0 is a promise. */
+NMFAMD_API int nmfamd_engine_set_sole_rank(nmfamd_engine* e, int sole);
 /* Row-block form of nmfamd_engine_w_finish for callers that reduce-scatter the panel themselves (the torch-facing wrapper
  * nmfgpu_amd/distributed.py; the native loop nmfamd_sharded_* does the same inside the library): num_rows = the reduced
  * (V H^T)^T rows [row0, row0 + rows) in panel layout (DEVICE), hht = the reduced H H^T (DEVICE, padded_rank^2), colsq =

@@ -291,6 +291,11 @@ int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error) {
 	                   [&](Engine<double>& g) { return g.h_step(compute_error != 0); });
 }
 
+int nmfamd_engine_set_sole_rank(nmfamd_engine* e, int sole) {
+	return dispatch(e, [&](Engine<float>& g) { g.set_sole_rank(sole != 0); return ST_OK; },
+	                   [&](Engine<double>& g) { g.set_sole_rank(sole != 0); return ST_OK; });
+}
+
 int nmfamd_engine_w_products(nmfamd_engine* e, void* exchange) {
 	if (!exchange) return NMFAMD_INVALID_ARGUMENT;
 	return dispatch(e, [&](Engine<float>& g) { return g.w_products((float*)exchange); },

@@ -857,7 +857,7 @@ Status Engine<T>::w_products(T* exchange) {
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (tri_) {
-			if (Status s = tri_prepare_h(ex_hht, false)) return s;
+			if (Status s = tri_prepare_h(ex_hht, sole_rank_)) return s;      // (a team of one: nothing is added to ex_hht before the W update reads it)
 			if (Status s = product_w(H_, nullptr, exchange, true)) return s;
 			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
@@ -942,7 +942,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	wx3_valid_ = false;
-	if (tri_) return tri_update_w(exchange, 1, 0, ex_hht);
+	if (tri_) return tri_update_w(exchange, 1, 0, (sole_rank_ && qx3_holds_hht_) ? nullptr : ex_hht);
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 	return ST_OK;
@@ -1028,10 +1028,10 @@ Status Engine<T>::tri_prepare_w() {
 }
 
 // hht = (S H)(S H)^T for the W step, from the bf16 fragments of the smoothed columns the H update left in Hb_ -- the Gram matrix of exactly the operand
-// V is multiplied with.  (local_q is kept for the callers' sake: the split image of hht is made by the update's launcher either way.)
+// V is multiplied with.  local_q: hht stays what the W update multiplies with (no reduction over ranks in between), so the reduction also leaves its split
+// image in qx3_ and the update's launcher need not pack it (k_pack_panel_x3, 4.9 us).
 template <typename T>
 Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
-	(void)local_q;
 	if constexpr (std::is_same<T, float>::value) {
 		if (!hb_valid_) {
 			// H did not come from this engine's H update (set_factors / randomize between the two half-steps): one finishing pass makes the fragments
@@ -1040,9 +1040,11 @@ Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
 			HIPX(launch_finish_panel_bf16(H_, RP_, r_, 0, npad_, nullptr, 0, off, diag, Hb_, ksW_, stream_));
 			hb_valid_ = true;
 		}
-		HIPX(launch_gram_tri_bf16(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, nullptr, 0, num_cus_, stream_));
+		const bool image = local_q && qx3_ != nullptr && panel_update_wide_available(RP_);
+		if (image) HIPX(launch_gram_tri_bf16_image(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, qx3_, nullptr, num_cus_, stream_));
+		else HIPX(launch_gram_tri_bf16(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, nullptr, 0, num_cus_, stream_));
 		qx3_holds_g_ = false;
-		qx3_holds_hht_ = false;
+		qx3_holds_hht_ = image;
 	}
 	return ST_OK;
 }

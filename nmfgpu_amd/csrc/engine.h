@@ -42,6 +42,8 @@ public:
 	// Row-block form of the sharded W step (sharded.cpp): the padded row count becomes a multiple of 128 * blocks, so that
 	// the Wt panel splits into `blocks` equal row blocks.  Call before allocate().
 	void set_row_blocks(int blocks) { row_blocks_ = blocks > 1 ? blocks : 1; }
+	// the sharded three-phase API driven by a team of ONE rank: the exchange buffer goes from w_products() to w_finish() as it is
+	void set_sole_rank(bool sole) { sole_rank_ = sole; }
 	// The one-pass iteration (kernels_onepass.hip) claims every CU of the device for one persistent launch: engines that run
 	// beside others on one device (rank threads of a team) opt out.  Call before allocate().
 	void set_one_pass(bool allow) { one_pass_allowed_ = allow; }
@@ -220,6 +222,7 @@ private:
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
+	bool sole_rank_ = false;
 	bool tri_w_den_bf16_ = true;     // the W update's r x r product takes the old rows rounded to bf16 (NMFAMD_TRI_FP32_DEN=1: six-term fp32-accurate product)
 	bool hb_valid_ = false;          // Hb_ holds the bf16 fragments of the current smoothed H (written by the H update)
 	// Gw_raw_ holds W^T W without the pending scale: what the error term's trace multiplies it with

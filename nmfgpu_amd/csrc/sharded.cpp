@@ -26,6 +26,7 @@ Status ShardedRank<T>::prepare() {
 	if (!eng_ || !comm_ || (mode_ != SHARD_ROW_BLOCKS && mode_ != SHARD_REPLICATED)) return ST_INVALID;
 	if (eng_->error_terms_per_factor_row() && mode_ != SHARD_REPLICATED) { last_error_ = "GDCLS / ALS family: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	const int world = comm_->world(), rank = comm_->rank();
+	eng_->set_sole_rank(world == 1 && mode_ == SHARD_REPLICATED);
 	long first = 0, count = 0;
 	shard_columns(total_columns_, world, rank, &first, &count);
 	if (count != eng_->n() || rows_ != eng_->m()) { last_error_ = "shard shape does not match shard_columns()"; return ST_INVALID; }

@@ -162,6 +162,8 @@ class ShardedMU:
         # force_collectives: issue the all-reduce / all-gather even in a one-rank group (they are identities there);
         # lets a single-GPU box exercise the RCCL calls, their stream ordering against the engine's kernels included
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
+        if self.world == 1 and mode == "replicated" and hasattr(backend, "engine"):
+            backend.engine.set_sole_rank(True)      # (identity collectives included: the buffer reaches w_finish as w_products left it)
         self.total_elements = int(np.uint32(rows) * np.uint32(total_columns))  # the reference multiplies unsigned ints
         self._frobenius = 0.0
         self._rmsd = 0.0

@@ -187,6 +187,10 @@ class Engine:
     def h_step(self, compute_error: bool = False):
         self._check(self._lib.nmfamd_engine_h_step(self._h, int(compute_error)), "h_step")
 
+    def set_sole_rank(self, sole: bool):
+        """A team of one rank: the exchange buffer goes from w_products to w_finish unchanged (nmfamd_engine_set_sole_rank)."""
+        self._check(self._lib.nmfamd_engine_set_sole_rank(self._h, int(bool(sole))), "set_sole_rank")
+
     def w_products(self, exchange_ptr: int):
         self._check(self._lib.nmfamd_engine_w_products(self._h, C.c_void_p(exchange_ptr)), "w_products")
 

@@ -222,12 +222,12 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		if (idx >= 0) shard_mode = d.parameters[idx].value != 0 ? nmfamd::SHARD_REPLICATED : nmfamd::SHARD_ROW_BLOCKS;
 		if (num_gpus > 1) {
 			const bool mult = d.algorithm == NmfAlgorithm::Multiplicative || d.algorithm == NmfAlgorithm::nsNMF;
-			if (d.useConstantBasisVectors || prm.divergence != 0 || num_gpus > 16 || (unsigned)num_gpus > d.inputMatrix.columns) {
-				log_error("[ERROR] 'numGpus' > 1 needs the Frobenius objective, no constant basis vectors, and at most 16 ranks!");
+			if (d.useConstantBasisVectors || num_gpus > 16 || (unsigned)num_gpus > d.inputMatrix.columns) {
+				log_error("[ERROR] 'numGpus' > 1 needs a problem without constant basis vectors and at most 16 ranks!");
 				return ResultType::ErrorInvalidArgument;
 			}
-			// GDCLS and the ALS family: W is updated from the all-reduced sums on every rank (the row-block form covers the multiplicative rule)
-			if (!mult) shard_mode = nmfamd::SHARD_REPLICATED;
+			// GDCLS, the ALS family and the KL update: W is updated from the all-reduced sums on every rank (the row-block form covers the Frobenius multiplicative rule)
+			if (!mult || prm.divergence != 0) shard_mode = nmfamd::SHARD_REPLICATED;
 		}
 	}
 

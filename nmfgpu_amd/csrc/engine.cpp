@@ -707,7 +707,7 @@ void Engine<T>::finalize_error(bool resolve) {
 		kl_unresolved_ = true;
 	}
 	if (resolve && kl_unresolved_) {
-		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
+		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)(err_total_columns_ > 0 ? err_total_columns_ : n_)));
 		double d = -sum_v_;
 		for (int i = 0; i < m_; ++i) d += (double)h_klrow_[i];
 		for (int c = 0; c < r_; ++c) d += (double)h_sW_[c] * (double)h_sH_[c];
@@ -722,7 +722,7 @@ void Engine<T>::finalize_error(bool resolve) {
 		err_unresolved_ = true;
 	}
 	if (resolve && err_unresolved_) {
-		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)n_));
+		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)(err_total_columns_ > 0 ? err_total_columns_ : n_)));
 		err_unresolved_ = false;
 	}
 }
@@ -739,6 +739,7 @@ template <typename T>
 Status Engine<T>::h_step(bool compute_error) {
 	// first call of an iteration in the sharded form: decides whether this iteration's products are timed
 	timing_now_ = timing_ && (timing_iter_++ % timing_stride_ == 0);
+	if (prm_.divergence != 0) { kl_err_iter_ = compute_error; return kl_h_step(); }
 	return h_step_impl(compute_error);
 }
 
@@ -843,7 +844,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 
 template <typename T>
 Status Engine<T>::w_products(T* exchange) {
-	if (prm_.divergence != 0) return ST_INVALID;      // (the KL update is not sharded; sparse Frobenius compute is: the two products are SpMMs over the shard's CSC / CSR images)
+	if (prm_.divergence != 0) return kl_w_products(exchange, kl_err_iter_);      // (sparse Frobenius compute shards through the code below: its two products are SpMMs over the shard's images)
 	T* ex_hht = exchange + (long)RP_ * mpad_;
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
@@ -880,7 +881,7 @@ Status Engine<T>::w_products(T* exchange) {
 
 template <typename T>
 Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
-	if (prm_.divergence != 0) return ST_INVALID;      // (the KL update is not sharded; sparse Frobenius compute is: the two products are SpMMs over the shard's CSC / CSR images)
+	if (prm_.divergence != 0) return kl_w_finish(exchange, compute_error);
 	const T eps = std::numeric_limits<T>::epsilon();
 	const T* ex_hht = exchange + (long)RP_ * mpad_;
 	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) {
@@ -1513,6 +1514,82 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	}
 	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
 	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
+	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+	return ST_OK;
+}
+
+// ---- the KL update in the three phases of the column-sharded form ---------------------------------------------------------------------
+// Rank g holds the CSC / CSR images of V(:, J_g), H(:, J_g) and a replica of W.  The H half-step is local.  The W half-step's numerator
+// sum_j Q(i, j) H(:, j) and the row sums of H are sums over ALL columns: every rank contributes its columns' part through the exchange buffer
+// (layout: Engine::exchange_count), as do the per-row error terms; the W update and its normalisation then run replicated.
+template <typename T>
+Status Engine<T>::kl_h_step() {
+	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	record_begin();
+	if (kl_blocks_h_ > 1) HIPX(launch_kl_fused<T>(csc_bptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, kl_part_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, kl_blocks_h_, (long)RP_ * npad_));
+	else HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
+	record_end();
+	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
+	if (kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_));
+	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::kl_w_products(T* exchange, bool compute_error) {
+	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	T* num = exchange;
+	T* hht = num + (long)RP_ * mpad_;
+	T* sh = hht + (long)RP_ * RP_;
+	T* tv = sh + RP_;
+	T* tk = tv + mpad_;
+	record_begin();
+	if (kl_blocks_w_ > 1) {
+		HIPX(launch_kl_fused<T>(csr_bptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, kl_part_, compute_error ? kl_tpart_ : (T*)nullptr,
+		                        compute_error ? kl_tpart_ + (long)kl_blocks_w_ * mpad_ : (T*)nullptr, m_, (int)mpad_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
+		// the blocks' partial numerator panels (and error terms), block order, before the sum over ranks
+		HIPX(launch_reduce_partials<T>(kl_part_, kl_blocks_w_, (long)RP_ * mpad_, num, (long)RP_ * mpad_, stream_));
+		if (compute_error) {
+			HIPX(launch_reduce_partials<T>(kl_tpart_, kl_blocks_w_, mpad_, tv, m_, stream_));
+			HIPX(launch_reduce_partials<T>(kl_tpart_ + (long)kl_blocks_w_ * mpad_, kl_blocks_w_, mpad_, tk, m_, stream_));
+		}
+	} else {
+		HIPX(launch_kl_fused<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, num, compute_error ? tv : (T*)nullptr, compute_error ? tk : (T*)nullptr,
+		                        m_, (int)mpad_, stream_));
+	}
+	record_end();
+	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sh, stream_));
+	if (compute_error) HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, hht, stream_));
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::kl_w_finish(const T* exchange, bool compute_error) {
+	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	const T eps = std::numeric_limits<T>::epsilon();
+	const int norm_parts = (int)(mpad_ / 128);
+	const T* num = exchange;
+	const T* hht = num + (long)RP_ * mpad_;
+	const T* sh = hht + (long)RP_ * RP_;
+	const T* tv = sh + RP_;
+	const T* tk = tv + mpad_;
+	if (compute_error) {
+		// as iterate_kl: Frobenius error by the trace formula with (W_{k-1}, H_k), KL divergence next to it -- from the reduced terms
+		HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G_, stream_));
+		HIPX(launch_trace_small<T>(hht, G_, RP_, r_, psR_, stream_));
+		finalize_error(false);
+		T* p = pin_kl_;
+		HIPX(hipMemcpyAsync(p, tv, sizeof(T) * m_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(p + m_, tk, sizeof(T) * m_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(p + 2 * (size_t)m_, sW_, sizeof(T) * RP_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(p + 2 * (size_t)m_ + RP_, sh, sizeof(T) * RP_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipMemcpyAsync(p + 2 * (size_t)m_ + 2 * RP_, psR_, sizeof(T) * r_, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipEventRecord(err_event_, stream_));
+		kl_pending_ = true;
+	}
+	HIPX(launch_kl_update<T>(Wt_, num, sh, RP_, (int)mpad_, eps, sumsq_part_, stream_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
 	return ST_OK;
 }

@@ -71,7 +71,13 @@ public:
 	Status h_step(bool compute_error);
 	Status w_products(T* exchange);
 	Status w_finish(const T* exchange, bool compute_error);
-	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_; }
+	// KL update (sparse V): the exchange also carries the row sums of the local H and, on error iterations, the per-row error terms:
+	//   [ numerator panel RP x mpad | H_g H_g^T RP x RP | rowsum(H_g) RP | tr terms mpad | KL terms mpad ]
+	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_ + (prm_.divergence != 0 ? (long)RP_ + 2 * mpad_ : 0); }
+	bool is_kl() const { return prm_.divergence != 0; }
+	// sharded runs: the error terms refer to the whole matrix (sorted tr(V^T V) terms of ALL columns, sum of ALL entries, total column count)
+	void set_error_globals(const std::vector<T>& vtv_sorted_all, double sum_v_all, long total_columns) { h_vtv_ = vtv_sorted_all; sum_v_ = sum_v_all; err_total_columns_ = total_columns; }
+	double sum_v() const { return sum_v_; }
 	// Row-block form of w_finish (reduce-scatter by row blocks of W -> every GPU updates its rows -> all-reduce
 	// of the r column-norm partials -> all-gather of the normalised rows).  num_rows: the reduced (V H^T)^T rows
 	// [row0, row0 + rows) in panel layout; hht: the reduced H H^T.  w_update_rows leaves the r partial sums of squares of
@@ -223,6 +229,11 @@ private:
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
 	bool sole_rank_ = false;
+	bool kl_err_iter_ = false;       // sharded KL: h_step's compute_error, for the W-side evaluation in w_products
+	long err_total_columns_ = 0;     // sharded runs: columns of the whole matrix (0: this engine's own n)
+	Status kl_h_step();
+	Status kl_w_products(T* exchange, bool compute_error);
+	Status kl_w_finish(const T* exchange, bool compute_error);
 	bool tri_w_den_bf16_ = true;     // the W update's r x r product takes the old rows rounded to bf16 (NMFAMD_TRI_FP32_DEN=1: six-term fp32-accurate product)
 	bool hb_valid_ = false;          // Hb_ holds the bf16 fragments of the current smoothed H (written by the H update)
 	// Gw_raw_ holds W^T W without the pending scale: what the error term's trace multiplies it with

@@ -24,6 +24,7 @@ ShardedRank<T>::~ShardedRank() {
 template <typename T>
 Status ShardedRank<T>::prepare() {
 	if (!eng_ || !comm_ || (mode_ != SHARD_ROW_BLOCKS && mode_ != SHARD_REPLICATED)) return ST_INVALID;
+	if (eng_->is_kl() && mode_ != SHARD_REPLICATED) { last_error_ = "KL update: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	if (eng_->error_terms_per_factor_row() && mode_ != SHARD_REPLICATED) { last_error_ = "GDCLS / ALS family: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	const int world = comm_->world(), rank = comm_->rank();
 	eng_->set_sole_rank(world == 1 && mode_ == SHARD_REPLICATED);
@@ -59,6 +60,18 @@ Status ShardedRank<T>::prepare() {
 	vtv_all_.clear();
 	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); vtv_all_.insert(vtv_all_.end(), err_pin_ + (long)p * L, err_pin_ + (long)p * L + c); }
 	std::sort(vtv_all_.begin(), vtv_all_.end());
+	if (eng_->is_kl()) {
+		// the KL divergence needs sum(V) over ALL columns: every rank's sum as a (high, low) pair of T, summed over the ranks (a plain fp32 sum of
+		// 10^7-sized values would lose the units digit)
+		const double mine = eng_->sum_v();
+		T pair[4] = {(T)mine, (T)(mine - (double)(T)mine), T(0), T(0)};
+		if (hipMemcpyAsync(err_dev_, pair, sizeof(T) * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail("hipMemcpyAsync(sum V)");
+		if (hipStreamSynchronize(s) != hipSuccess) return fail("hipStreamSynchronize");
+		if (world > 1) { if (Status st = comm_->all_reduce(err_dev_, 4, (int)sizeof(T), s)) { last_error_ = comm_->last_error(); return st; } }
+		if (hipMemcpyAsync(pair, err_dev_, sizeof(T) * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync(sum V back)");
+		if (hipStreamSynchronize(s) != hipSuccess) return fail("hipStreamSynchronize");
+		eng_->set_error_globals(vtv_all_, (double)pair[0] + (double)pair[1], total_columns_);
+	}
 	if (hipMemsetAsync(err_dev_, 0, sizeof(T) * (size_t)(L * world), s) != hipSuccess) return fail("hipMemsetAsync");
 	return ST_OK;
 }
@@ -90,7 +103,7 @@ Status ShardedRank<T>::iterate(bool compute_error) {
 		if (Status st = comm_->all_gather_inplace(eng_->w_panel(), RP * blk_rows_, eb, s)) return comm_fail(st);
 		eng_->w_rows_replaced();
 	}
-	if (compute_error) return launch_error_gather();
+	if (compute_error && !eng_->is_kl()) return launch_error_gather();      // (KL: the terms travelled in the exchange buffer, the engine keeps them)
 	return ST_OK;
 }
 

@@ -40,8 +40,10 @@ public:
 	Status prepare();                       // buffers + the gathered, sorted tr(V^T V) terms (after the upload)
 	Status iterate(bool compute_error);
 	Status run(int count, int first_iteration, int error_every, int last_iteration);
-	double frobenius() { finalize(); return frob_; }
-	double rmsd() { finalize(); return rmsd_; }
+	// (KL update: the engine resolves its own, reduced, error terms -- per row of W, not per column)
+	double frobenius() { if (eng_->is_kl()) return eng_->frobenius(); finalize(); return frob_; }
+	double rmsd() { if (eng_->is_kl()) return eng_->rmsd(); finalize(); return rmsd_; }
+	double kl_divergence() { return eng_->is_kl() ? eng_->kl_divergence() : 0.0; }
 	int mode() const { return mode_; }
 	const char* last_error() const { return last_error_; }
 

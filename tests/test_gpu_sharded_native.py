@@ -168,12 +168,59 @@ def test_compute_with_numgpus_sparse_compute_shards_the_csc_and_csr_images(ranks
     assert fn == pytest.approx(ref["frobenius"], rel=1e-4) and fn == pytest.approx(f1, rel=1e-5)
 
 
+@pytest.mark.parametrize("ranks,r,dtype,tol", [(2, 8, np.float32, 5e-4), (3, 70, np.float32, 5e-4), (2, 5, np.float64, 1e-9)])
+def test_compute_with_numgpus_kl_divergence_update(ranks, r, dtype, tol):
+    """The KL-divergence update (extension; Lee & Seung 2001) on N column shards: H half-step local, the W half-step's numerator, the row sums of H and
+    the per-row error terms summed over the ranks in ONE all-reduce, W update replicated.  Against the literature oracle and the one-GPU engine."""
+    import scipy.sparse as sp
+    m, n, iters = 260, 230, 20
+    rng = np.random.default_rng(31 + r)
+    D = F((rng.random((m, n)) * (rng.random((m, n)) < 0.25)).astype(dtype))
+    W0 = F((1.0 - rng.random((m, r))).astype(dtype)); H0 = F((1.0 - rng.random((r, n))).astype(dtype))
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W0, H0))
+    ref = oracle.run_kl(D64, W64, H64, iters)
+    sm = sp.csc_matrix(D)
+    vals = np.ascontiguousarray(sm.data, dtype); ptr = np.ascontiguousarray(sm.indptr, np.int32); idx = np.ascontiguousarray(sm.indices, np.int32)
+    desc = na.api.sparse_description(na.StorageFormat.CSC, m, n, vals, ptr, idx)
+    out = []
+    for params in ({"divergence": 1}, {"divergence": 1, "numGpus": ranks}):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(desc, W, H, iterations=iters, parameters=params, summary=s) == na.ResultType.Success
+        out.append((W, H, s.record(0).frobenius, s.record(0).rmsd))
+    (W1, H1, f1, r1), (Wn, Hn, fn, rn) = out
+    assert rel(Wn, W64) < tol and rel(Hn, H64) < tol
+    assert rel(Wn, W1) < tol and rel(Hn, H1) < tol
+    assert fn == pytest.approx(ref["frobenius"], rel=1e-4 if dtype == np.float32 else 1e-9)
+    assert fn == pytest.approx(f1, rel=1e-5) and rn == pytest.approx(r1, rel=1e-5)
+
+
+def test_compute_with_numgpus_kl_divergence_update_with_a_blocked_gather(monkeypatch):
+    """The same with the W half-step's gather of H cut into L2-sized blocks on every rank (13 000 columns per rank x 64 padded features > 3 MiB;
+    1 MiB blocks asked for): the blocks' partial numerators are summed in block order before they join the sum over the ranks."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("NMFAMD_KL_BLOCK_KB", "1024")
+    m, n, r, iters = 200, 26000, 8, 10
+    rng = np.random.default_rng(3)
+    D = F((rng.random((m, n)) * (rng.random((m, n)) < 0.02)).astype(np.float32))
+    W0 = F((1.0 - rng.random((m, r))).astype(np.float32)); H0 = F((1.0 - rng.random((r, n))).astype(np.float32))
+    D64, W64, H64 = (F(x.astype(np.float64)) for x in (D, W0, H0))
+    ref = oracle.run_kl(D64, W64, H64, iters)
+    sm = sp.csr_matrix(D)
+    vals = np.ascontiguousarray(sm.data, np.float32); ptr = np.ascontiguousarray(sm.indptr, np.int32); idx = np.ascontiguousarray(sm.indices, np.int32)
+    desc = na.api.sparse_description(na.StorageFormat.CSR, m, n, vals, ptr, idx)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    s = na.Summary()
+    assert na.compute(desc, W, H, iterations=iters, parameters={"divergence": 1, "numGpus": 2}, summary=s) == na.ResultType.Success
+    assert rel(W, W64) < 5e-4 and rel(H, H64) < 5e-4
+    assert s.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
+
+
 def test_compute_with_numgpus_rejects_what_does_not_shard():
     V, W, H = problem(60, 50, 4, np.float32)
-    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
-    assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 2, "sparseCompute": 1, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, algorithm=na.NmfAlgorithm.nsNMF, parameters={"numGpus": 2, "divergence": 1, "theta": 0.5}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success
 
 

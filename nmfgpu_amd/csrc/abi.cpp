@@ -222,8 +222,8 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 		if (idx >= 0) shard_mode = d.parameters[idx].value != 0 ? nmfamd::SHARD_REPLICATED : nmfamd::SHARD_ROW_BLOCKS;
 		if (num_gpus > 1) {
 			const bool mult = d.algorithm == NmfAlgorithm::Multiplicative || d.algorithm == NmfAlgorithm::nsNMF;
-			if (d.useConstantBasisVectors || num_gpus > 16 || (unsigned)num_gpus > d.inputMatrix.columns) {
-				log_error("[ERROR] 'numGpus' > 1 needs a problem without constant basis vectors and at most 16 ranks!");
+			if (num_gpus > 16 || (unsigned)num_gpus > d.inputMatrix.columns) {
+				log_error("[ERROR] 'numGpus' > 1: at most 16 ranks and at least one column of the input matrix per rank!");
 				return ResultType::ErrorInvalidArgument;
 			}
 			// GDCLS, the ALS family and the KL update: W is updated from the all-reduced sums on every rank (the row-block form covers the Frobenius multiplicative rule)

@@ -29,6 +29,13 @@ namespace nmfamd {
 
 template <typename T>
 double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw) {
+	return std::sqrt(resolve_frobenius_squared<T>(vtv_sorted, htwtv, hhtwtw));
+}
+template double resolve_frobenius<float>(const std::vector<float>&, std::vector<float>&, std::vector<float>&);
+template double resolve_frobenius<double>(const std::vector<double>&, std::vector<double>&, std::vector<double>&);
+
+template <typename T>
+double resolve_frobenius_squared(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw) {
 	std::sort(htwtv.begin(), htwtv.end());
 	std::sort(hhtwtw.begin(), hhtwtw.end());
 	double acc = 0.0;
@@ -38,10 +45,10 @@ double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv
 		if (j < htwtv.size()) acc -= 2.f * htwtv[j];   // float literal: the product is formed in T, as in the reference
 		if (j < hhtwtw.size()) acc += hhtwtw[j];
 	}
-	return std::sqrt(acc);
+	return acc;
 }
-template double resolve_frobenius<float>(const std::vector<float>&, std::vector<float>&, std::vector<float>&);
-template double resolve_frobenius<double>(const std::vector<double>&, std::vector<double>&, std::vector<double>&);
+template double resolve_frobenius_squared<float>(const std::vector<float>&, std::vector<float>&, std::vector<float>&);
+template double resolve_frobenius_squared<double>(const std::vector<double>&, std::vector<double>&, std::vector<double>&);
 
 // Size of the device's memory-side cache (AMD Infinity Cache): not in hipDeviceProp_t, so a table by architecture -- 256 MiB
 // on gfx942 / gfx950 in SPX mode (/opt/skills/guides/MI355X_MICROARCH.md, "Infinity Cache (L3) 256 MiB") -- which
@@ -729,7 +736,8 @@ void Engine<T>::finalize_error(bool resolve) {
 
 template <typename T>
 void Engine<T>::resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements) {
-	frob_ = resolve_frobenius<T>(vtv_sorted, htwtv, hhtwtw);
+	frob2_ = resolve_frobenius_squared<T>(vtv_sorted, htwtv, hhtwtw);
+	frob_ = std::sqrt(frob2_);
 	rmsd_ = frob_ / std::sqrt((double)total_elements);
 }
 

@@ -102,6 +102,7 @@ public:
 	bool sparse_mode() const { return sparse_; }
 	long nnz() const { return nnz_; }
 	double frobenius() { finalize_error(true); return frob_; }
+	double frobenius_squared() { finalize_error(true); return frob2_; }      // the resolved sum before the root
 	double rmsd() { finalize_error(true); return rmsd_; }
 
 	// Timing of the dominant kernel (the factor product): when enabled, every launch is bracketed
@@ -272,7 +273,7 @@ private:
 	bool err_pending_ = false, err_unresolved_ = false;
 	int err_count_ = 0;
 	std::vector<T> h_vtv_, h_psN_, h_psR_;
-	double frob_ = 0, rmsd_ = 0;
+	double frob_ = 0, frob2_ = 0, rmsd_ = 0;
 
 	bool timing_ = false;
 	int timing_stride_ = 1;
@@ -286,5 +287,8 @@ private:
 // (source/nmf/FrobeniusResolver.cpp:29-51).  The two iteration-dependent vectors are sorted here.
 template <typename T>
 double resolve_frobenius(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw);
+// ... before the root (negative for a term vector that is not an error at all: the ALS family's constant-W trace)
+template <typename T>
+double resolve_frobenius_squared(const std::vector<T>& vtv_sorted, std::vector<T>& htwtv, std::vector<T>& hhtwtw);
 
 } // namespace nmfamd

@@ -207,14 +207,34 @@ public:
 		}
 		return command(CMD_INIT);
 	}
-	Status set_constant_w(NmfDescription<T>&) override { return nmfamd::ST_INVALID; }
-	Status iterate(bool compute_error, bool constant_w) override {
-		if (constant_w) return nmfamd::ST_INVALID;
-		compute_error_ = compute_error;
-		return command(CMD_ITERATE);
+	// Constant basis vectors (every algorithm): W is given and stays, so the column shards are INDEPENDENT problems -- each rank fits its own columns of H
+	// with its engine's single-GPU iteration (reference quirks of that mode included), no collective; ||V - W H||_F^2 is the sum of the shards' squares.
+	Status set_constant_w(NmfDescription<T>& d) override {
+		hostW_ = d.outputMatrixW.dense.values; ldw_ = d.outputMatrixW.dense.leadingDimension;
+		// ALS / ACLS / AHCLS in this mode report the reference's literal term vector: tr(H^T W^T V) is replaced by sum_c ||W(:, c)||^2 (W traced against
+		// itself).  That term is the same on every rank, so the shards' sums hold it N times where the one-GPU value holds it once.
+		const_w_trace_ = 0.0;
+		if (alg_ == nmfamd::ALG_ALS || alg_ == nmfamd::ALG_ACLS || alg_ == nmfamd::ALG_AHCLS) {
+			for (long c = 0; c < r_; ++c)
+				for (long i = 0; i < m_; ++i) { const double w = (double)hostW_[c * ldw_ + i]; const_w_trace_ += w * w; }
+		}
+		return command(CMD_CONSTW);
 	}
-	double frobenius() override { return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->frobenius() : 0.0; }
-	double rmsd() override { return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->rmsd() : 0.0; }
+	Status iterate(bool compute_error, bool constant_w) override {
+		compute_error_ = compute_error;
+		constant_w_ = constant_w;
+		const Status st = command(CMD_ITERATE);
+		if (st == nmfamd::ST_OK && constant_w && compute_error) return command(CMD_ERROR);
+		return st;
+	}
+	double frobenius() override {
+		if (constant_w_) { double s = 2.0 * (world_ - 1) * const_w_trace_; for (auto& rk : ranks_) s += rk->frob2; return std::sqrt(s); }
+		return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->frobenius() : 0.0;
+	}
+	double rmsd() override {
+		if (constant_w_) return frobenius() / std::sqrt((double)(unsigned)((unsigned)m_ * (unsigned)n_));      // (unsigned product, like the reference)
+		return (!ranks_.empty() && ranks_[0]->sh) ? ranks_[0]->sh->rmsd() : 0.0;
+	}
 	Status store(NmfDescription<T>& d) override {
 		outW_ = d.outputMatrixW.dense.values; out_ldw_ = d.outputMatrixW.dense.leadingDimension;
 		outH_ = d.outputMatrixH.dense.values; out_ldh_ = d.outputMatrixH.dense.leadingDimension;
@@ -225,7 +245,7 @@ public:
 	const char* last_error() const override { return error_.c_str(); }
 
 private:
-	enum Command { CMD_SETUP, CMD_INIT, CMD_ITERATE, CMD_STORE, CMD_SYNC, CMD_EXIT };
+	enum Command { CMD_SETUP, CMD_INIT, CMD_ITERATE, CMD_STORE, CMD_SYNC, CMD_CONSTW, CMD_ERROR, CMD_EXIT };
 	struct Rank {
 		int device = 0;
 		long col0 = 0, ncols = 0;
@@ -234,6 +254,7 @@ private:
 		std::unique_ptr<nmfamd::Comm> comm;
 		std::unique_ptr<nmfamd::ShardedRank<T>> sh;
 		Status status = nmfamd::ST_OK;
+		double frob2 = 0.0;                 // constant basis vectors: this shard's own squared Frobenius error
 		~Rank() { sh.reset(); comm.reset(); eng.reset(); if (stream) (void)hipStreamDestroy(stream); }
 	};
 
@@ -275,7 +296,9 @@ private:
 		switch (c) {
 		case CMD_SETUP: rk.status = do_setup(g); break;
 		case CMD_INIT: rk.status = rk.sh ? do_init(g) : nmfamd::ST_INVALID; break;      // (no sharded run: the set-up failed on some rank)
-		case CMD_ITERATE: rk.status = rk.sh ? rk.sh->iterate(compute_error_) : nmfamd::ST_INVALID; break;
+		case CMD_ITERATE: rk.status = !rk.sh ? nmfamd::ST_INVALID : constant_w_ ? rk.eng->iterate(compute_error_, true) : rk.sh->iterate(compute_error_); break;
+		case CMD_CONSTW: rk.status = rk.sh ? rk.eng->set_factors(hostW_, ldw_, nullptr, 0) : nmfamd::ST_INVALID; break;
+		case CMD_ERROR: rk.frob2 = rk.eng->frobenius_squared(); break;      // (the shard's own squared error: its columns of V against W H)
 		case CMD_STORE: {
 			T* hcols = outH_ + (size_t)rk.col0 * out_ldh_;
 			rk.status = rk.sh ? rk.eng->get_factors(g == 0 ? outW_ : nullptr, out_ldw_, hcols, out_ldh_) : nmfamd::ST_INVALID;
@@ -353,7 +376,8 @@ private:
 	const NmfDescription<T>* input_ = nullptr;
 	NmfInitializationMethod init_method_ = NmfInitializationMethod::CopyExisting;
 	unsigned seed_ = 0;
-	bool want_h_ = true, compute_error_ = false;
+	bool want_h_ = true, compute_error_ = false, constant_w_ = false;
+	double const_w_trace_ = 0.0;
 	const T* hostW_ = nullptr; const T* hostH_ = nullptr; long ldw_ = 0, ldh_ = 0;
 	T* outW_ = nullptr; T* outH_ = nullptr; long out_ldw_ = 0, out_ldh_ = 0;
 };

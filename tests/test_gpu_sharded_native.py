@@ -216,9 +216,31 @@ def test_compute_with_numgpus_kl_divergence_update_with_a_blocked_gather(monkeyp
     assert s.record(0).frobenius == pytest.approx(ref["frobenius"], rel=1e-4)
 
 
+@pytest.mark.parametrize("alg,params,r", [(na.NmfAlgorithm.Multiplicative, {}, 24), (na.NmfAlgorithm.nsNMF, {"theta": 0.4}, 64),
+                                          (na.NmfAlgorithm.AHCLS, {"lambdaW": 0.01, "lambdaH": 0.01, "alphaW": 0.01, "alphaH": 0.01}, 16),
+                                          (na.NmfAlgorithm.GDCLS, {"lambda": 0.01}, 16)])
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_compute_with_numgpus_constant_basis_vectors(alg, params, r, ranks):
+    """useConstantBasisVectors (ref AlgorithmMultiplicativeFrobenius.h:144-146,218-228 and siblings) on N ranks: W is given and stays, so every rank
+    fits its own columns of H alone; the error is the root of the shards' summed squares.  Same H and error as the one-GPU run (other K split of the
+    product per shard: fp32 rounding), W untouched."""
+    m, n, iters = 500, 410, 20
+    V, W0, H0 = problem(m, n, r, np.float32, seed=r + ranks)
+    out = []
+    for extra in ({}, {"numGpus": ranks}):
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(V, W, H, algorithm=alg, iterations=iters, constant_basis_vectors=True, parameters=dict(params, **extra), summary=s) == na.ResultType.Success
+        out.append((W, H, s.record(0).frobenius, s.record(0).rmsd))
+    (W1, H1, f1, r1), (Wn, Hn, fn, rn) = out
+    assert rel(Hn, H1) < 1e-4
+    assert rel(Wn, W1) < 1e-6                       # (what compute returns for W in this mode is the same on one and on N ranks)
+    assert fn == pytest.approx(f1, rel=1e-4) and rn == pytest.approx(r1, rel=1e-4)
+
+
 def test_compute_with_numgpus_rejects_what_does_not_shard():
     V, W, H = problem(60, 50, 4, np.float32)
-    assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2}) == na.ResultType.ErrorInvalidArgument
+    assert na.compute(V, W, H, iterations=2, constant_basis_vectors=True, parameters={"numGpus": 2, "divergence": 1}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 17}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, algorithm=na.NmfAlgorithm.nsNMF, parameters={"numGpus": 2, "divergence": 1, "theta": 0.5}) == na.ResultType.ErrorInvalidArgument
     assert na.compute(V, W, H, iterations=2, parameters={"numGpus": 1}) == na.ResultType.Success

@@ -331,8 +331,8 @@ private:
 		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); st = nmfamd::ST_NO_DEVICE; }
 		// Ranks that share a device share ONE stream (created by the lowest of them).  Eight rank threads with a stream each on one device -- more streams
 		// than hardware queues (GPU_MAX_HW_QUEUES) -- produced wrong factors on one or two ranks per run at config 4's shape (round 3: right with
-		// GPU_MAX_HW_QUEUES=16; still wrong with the transport's rendezvous ordered through the host instead of by event waits, so those waits are not the
-		// cause; right with one stream -- tools/c4_modes_repeat.py).  The inputs of the affected rank's H update check out afterwards, its output does not:
+		// GPU_MAX_HW_QUEUES=16; still wrong with the transport's rendezvous ordered through the host instead of by event waits, and even with no
+		// cross-stream event wait left at all; right with one stream -- tools/c4_modes_repeat.py).  The inputs of the affected rank's H update check out afterwards, its output does not:
 		// something is consumed too early once streams share a hardware queue, and we could not pin it on our side.  One stream per device orders
 		// everything by construction; teams on one device are rehearsals and tests, production teams have a device (and a stream) per rank.
 		const int owner = g % ndev_;

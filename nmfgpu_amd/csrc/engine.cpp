@@ -259,7 +259,7 @@ Status Engine<T>::allocate() {
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
-		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr) {
+		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr && !no_side_stream_) {
 			HIPX(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
 			HIPX(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 			HIPX(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));

@@ -349,6 +349,7 @@ private:
 		auto make_engine = [&](const nmfamd::AlgorithmParams& prm) -> Status {
 			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm));
 			rk.eng->set_one_pass(false);       // rank threads may share a device: no persistent launch that claims every CU
+			rk.eng->set_no_side_stream(world_ > ndev_);
 			rk.eng->set_stream(rk.stream);
 			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
 			Status s = rk.eng->allocate();

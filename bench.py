@@ -21,11 +21,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# A rank's process holds a handful of streams (torch's, the process group's, the engine's).  ROCm multiplexes a process's streams onto
-# GPU_MAX_HW_QUEUES hardware queues (4 by default); round 3 saw wrong results from streams that shared a hardware queue (eight rank
-# threads on one device), so give every stream its own queue.  No effect on the single-stream timings (98.5 us either way).  Must be in the
-# environment before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 M, N_COLS, R = 10000, 5000, 64
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS spec"

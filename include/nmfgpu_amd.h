@@ -265,7 +265,8 @@ NMFAMD_API int nmfamd_op_tri_update_f32(const float* P, const float* num, const 
                                         const float* num_colsq, float theta, float frag_theta, int transform_den, float* P_out, float* pack_out,
                                         float* scale_out, float* gram_out, float* gram_raw_out, float* gram_image_out, float* diag_out);
 /* Test access to an engine's device intermediates in panel layout: which = 0 Wt, 1 H, 2 W^T W,
- * 3 H H^T, 4 slabs, 5 inverse, 6 V, 7 Vt. */
+ * 3 H H^T, 4 slabs, 5 inverse, 6 V, 7 Vt; rank-256 fp32 engines also 8 W^T W as last reduced, 9 staged column sums of squares,
+ * 10 / 11 the bf16 fragments of W / H as 4-byte words. */
 NMFAMD_API int nmfamd_engine_debug_read(nmfamd_engine* e, int which, void* out, long count);
 
 #ifdef __cplusplus

@@ -10,9 +10,11 @@ reference's (source/CMakeLists.txt:78-92) so existing loaders find it.
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -27,7 +29,11 @@ ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 HOST_ONLY = {"host_init.cpp"}
 # per-source extra flags.  kernels_x3.hip: the SLP vectoriser pairs the scalar subtractions of the operand split
 # into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
-EXTRA_FLAGS = {"kernels_x3.hip": ["-fno-slp-vectorize"], "kernels_onepass.hip": ["-fno-slp-vectorize"]}
+# Since round 3 the SLP vectoriser is off for EVERY device source (DEVICE_FLAGS): it also pairs `uniform * x + uniform` into
+# v_pk_fma_f32 with a scalar-register source, which gave wrong low halves in lanes 48..63 whenever waves of another kernel shared
+# the SIMD (csrc/split3.h in_vgpr; check_packed_scalar_sources below).
+EXTRA_FLAGS = {}
+DEVICE_FLAGS = ["-fno-slp-vectorize"]
 # experiment switches: NMFAMD_CXXFLAGS="-DNAME=1 ..." is appended to every compile (and forces nothing: use --force)
 USER_FLAGS = os.environ.get("NMFAMD_CXXFLAGS", "").split()
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNMFGPU_EXPORTING",
@@ -49,6 +55,32 @@ def _deps() -> float:
     return newest
 
 
+_PACKED_SCALAR = re.compile(r"\bv_pk_\w+_[fb]32\b.*(?<![\w.])s(\d+|\[\d+:\d+\])")
+
+
+def packed_scalar_sources(obj: str) -> list:
+    """Disassembles the gfx950 code object inside a compiled .hip object and returns "kernel: instruction" for every packed 32-bit
+    instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32) that reads a scalar register -- the form that misbehaved
+    when other kernels' waves shared the SIMD.  Empty list = clean."""
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "copy.o")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                               f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--output={co}"])
+        text = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout
+    found, kernel = [], "?"
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            kernel = m.group(1)
+            continue
+        ins = line.split("//")[0].strip()
+        if _PACKED_SCALAR.search(ins):
+            found.append(f"{kernel}: {ins}")
+    return found
+
+
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     """diag: the measurement build (-DNMFAMD_DIAG_BUILD, csrc/tuning.h) -> lib/libnmfgpu64_diag.so; select it with NMFAMD_LIBRARY."""
     global LIB, OBJDIR, USER_FLAGS
@@ -68,7 +100,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
         if src in HOST_ONLY:
             cmd = [cc, *[f for f in FLAGS if not f.startswith("--offload-arch")], "-x", "c++", "-pthread", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
-            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), *USER_FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc, *FLAGS, *DEVICE_FLAGS, *EXTRA_FLAGS.get(src, []), *USER_FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -82,6 +114,12 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
+    bad = []
+    for src, obj in zip(SOURCES, objs):
+        if src not in HOST_ONLY and src.endswith(".hip"):
+            bad += [f"{src}: {line}" for line in packed_scalar_sources(obj)]
+    if bad:
+        raise RuntimeError("packed fp32 instructions with a scalar-register source (csrc/split3.h, in_vgpr):\n" + "\n".join(bad[:40]))
     # -z defs: an undefined symbol fails the link here, not at the first call inside a running process
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB + ".tmp", *objs]
     subprocess.check_call(cmd)

@@ -259,7 +259,7 @@ Status Engine<T>::allocate() {
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
-		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr && !no_side_stream_) {
+		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr) {
 			HIPX(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
 			HIPX(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 			HIPX(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -1612,6 +1612,17 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 	case 3: src = HHt_; avail = (long)RP_ * RP_; break;
 	case 4: src = slabs_; avail = slab_stride_ * std::max(planH_.splits, planW_.splits); break;
 	case 5: src = Qinv_; avail = (long)RP_ * RP_; break;
+	case 8: case 9: case 10: case 11: {
+		// rank-256 intermediates, read as fp32 words (diagnosis of runs that share a device: tools/shared_device_diff.py):
+		// 8 = W^T W as the last Gram reduction left it, 9 = the staged column sums of squares, 10 / 11 = the bf16 fragments of W / of H
+		if (!tri_ || sizeof(T) != 4) return ST_INVALID;
+		const void* p = which == 8 ? (const void*)Gw_raw_ : which == 9 ? (const void*)colsq_ : which == 10 ? (const void*)Wtb_ : (const void*)Hb_;
+		avail = which == 8 ? (long)RP_ * RP_ : which == 9 ? (long)RP_ : which == 10 ? (long)RP_ * mpad_ / 2 : (long)RP_ * npad_ / 2;
+		if (!p || count > avail) return ST_INVALID;
+		HIPX(hipMemcpyAsync(out, p, sizeof(T) * count, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipStreamSynchronize(stream_));
+		return ST_OK;
+	}
 	case 6: case 7: {
 		if (sparse_ || bf16_ || (one_image_ && which == 7)) return ST_INVALID;   // no fp32 dense image in sparse / bf16 mode; no V^T image
 		// V (ld mpad_) / Vt (ld npad_) as column-major images; the MFMA path keeps them x-tiled

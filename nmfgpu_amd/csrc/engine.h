@@ -44,8 +44,6 @@ public:
 	void set_row_blocks(int blocks) { row_blocks_ = blocks > 1 ? blocks : 1; }
 	// the sharded three-phase API driven by a team of ONE rank: the exchange buffer goes from w_products() to w_finish() as it is
 	void set_sole_rank(bool sole) { sole_rank_ = sole; }
-	// before allocate(): no second stream for the least-squares family's inverse (teams whose ranks share a device keep to ONE stream per device, runner.h)
-	void set_no_side_stream(bool none) { no_side_stream_ = none; }
 	// The one-pass iteration (kernels_onepass.hip) claims every CU of the device for one persistent launch: engines that run
 	// beside others on one device (rank threads of a team) opt out.  Call before allocate().
 	void set_one_pass(bool allow) { one_pass_allowed_ = allow; }
@@ -231,7 +229,7 @@ private:
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
-	bool sole_rank_ = false, no_side_stream_ = false;
+	bool sole_rank_ = false;
 	bool kl_err_iter_ = false;       // sharded KL: h_step's compute_error, for the W-side evaluation in w_products
 	long err_total_columns_ = 0;     // sharded runs: columns of the whole matrix (0: this engine's own n)
 	Status kl_h_step();

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "split3.h"
 
 namespace nmfamd {
 
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 	const long base = (long)blockIdx.x * 128 * RP;
 	const int per_row = RP / 4, c4 = threadIdx.x % per_row, yy = threadIdx.x / per_row, ystep = 256 / per_row;
 	T4 d = *reinterpret_cast<const T4*>(den + 4 * c4);
-	d += eps;
+	d += in_vgpr(eps);      // (a scalar operand of a packed add otherwise: split3.h)
 	T4 ss = {0, 0, 0, 0};
 	for (int y = yy; y < 128; y += ystep) {
 		const long e = base + (long)y * RP + 4 * c4;

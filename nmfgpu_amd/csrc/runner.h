@@ -176,13 +176,12 @@ public:
 		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
 		if (world_ < 2 || world_ > 16 || (long)world_ > (long)n_) return nmfamd::ST_INVALID;
 		const char* force = std::getenv("NMFAMD_COMM");
-		ndev_ = ndev;
 		const bool shared = world_ > ndev;
 		local_ = shared || (force != nullptr && (std::strcmp(force, "p2p") == 0 || std::strcmp(force, "local") == 0)) || !nmfamd::rccl_available();
 		if (force != nullptr && std::strcmp(force, "rccl") == 0) { if (shared || !nmfamd::rccl_available()) return nmfamd::ST_INVALID; local_ = false; }
 		for (int g = 0; g < world_; ++g) {
 			ranks_.emplace_back(new Rank());
-			ranks_[g]->device = (first_device_ + g) % ndev;      // (ranks g and g' share a device iff g = g' mod ndev)
+			ranks_[g]->device = (first_device_ + g) % ndev;
 			nmfamd::shard_columns((long)n_, world_, g, &ranks_[g]->col0, &ranks_[g]->ncols);
 		}
 		rendezvous_ = nmfamd::local_group_create(world_);
@@ -256,8 +255,7 @@ private:
 		std::unique_ptr<nmfamd::ShardedRank<T>> sh;
 		Status status = nmfamd::ST_OK;
 		double frob2 = 0.0;                 // constant basis vectors: this shard's own squared Frobenius error
-		bool owns_stream = false;
-		~Rank() { sh.reset(); comm.reset(); eng.reset(); if (stream && owns_stream) (void)hipStreamDestroy(stream); }
+		~Rank() { sh.reset(); comm.reset(); eng.reset(); if (stream) (void)hipStreamDestroy(stream); }
 	};
 
 	// the calling thread is rank 0: publish the command, run rank 0's share, collect every rank's status
@@ -281,15 +279,9 @@ private:
 			nmfamd::local_group_barrier(*rendezvous_);
 			const Command c = command_;
 			if (c != CMD_EXIT) execute(g, c);
-			else { Rank& rk = *ranks_[g]; (void)hipSetDevice(rk.device); rk.sh.reset(); rk.comm.reset(); rk.eng.reset(); }
+			else { Rank& rk = *ranks_[g]; (void)hipSetDevice(rk.device); rk.sh.reset(); rk.comm.reset(); rk.eng.reset(); if (rk.stream) { (void)hipStreamDestroy(rk.stream); rk.stream = nullptr; } }
 			nmfamd::local_group_barrier(*rendezvous_);
-			if (c == CMD_EXIT) {
-				// (a stream is shared by the ranks of one device and owned by the lowest of them: destroyed once every engine on it is gone)
-				Rank& rk = *ranks_[g];
-				if (rk.stream && rk.owns_stream) (void)hipStreamDestroy(rk.stream);
-				rk.stream = nullptr;
-				return;
-			}
+			if (c == CMD_EXIT) return;
 		}
 	}
 	void execute(int g, Command c) {
@@ -329,27 +321,11 @@ private:
 		Rank& rk = *ranks_[g];
 		Status st = nmfamd::ST_OK;
 		if (hipSetDevice(rk.device) != hipSuccess) { (void)hipGetLastError(); st = nmfamd::ST_NO_DEVICE; }
-		// Ranks that share a device share ONE stream (created by the lowest of them).  Eight rank threads with a stream each on one device -- more streams
-		// than hardware queues (GPU_MAX_HW_QUEUES) -- produced wrong factors on one or two ranks per run at config 4's shape (round 3: right with
-		// GPU_MAX_HW_QUEUES=16; still wrong with the transport's rendezvous ordered through the host instead of by event waits, and even with no
-		// cross-stream event wait left at all; right with one stream -- tools/c4_modes_repeat.py).  The inputs of the affected rank's H update check out afterwards, its output does not:
-		// something is consumed too early once streams share a hardware queue, and we could not pin it on our side.  One stream per device orders
-		// everything by construction; teams on one device are rehearsals and tests, production teams have a device (and a stream) per rank.
-		const int owner = g % ndev_;
-		if (g == owner) {
-			if (st == nmfamd::ST_OK && hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; st = nmfamd::ST_HIP_ERROR; }
-			rk.owns_stream = rk.stream != nullptr;
-		}
-		nmfamd::local_group_barrier(*rendezvous_);
-		if (g != owner) {
-			rk.stream = ranks_[owner]->stream;
-			if (st == nmfamd::ST_OK && rk.stream == nullptr) st = nmfamd::ST_HIP_ERROR;
-		}
+		if (st == nmfamd::ST_OK && hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rk.stream = nullptr; st = nmfamd::ST_HIP_ERROR; }
 		const MatrixDescription<T>& V = input_->inputMatrix;
 		auto make_engine = [&](const nmfamd::AlgorithmParams& prm) -> Status {
 			rk.eng.reset(new nmfamd::Engine<T>((int)m_, (int)rk.ncols, (int)r_, alg_, prm));
 			rk.eng->set_one_pass(false);       // rank threads may share a device: no persistent launch that claims every CU
-			rk.eng->set_no_side_stream(world_ > ndev_);
 			rk.eng->set_stream(rk.stream);
 			if (mode_ == nmfamd::SHARD_ROW_BLOCKS) rk.eng->set_row_blocks(world_);
 			Status s = rk.eng->allocate();
@@ -401,7 +377,6 @@ private:
 	NmfInitializationMethod init_method_ = NmfInitializationMethod::CopyExisting;
 	unsigned seed_ = 0;
 	bool want_h_ = true, compute_error_ = false, constant_w_ = false;
-	int ndev_ = 1;
 	double const_w_trace_ = 0.0;
 	const T* hostW_ = nullptr; const T* hostH_ = nullptr; long ldw_ = 0, ldh_ = 0;
 	T* outW_ = nullptr; T* outH_ = nullptr; long out_ldw_ = 0, out_ldh_ = 0;

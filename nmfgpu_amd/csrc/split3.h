@@ -62,6 +62,13 @@ __device__ inline void store_split3(bf16x8* __restrict__ dst, long ks, int NBT, 
 	o[0] = hi; o[64] = mid; o[128] = lo;
 }
 
+// gfx950 rule ("packed fp32 with a scalar source"): v_pk_fma / mul / add_f32 must not take a scalar register as a source --
+// with waves of OTHER kernels on the same SIMD the low half of the result came out wrong in lanes 48..63 (found with tools/shared_device_diff.py).
+// The build disables the SLP vectoriser (which forms those instructions from uniform kernel arguments) and checks every object for such
+// an instruction (build.py); a uniform value that meets a vector type in the source goes through here first.
+__device__ inline float in_vgpr(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ inline double in_vgpr(double x) { return x; }
+
 // d(c) of a pending column scale handed over as staged sums of squares (PanelTriExtras, kernels.h): the vectors are added in order, every consumer
 // through this one function
 __device__ inline float tri_pending_scale(const float* __restrict__ colsq, int parts, int RP, int c) {

@@ -149,3 +149,20 @@ def test_package_does_not_import_the_oracle():
                     assert names and all("rccl" in n for n in names), names
                     text = text.replace("dlopen", "")
                 assert not uses.search(text), f
+
+
+def test_no_packed_fp32_instruction_reads_a_scalar_register():
+    """gfx950 rule found in round 3: v_pk_fma / mul / add_f32 with a scalar-register source returned wrong low
+    halves in lanes 48..63 whenever another kernel's waves shared the SIMD.  The build refuses such code (nmfgpu_amd/build.py);
+    this re-checks the objects the loaded library was linked from, and that the check itself still sees the offending form."""
+    from nmfgpu_amd import build as b
+    objs = [os.path.join(b.OBJDIR, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s.endswith(".hip")]
+    assert len(objs) >= 10 and all(os.path.exists(o) for o in objs)
+    for o in objs:
+        assert b.packed_scalar_sources(o) == [], o
+    assert "-fno-slp-vectorize" in b.DEVICE_FLAGS
+    assert b._PACKED_SCALAR.search("v_pk_fma_f32 v[14:15], s[38:39], v[14:15], v[36:37] op_sel:[0,0,1] op_sel_hi:[0,1,1]")
+    assert b._PACKED_SCALAR.search("v_pk_add_f32 v[18:19], s[30:31], v[18:19] op_sel:[1,0]")
+    assert b._PACKED_SCALAR.search("v_pk_mul_f32 v[2:3], v[2:3], s4")
+    assert not b._PACKED_SCALAR.search("v_pk_fma_f32 v[22:23], v[36:37], v[22:23], v[42:43] op_sel_hi:[0,1,0]")
+    assert not b._PACKED_SCALAR.search("v_pk_mul_f32 v[2:3], v[2:3], v[36:37]")

@@ -5,8 +5,7 @@ src=$1; name=$2; flags=$3
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=$root/nmfgpu_amd/lib/obj
 mkdir -p $root/nmfgpu_amd/lib/variants /tmp/variant_$name
-extra=""
-[ "$src" = kernels_x3.hip ] && extra="-fno-slp-vectorize"
+extra="-fno-slp-vectorize"      # as build.py DEVICE_FLAGS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DNMFGPU_EXPORTING -Wno-unknown-pragmas -Wno-unused-function -Wno-unused-result \
   $extra $flags -x hip -c $root/nmfgpu_amd/csrc/$src -o /tmp/variant_$name/${src%.*}.o || exit 1
 objs=""

@@ -82,6 +82,7 @@ Engine<T>::~Engine() {
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
+	if (Graw64_) (void)hipFree(Graw64_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
 	{ void* ob[] = {op_part_, op_hfrag_, op_ctl_, op_slabs_, op_hh_part_, op_ps4_, op_H2_, op_stamps_}; for (void* b : ob) if (b) (void)hipFree(b); }
@@ -291,6 +292,7 @@ Status Engine<T>::allocate() {
 	}
 	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
+		HIPX(hipMalloc((void**)&Graw64_, sizeof(float) * 4096));      // the reduced, unscaled W^T W of normalize_w's one-launch form
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
 	}
@@ -1113,9 +1115,14 @@ template <typename T>
 Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (from_gram_partials) {
+			if (x3_ && Graw64_ != nullptr) {
+				// reduction, then ONE launch: scales from the raw diagonal, G = D Graw D, W <- W D and its split image for the next W^T V
+				HIPX(launch_gram64_normalize_all(gramW_part_, (int)(mpad_ / 64), Graw64_, G_, scale_, Wt_, (int)mpad_, Wx3_, ksH_, stream_));
+			} else {
 			HIPX(launch_gram64_from_partials(gramW_part_, (int)(mpad_ / 64), G_, scale_, stream_));
 			// the scaling pass also leaves the split image of the normalised W for the next W^T V
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_, x3_ ? Wx3_ : nullptr, ksH_));
+			}
 			wx3_valid_ = x3_;
 			gram_w_ready_ = true;
 			return ST_OK;

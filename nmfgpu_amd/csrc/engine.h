@@ -214,7 +214,7 @@ private:
 	bool kl_pending_ = false, kl_unresolved_ = false;
 	std::vector<T> h_klrow_, h_sW_, h_sH_;
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
-	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr;
+	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr, *Graw64_ = nullptr;
 	bool fused_ready_ = false, w_pending_ = false;
 	// split-operand path: Gram matrices from the split images (gram_image.h), 32-column update kernel -- no partial Gram matrices
 	bool gram_image_ = false;

@@ -99,6 +99,7 @@ hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hi
 // G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and
 // G <- diag(scale) G diag(scale): the stand-alone (not passenger) form of the Gram reduction
 hipError_t launch_gram64_from_partials(const float* partials, int parts, float* G, float* scale, hipStream_t stream);
+hipError_t launch_gram64_normalize_all(const float* partials, int parts, float* Graw, float* G, float* scale, float* P, int len_pad, void* x3_out, int x3_ks, hipStream_t stream);
 
 // Generic (VALU) form, writes the finished panel (no slabs).  Xpad multiple of 64, RP multiple of 32.
 template <typename T>

@@ -506,6 +506,48 @@ __global__ __launch_bounds__(256) void k_mu64_apply_scale_x3(float* __restrict__
 	}
 }
 
+// normalize_w of the rank-64 least-squares path in ONE launch after the reduction of the partial Gram matrices (k_scale_gram64 + k_mu64_apply_scale_x3:
+// 4.8 + 5.4 us of launch floor): every workgroup takes the column scales from the diagonal of the reduced, still unscaled matrix itself (64 elements, L2 hits),
+// scales its 16 panel rows and writes their split image; one extra workgroup publishes the scales and G = D Graw D.  Same arithmetic per element as the two kernels.
+__global__ __launch_bounds__(256) void k_mu64_scale_all_x3(float* __restrict__ P, const float* __restrict__ Graw, float* __restrict__ G, float* __restrict__ scale,
+                                                          bf16x8* __restrict__ x3_out, int x3_ks, int row_blocks) {
+	__shared__ __attribute__((aligned(16))) float s_v[16][68];
+	__shared__ __attribute__((aligned(16))) float s_scale[64];
+	const int tid = threadIdx.x;
+	if (tid < 64) {
+		const float d = Graw[tid * 65];
+		s_scale[tid] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+	}
+	__syncthreads();
+	if ((int)blockIdx.x == row_blocks) {
+		if (tid < 64) scale[tid] = s_scale[tid];
+		for (int e = tid; e < 4096; e += 256) G[e] = (Graw[e] * s_scale[e & 63]) * s_scale[e >> 6];
+		return;
+	}
+	const long e = (long)blockIdx.x * 256 + tid;
+	f32x4 v = *reinterpret_cast<f32x4*>(P + 4 * e);
+	v *= *reinterpret_cast<const f32x4*>(s_scale + (4 * tid) % 64);
+	*reinterpret_cast<f32x4*>(P + 4 * e) = v;
+	*reinterpret_cast<f32x4*>(&s_v[tid >> 4][4 * (tid & 15)]) = v;
+	__syncthreads();
+	if (tid < 128 && (int)blockIdx.x < x3_ks) {
+		const int r = tid & 31, h = (tid >> 5) & 1, nb = tid >> 6;
+		float w[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) w[j] = s_v[8 * h + j][32 * nb + r];
+		store_split3(x3_out, blockIdx.x, 2, nb, h, r, w);
+	}
+}
+
+// partials -> Graw (unscaled sum), then the launch above: G, scale, the scaled panel and its split image
+hipError_t launch_gram64_normalize_all(const float* partials, int parts, float* Graw, float* G, float* scale, float* P, int len_pad, void* x3_out, int x3_ks, hipStream_t stream) {
+	hipError_t e = launch_reduce_partials<float>(partials, parts, 4096, Graw, 4096, stream);
+	if (e != hipSuccess) return e;
+	const int row_blocks = len_pad / 16;
+	hipLaunchKernelGGL(k_mu64_scale_all_x3, dim3((unsigned)row_blocks + 1), dim3(256), 0, stream, P, Graw, G, scale, reinterpret_cast<bf16x8*>(x3_out), x3_ks, row_blocks);
+	return hipGetLastError();
+}
+
 // x3_out (optional): split image of the scaled panel, x3_ks K-steps of 16 rows (len_pad is a multiple of 128)
 hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream, void* x3_out, int x3_ks) {
 	if (x3_out != nullptr) {

@@ -115,9 +115,12 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     if failed:
         raise RuntimeError("hipcc failed")
     bad = []
-    for src, obj in zip(SOURCES, objs):
-        if src not in HOST_ONLY and src.endswith(".hip"):
-            bad += [f"{src}: {line}" for line in packed_scalar_sources(obj)]
+    try:
+        for src, obj in zip(SOURCES, objs):
+            if src not in HOST_ONLY and src.endswith(".hip"):
+                bad += [f"{src}: {line}" for line in packed_scalar_sources(obj)]
+    except FileNotFoundError as exc:      # (no llvm-objcopy / clang-offload-bundler / llvm-objdump beside hipcc: the flag above still holds, tests/test_abi.py re-checks)
+        sys.stderr.write(f"nmfgpu_amd.build: packed-instruction check skipped ({exc})\n")
     if bad:
         raise RuntimeError("packed fp32 instructions with a scalar-register source (csrc/split3.h, in_vgpr):\n" + "\n".join(bad[:40]))
     # -z defs: an undefined symbol fails the link here, not at the first call inside a running process

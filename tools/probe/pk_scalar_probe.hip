@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // FORM: 0 v_pk_fma_f32 with a scalar pair, 1 the same from VGPRs, 2 v_pk_mul_f32 scalar, 3 v_pk_add_f32 scalar, 4 v_fma_f64 scalar, 5 v_lshl_add_u64 scalar,
-//       6 v_fma_f32 (plain, 32-bit scalar), 7 v_pk_mul_f32 with the scalar pair as SECOND source
+//       6 v_fma_f32 (plain, 32-bit scalar), 7 v_pk_mul_f32 with the scalar pair as SECOND source, 8 - 13 operand-select variants, 14 - 17 the scalar-operand
+//       forms the shipped kernels use most (mask of a select, 64-bit multiply-add, carry chain, 32-bit multiply)
 template <int FORM>
 __global__ __launch_bounds__(256, 2) void k_victim(const float* __restrict__ in, float a, float b, int steps, unsigned* __restrict__ bad, float* __restrict__ out) {
 	extern __shared__ float pad[];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void k_victim(const float* __restrict__ in,
 			double d = (double)x0 + (double)x1 * 1e-3, td = (double)tau;
 			const double ref = __builtin_fma(dv, d, td);
 			const uint64_t db = __double_as_longlong(dab);      // (computed by the VALU: brought back into a scalar pair)
-			const uint64_t dabs = (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)db) | ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(db >> 32)) << 32);
+			const uint64_t dabs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)db) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(db >> 32)) << 32);
 			asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(d) : "s"(dabs), "v"(td));
 			const uint64_t u = __double_as_longlong(d), ur = __double_as_longlong(ref);
 			acc[0] = __uint_as_float((unsigned)u); acc[1] = __uint_as_float((unsigned)(u >> 32));
@@ -93,7 +94,35 @@ __global__ __launch_bounds__(256, 2) void k_victim(const float* __restrict__ in,
 		} else if (FORM == 12) {      // scalar pair as the ADDEND: lo = x0 * t1 + a, hi = x1 * t1 + b
 			asm volatile("v_pk_fma_f32 %0, %0, %2, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(ab), "v"(t));
 			r0 = __builtin_fmaf(x0, t[1], av); r1 = __builtin_fmaf(x1, t[1], bv);
-		} else {                      // scalar pair in the middle: lo = x0 * a + t1, hi = x1 * a + t1  (commuted form 0)
+		} else if (FORM == 14) {      // a scalar pair as the LANE MASK of a select
+			const uint64_t mask = ab ^ (0x9e3779b97f4a7c15ull * (uint64_t)(s + 1));       // uniform, differs per step
+			const uint64_t ms = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)mask) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(mask >> 32)) << 32);
+			float y0;
+			asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(y0) : "v"(x0), "v"(x1), "s"(ms));
+			const uint64_t mv = (uint64_t)__float_as_uint(av) | ((uint64_t)__float_as_uint(bv) << 32);
+			const uint64_t mref = mv ^ (0x9e3779b97f4a7c15ull * (uint64_t)(s + 1));
+			acc[0] = y0; acc[1] = 0.f;
+			r0 = ((mref >> lane) & 1) ? x1 : x0; r1 = 0.f;
+		} else if (FORM == 15) {      // 64-bit multiply-add with a scalar factor
+			uint64_t v = ((uint64_t)__float_as_uint(x1) << 32) | __float_as_uint(x0);
+			const unsigned sa = __float_as_uint(a);
+			const uint64_t ref = (uint64_t)__float_as_uint(av) * (uint64_t)__float_as_uint(x0) + v;
+			asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "s"(sa), "v"(__float_as_uint(x0)) : "vcc");
+			acc[0] = __uint_as_float((unsigned)v); acc[1] = __uint_as_float((unsigned)(v >> 32));
+			r0 = __uint_as_float((unsigned)ref); r1 = __uint_as_float((unsigned)(ref >> 32));
+		} else if (FORM == 16) {      // carry chain through VCC: 64-bit add of a scalar pair in two halves
+			const unsigned lo = __float_as_uint(x0) | 0x80000000u, hi = __float_as_uint(x1);      // (the low add carries about half the time)
+			unsigned o0, o1;
+			asm volatile("v_add_co_u32_e32 %0, vcc, %2, %3\n\tv_addc_co_u32_e32 %1, vcc, %4, %5, vcc" : "=&v"(o0), "=v"(o1) : "s"((unsigned)ab), "v"(lo), "v"(__float_as_uint(bv)), "v"(hi) : "vcc");      // (VCC is the second scalar of the high add: its addend comes from a VGPR)
+			const uint64_t ref = (((uint64_t)hi << 32) | lo) + abv;
+			acc[0] = __uint_as_float(o0); acc[1] = __uint_as_float(o1);
+			r0 = __uint_as_float((unsigned)ref); r1 = __uint_as_float((unsigned)(ref >> 32));
+		} else if (FORM == 17) {      // 32-bit integer multiply with a scalar
+			unsigned o0 = __float_as_uint(x0), o1 = __float_as_uint(x1);
+			asm volatile("v_mul_lo_u32 %0, %2, %0\n\tv_mul_lo_u32 %1, %2, %1" : "+v"(o0), "+v"(o1) : "s"(__float_as_uint(a)));
+			acc[0] = __uint_as_float(o0); acc[1] = __uint_as_float(o1);
+			r0 = __uint_as_float(__float_as_uint(av) * __float_as_uint(x0)); r1 = __uint_as_float(__float_as_uint(av) * __float_as_uint(x1));
+		} else {                      // (FORM == 13) scalar pair in the middle: lo = x0 * a + t1, hi = x1 * a + t1  (commuted form 0)
 			asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(ab), "v"(t));
 			r0 = __builtin_fmaf(x0, av, t[1]); r1 = __builtin_fmaf(x1, av, t[1]);
 		}
@@ -164,16 +193,16 @@ int main(int argc, char** argv) {
 	hipStream_t sv, sa;
 	hipStreamCreateWithFlags(&sv, hipStreamNonBlocking); hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
 	const size_t lds = 100 * 1024;
-	static const char* form_name[14] = {"v_pk_fma_f32 scalar pair", "v_pk_fma_f32 vector", "v_pk_mul_f32 scalar pair (src0)", "v_pk_add_f32 scalar pair", "v_fma_f64 scalar pair",
+	static const char* form_name[18] = {"v_pk_fma_f32 scalar pair", "v_pk_fma_f32 vector", "v_pk_mul_f32 scalar pair (src0)", "v_pk_add_f32 scalar pair", "v_fma_f64 scalar pair",
 	                                   "v_lshl_add_u64 scalar pair", "v_fma_f32 scalar (32-bit)", "v_pk_mul_f32 scalar pair (src1)", "v_pk_fma_f32 scalar, no op_sel",
 	                                    "v_pk_fma_f32 scalar, op_sel_hi src0", "v_pk_mul_f32 scalar, op_sel_hi src0", "v_pk_add_f32 scalar, op_sel src0", "v_pk_fma_f32 scalar as addend",
-	                                    "v_pk_fma_f32 scalar as src1"};
+	                                    "v_pk_fma_f32 scalar as src1", "v_cndmask_b32 scalar-pair mask", "v_mad_u64_u32 scalar factor", "v_add_co / v_addc_co scalar + VCC", "v_mul_lo_u32 scalar"};
 	static const char* agg_name[3] = {"alone", "beside the MFMA / LDS aggressor", "beside the scalar-load aggressor"};
 	typedef void (*victim_t)(const float*, float, float, int, unsigned*, float*);
-	victim_t victims[14] = {k_victim<0>, k_victim<1>, k_victim<2>, k_victim<3>, k_victim<4>, k_victim<5>, k_victim<6>, k_victim<7>, k_victim<8>, k_victim<9>, k_victim<10>, k_victim<11>, k_victim<12>, k_victim<13>};
-	for (int form = 0; form < 14; ++form) {
+	victim_t victims[18] = {k_victim<0>, k_victim<1>, k_victim<2>, k_victim<3>, k_victim<4>, k_victim<5>, k_victim<6>, k_victim<7>, k_victim<8>, k_victim<9>, k_victim<10>, k_victim<11>, k_victim<12>, k_victim<13>, k_victim<14>, k_victim<15>, k_victim<16>, k_victim<17>};
+	for (int form = 0; form < 18; ++form) {
 		hipFuncSetAttribute(reinterpret_cast<const void*>(victims[form]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		for (int with_aggressor = (form >= 2 ? 2 : 0); with_aggressor < 3; ++with_aggressor) {
+		for (int with_aggressor = (form >= 2 && form != 14 ? 2 : 0); with_aggressor < 3; ++with_aggressor) {
 			hipMemset(dbad, 0, 64);
 			for (int r = 0; r < rounds; ++r) {
 				if (with_aggressor == 1) hipLaunchKernelGGL(k_aggressor, dim3(cus * 4), dim3(512), 0, sa, ain, aout, 4000, 0.999f, 1.001f);

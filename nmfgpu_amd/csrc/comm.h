@@ -22,7 +22,7 @@ namespace nmfamd {
 
 class Comm {
 public:
-	virtual ~Comm() {}
+	virtual ~Comm() { for (void* p : xbuf_) if (p) (void)hipFree(p); }
 	virtual int rank() const = 0;
 	virtual int world() const = 0;
 	virtual const char* transport() const = 0;
@@ -32,10 +32,28 @@ public:
 	virtual Status reduce_scatter(const void* send, void* recv, long count, int elem_bytes, hipStream_t s) = 0;
 	// buf holds world * count elements; rank p's part [p * count, (p + 1) * count) is filled in from rank p (in place)
 	virtual Status all_gather_inplace(void* buf, long count, int elem_bytes, hipStream_t s) = 0;
+	// ---- exchange by direct reads (the small-message form of the W step, sharded.cpp) ------------------------------------------------------------
+	// true: every rank can read every rank's exchange buffer where it lies (ranks are threads of one process on one device or on peer-mapped devices;
+	// a team of one).  The consumer kernel then sums the ranks' buffers itself, in rank order -- no reduction kernel, no copy, ONE rendezvous per iteration.
+	virtual bool direct_exchange() const { return world() == 1; }
+	// `slots` buffers of `bytes` each (two: consecutive iterations alternate, which is what lets the readers of iteration k run while the writers of
+	// iteration k + 1 already fill the other slot -- see exchange_publish).  The transport owns them.  mine[i] receives this rank's buffers.
+	virtual Status exchange_alloc(size_t bytes, int slots, void** mine);
+	// This rank has enqueued, on s, everything that writes its buffer `slot`.  On return s is ordered behind the writers of EVERY rank's buffer `slot`, and
+	// peers[p] is rank p's buffer (p = 0 .. world - 1).  Slot reuse needs no second rendezvous: a rank overwrites slot i two publishes later, i.e. after it
+	// waited (in the publish between) for every peer's NEXT writers, which those peers enqueued behind their readers of slot i.
+	virtual Status exchange_publish(int slot, hipStream_t s, const void** peers);
 	// several collectives issued between begin and end may be fused by the transport (ncclGroupStart / ncclGroupEnd)
 	virtual void group_begin() {}
 	virtual Status group_end() { return ST_OK; }
 	virtual const char* last_error() const { return ""; }
+
+protected:
+	std::vector<void*> xbuf_;          // exchange buffers of the default (one-rank) implementation
+public:
+	Comm() = default;
+	Comm(const Comm&) = delete;
+	Comm& operator=(const Comm&) = delete;
 };
 
 // ---- RCCL ---------------------------------------------------------------------------------------------------------

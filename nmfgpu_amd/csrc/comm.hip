@@ -12,6 +12,25 @@
 
 namespace nmfamd {
 
+// ---- exchange buffers: the part every transport shares (a team of one reads its own buffer) ---------------------------
+Status Comm::exchange_alloc(size_t bytes, int slots, void** mine) {
+	if (bytes == 0 || slots < 1 || slots > 2 || mine == nullptr || !xbuf_.empty()) return ST_INVALID;
+	for (int i = 0; i < slots; ++i) {
+		void* p = nullptr;
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_NO_DEVICE_MEMORY; }
+		xbuf_.push_back(p);
+		if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_HIP_ERROR; }
+		mine[i] = p;
+	}
+	return ST_OK;
+}
+
+Status Comm::exchange_publish(int slot, hipStream_t, const void** peers) {
+	if (world() != 1 || slot < 0 || slot >= (int)xbuf_.size() || peers == nullptr) return ST_INVALID;
+	peers[0] = xbuf_[slot];
+	return ST_OK;
+}
+
 // =====================================================================================================================
 // RCCL through its C API.  The library is loaded on first use (dlopen): a single-GPU caller never pays for it, and
 // libnmfgpu64.so keeps linking without RCCL installed.  ncclReduceScatter / ncclAllGather are the direct algorithms
@@ -142,10 +161,17 @@ struct LocalGroup {
 		const void* buf = nullptr;
 		hipEvent_t ready = nullptr, done = nullptr;
 		int device = -1;
+		// exchange by direct reads (Comm::exchange_alloc / exchange_publish): this rank's two buffers and the events behind their writers
+		const void* xbuf[2] = {nullptr, nullptr};
+		hipEvent_t xready[2] = {nullptr, nullptr};
 	};
 	std::vector<Slot> slots;
 	~LocalGroup() {
-		for (Slot& s : slots) { if (s.ready) (void)hipEventDestroy(s.ready); if (s.done) (void)hipEventDestroy(s.done); }
+		for (Slot& s : slots) {
+			if (s.ready) (void)hipEventDestroy(s.ready);
+			if (s.done) (void)hipEventDestroy(s.done);
+			for (hipEvent_t e : s.xready) if (e) (void)hipEventDestroy(e);
+		}
 	}
 };
 
@@ -258,6 +284,33 @@ public:
 		else hipLaunchKernelGGL((k_local_gather<float>), blocks2(count, 4), dim3(256), 0, s, pp, g_->world, rank_, static_cast<float*>(buf), count);
 		if (hipGetLastError() != hipSuccess) return fail("all_gather: launch");
 		return retire(s);
+	}
+
+	bool direct_exchange() const override { return true; }
+	Status exchange_alloc(size_t bytes, int slots, void** mine) override {
+		Status st = Comm::exchange_alloc(bytes, slots, mine);
+		LocalGroup::Slot& me = g_->slots[rank_];
+		for (int i = 0; i < slots && st == ST_OK; ++i) {
+			me.xbuf[i] = mine[i];
+			if (hipEventCreateWithFlags(&me.xready[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st = ST_HIP_ERROR; }
+		}
+		if (st != ST_OK) g_->aborted.store(true, std::memory_order_release);
+		if (!barrier(*g_)) return st != ST_OK ? st : ST_HIP_ERROR;          // every rank's buffers and events exist from here on
+		return ST_OK;
+	}
+	Status exchange_publish(int slot, hipStream_t s, const void** peers) override {
+		if (slot < 0 || slot > 1 || peers == nullptr) return ST_INVALID;
+		LocalGroup::Slot& me = g_->slots[rank_];
+		if (me.xready[slot] == nullptr) return ST_INVALID;
+		if (g_->world > 1) {
+			if (hipEventRecord(me.xready[slot], s) != hipSuccess) return fail("event record");
+			if (!barrier(*g_)) return ST_HIP_ERROR;                     // every rank has recorded: the waits below see THIS iteration's records
+		}
+		for (int p = 0; p < g_->world; ++p) {
+			peers[p] = g_->slots[p].xbuf[slot];
+			if (p != rank_ && hipStreamWaitEvent(s, g_->slots[p].xready[slot], 0) != hipSuccess) return fail("event wait");
+		}
+		return ST_OK;
 	}
 
 private:

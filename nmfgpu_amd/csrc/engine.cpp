@@ -82,6 +82,8 @@ Engine<T>::~Engine() {
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
+	if (wsq_part_) (void)hipFree(wsq_part_);
+	if (Gpart_) (void)hipFree(Gpart_);
 	if (Graw64_) (void)hipFree(Graw64_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -154,7 +156,17 @@ Status Engine<T>::allocate() {
 		planH_.th = planW_.th = 128;
 		planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128);
 		ksW_ = (n_ + 15) / 16; ksH_ = (m_ + 15) / 16;
-		planH_.splits = plan_splits_x3(planH_.xtiles, ksH_, num_cus_);
+		// W^T W rides in the W^T V launch as passenger workgroups (gram_image.h).  Its chain -- the fragments of all m rows through ONE CU per tile, 24 us at
+		// config 2's m -- must stay shorter than the product: for a column shard narrower than config 2 the K range is
+		// cut into slices (10 passenger workgroups each, CUs the product plan leaves free); config 2 itself keeps one slice and its plan (measured hidden).
+		gram_ksplit_ = 1;
+		if (fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr) {
+			const double product_us = 6.0 + (double)sizeof(T) * (double)pad128(m_) * (double)pad128(n_) / 5.0e6;       // (bytes at ~5 TB/s + launch and fill)
+			const double pairs = (ksH_ + 2) / 2;
+			while (gram_ksplit_ < GRAM_KSPLIT_MAX && 24.0 * (pairs / 317.0) / gram_ksplit_ > 0.55 * product_us) gram_ksplit_ *= 2;      // (24 us for config 2's 317 pairs in one slice: one CU's L2 rate, gram_image.h)
+			if (const char* e = tuning_env("NMFAMD_GRAM_KSPLIT")) gram_ksplit_ = std::max(1, std::min(GRAM_KSPLIT_MAX, std::atoi(e)));
+		}
+		planH_.splits = plan_splits_x3(planH_.xtiles, ksH_, num_cus_, gram_ksplit_ > 1 ? GRAM_IMAGE_TILES * gram_ksplit_ : 0);
 		planW_.splits = plan_splits_x3(planW_.xtiles, ksW_, num_cus_);
 		planHx_ = planH_; planWx_ = planW_;
 		planHx_.steps_total = ksH_; planWx_.steps_total = ksW_;
@@ -295,6 +307,9 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&Graw64_, sizeof(float) * 4096));      // the reduced, unscaled W^T W of normalize_w's one-launch form
 		HIPX(hipMalloc((void**)&gramH_part_, sizeof(float) * 4096 * (size_t)(npad_ / 64)));
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
+		HIPX(hipMalloc((void**)&Gpart_, sizeof(float) * 4096 * GRAM_KSPLIT_MAX));
+		HIPX(hipMalloc((void**)&wsq_part_, sizeof(float) * 64 * (size_t)(mpad_ / 32)));
+		HIPX(hipMemsetAsync(wsq_part_, 0, sizeof(float) * 64 * (size_t)(mpad_ / 32), stream_));
 	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
 	pin_psR_ = pin_psN_ + ps_stride_;
@@ -519,20 +534,26 @@ void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_ov
 template <typename T>
 GramReduceArgs Engine<T>::gram_args(bool of_w, float* G, float* scale, int normalize) const {
 	GramReduceArgs rg = {of_w ? gramW_part_ : gramH_part_, (int)((of_w ? mpad_ : npad_) / 64), G, scale, normalize};
-	if (gram_image_) { rg.partials = nullptr; rg.parts = 0; rg.image = of_w ? Wx3_ : Hx3_; rg.image_ks = of_w ? ksH_ : ksW_; }
+	if (gram_image_) {
+		rg.partials = nullptr; rg.parts = 0; rg.image = of_w ? Wx3_ : Hx3_; rg.image_ks = of_w ? ksH_ : ksW_;
+		// the pending column scale of W from the sums of squares its update left (one vector per 32 panel rows)
+		if (of_w && normalize != 0 && wsq_part_ != nullptr) { rg.colsq_part = wsq_part_; rg.colsq_parts = (int)(mpad_ / 32); }
+		// W^T W beside the W^T V launch of a column shard: K slices into Gpart_, added and scaled by the H update (mu64_update)
+		if (of_w && (const void*)G == (const void*)G_ && gram_ksplit_ > 1 && Gpart_ != nullptr && (normalize == 0 || rg.colsq_part != nullptr)) { rg.ksplit = gram_ksplit_; rg.G = Gpart_; }
+	}
 	return rg;
 }
 
 template <typename T>
 Status Engine<T>::standalone_gram(const GramReduceArgs& rg) {
-	if (rg.image != nullptr) HIPX(launch_gram_from_image(rg.image, rg.image_ks, rg.G, rg.scale, rg.normalize, stream_));
+	if (rg.image != nullptr) HIPX(launch_gram_image_args(rg, stream_));
 	else HIPX(launch_mu64_gram_reduce(rg, stream_));
 	return ST_OK;
 }
 
 // U_H / U_W of the rank-64 fast path (kernels_mu64.hip)
 template <typename T>
-Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error) {
+Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error, const PeerSlabs* peers) {
 	if constexpr (std::is_same<T, float>::value) {
 		const float eps = std::numeric_limits<float>::epsilon();
 		float* P = is_w ? Wt_ : H_;
@@ -540,7 +561,9 @@ Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride
 		const int len = is_w ? m_ : n_, len_pad = (int)(is_w ? mpad_ : npad_);
 		void* xo = x3_ ? (is_w ? Wx3_ : Hx3_) : nullptr;
 		const int xks = is_w ? ksH_ : ksW_;
-		if (gram_image_) HIPX(launch_mu64_update32(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? G_ : nullptr, compute_error ? 1 : 0, stream_, xo, xks));
+		if (peers != nullptr && !gram_image_) return ST_INVALID;
+		if (gram_image_) HIPX(launch_mu64_update32(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? G_ : nullptr, compute_error ? 1 : 0, stream_, xo, xks, peers,
+		                                           is_w ? wsq_part_ : nullptr, (!is_w && (const void*)Q == (const void*)Gpart_) ? gram_ksplit_ : 0, (!is_w && (const void*)Q == (const void*)Gpart_) ? G_ : nullptr));
 		else HIPX(launch_mu64_update(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? gramW_part_ : gramH_part_, is_w ? G_ : nullptr,
 		                             compute_error ? 1 : 0, stream_, xo, xks));
 	}
@@ -569,7 +592,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
-			if (rg && (RP_ != 64 || planHx_.xtiles < GRAM_REDUCE_BLOCKS)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && !passengers_ride(planHx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_));
 			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
@@ -620,7 +643,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
-			if (rg && (RP_ != 64 || planWx_.xtiles < GRAM_REDUCE_BLOCKS)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_));
 			record_end();
@@ -665,6 +688,16 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 	HIPX(launch_inverse_small<T>(A, RP_, r_, Qinv_, inv_work_, offdiag, diag, aux_));
 	HIPX(hipEventRecord(ev_join_, aux_));
 	return ST_OK;
+}
+
+// Split-operand product at padded rank 64: the sixteen passenger workgroups (Gram matrix from the split image, or the one that inverts) sit BEHIND the
+// product blocks in the grid.  They ride when the product has at least sixteen x-tiles (config 2's shapes: the grid is several waves of workgroups and the
+// passengers start as CUs drain) or when the whole grid fits the chip at once (column shards: few x-tiles, e.g. 5 x 26 + 16 workgroups at n = 625) --
+// round 3 sent the latter to a stand-alone 16-workgroup launch of 28 us.
+template <typename T>
+bool Engine<T>::passengers_ride(const FactorProductPlan& plan) const {
+	const int passengers = (&plan == &planHx_ && gram_ksplit_ > 1) ? GRAM_IMAGE_TILES * gram_ksplit_ : GRAM_REDUCE_BLOCKS;
+	return RP_ == 64 && ((plan.xtiles >= GRAM_REDUCE_BLOCKS && passengers == GRAM_REDUCE_BLOCKS) || plan.xtiles * plan.splits + passengers <= num_cus_);
 }
 
 // fp32 product (native MFMA or split-operand kernel) at padded rank 64 with passenger blocks in its grid
@@ -766,7 +799,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			}
 			GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, G_, compute_error)) return s;
+			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, rgW.ksplit > 1 ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 			hx3_valid_ = x3_;
 			return ST_OK;
 		}
@@ -861,8 +894,11 @@ Status Engine<T>::w_products(T* exchange) {
 			// K_W with the local H H^T reduced straight into the exchange buffer by the passenger
 			// workgroups, then the local split-K slabs summed into the exchange panel
 			GramReduceArgs rgH = gram_args(false, ex_hht, nullptr, 0);
-			if (Status s = product_w(H_, &rgH, nullptr, x3_ && hx3_valid_)) return s;
-			HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
+			// a team of one: w_finish() sums the split-K slabs itself, as iterate_mu64() does -- no pass over the panel in between
+			if (sole_rank_ && gram_image_) return product_w(H_, &rgH, nullptr, x3_ && hx3_valid_);
+			// one K slice (short column shards) writes the exchange panel itself
+			if (Status s = product_w(H_, &rgH, exchange, x3_ && hx3_valid_)) return s;
+			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
 		}
 	}
@@ -934,8 +970,9 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
-			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T
-			if (Status s = mu64_update(true, exchange, 1, 0, ex_hht, compute_error)) return s;
+			// U_W on the all-reduced sums: one "slab" (the exchange panel), Q = the reduced H H^T  (a team of one: the split-K slabs as w_products left them)
+			if (sole_rank_ && gram_image_) { if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, ex_hht, compute_error)) return s; }
+			else if (Status s = mu64_update(true, exchange, 1, 0, ex_hht, compute_error)) return s;
 			wx3_valid_ = x3_;
 			normalize_next_ = 1;
 			w_pending_ = true;
@@ -956,6 +993,27 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 	if (tri_) return tri_update_w(exchange, 1, 0, (sole_rank_ && qx3_holds_hht_) ? nullptr : ex_hht);
 	HIPX(launch_panel_update<T>(PANEL_MU, Wt_, exchange, 1, 0, ex_hht, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, nullptr, nullptr, 0, qx3_));
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
+	return ST_OK;
+}
+
+// W step of a column-sharded run whose ranks read each other's exchange buffers (comm.h, direct_exchange): the W update sums the ranks' (V_g H_g^T)^T panels in
+// its prologue, in rank order -- every rank adds the same values in the same order, so the replicas of W stay bit-identical; the r x r parts are summed first
+// (one small launch; nothing to do for a team of one).  Rank-64 multiplicative update on the split-operand path only (direct_w_finish()).
+template <typename T>
+Status Engine<T>::w_finish_peers(const T* const* exchanges, int count, bool compute_error) {
+	if (!direct_w_finish() || count < 1 || count > PEER_SLABS_MAX || exchanges == nullptr) return ST_INVALID;
+	if constexpr (std::is_same<T, float>::value) {
+		PeerSlabs panels = {}, hhts = {};
+		panels.count = hhts.count = count;
+		for (int p = 0; p < count; ++p) { panels.p[p] = exchanges[p]; hhts.p[p] = exchanges[p] + (long)RP_ * mpad_; }
+		const float* Q = hhts.p[0];
+		if (count > 1) { HIPX(launch_sum_peers(hhts, HHt_, RP_ * RP_, stream_)); Q = HHt_; }
+		if (Status s = mu64_update(true, nullptr, count, 0, Q, compute_error, &panels)) return s;
+		wx3_valid_ = x3_;
+		normalize_next_ = 1;
+		w_pending_ = true;
+		if (compute_error) { if (Status s = fetch_error_terms(n_)) return s; }
+	}
 	return ST_OK;
 }
 
@@ -1166,6 +1224,7 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		if (!fused_ready_) { normalize_next_ = 0; fused_ready_ = true; }
 		if (!wx3_valid_) { HIPX(launch_pack_panel_x3(Wt_, RP_, m_, Wx3_, ksH_, stream_)); wx3_valid_ = true; }
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
+		rgW.ksplit = 0; rgW.G = G_;                       // (the persistent launch reads the finished matrix)
 		if (Status s = standalone_gram(rgW)) return s;
 		OnePassArgs a;
 		a.V = V_; a.tile_stride = strideV_;
@@ -1231,7 +1290,7 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 		}
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, G_, compute_error)) return s;
+		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, rgW.ksplit > 1 ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 		GramReduceArgs rgH = gram_args(false, HHt_, nullptr, 0);
 		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
 		if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, HHt_, compute_error)) return s;

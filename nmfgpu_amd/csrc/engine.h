@@ -71,6 +71,10 @@ public:
 	Status h_step(bool compute_error);
 	Status w_products(T* exchange);
 	Status w_finish(const T* exchange, bool compute_error);
+	// ... and without a reduction in between: exchanges[p] = rank p's exchange buffer as its w_products() left it, readable from this device (count ranks, rank
+	// order).  Available where direct_w_finish() says so (rank-64 multiplicative update on the split-operand path).
+	Status w_finish_peers(const T* const* exchanges, int count, bool compute_error);
+	bool direct_w_finish() const { return fused_capable() && gram_image_ && prm_.divergence == 0; }
 	// KL update (sparse V): the exchange also carries the row sums of the local H and, on error iterations, the per-row error terms:
 	//   [ numerator panel RP x mpad | H_g H_g^T RP x RP | rowsum(H_g) RP | tr terms mpad | KL terms mpad ]
 	long exchange_count() const { return (long)RP_ * mpad_ + (long)RP_ * RP_ + (prm_.divergence != 0 ? (long)RP_ + 2 * mpad_ : 0); }
@@ -147,6 +151,7 @@ private:
 	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
 	Status normal_inverse_fork(T* A, T offdiag, T diag);   // the same on the side stream; normal_inverse_join() before Qinv_ is read
 	Status normal_inverse_join();
+	bool passengers_ride(const FactorProductPlan& plan) const; // split-operand product, rank 64: the Gram passengers find CUs beside the product blocks
 	bool inverse_rides(const FactorProductPlan& plan) const;   // the inverse can be a passenger workgroup of the product launch
 	Status finish_upload(T* Vcol);
 	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC
@@ -215,12 +220,15 @@ private:
 	std::vector<T> h_klrow_, h_sW_, h_sH_;
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr, *Graw64_ = nullptr;
+	int gram_ksplit_ = 1;            // K slices of the W^T W passengers (gram_image.h): > 1 for column shards narrower than config 2
+	float* Gpart_ = nullptr;         // [GRAM_KSPLIT_MAX][4096] unscaled slices of W^T W (the H update adds and scales them, and stores G_)
+	float* wsq_part_ = nullptr;      // [mpad / 32][64] partial sums of squares of the rows the last W update wrote (k_mu64_update32<true>): the pending column scale's source
 	bool fused_ready_ = false, w_pending_ = false;
 	// split-operand path: Gram matrices from the split images (gram_image.h), 32-column update kernel -- no partial Gram matrices
 	bool gram_image_ = false;
 	GramReduceArgs gram_args(bool of_w, float* G, float* scale, int normalize) const;
 	Status standalone_gram(const GramReduceArgs& rg);
-	Status mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error);
+	Status mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error, const PeerSlabs* peers = nullptr);
 	// generic rank-64 fp32 path: the update kernel leaves partial Gram matrices of what it wrote (gram_from_update())
 	bool gram_w_ready_ = false;      // G_ holds W^T W of the current (normalised) W
 	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams

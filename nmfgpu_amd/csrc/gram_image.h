@@ -18,34 +18,65 @@ namespace nmfamd {
 
 // One workgroup of 256 threads = one 16 x 16 tile (ti, tj), ti <= tj, of the upper triangle (blocks with ti > tj return at
 // once); the mirrored tile is written from the same values, so G is exactly symmetric.  The four waves split the K-steps;
-// partial tiles are added in wave order.  With rg.normalize the tile is scaled on both sides by 1 / sqrt(diag) (1 where
-// the diagonal is 0: kernel::normalizeColumns' `sum > 0` guard): an off-diagonal block also accumulates the two diagonal
-// tiles it needs the diagonal of -- the same instructions on the same data as the diagonal blocks run, hence the same bits.
-// lds: 3456 floats.
+// partial tiles are added in wave order.  With rg.normalize the tile is scaled on both sides by 1 / sqrt(sum of squares of
+// the column) (1 where that is 0: kernel::normalizeColumns' `sum > 0` guard, KernelNormalizeColumns.cu:37-58).
+// Where the sums of squares come from:
+//   rg.colsq_part != nullptr (round 4): the update kernel that wrote the panel left one vector of 64 partial sums per workgroup
+//     (k_mu64_update32<true>); every block adds the `colsq_parts` vectors of its 32 columns in a fixed order -- fp32 sums of the
+//     squares of the fp32 values, which is what the reference's kernel forms;
+//   else: the diagonal of the six-term product itself (rounds 2-3): an off-diagonal block also accumulates the two diagonal tiles
+//     -- 18 dependent MFMAs per pair of K-steps instead of 6, a 23 us chain for config 2's W (10 112 rows) that a 42 us product hides
+//     and a column shard's 12 us product does not (profiles/r04_shard_trace.md).
+// K-split form (rg.ksplit > 1, column shards -- round 4): the chain above is a chain of memory round trips (four pairs in flight per wave, ~1.2 us each under
+// the product's stream: 24 us for 10 112 rows whatever the MFMA count), so the K range is cut into rg.ksplit slices and the grid holds 10 * ksplit blocks
+// (block = slice * 10 + upper-triangle tile).  A block writes its UNSCALED partial tile (and its mirror image) into rg.G + slice * 4096; the slices are added, in
+// order, and scaled by the consumer (k_mu64_update32<false>, qsplit) -- no atomics, no fence, same bits run after run.  Slice 0's diagonal blocks publish
+// the column scales (from rg.colsq_part, or ones).
+// lds: GRAM_IMAGE_LDS_FLOATS floats.
+constexpr int GRAM_IMAGE_LDS_FLOATS = 3456 + 256;
+#ifndef GRAM_IMAGE_RING
+#define GRAM_IMAGE_RING 4
+#endif
 __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float* lds) {
 	typedef float f32x4v __attribute__((ext_vector_type(4)));
-	const int ti = blk >> 2, tj = blk & 3;
+	const int ksplit = rg.ksplit > 1 ? rg.ksplit : 1;
+	int ti = blk >> 2, tj = blk & 3, slice = 0;
+	if (ksplit > 1) {
+		// tile t of the upper triangle, row by row: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+		const int t = blk % GRAM_IMAGE_TILES;
+		slice = blk / GRAM_IMAGE_TILES;
+		if (slice >= ksplit) return;
+		ti = t < 4 ? 0 : t < 7 ? 1 : t < 9 ? 2 : 3;
+		tj = t < 4 ? t : t < 7 ? t - 3 : t < 9 ? t - 5 : 3;
+	}
 	if (ti > tj) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
 	const bf16x8* F = reinterpret_cast<const bf16x8*>(rg.image);
 	const int KS = rg.image_ks;                       // K-steps of 16 panel rows; step KS is the all-zero step that closes the image
 	const bool diag_block = ti == tj;
-	const bool need_diag = rg.normalize != 0 && !diag_block;
+	const bool from_parts = rg.normalize != 0 && rg.colsq_part != nullptr && slice == 0;
+	const bool need_diag = rg.normalize != 0 && !diag_block && rg.colsq_part == nullptr && ksplit == 1;
 	// slot of (K-step ks, column c, plane, half h): ((ks * 2 + (c >> 5)) * 3 + plane) * 64 + h * 32 + (c & 31)
 	const int ci = 16 * ti + l15, cj = 16 * tj + l15;
 	const long offi = (long)(ci >> 5) * 192 + (q & 1) * 32 + (ci & 31);
 	const long offj = (long)(cj >> 5) * 192 + (q & 1) * 32 + (cj & 31);
 	const int pairs = (KS + 2) / 2;                    // 32 k per MFMA = two K-steps
-	const int p0 = (pairs * wave) / 4, p1 = (pairs * (wave + 1)) / 4;
+	const int piece = slice * 4 + wave, pieces = 4 * ksplit;
+	const int p0 = (int)(((long)pairs * piece) / pieces), p1 = (int)(((long)pairs * (piece + 1)) / pieces);
 	f32x4v aij = {0.f, 0.f, 0.f, 0.f}, aii = aij, ajj = aij;
-	bf16x8 a[2][3], b[2][3];
+	// RD pairs of K-steps in flight per wave (6 sixteen-byte loads each).  Round 3 kept ONE pair ahead of the MFMAs.  What bounds the block is not that
+	// latency but what ONE CU can pull from L2: 1.9 MB of fragments for the 632 K-steps of config 2's W = 24 us at ~80 GB/s, the same with four or
+	// eight pairs in flight (RD = 8: slower, 36 us) -- hidden behind a 42 us product at n = 5 000, the critical path of W^T V for a column shard.  Hence
+	// the K-split form (more CUs), see above.  The pairs are still summed in ascending order: same bits.
+	constexpr int RD = GRAM_IMAGE_RING;
+	bf16x8 a[RD][3], b[RD][3];
 	auto fetch = [&](int p, bf16x8 (&fa)[3], bf16x8 (&fb)[3]) {
 		int ks = 2 * p + (q >> 1);
-		ks = ks < KS ? ks : KS;
+		ks = (ks < KS && p < p1) ? ks : KS;             // (past this wave's range: the all-zero step -- adds +0, keeps the loop branch-free)
 		const bf16x8* base = F + (long)ks * 384;
 #pragma unroll
-		for (int pl = 0; pl < 3; ++pl) { fa[pl] = base[offi + pl * 64]; fb[pl] = base[offj + pl * 64]; }
+		for (int pl = 0; pl < 3; ++pl) { fa[pl] = base[offi + pl * 64]; fb[pl] = base[offj + pl * 64]; }      // (no branch in here: the waits must stay counted)
 	};
 	auto six = [&](const bf16x8 (&x)[3], const bf16x8 (&y)[3], f32x4v acc) -> f32x4v {
 		// smallest terms first, as in k_factor_product_x3
@@ -57,16 +88,31 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 		acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], y[0], acc, 0, 0, 0);
 		return acc;
 	};
-	if (p0 < p1) fetch(p0, a[0], b[0]);
-	for (int p = p0; p < p1; p += 2) {
-		// two pairs per turn, the fetch of each one a pair ahead of its MFMAs
-		if (p + 1 < p1) fetch(p + 1, a[1], b[1]);
-		aij = six(a[0], b[0], aij);
-		if (need_diag) { aii = six(a[0], a[0], aii); ajj = six(b[0], b[0], ajj); }
-		if (p + 2 < p1) fetch(p + 2, a[0], b[0]);
-		if (p + 1 < p1) {
-			aij = six(a[1], b[1], aij);
-			if (need_diag) { aii = six(a[1], a[1], aii); ajj = six(b[1], b[1], ajj); }
+#pragma unroll
+	for (int d = 0; d < RD; ++d) fetch(p0 + d, a[d], b[d]);
+	float* s_sq = lds + 3456;                            // [8][32]: partial sums of squares of the tile's 16 row- and 16 column-indices, eight groups of parts
+	if (from_parts) {
+		// thread (g = tid >> 5, c = tid & 31) adds the parts g, g + 8, ... of column c -- up to 40 of them requested together (ONE round trip for the 316 parts
+		// of config 2's W: five batches of eight took 5 us of a column shard's 12 us launch), further batches beyond; the groups are added in order below
+		const int c = tid & 31, g = tid >> 5;
+		const float* src = rg.colsq_part + (c < 16 ? 16 * ti + c : 16 * tj + c - 16);
+		float sum = 0.f;
+		for (int p = g; p < rg.colsq_parts; p += 320) {
+			float v[40];
+#pragma unroll
+			for (int u = 0; u < 40; ++u) v[u] = p + 8 * u < rg.colsq_parts ? src[(long)(p + 8 * u) * 64] : 0.f;
+#pragma unroll
+			for (int u = 0; u < 40; ++u) sum += v[u];
+		}
+		s_sq[g * 32 + c] = sum;
+	}
+	for (int p = p0; p < p1; p += RD) {
+		// RD pairs per turn; a slot is refilled (pair p + d + RD) as soon as its MFMAs are issued
+#pragma unroll
+		for (int d = 0; d < RD; ++d) {
+			aij = six(a[d], b[d], aij);
+			if (need_diag) { aii = six(a[d], a[d], aii); ajj = six(b[d], b[d], ajj); }
+			fetch(p + d + RD, a[d], b[d]);
 		}
 	}
 	// partial tiles of the four waves, added in wave order.  C/D map of the 16 x 16 MFMA: register g of lane l is
@@ -94,9 +140,15 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 		for (int g = 0; g < 4; ++g) { const int r = 4 * q + g, c = l15; vij[g] = r <= c ? s_tile[r * 16 + c] : s_tile[c * 16 + r]; }
 		if (lane < 16) {
 			const float d = s_tile[lane * 17];
-			const float s = rg.normalize ? (d > 0.f ? 1.0f / sqrtf(d) : 1.0f) : 1.0f;
+			float s = rg.normalize ? (d > 0.f ? 1.0f / sqrtf(d) : 1.0f) : 1.0f;
+			if (from_parts) {
+				float q2 = s_sq[lane];
+#pragma unroll
+				for (int g = 1; g < 8; ++g) q2 += s_sq[g * 32 + lane];
+				s = q2 > 0.f ? 1.0f / sqrtf(q2) : 1.0f;
+			}
 			s_d[lane] = s; s_d[16 + lane] = s;
-			if (rg.scale) rg.scale[16 * ti + lane] = s;
+			if (rg.scale && slice == 0) rg.scale[16 * ti + lane] = s;
 		}
 	} else {
 		if (need_diag) {
@@ -109,10 +161,29 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 			__builtin_amdgcn_s_waitcnt(0xc07f);
 			__builtin_amdgcn_wave_barrier();
 			if (lane < 32) { const float d = s_di[lane]; s_d[lane] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f; }
+		} else if (from_parts) {
+			if (lane < 32) {
+				float q2 = s_sq[lane];
+#pragma unroll
+				for (int g = 1; g < 8; ++g) q2 += s_sq[g * 32 + lane];
+				s_d[lane] = q2 > 0.f ? 1.0f / sqrtf(q2) : 1.0f;
+			}
 		} else if (lane < 32) s_d[lane] = 1.0f;
 	}
 	__builtin_amdgcn_s_waitcnt(0xc07f);
 	__builtin_amdgcn_wave_barrier();
+	if (ksplit > 1) {
+		// this slice's partial tile as it is; the consumer adds the slices and scales.  The scales: slice 0, off-diagonal blocks hold them too but only the
+		// diagonal ones publish (above)
+		float* Gk = rg.G + (long)slice * 4096;
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const int r = 4 * q + g, c = l15;
+			Gk[(long)(16 * ti + r) * 64 + 16 * tj + c] = vij[g];
+			if (!diag_block) Gk[(long)(16 * tj + c) * 64 + 16 * ti + r] = vij[g];
+		}
+		return;
+	}
 #pragma unroll
 	for (int g = 0; g < 4; ++g) {
 		const int r = 4 * q + g, c = l15;

@@ -53,8 +53,17 @@ struct GramReduceArgs {
 	// (gram_image.h); image_ks = K-steps of 16 panel rows in the image (the all-zero step that closes it not counted)
 	const void* image = nullptr;
 	int image_ks = 0;
+	// ... with normalize: the column scales from per-workgroup partial sums of squares the update kernel left ([colsq_parts][64], gram_image.h) instead of
+	// from the diagonal of the product
+	const float* colsq_part = nullptr;
+	int colsq_parts = 0;
+	// ... cut into ksplit slices of the K range (gram_image.h): 10 * ksplit passenger blocks, G then receives ksplit UNSCALED partial matrices ([ksplit][4096])
+	// that the consumer adds and scales (launch_mu64_update32, qsplit); with normalize the scales must come from colsq_part
+	int ksplit = 0;
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
+constexpr int GRAM_IMAGE_TILES = 10;               // gram_image.h: upper triangle of the 4 x 4 grid of 16 x 16 tiles
+constexpr int GRAM_KSPLIT_MAX = 8;                 // ... and the most K slices its K-split form is cut into
 
 // X: valid output length (the plan picks the tile height; panels must be allocated for xtiles * th rows).
 // A is x-TILED: A(x, y) at A[(x/th) * tile_stride + y*th + x%th] (launch_tile / launch_tile_transposed).
@@ -88,12 +97,23 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 // The same update on 32-column tiles WITHOUT the partial Gram matrices (twice the workgroups, half the serial MFMA work per
 // workgroup, no Gram in the critical path): for callers that take the Gram matrices from the split image (gram_image.h).
 // x3_out is mandatory here.
+// peers (optional): the summands are peers->count panels given by pointer (the exchange panels of a column-sharded run's ranks, in rank order; on this
+// device or in a peer's memory) instead of S slabs slab_stride apart
+constexpr int PEER_SLABS_MAX = 16;
+struct PeerSlabs { const float* p[PEER_SLABS_MAX]; int count; };
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
-                                void* x3_out, int x3_ks);
+                                void* x3_out, int x3_ks, const PeerSlabs* peers = nullptr, float* colsq_part = nullptr, int qsplit = 0, float* q_out = nullptr);
+// (qsplit > 1, H update: Q holds qsplit unscaled partial matrices 4096 elements apart -- the K-split Gram passengers' output, GramReduceArgs::ksplit; every
+//  workgroup adds them in order and scales the sum by `scale` on both sides, workgroup 0 also stores the finished matrix to q_out)
+// (colsq_part, W update only: len_pad / 32 vectors of 64 partial sums of squares of the new rows, one per workgroup -- what the next Gram passengers turn into
+//  the pending column scale, GramReduceArgs::colsq_part)
+// out[i] = sum_k src.p[k][i] (rank order), count a multiple of 4: the r x r parts of the ranks' exchange buffers
+hipError_t launch_sum_peers(const PeerSlabs& src, float* out, int count, hipStream_t stream);
 // G (64 x 64) = P P^T from the split image of P (image_ks K-steps); normalize / scale as in GramReduceArgs.  Stand-alone form
 // of the passenger workgroups of the split-operand product launch.
-hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream);
+hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream, const float* colsq_part = nullptr, int colsq_parts = 0);
+hipError_t launch_gram_image_args(const GramReduceArgs& rg, hipStream_t stream);      // ... every field of rg as given, the K-split form included
 // P(c, y) *= scale(c)
 hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hipStream_t stream, void* x3_out = nullptr, int x3_ks = 0);
 // G <- sum of `parts` partial 64 x 64 matrices; with scale != nullptr also scale(c) = 1 / sqrt(G(c, c)) (1 if 0) and
@@ -293,7 +313,7 @@ hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int 
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
                                     unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128);
-int plan_splits_x3(int xtiles, int KS, int num_cus);
+int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve = 0);
 
 // ---- one pass over V per multiplicative-update iteration at padded rank 64 (kernels_onepass.hip) -----------------------
 // The H update is column-separable once W^T W is known (reference: RN2 = RR H, RN = W^T V, multiplyDivide per element,

@@ -220,11 +220,15 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 // product on v_mfma_f32_16x16x4_f32 with the K order chosen so that both operands are 16-byte reads (lane group q of the
 // MFMA holds c' = 16 q + t in step t), no Gram.
 // Workgroup = 4 waves = 32 panel columns.  Wave w owns result rows c = 16 w .. 16 w + 15 for both 16-column halves.
-template <bool IS_W>
+// U: further slabs requested together with the first one (and per later batch): 7 for the few slabs of a whole problem, 13 for the many a short
+// column shard's W^T V is cut into (26 slabs at n = 625: two round trips instead of four)
+// QS: K slices the r x r operand arrives in (H update; 1: the finished matrix)
+template <bool IS_W, int U = 7, int QS = 1>
 __global__ __launch_bounds__(256) void k_mu64_update32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
-	float* __restrict__ ps, int len_valid, const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks) {
+	float* __restrict__ ps, int len_valid, const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks, PeerSlabs peers,
+	float* __restrict__ colsq_part, int qsplit, float* __restrict__ q_out) {
 	typedef float f32x4v __attribute__((ext_vector_type(4)));
 	__shared__ __attribute__((aligned(16))) float s_num[32][68];   // reduced numerator, later the new values
 	__shared__ __attribute__((aligned(16))) float s_old[32][68];   // old values (scaled for the W update)
@@ -237,36 +241,56 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 	const int yl0 = tid >> 4;               // its panel column in step j is yl0 + 16 j
 
 	// ---- linear pass: slab sum (slab order), pending scale, into LDS ---------------------------
+	// peers.count > 0: the "slabs" are the exchange panels of the ranks of a column-sharded run, read where they lie (this device or a peer's memory,
+	// comm.h exchange_publish) and added in rank order -- the all-reduce of SURVEY 8(e) happens in this kernel's prologue
+	if (peers.count > 0) S = peers.count;
+	auto slab_at = [&](int k) -> const float* { return peers.count > 0 ? peers.p[k] : slabs + (long)k * slab_stride; };
+	f32x4v qa[4];
+	f32x4v qs[QS > 1 ? QS - 1 : 1][4];
 	f32x4v nl[2], ol[2];
 	{
-		f32x4v t[7][2];
+		f32x4v t[U][2];
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			const long e = tile + 4 * (tid + 256 * j);
-			nl[j] = *reinterpret_cast<const f32x4v*>(slabs + e);
+			nl[j] = *reinterpret_cast<const f32x4v*>(slab_at(0) + e);
 			ol[j] = *reinterpret_cast<const f32x4v*>(P + e);
 #pragma unroll
-			for (int u = 0; u < 7; ++u) {
+			for (int u = 0; u < U; ++u) {
 				const int k = 1 + u < S ? 1 + u : 0;   // clamped duplicate, discarded below
-				t[u][j] = *reinterpret_cast<const f32x4v*>(slabs + (long)k * slab_stride + e);
+				t[u][j] = *reinterpret_cast<const f32x4v*>(slab_at(k) + e);
 			}
 		}
+		__builtin_amdgcn_sched_barrier(0);
+		// A operand of the r x r product: Q(c = 16 wave + l15, c' = 16 q + t), t = 0 .. 15 (Q is symmetric: a row is a column).  Requested right BEHIND the slabs' first
+		// batch: the wait for that batch then leaves these in flight, and they arrive while the slabs are summed and parked in LDS (in front of the batch they
+		// made every workgroup of the launch wait for the same few lines first: 7.4 -> 10 us with four K slices)
+	#pragma unroll
+		for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+		if (!IS_W && QS > 1) {
+			// Q arrives as QS unscaled K slices of Wu^T Wu (gram_image.h, K-split form): all requested together, added in order below
+	#pragma unroll
+			for (int k = 1; k < QS; ++k)
+	#pragma unroll
+				for (int u = 0; u < 4; ++u) qs[k - 1][u] = *reinterpret_cast<const f32x4v*>(Q + (long)k * 4096 + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+		}
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int u = 0; u < 7; ++u)
+		for (int u = 0; u < U; ++u)
 			if (1 + u < S) {
 #pragma unroll
 				for (int j = 0; j < 2; ++j) nl[j] += t[u][j];
 			}
-		for (int k0 = 8; k0 < S; k0 += 7) {      // more than eight slabs: further batches of seven
+		for (int k0 = 1 + U; k0 < S; k0 += U) {      // more slabs than one batch: further batches of U
 #pragma unroll
 			for (int j = 0; j < 2; ++j)
 #pragma unroll
-				for (int u = 0; u < 7; ++u) {
+				for (int u = 0; u < U; ++u) {
 					const int k = k0 + u < S ? k0 + u : 0;
-					t[u][j] = *reinterpret_cast<const f32x4v*>(slabs + (long)k * slab_stride + tile + 4 * (tid + 256 * j));
+					t[u][j] = *reinterpret_cast<const f32x4v*>(slab_at(k) + tile + 4 * (tid + 256 * j));
 				}
 #pragma unroll
-			for (int u = 0; u < 7; ++u)
+			for (int u = 0; u < U; ++u)
 				if (k0 + u < S) {
 #pragma unroll
 					for (int j = 0; j < 2; ++j) nl[j] += t[u][j];
@@ -274,10 +298,20 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		}
 	}
 	const f32x4v sc = *reinterpret_cast<const f32x4v*>(scale + c4);
-	// A operand of the r x r product: Q(c = 16 wave + l15, c' = 16 q + t), t = 0 .. 15 (Q is symmetric: a row is a column)
-	f32x4v qa[4];
+	if (!IS_W && QS > 1) {
+		// ... then D (.) D as the one-slice passengers do: (v * d(column)) * d(row)
 #pragma unroll
-	for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+		for (int k = 1; k < QS; ++k)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) qa[u] += qs[k - 1][u];
+		const float srow = scale[16 * wave + l15];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const f32x4v scol = *reinterpret_cast<const f32x4v*>(scale + 16 * q + 4 * u);
+			qa[u] = (qa[u] * scol) * srow;
+			if (blockIdx.x == 0 && q_out != nullptr) *reinterpret_cast<f32x4v*>(q_out + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u) = qa[u];
+		}
+	}
 #pragma unroll
 	for (int j = 0; j < 2; ++j) {
 		// the pending column scale of W goes on the numerator W^T V (H update) or on W itself (W update)
@@ -302,6 +336,7 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u][g], ob[1][u][g], acc[1], 0, 0, 0);
 		}
 	// C/D map: register g of lane (q, l15) is row c = 16 wave + 4 q + g, column y = 16 yt + l15
+	f32x4v sq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 	for (int yt = 0; yt < 2; ++yt) {
 		const int y = 16 * yt + l15;
@@ -313,6 +348,7 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		for (int g = 0; g < 4; ++g) {
 			o[g] = oldv[g] * numv[g] / (acc[yt][g] + eps);
 			psum += o[g] * numv[g];
+			if (IS_W) sq[g] += o[g] * o[g];
 		}
 		// each (column, four rows) of s_num is read and then overwritten by exactly one lane
 		*reinterpret_cast<f32x4v*>(&s_num[y][16 * wave + 4 * q]) = o;
@@ -321,6 +357,17 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 			psum += __shfl_xor(psum, 32);
 			if (q == 0) s_ps[wave][y] = psum;
 		}
+	}
+	if (IS_W && colsq_part != nullptr) {
+		// this workgroup's 32 new rows: their sums of squares per factor column (kernel::normalizeColumns' sums, KernelNormalizeColumns.cu:37-49, in parts; rows
+		// past the valid length are exactly 0): over the 16 lanes of a quarter, then one 16-byte store per quarter
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			float v = sq[g];
+			v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+			sq[g] = v;
+		}
+		if (l15 == 0) *reinterpret_cast<f32x4v*>(colsq_part + (long)blockIdx.x * 64 + 16 * wave + 4 * q) = sq;
 	}
 	if (IS_W && compute_error && blockIdx.x == 0) {
 		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (AlgorithmMultiplicativeFrobenius.h:212)
@@ -355,26 +402,65 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 	}
 }
 
+template <bool IS_W, int U, int QS>
+static void launch_update32_inst(dim3 grid, hipStream_t stream, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale, float eps, float* ps,
+                                 int len_valid, const float* Gprev, int compute_error, bf16x8* xo, int x3_ks, const PeerSlabs& peers, float* colsq_part, float* q_out) {
+	hipLaunchKernelGGL((k_mu64_update32<IS_W, U, QS>), grid, dim3(256), 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, peers,
+	                   colsq_part, QS, q_out);
+}
+
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
-                                void* x3_out, int x3_ks) {
-	if (x3_out == nullptr || len_pad % 32 != 0) return hipErrorInvalidValue;
-	dim3 grid(len_pad / 32), block(256);
+                                void* x3_out, int x3_ks, const PeerSlabs* peers, float* colsq_part, int qsplit, float* q_out) {
+	if (x3_out == nullptr || len_pad % 32 != 0 || (qsplit > 1 && is_w) || (qsplit > 1 && qsplit != 2 && qsplit != 4 && qsplit != 8)) return hipErrorInvalidValue;
+	PeerSlabs pa = {};
+	if (peers != nullptr) {
+		if (peers->count < 1 || peers->count > PEER_SLABS_MAX) return hipErrorInvalidValue;
+		pa = *peers;
+		S = peers->count;
+	}
+	dim3 grid(len_pad / 32);
 	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
-	if (is_w) hipLaunchKernelGGL((k_mu64_update32<true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks);
-	else hipLaunchKernelGGL((k_mu64_update32<false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks);
+#define NMFAMD_U32(ISW, UU, QQ) launch_update32_inst<ISW, UU, QQ>(grid, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, pa, colsq_part, q_out)
+	if (is_w) { if (S > 8) NMFAMD_U32(true, 13, 1); else NMFAMD_U32(true, 7, 1); }
+	else if (S > 8) { if (qsplit == 2) NMFAMD_U32(false, 13, 2); else if (qsplit == 4) NMFAMD_U32(false, 13, 4); else if (qsplit == 8) NMFAMD_U32(false, 13, 8); else NMFAMD_U32(false, 13, 1); }
+	else { if (qsplit == 2) NMFAMD_U32(false, 7, 2); else if (qsplit == 4) NMFAMD_U32(false, 7, 4); else if (qsplit == 8) NMFAMD_U32(false, 7, 8); else NMFAMD_U32(false, 7, 1); }
+#undef NMFAMD_U32
+	return hipGetLastError();
+}
+
+// out[i] = sum over k (ascending) of src.p[k][i], i < count (a multiple of 4): the r x r part of the exchange (H_g H_g^T of every rank) before the W update
+__global__ __launch_bounds__(256) void k_sum_peers(PeerSlabs src, float* __restrict__ out, int count) {
+	const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
+	if (i >= count) return;
+	f32x4 s = *reinterpret_cast<const f32x4*>(src.p[0] + i);
+	for (int k = 1; k < src.count; ++k) s += *reinterpret_cast<const f32x4*>(src.p[k] + i);
+	*reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+hipError_t launch_sum_peers(const PeerSlabs& src, float* out, int count, hipStream_t stream) {
+	if (src.count < 1 || src.count > PEER_SLABS_MAX || count % 4 != 0) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, stream, src, out, count);
 	return hipGetLastError();
 }
 
 // Stand-alone form of the Gram-from-image passengers (callers that have no product launch to ride in)
 __global__ __launch_bounds__(256) void k_gram_image(GramReduceArgs rg) {
-	__shared__ __attribute__((aligned(16))) float lds[3456];
+	__shared__ __attribute__((aligned(16))) float lds[GRAM_IMAGE_LDS_FLOATS];
 	gram_image_block(rg, blockIdx.x, lds);
 }
 
-hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream) {
+// every field of rg as given (the K-split form included: 10 * ksplit blocks)
+hipError_t launch_gram_image_args(const GramReduceArgs& rg, hipStream_t stream) {
+	if (rg.image == nullptr || rg.ksplit > GRAM_KSPLIT_MAX || (rg.ksplit > 1 && rg.normalize != 0 && rg.colsq_part == nullptr)) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_gram_image, dim3(rg.ksplit > 1 ? GRAM_IMAGE_TILES * rg.ksplit : GRAM_REDUCE_BLOCKS), dim3(256), 0, stream, rg);
+	return hipGetLastError();
+}
+
+hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream, const float* colsq_part, int colsq_parts) {
 	GramReduceArgs rg = {nullptr, 0, G, scale, normalize};
 	rg.image = image; rg.image_ks = image_ks;
+	rg.colsq_part = colsq_part; rg.colsq_parts = colsq_parts;
 	hipLaunchKernelGGL(k_gram_image, dim3(GRAM_REDUCE_BLOCKS), dim3(256), 0, stream, rg);
 	return hipGetLastError();
 }

@@ -425,8 +425,15 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 }
 
 // Every wave piece (four per slice) gets at least two turns of the 3-deep ring; as many slices as fill the chip.
-int plan_splits_x3(int xtiles, int KS, int num_cus) {
-	const int by_fill = std::max(1, num_cus / std::max(1, xtiles));
+// reserve: CUs kept free for passenger workgroups beyond the sixteen (K-split Gram passengers of a column shard's W^T V)
+int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
+	if (reserve > 0) {
+		const int by_fill = std::max(1, (num_cus - reserve) / std::max(1, xtiles));
+		const int by_depth = std::max(1, KS / (6 * 4));
+		return std::max(1, std::min(by_fill, by_depth));
+	}
+	// (fewer than sixteen x-tiles -- a column shard's W^T V: leave the sixteen passenger workgroups a CU each, Engine::passengers_ride)
+	const int by_fill = std::max(1, (xtiles < GRAM_REDUCE_BLOCKS ? num_cus - GRAM_REDUCE_BLOCKS : num_cus) / std::max(1, xtiles));
 	const int by_depth = std::max(1, KS / (6 * 4));
 	return std::max(1, std::min(by_fill, by_depth));
 }
@@ -436,9 +443,11 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
 	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
-	const bool with_reduce = wanted && RP == 64 && p.xtiles >= GRAM_REDUCE_BLOCKS;
+	// (the passengers sit behind the product blocks in the grid, whatever the number of x-tiles; the caller sees to it that they find a CU
+	//  while the product runs -- Engine::passengers_ride)
+	const bool with_reduce = wanted && RP == 64;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
-	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : GRAM_REDUCE_BLOCKS);
+	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};

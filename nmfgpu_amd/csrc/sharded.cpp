@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace nmfamd {
@@ -27,7 +28,16 @@ Status ShardedRank<T>::prepare() {
 	if (eng_->is_kl() && mode_ != SHARD_REPLICATED) { last_error_ = "KL update: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	if (eng_->error_terms_per_factor_row() && mode_ != SHARD_REPLICATED) { last_error_ = "GDCLS / ALS family: the sharded W step is the replicated form (shard mode 1)"; return ST_INVALID; }
 	const int world = comm_->world(), rank = comm_->rank();
-	eng_->set_sole_rank(world == 1 && mode_ == SHARD_REPLICATED);
+	// The small-message form of the W step (replicated mode, rank-64 multiplicative update on the split-operand path, a transport whose ranks can read each
+	// other's memory): no reduction kernel and no copy -- the W update reads every rank's exchange panel where it lies (Engine::w_finish_peers), two exchange
+	// buffers alternate, ONE rendezvous per iteration (Comm::exchange_publish).  NMFAMD_SHARD_REHEARSE=1 makes a team of ONE go through exactly that path
+	// (panel written, published, read back by pointer, r x r part summed by the small launch) instead of the fused single-GPU iteration it would otherwise
+	// equal: what a rank of an N-GPU team runs, minus link time and the cross-device event wait -- the basis of DESIGN section 6's projection.
+	const char* rehearse = std::getenv("NMFAMD_SHARD_REHEARSE");
+	rehearse_ = world == 1 && rehearse != nullptr && std::atoi(rehearse) != 0;
+	const char* no_direct = std::getenv("NMFAMD_SHARD_NO_DIRECT");
+	direct_ = mode_ == SHARD_REPLICATED && eng_->direct_w_finish() && comm_->direct_exchange() && !(no_direct != nullptr && std::atoi(no_direct) != 0);
+	eng_->set_sole_rank(world == 1 && mode_ == SHARD_REPLICATED && !rehearse_);
 	long first = 0, count = 0;
 	shard_columns(total_columns_, world, rank, &first, &count);
 	if (count != eng_->n() || rows_ != eng_->m()) { last_error_ = "shard shape does not match shard_columns()"; return ST_INVALID; }
@@ -37,7 +47,11 @@ Status ShardedRank<T>::prepare() {
 		if (hipMalloc((void**)p, sizeof(T) * (size_t)elems) != hipSuccess) return false;
 		return hipMemsetAsync(*p, 0, sizeof(T) * (size_t)elems, s) == hipSuccess;
 	};
-	if (!dalloc(&exchange_, eng_->exchange_count())) return fail("hipMalloc(exchange)");
+	if (direct_) {
+		void* mine[2] = {nullptr, nullptr};
+		if (Status st = comm_->exchange_alloc(sizeof(T) * (size_t)eng_->exchange_count(), 2, mine)) { last_error_ = "exchange_alloc"; return st; }
+		xslot_[0] = static_cast<T*>(mine[0]); xslot_[1] = static_cast<T*>(mine[1]);
+	} else if (!dalloc(&exchange_, eng_->exchange_count())) return fail("hipMalloc(exchange)");
 	if (mode_ == SHARD_ROW_BLOCKS) {
 		if (mpad % (128l * world) != 0) { last_error_ = "engine was not created with set_row_blocks(world)"; return ST_INVALID; }
 		blk_rows_ = mpad / world;
@@ -84,6 +98,20 @@ Status ShardedRank<T>::iterate(bool compute_error) {
 	hipStream_t s = eng_->stream();
 	auto comm_fail = [&](Status st) { last_error_ = comm_->last_error(); return st; };
 	if (Status st = eng_->h_step(compute_error)) { last_error_ = eng_->last_error(); return st; }
+	if (direct_) {
+		T* mine = xslot_[iterations_++ & 1];
+		if (Status st = eng_->w_products(mine)) { last_error_ = eng_->last_error(); return st; }
+		if (world == 1 && !rehearse_) {
+			if (Status st = eng_->w_finish(mine, compute_error)) { last_error_ = eng_->last_error(); return st; }
+		} else {
+			const void* peers[PEER_SLABS_MAX];
+			if (world > PEER_SLABS_MAX) return ST_INVALID;
+			if (Status st = comm_->exchange_publish((int)((iterations_ - 1) & 1), s, peers)) return comm_fail(st);
+			if (Status st = eng_->w_finish_peers(reinterpret_cast<const T* const*>(peers), world, compute_error)) { last_error_ = eng_->last_error(); return st; }
+		}
+		if (compute_error) return launch_error_gather();
+		return ST_OK;
+	}
 	if (Status st = eng_->w_products(exchange_)) { last_error_ = eng_->last_error(); return st; }
 	if (mode_ == SHARD_REPLICATED) {
 		if (world > 1) { if (Status st = comm_->all_reduce(exchange_, eng_->exchange_count(), eb, s)) return comm_fail(st); }

@@ -61,6 +61,9 @@ private:
 	long blk_rows_ = 0;                     // rows of W per rank (ROW_BLOCKS)
 	long nloc_max_ = 0;
 	T* exchange_ = nullptr;                 // [panel RP x mpad | H H^T RP x RP]
+	bool direct_ = false, rehearse_ = false; // the W update reads the ranks' exchange buffers itself (sharded.cpp, prepare)
+	T* xslot_[2] = {nullptr, nullptr};      // ... this rank's two exchange buffers (the transport's), alternating by iteration
+	unsigned long iterations_ = 0;
 	T* blk_ = nullptr;                      // reduced (V H^T)^T rows of this rank
 	T* colsq_ = nullptr;                    // RP sums of squares
 	T* err_dev_ = nullptr;                  // world * (nloc_max + r) gathered error terms

@@ -5,9 +5,10 @@
 N = 1: BASELINE config 2 -- dense V 10 000 x 5 000, r = 64, Lee-Seung MU (Frobenius), fp32, V resident
 in HBM; one step = one MU iteration (error terms evaluated every 10th iteration, as in the reference's
 loop, source/nmf/SingleGpuDispatcher.cpp:171-201).
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank holds one
-10 000 x 5 000 column shard (global V is 10 000 x 5 000 N), W replicated, one RCCL all-reduce of
-(V H^T | H H^T) per iteration; value = N * K shard-iterations / max-over-ranks time.
+N > 1: the SAME 10 000 x 5 000 problem column-sharded over the N GPUs (BASELINE north_star's 1/2/4/8 series; "scaling": "strong",
+value = iterations/s of that problem; --scaling weak: one such matrix per GPU).  Launched by torch.distributed.run (one rank per
+GPU) or by itself; two transports (team: one process, a rank thread per GPU, peer reads over xGMI; rccl: a process per GPU, RCCL's
+C API), every phase under a deadline -- see "N > 1" below.
 
 Prints ONE JSON line on rank 0.
 """
@@ -165,16 +166,111 @@ def cpu_baseline_blas(V, W, H, threads: int, budget_s: float = 6.0):
             "sample": f"{iters} MU iterations of the full 10000x5000 r=64 problem"}
 
 
-def self_launch(args):
-    """`python bench.py --gpus N` outside torchrun: start the N rank processes here (one per GPU, torch.distributed.run on the
-    loopback interface) -- BEFORE anything in this process touches the GPU (counting devices does not) -- and leave with their exit
-    code.  Fewer than N devices: refuse (non-zero exit, nothing on stdout) rather than print a line measured on fewer GPUs than it
-    claims, unless --allow-shared-device asks for a rehearsal."""
-    import socket
+# ---- N > 1: launching, deadlines, phases -----------------------------------------------------------------------------------------------------------
+# Two transports carry the per-iteration exchange of a column-sharded run:
+#   team  -- ONE process, N rank threads, one per GPU (include/nmfgpu_amd.h, nmfamd_local_group_*): every rank's W update reads the peers' exchange panels
+#            where they lie (xGMI peer access), no reduction kernel, one rendezvous per iteration.  What nmfgpu::compute runs with Parameter "numGpus".
+#   rccl  -- one process per GPU (torch.distributed.run), RCCL through its C API on the engine's stream; torch.distributed (gloo) only carries the unique id,
+#            the barriers and the MAX of the timings.
+# `--transport auto` (default): team first, rccl when the team could not be set up (devices that cannot map each other's memory, a failed rank).  Every
+# phase runs under ONE deadline (NMFAMD_BENCH_DEADLINE seconds, default 900): a run that passes it is killed -- child ranks included, which are fresh
+# processes, never a re-exec of a process that touched the GPU -- and bench.py exits non-zero naming the phase that hung.
+_PHASE = {"name": "start", "file": os.environ.get("NMFAMD_BENCH_PHASE_FILE")}
+
+
+def deadline_seconds() -> float:
+    return float(os.environ.get("NMFAMD_BENCH_DEADLINE", "900"))
+
+
+def phase(name: str):
+    """Where this process is, for the message of a deadline kill (kept in a file the launcher reads after it killed the process)."""
+    _PHASE["name"] = name
+    if _PHASE["file"]:
+        try:
+            with open(_PHASE["file"], "w") as f:
+                f.write(name)
+        except OSError:
+            pass
+
+
+def start_watchdog(what: str):
+    """A rank under torch.distributed.run cannot be killed by bench.py's own launcher (there is none): it ends itself, non-zero, when the deadline passes --
+    the elastic agent then ends the other ranks."""
+    import threading
+    t_end = time.monotonic() + deadline_seconds()
+
+    def watch():
+        while time.monotonic() < t_end:
+            time.sleep(0.5)
+        print(f"bench.py: {what} passed the deadline of {deadline_seconds():.0f} s in phase '{_PHASE['name']}': giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+    threading.Thread(target=watch, daemon=True).start()
+
+
+def run_child(cmd, env, what: str, timeout: float):
+    """A child process (group) under a deadline.  Returns (returncode, stdout, stderr, hung_phase); the whole process group is killed when the time is up."""
+    import signal
     import subprocess
+    import tempfile
+    fd, phase_file = tempfile.mkstemp(prefix="nmfamd_bench_phase_")
+    os.close(fd)
+    env = dict(env, NMFAMD_BENCH_PHASE_FILE=phase_file)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    hung = None
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            p.kill()
+        out, err = p.communicate()
+        try:
+            hung = open(phase_file).read().strip() or "start"
+        except OSError:
+            hung = "unknown"
+        print(f"bench.py: {what} passed its deadline of {timeout:.0f} s in phase '{hung}': killed", file=sys.stderr, flush=True)
+    finally:
+        try:
+            os.unlink(phase_file)
+        except OSError:
+            pass
+    return (p.returncode if hung is None else 3), out, err, hung
+
+
+def worker_argv(args, role: str):
+    argv = [sys.executable, os.path.abspath(__file__), role, "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
+            "--scaling", args.scaling, "--shard-mode", str(args.shard_mode), "--event-stride", str(args.event_stride)]
+    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-kernel-events", args.no_kernel_events), ("--allow-shared-device", args.allow_shared_device)):
+        if on:
+            argv.append(flag)
+    return argv
+
+
+def clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                              "TORCHELASTIC_RUN_ID", "NMFAMD_BENCH_PHASE_FILE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def launch_team(args, timeout: float):
+    """The in-library team as a child process (one process, N rank threads).  Returns (ok, json_line or None, returncode)."""
+    rc, out, err, hung = run_child(worker_argv(args, "--team-worker"), clean_env(), f"the {args.gpus}-rank team", timeout)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc == 0 and len(lines) == 1:
+        return True, lines[0], 0
+    sys.stderr.write(err[-4000:])
+    return False, None, rc
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun.  BEFORE anything in this process touches the GPU (counting devices does not): fewer than N devices -> refuse
+    (non-zero exit, nothing on stdout) rather than print a line measured on fewer GPUs than it claims, unless --allow-shared-device asks for a rehearsal.  Then
+    the team (one child process), and if that cannot be set up the rank processes under torch.distributed.run on the loopback interface -- each under the deadline."""
+    import socket
     import torch
     devices = torch.cuda.device_count()
-    argv = list(sys.argv[1:])
     if devices < args.gpus:
         if not args.allow_shared_device:
             print(f"bench.py: --gpus {args.gpus} asked for, {devices} HIP device(s) visible: not running (a line measured on fewer GPUs than it names "
@@ -183,16 +279,28 @@ def self_launch(args):
         if devices < 1:
             print("bench.py needs a HIP device: the engine has no CPU fallback", file=sys.stderr, flush=True)
             raise SystemExit(2)
-        if "--backend" not in argv:
-            argv += ["--backend", "gloo"]          # RCCL wants one device per rank
+    t_end = time.monotonic() + deadline_seconds()
+    if args.transport in ("auto", "team") or devices < args.gpus:          # (ranks that share a device: the team is the only transport -- RCCL wants a device per rank)
+        ok, line, rc = launch_team(args, max(5.0, t_end - time.monotonic()))
+        if ok:
+            print(line, flush=True)
+            raise SystemExit(0)
+        if args.transport == "team" or devices < args.gpus or rc == 3:
+            raise SystemExit(rc or 1)
+        print("bench.py: the team could not be set up; trying one process per GPU over RCCL", file=sys.stderr, flush=True)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    if "--transport" not in argv:
+        argv += ["--transport", "rccl"]
+    else:
+        argv[argv.index("--transport") + 1] = "rccl"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *argv]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    rc = subprocess.run(cmd, env=env).returncode
+    rc, out, err, hung = run_child(cmd, clean_env(), f"the {args.gpus} RCCL ranks", max(5.0, t_end - time.monotonic()))
+    sys.stdout.write(out)
+    sys.stderr.write(err[-6000:])
     raise SystemExit(rc)
 
 
@@ -202,94 +310,66 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
-    ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API (no collective) instead of the fused loop")
+    ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API from Python (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=8, help="time the factor-product launches of every k-th timed iteration")
-    ap.add_argument("--rccl1", action="store_true", help="with --sharded at N = 1: one-rank RCCL group, the all-reduce / all-gather are issued for real (identities): "
-                                                         "the fixed cost of the collective calls on one GPU")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
                          "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak (default) = one 10000x5000 column shard per GPU; strong = the ONE 10000x5000 problem of configs[1] "
-                         "column-sharded over the N GPUs (BASELINE north_star's 1/2/4/8-GPU series); strong implies --native-comm")
-    ap.add_argument("--native-comm", action="store_true",
-                    help="drive the sharded iteration inside libnmfgpu64.so (RCCL through its C API, reduce-scatter by row blocks of W) "
-                         "instead of the torch.distributed wrapper; torch.distributed then only carries the RCCL unique id and the timing")
-    ap.add_argument("--torch-comm", action="store_true", help="N > 1: drive the sharded iteration from Python through torch.distributed (the round-1 wrapper) instead of natively")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="N > 1, c2: strong (what auto means there) = the ONE 10000x5000 problem of configs[1] column-sharded over the N GPUs -- BASELINE north_star's "
+                         "1/2/4/8-GPU series, value in iterations/s of that problem; weak = one 10000x5000 column shard per GPU.  c4 is one shard per GPU (weak) by definition")
+    ap.add_argument("--transport", choices=["auto", "team", "rccl"], default="auto",
+                    help="N > 1: team = one process, one rank thread per GPU, the W update reads the peers' exchange panels in place (xGMI peer access); rccl = one process per "
+                         "GPU, RCCL through its C API; auto (default) = team, and rccl when the team cannot be set up")
     ap.add_argument("--shard-mode", type=int, choices=[-1, 0, 1], default=-1,
-                    help="native loop: 0 reduce-scatter / all-gather by row blocks of W, 1 one all-reduce + replicated update, "
-                         "-1 (default) by message size: row blocks when the m x r panel is 8 MB or more (config 4), else the single all-reduce")
+                    help="W step of the sharded loop: 0 reduce-scatter / all-gather by row blocks of W, 1 replicated update on the summed exchange buffer, "
+                         "-1 (default) by message size: row blocks when the m x r panel is 8 MB or more (config 4)")
     ap.add_argument("--allow-shared-device", action="store_true",
-                    help="--gpus N with fewer than N HIP devices visible: rehearse with ranks sharing devices (gloo backend, no RCCL) "
-                         "instead of refusing; the line says so in config.parallelism")
+                    help="--gpus N with fewer than N HIP devices visible: rehearse with rank threads sharing devices instead of refusing; the line says so in config.parallelism")
+    ap.add_argument("--team-worker", action="store_true", help=argparse.SUPPRESS)      # (internal: the child process that runs the N rank threads)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        return self_launch(args)
     if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):
         # debugging aid: where is every thread after N seconds (a rank that waits for its peers says nothing otherwise)
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["NMFAMD_BENCH_DUMP_AFTER"]), exit=False)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        if args.workload not in ("c2", "c4"):
+            raise SystemExit(f"--workload {args.workload} is a single-GPU workload (BASELINE: 1 x MI355X)")
+        if args.team_worker:
+            return team_worker(args)
+        if world > 1:
+            return rccl_ranks(args)            # under torch.distributed.run (the driver's launch, or self_launch's)
+        return self_launch(args)
     if args.workload == "c3":
         return main_c3(args)
-    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if args.workload in ("c2", "c4") and not args.torch_comm and (args.native_comm or args.scaling == "strong" or multi):
-        if main_native(args) is not False:
-            return
-        # the native communicator could not be set up on some rank (every rank agreed on that): the torch-driven loop below
-        if args.scaling == "strong":
-            raise SystemExit("--scaling strong needs the native loop")
     if args.workload == "c4":
         return main_c4(args)
     algorithm, alg_kw = "mu", {}
     if args.workload.startswith("c5"):
         algorithm = "gdcls" if args.workload.endswith("gdcls") else "ahcls"
         alg_kw = C5[algorithm]
-        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            raise SystemExit("--workload c5 is a single-GPU workload (BASELINE configs[4]: algorithm-dispatch coverage on 1 x MI355X)")
 
     import torch
     import nmfgpu_amd as na
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank = 0
     if not torch.cuda.is_available() or na.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank on a real node
-    torch.cuda.set_device(device_index)
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
-        if dist.is_initialized():
-            pass                                  # (left by main_native's fallback)
-        elif args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=args.backend)
-    elif args.sharded and args.rccl1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", device_index))
+    torch.cuda.set_device(0)
 
     V, W, H = make_problem(rank)
     K, Wm = args.steps, args.warmup
 
     def barrier():
-        if distributed:
-            dist.barrier()
         torch.cuda.synchronize()
 
     kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
-    if not distributed and not args.sharded:
+    world = 1
+    if not args.sharded:
         eng = na.Engine(M, N_COLS, R, algorithm, dtype=np.float32, stream=engine_stream(torch), **alg_kw)
         eng.upload(V)
         eng.set_factors(W, H)
@@ -312,12 +392,8 @@ def main():
     else:
         from nmfgpu_amd.distributed import EngineShard, ShardedMU
         shard = EngineShard(V, W, H)
-        drv = ShardedMU(shard, total_columns=N_COLS * world, rows=M, force_collectives=args.rccl1)
-        # set-up, not steps: the first collectives of a process group, the pinned landing buffers of the error terms and
-        # the first launches of every kernel are one-time costs, and with a collective in the loop the iteration time keeps
-        # falling for the first ~150 iterations (tools/time_sharded_profile.py: 223, 171, 165, 160, ... 152 us per block of
-        # 20); run through that before the factors are (re)set to W0, H0.  Same count on every rank.
-        drv.run(240 if (distributed or args.rccl1) else 30, first_iteration=1, error_every=10)
+        drv = ShardedMU(shard, total_columns=N_COLS, rows=M)
+        drv.run(30, first_iteration=1, error_every=10)      # set-up (first launches), then back to W0, H0
         shard.synchronize()
         shard.engine.set_factors(W, H)
         drv.run(Wm, first_iteration=1, error_every=10)
@@ -334,13 +410,7 @@ def main():
             kernel_ms, kernel_launches, pair_overhead_ms = shard.engine.kernel_timing_read2()
         frob = drv.frobenius
         product_kernel = shard.engine.geometry()["product_kernel"]
-        if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        parallelism = f"column shards x{world}, W replicated, {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of (V H^T | H H^T) per iteration"
-        if world > torch.cuda.device_count():
-            parallelism += f" -- REHEARSAL: {world} ranks share {torch.cuda.device_count()} device(s) (--allow-shared-device), not a scaling measurement"
+        parallelism = "single GPU, three-phase sharded API driven from Python (team of one)"
 
     if rank == 0:
         flops_per_launch = 2.0 * M * N_COLS * R               # one product against V (algorithmic, unpadded)
@@ -369,8 +439,6 @@ def main():
                 traffic, traffic_source = measured_traffic("factor_product", "nmfgpu_amd/csrc/kernels.hip")
                 roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_factor_product_f32", **common}
-        if args.rccl1 and not distributed:
-            parallelism += " (one-rank RCCL group: collectives issued, identities)"
         names = {"mu": "MU", "ahcls": "AHCLS", "gdcls": "GDCLS"}
         out = {
             "metric": f"NMF {names[algorithm]} iterations/sec, dense 10kx5k r=64",
@@ -398,162 +466,277 @@ def main():
             if algorithm == "mu":
                 out["cpu_baseline_blas"] = cpu_baseline_blas(V, W, H, out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
-    if distributed or (args.sharded and args.rccl1):
-        dist.destroy_process_group()
 
 
-def main_native(args):
-    """configs[1] column-sharded with the iteration driven natively (nmfamd_sharded_*): RCCL through its C API on the
-    engine's stream, no Python between the kernels and the collectives of an iteration.  strong: the one 10000 x 5000
-    matrix split over the ranks (value = iterations/s of THAT problem); weak: one 10000 x 5000 shard per rank."""
-    import torch
+def multi_problem(args, world: int, rank: int):
+    """This rank's share of an N-GPU run.  c2, strong (default; BASELINE north_star's 1/2/4/8 series): the ONE 10000 x 5000 matrix of configs[1], columns dealt to the
+    ranks; c2, weak: one 10000 x 5000 matrix per rank; c4: one 50000 x 6250 column shard of configs[3] per rank (its stated cut: 8 shards)."""
     import nmfgpu_amd as na
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available() or na.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    if not na.RcclComm.available():
-        raise SystemExit("librccl.so could not be loaded")
-    device_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(device_index)
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=args.backend)
-    strong = args.scaling == "strong"
     c4 = args.workload == "c4"
+    strong = (not c4) and args.scaling != "weak"
+    if args.scaling == "strong" and c4:
+        raise SystemExit("--scaling strong is defined for configs[1] (the north_star's 1/2/4/8-GPU series); configs[3] is one shard per GPU")
     rows, cols, feats = (C4["rows"], C4["columns_per_gpu"], C4["features"]) if c4 else (M, N_COLS, R)
     alg, alg_kw = ("nsnmf", dict(theta=C4["theta"], precision="bf16")) if c4 else ("mu", {})
     if strong:
-        if c4:
-            raise SystemExit("--scaling strong is defined for configs[1] (the north_star's 1/2/4/8-GPU series)")
         V, W, H = make_problem(0)
         c0, nc = na.shard_columns(cols, world, rank)
-        V = np.asfortranarray(V[:, c0:c0 + nc]); H = np.asfortranarray(H[:, c0:c0 + nc])
-        total_columns = cols
+        Vs, Hs = np.asfortranarray(V[:, c0:c0 + nc]), np.asfortranarray(H[:, c0:c0 + nc])
+        total = cols
+        full = (V, W, H) if rank == 0 else None
     else:
-        V, W, H = make_problem(rank, rows, cols, feats)
-        nc, total_columns = cols, cols * world
+        Vs, W, Hs = make_problem(rank, rows, cols, feats)
+        nc, total = cols, cols * world
+        full = (Vs, W, Hs) if rank == 0 else None
     mode = args.shard_mode if args.shard_mode >= 0 else (0 if 4.0 * rows * feats >= 8e6 else 1)
-    comm = eng = run = None
-    failure = None
-    if distributed:
-        # RCCL wants one device per rank: two ranks on the same device (a rehearsal on a one-GPU box) must not even try -- a communicator
-        # set-up that fails on one rank while its peer is still connecting can hang the peer.  Every rank sees the same gathered list.
-        import socket
-        me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""), device_index)
-        seen = [None] * world
-        dist.all_gather_object(seen, me)
-        if len(set(seen)) < world:
+    return dict(c4=c4, strong=strong, rows=rows, cols=cols, feats=feats, alg=alg, alg_kw=alg_kw, V=Vs, W=W, H=Hs, nc=nc, total=total, mode=mode, full=full)
+
+
+def multi_line(args, pb, world, elapsed, kernel, frob, transport: str, shared_devices: int = 0):
+    """The JSON line of an N-GPU run (rank 0)."""
+    K, Wm = args.steps, args.warmup
+    c4, strong, rows, cols, feats, nc = pb["c4"], pb["strong"], pb["rows"], pb["cols"], pb["feats"], pb["nc"]
+    kernel_ms, kernel_launches, pair_overhead_ms = kernel
+    bytes_per_launch = (2.0 if c4 else 4.0) * rows * nc    # rank 0's image of its columns of V (bf16 at config 4), one product
+    roofline = None
+    if kernel_launches > 0:
+        avg_s = kernel_ms / 1e3 / kernel_launches
+        roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
+                    "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0] if c4 else measured_traffic("factor_product_x3", "nmfgpu_amd/csrc/kernels_x3.hip")[0],
+                    "kernel": "factor product (rank 0's launches)",
+                    "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
+    mode_text = ("row-block W step: reduce-scatter of (V H^T)^T by row blocks of W + all-reduce of H H^T, every rank updates its rows, all-reduce of the column norms, all-gather of W"
+                 if pb["mode"] == 0 else "replicated W step on the summed (V H^T | H H^T)")
+    parallelism = f"column shards x{world}, {transport}: {mode_text}"
+    if shared_devices:
+        parallelism += f" -- REHEARSAL: {world} ranks share {shared_devices} device(s) (--allow-shared-device), not a scaling measurement"
+    out = {"metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256" if c4 else "NMF MU iterations/sec, dense 10kx5k r=64",
+           "value": (K if strong else world * K) / elapsed,
+           "unit": "iterations/s" if strong else f"shard-iterations/s (one {rows}x{cols} column shard per GPU)",
+           "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+           "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if c4 else "f32", "data": "synthetic",
+           "config": {"workload": ("configs[3]: dense random V 50000 x (6250 per GPU) column shards, r=256, nsNMF theta=0.5, bf16 MFMA operands" if c4 else
+                                   "configs[1]: the ONE dense random V 10000x5000, r=64, MU Frobenius, fp32, column-sharded over the GPUs" if strong else
+                                   "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32"),
+                      "rows": rows, "columns_per_gpu": nc, "total_columns": pb["total"], "features": feats, "error_every": 10, "parallelism": parallelism},
+           "frobenius_last": frob,
+           "roofline": whole_iteration(roofline, elapsed / K, floor_bytes=2.0 * bytes_per_launch, basis="rank 0's two passes over its image of V per iteration at the HBM peak")}
+    if not args.no_cpu_baseline and pb["full"] is not None:
+        phase("cpu baseline")
+        Vf, Wf, Hf = pb["full"]
+        out["cpu_baseline"] = (cpu_baseline(Vf, Wf, Hf, budget_s=12.0, algorithm="nsnmf", theta=C4["theta"]) if c4 else cpu_baseline(Vf, Wf, Hf))
+    return out
+
+
+def team_worker(args):
+    """`bench.py --team-worker`: ONE process, N rank threads, rank g on device g (ranks share devices only in a rehearsal), the in-process transport of
+    include/nmfgpu_amd.h.  The timed region: every rank passes a thread barrier with its device idle, runs K iterations of the native sharded loop, waits for its
+    stream; elapsed = the longest of the ranks' times."""
+    import threading
+    import torch
+    import nmfgpu_amd as na
+    N = args.gpus
+    phase("team: counting devices")
+    devices = torch.cuda.device_count()
+    if devices < 1 or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if devices < N and not args.allow_shared_device:
+        print(f"bench.py: --gpus {N} asked for, {devices} HIP device(s) visible", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    K, Wm = args.steps, args.warmup
+    phase("team: generating the problem")
+    problems = [multi_problem(args, N, g) for g in range(N)]
+    group = na.LocalGroup(N)
+    gate = threading.Barrier(N)
+    res = [None] * N
+    errors = []
+
+    def rank_thread(g):
+        eng = run = comm = None
+        try:
+            pb = problems[g]
+            torch.cuda.set_device(g % devices)
+            stream = torch.cuda.Stream()
+            if os.environ.get("NMFAMD_BENCH_TEST_HANG") and g == N - 1:
+                phase(f"team: rank {g} joining the group (NMFAMD_BENCH_TEST_HANG: never)")
+                time.sleep(10 ** 6)
+            phase(f"team: rank {g} joining the group")
+            comm = na.LocalComm(group, g)                   # blocks until every rank has joined; fails everywhere if two devices cannot map each other
+            phase(f"team: rank {g} uploading its shard")
+            eng = na.Engine(pb["rows"], pb["nc"], pb["feats"], pb["alg"], dtype=np.float32, stream=stream.cuda_stream, row_blocks=N, **pb["alg_kw"])
+            eng.upload(pb["V"])
+            eng.set_factors(pb["W"], pb["H"])
+            gate.wait()                                     # (every rank holds its engine before anybody enters the run's set-up, which is a collective)
+            run = na.ShardedRun(eng, comm, pb["rows"], pb["total"], pb["mode"])
+            phase(f"team: rank {g} first iterations (set-up)")
+            run.iterate(30 if not pb["c4"] else 12, first_iteration=1, error_every=10)
+            eng.synchronize()
+            eng.set_factors(pb["W"], pb["H"])
+            phase(f"team: rank {g} warm-up")
+            run.iterate(Wm, first_iteration=1, error_every=10)
+            eng.synchronize()
+            if g == 0 and not args.no_kernel_events:
+                eng.kernel_timing(args.event_stride)
+            torch.cuda.synchronize()
+            gate.wait()
+            phase(f"team: rank {g} timed iterations")
+            t0 = time.perf_counter()
+            run.iterate(K, first_iteration=Wm + 1, error_every=10)
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            gate.wait()
+            kernel = (0.0, 0, 0.0)
+            if g == 0 and not args.no_kernel_events:
+                kernel = eng.kernel_timing_read2()
+            res[g] = (dt, kernel, run.frobenius if g == 0 else 0.0)
+        except BaseException as e:                          # noqa: BLE001 -- a failed rank releases its peers (collectives, the gate) and the process exits non-zero
+            errors.append((g, e))
+            group.abort()
+            gate.abort()
+        finally:
+            for obj in (run, eng, comm):
+                if obj is not None:
+                    try:
+                        obj.close()
+                    except Exception:                       # noqa: BLE001
+                        pass
+
+    threads = [threading.Thread(target=rank_thread, args=(g,), daemon=True) for g in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    real = [(g, e) for g, e in errors if not isinstance(e, threading.BrokenBarrierError)]
+    if errors:
+        for g, e in (real or errors):
+            print(f"bench.py: team rank {g} failed in phase '{_PHASE['name']}': {e!r}", file=sys.stderr, flush=True)
+        raise SystemExit(4)
+    elapsed = max(r[0] for r in res)
+    out = multi_line(args, problems[0], N, elapsed, res[0][1], res[0][2],
+                     "in-library team (one process, one rank thread per GPU; the W update reads the ranks' exchange panels in place: peer access over xGMI)",
+                     shared_devices=devices if devices < N else 0)
+    print(json.dumps(out), flush=True)
+
+
+def rccl_ranks(args):
+    """One process per GPU under torch.distributed.run: rank 0 first tries the team (--transport auto) as a child process while the other ranks wait; otherwise, or
+    when that fails, every rank runs the native sharded loop with RCCL through its C API.  torch.distributed (gloo) carries the unique id, barriers and timings."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ["WORLD_SIZE"]); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    start_watchdog(f"rank {rank}")
+    phase("control group (gloo)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: the box's hostname may not resolve
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=deadline_seconds()))
+    devices = torch.cuda.device_count()                        # (does not initialise the GPU)
+    if args.transport in ("auto", "team") or devices < world:
+        phase("rank 0 runs the team as a child process")
+        box = [None]
+        if rank == 0:
+            ok, line, rc = launch_team(args, max(5.0, 0.6 * deadline_seconds()))
+            box[0] = (ok, line, rc)
+        dist.broadcast_object_list(box, src=0)
+        ok, line, rc = box[0]
+        if ok:
             if rank == 0:
-                print("bench.py: native communicator set-up failed before it began: ranks share a device (RCCL needs one per rank)", file=sys.stderr, flush=True)
-            return False
-    try:
-        uid = [na.RcclComm.unique_id() if rank == 0 else None]
-    except Exception as e:                        # noqa: BLE001 -- reported below, every rank takes the same way out
-        uid, failure = [None], e
-    if distributed:
-        dist.broadcast_object_list(uid, src=0)
-    try:
-        if failure is None and uid[0] is None:
-            raise RuntimeError("rank 0 could not create a communicator id")
-        if failure is None:
-            comm = na.RcclComm(uid[0], world, rank)       # blocks until every rank has joined the clique
-            eng = na.Engine(rows, nc, feats, alg, dtype=np.float32, stream=engine_stream(torch), row_blocks=world, **alg_kw)
-            eng.upload(V)
-            eng.set_factors(W, H)
-    except Exception as e:                        # noqa: BLE001
-        failure = e
+                print(line, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        if args.transport == "team" or devices < world:
+            dist.destroy_process_group()
+            raise SystemExit(rc or 1)
+        if rank == 0:
+            print("bench.py: the team could not be set up; one process per GPU over RCCL", file=sys.stderr, flush=True)
+    import nmfgpu_amd as na
+    phase("RCCL: device and library")
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank % devices)
+    pb = multi_problem(args, world, rank)
+    comm = eng = run = None
+    failure = None if na.RcclComm.available() else RuntimeError("librccl.so could not be loaded")
 
     def agree(failure):
-        if not distributed:
-            return failure is not None
-        flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return int(flag.item()) != 0
 
-    # every rank must hold its engine and its shard before anybody enters the sharded run's set-up: that set-up is a collective
-    # (all-gather of the shard geometry on the engine's stream), and a rank that failed above would never join it
-    failed_somewhere = agree(failure)
-    if not failed_somewhere:
+    phase("RCCL: unique id")
+    uid = [None]
+    if rank == 0 and failure is None:
         try:
-            run = na.ShardedRun(eng, comm, rows, total_columns, mode)
+            uid[0] = na.RcclComm.unique_id()
         except Exception as e:                    # noqa: BLE001
             failure = e
-        failed_somewhere = agree(failure)
-    if failed_somewhere:
-        print(f"bench.py: native communicator set-up failed on rank {rank}: {failure!r}" if failure is not None else
-              "bench.py: native communicator set-up failed on another rank", file=sys.stderr, flush=True)
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is None and failure is None:
+        failure = RuntimeError("rank 0 could not create a communicator id")
+    if not agree(failure):
+        try:
+            phase("RCCL: communicator (blocks until every rank has joined)")
+            comm = na.RcclComm(uid[0], world, rank)
+            phase("RCCL: uploading the shard")
+            eng = na.Engine(pb["rows"], pb["nc"], pb["feats"], pb["alg"], dtype=np.float32, stream=engine_stream(torch), row_blocks=world, **pb["alg_kw"])
+            eng.upload(pb["V"])
+            eng.set_factors(pb["W"], pb["H"])
+        except Exception as e:                    # noqa: BLE001
+            failure = e
+        # every rank must hold its engine before anybody enters the sharded run's set-up (a collective on the engine's stream)
+        if not agree(failure):
+            try:
+                phase("RCCL: sharded run set-up (first collective)")
+                run = na.ShardedRun(eng, comm, pb["rows"], pb["total"], pb["mode"])
+            except Exception as e:                # noqa: BLE001
+                failure = e
+    if agree(failure):
+        print(f"bench.py: RCCL set-up failed on rank {rank}: {failure!r}" if failure is not None else f"bench.py: RCCL set-up failed on another rank (this is rank {rank})",
+              file=sys.stderr, flush=True)
         for obj in (run, eng, comm):
             if obj is not None:
                 obj.close()
-        if not distributed:
-            raise SystemExit(f"native loop unavailable: {failure!r}")
-        return False
+        dist.destroy_process_group()
+        raise SystemExit(5)
     K, Wm = args.steps, args.warmup
 
     def barrier():
-        if distributed:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not steps (as in the torch-driven path): the first collectives of a communicator and the first launches
-    run.iterate((240 if distributed else 30) if not c4 else 12, first_iteration=1, error_every=10)
+    # set-up, not steps: the first collectives of a communicator and the first launches of every kernel
+    phase("RCCL: first iterations (set-up)")
+    run.iterate(240 if not pb["c4"] else 12, first_iteration=1, error_every=10)
     eng.synchronize()
-    eng.set_factors(W, H)
+    eng.set_factors(pb["W"], pb["H"])
+    phase("RCCL: warm-up")
     run.iterate(Wm, first_iteration=1, error_every=10)
     eng.synchronize()
     if not args.no_kernel_events:
         eng.kernel_timing(args.event_stride)
     barrier()
+    phase("RCCL: timed iterations")
     t0 = time.perf_counter()
     run.iterate(K, first_iteration=Wm + 1, error_every=10)
     eng.synchronize()
-    barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
+    barrier()
+    kernel = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
     frob = run.frobenius
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
     if rank == 0:
-        bytes_per_launch = (2.0 if c4 else 4.0) * rows * nc    # this rank's image of its columns of V (bf16 at config 4), one product
-        roofline = None
-        if kernel_launches > 0:
-            avg_s = kernel_ms / 1e3 / kernel_launches
-            roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
-                        "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0] if c4 else measured_traffic("factor_product_x3", "nmfgpu_amd/csrc/kernels_x3.hip")[0],
-                        "kernel": "factor product (rank 0's launches)",
-                        "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
-        mode_text = ("reduce-scatter of (V H^T)^T by row blocks of W + all-reduce of H H^T, row-block W update, all-reduce of the column norms, "
-                     "all-gather of W") if mode == 0 else "one all-reduce of (V H^T | H H^T), replicated W update"
-        out = {"metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256" if c4 else "NMF MU iterations/sec, dense 10kx5k r=64",
-               "value": (K if strong else world * K) / elapsed,
-               "unit": "iterations/s" if (strong or world == 1) else f"shard-iterations/s (one {rows}x{cols} column shard per GPU)",
-               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-               "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16" if c4 else "f32", "data": "synthetic",
-               "config": {"workload": ("configs[3] per GPU: dense random V 50000x6250 column shard, r=256, nsNMF theta=0.5, bf16 MFMA operands" if c4 else
-                                       "configs[1]: dense random V 10000x5000, r=64, MU Frobenius, fp32, column-sharded over the GPUs" if strong else
-                                       "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32"),
-                          "rows": rows, "columns_per_gpu": nc, "total_columns": total_columns, "features": feats, "error_every": 10,
-                          "parallelism": f"column shards x{world}, native loop (RCCL C API): {mode_text}"},
-               "frobenius_last": frob,
-               "roofline": whole_iteration(roofline, elapsed / K, floor_bytes=2.0 * bytes_per_launch, basis="this rank's two passes over its image of V per iteration at the HBM peak")}
-        if c4 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(V, W, H, budget_s=12.0, algorithm="nsnmf", theta=C4["theta"])
-        print(json.dumps(out), flush=True)
+        print(json.dumps(multi_line(args, pb, world, elapsed, kernel, frob, "one process per GPU, native loop with RCCL through its C API")), flush=True)
     run.close(); eng.close(); comm.close()
-    if distributed:
-        dist.destroy_process_group()
+    phase("closing")
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main_c3(args):
@@ -562,8 +745,6 @@ def main_c3(args):
     (quotient V ./ (W H) and numerator in one gather pass each).  Same timing contract as the default.  roofline: that kernel."""
     import torch
     import nmfgpu_amd as na
-    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise SystemExit("--workload c3 is a single-GPU workload (BASELINE configs[2]: 1 x MI355X)")
     if not torch.cuda.is_available() or na.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(0)
@@ -633,23 +814,10 @@ def main_c4(args):
     import torch
     import nmfgpu_amd as na
     from nmfgpu_amd.distributed import EngineShard, ShardedMU
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank = 1, 0
     if not torch.cuda.is_available() or na.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    device_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(device_index)
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (one-node rehearsals: the box's hostname may not resolve)
-        if dist.is_initialized():
-            pass                                  # (left by main_native's fallback)
-        elif args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=args.backend)
+    torch.cuda.set_device(0)
     m, n, r, theta = C4["rows"], C4["columns_per_gpu"], C4["features"], C4["theta"]
     V, W, H = make_problem(rank, m, n, r)
     K, Wm = args.steps, args.warmup
@@ -660,8 +828,6 @@ def main_c4(args):
     shard.engine.set_factors(W, H)
 
     def barrier():
-        if distributed:
-            dist.barrier()
         torch.cuda.synchronize()
 
     drv.run(Wm, first_iteration=1, error_every=10)
@@ -675,10 +841,6 @@ def main_c4(args):
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else shard.engine.kernel_timing_read2()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     if rank == 0:
         bytes_per_launch = 2.0 * m * n                       # one pass over the bf16 image of the shard
         roofline = None
@@ -700,8 +862,6 @@ def main_c4(args):
             "achieved_tflops_whole_iteration": iter_flops * (K / elapsed) / 1e12,
             "roofline": whole_iteration(roofline, elapsed / K, floor_bytes=2.0 * bytes_per_launch, basis="two passes over the bf16 image of the shard per iteration (2 x 625 MB) at the HBM peak"),
             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline(V, W, H, budget_s=12.0, algorithm="nsnmf", theta=theta)})}), flush=True)
-    if distributed:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -191,6 +191,19 @@ NMFAMD_API int nmfamd_comm_rccl_available(void);
 NMFAMD_API int nmfamd_comm_unique_id(void* out_128_bytes);
 NMFAMD_API int nmfamd_comm_create_rccl(const void* id_128_bytes, int world, int rank, nmfamd_comm** out);
 NMFAMD_API void nmfamd_comm_destroy(nmfamd_comm* c);
+/* The in-process transport (csrc/comm.h, LocalComm): the ranks are THREADS of one process, each with its own HIP device current (the same device, or
+ * peer-mapped devices of one node); every rank's kernels read the peers' buffers where they lie -- over xGMI when the devices differ.  This is the
+ * transport of nmfgpu::compute with Parameter "numGpus" when RCCL is not used, and the one whose multiplicative update needs no reduction kernel at
+ * all (replicated mode at padded rank 64: the W update adds the ranks' exchange panels in its prologue, two buffers alternate, one rendezvous per
+ * iteration).  One thread creates the group, every rank thread calls nmfamd_comm_create_local (blocks until all `world` ranks have joined; fails on
+ * every rank when two devices cannot map each other's memory).  nmfamd_local_group_abort makes every rank waiting in a collective return an error. */
+typedef struct nmfamd_local_group nmfamd_local_group;
+NMFAMD_API int nmfamd_local_group_create(int world, nmfamd_local_group** out);
+NMFAMD_API void nmfamd_local_group_destroy(nmfamd_local_group* g);
+NMFAMD_API void nmfamd_local_group_abort(nmfamd_local_group* g);
+NMFAMD_API int nmfamd_comm_create_local(nmfamd_local_group* g, int rank, nmfamd_comm** out);
+/* "rccl" / "in-process (peer reads)" */
+NMFAMD_API const char* nmfamd_comm_transport(const nmfamd_comm* c);
 /* nmfamd_engine_create with the padded row count rounded up to a multiple of 128 * row_blocks (equal row blocks of W) */
 NMFAMD_API int nmfamd_engine_create_blocks(int m, int n, int r, int algorithm, const nmfamd_params* params, int elem_bytes, void* stream,
                                            int row_blocks, nmfamd_engine** out);

@@ -12,4 +12,4 @@ from .api import (  # noqa: F401
     initialize, finalize, version, choose_gpu, get_number_of_gpu, get_information_for_gpu_index,
     set_verbosity, compute, compute_kmeans, Summary, NmfError,
 )
-from .engine import Engine, EngineError, op_factor_product, op_factor_product_bf16, op_factor_product_x3, op_gram, op_inverse, op_factor_passes, op_tri_update, device_count, host_kmeans, host_init, RcclComm, ShardedRun, shard_columns, SHARD_ROW_BLOCKS, SHARD_REPLICATED  # noqa: F401
+from .engine import Engine, EngineError, op_factor_product, op_factor_product_bf16, op_factor_product_x3, op_gram, op_inverse, op_factor_passes, op_tri_update, device_count, host_kmeans, host_init, RcclComm, LocalGroup, LocalComm, ShardedRun, shard_columns, SHARD_ROW_BLOCKS, SHARD_REPLICATED  # noqa: F401

@@ -26,6 +26,10 @@ struct nmfamd_comm {
 	std::unique_ptr<Comm> c;
 };
 
+struct nmfamd_local_group {
+	std::shared_ptr<LocalGroup> g;
+};
+
 struct nmfamd_sharded {
 	int elem_bytes;
 	std::unique_ptr<ShardedRank<float>> f;
@@ -183,6 +187,34 @@ int nmfamd_comm_create_rccl(const void* id_128_bytes, int world, int rank, nmfam
 }
 
 void nmfamd_comm_destroy(nmfamd_comm* c) { delete c; }
+
+int nmfamd_local_group_create(int world, nmfamd_local_group** out) {
+	if (!out) return NMFAMD_INVALID_ARGUMENT;
+	*out = nullptr;
+	std::shared_ptr<LocalGroup> g = local_group_create(world);
+	if (!g) return NMFAMD_INVALID_ARGUMENT;
+	nmfamd_local_group* h = new (std::nothrow) nmfamd_local_group();
+	if (!h) return NMFAMD_NO_HOST_MEMORY;
+	h->g = std::move(g);
+	*out = h;
+	return NMFAMD_OK;
+}
+
+void nmfamd_local_group_destroy(nmfamd_local_group* g) { delete g; }
+void nmfamd_local_group_abort(nmfamd_local_group* g) { if (g && g->g) local_group_abort(*g->g); }
+
+int nmfamd_comm_create_local(nmfamd_local_group* g, int rank, nmfamd_comm** out) {
+	if (!g || !g->g || !out) return NMFAMD_INVALID_ARGUMENT;
+	*out = nullptr;
+	nmfamd_comm* c = new (std::nothrow) nmfamd_comm();
+	if (!c) { local_group_abort(*g->g); return NMFAMD_NO_HOST_MEMORY; }
+	Status st = local_comm_create(g->g, rank, &c->c);
+	if (st != ST_OK) { delete c; return (int)st; }
+	*out = c;
+	return NMFAMD_OK;
+}
+
+const char* nmfamd_comm_transport(const nmfamd_comm* c) { return (c && c->c) ? c->c->transport() : ""; }
 
 int nmfamd_sharded_create(nmfamd_engine* e, nmfamd_comm* c, int mode, long rows, long total_columns, nmfamd_sharded** out) {
 	if (!e || !c || !c->c || !out) return NMFAMD_INVALID_ARGUMENT;

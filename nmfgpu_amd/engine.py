@@ -276,6 +276,60 @@ class RcclComm:
             pass
 
 
+class LocalGroup:
+    """Shared state of the rank THREADS of one process (include/nmfgpu_amd.h, nmfamd_local_group_*): create one, hand it to every rank
+    thread, each constructs its LocalComm with its own HIP device current."""
+
+    def __init__(self, world: int):
+        self._lib = library()
+        h = C.c_void_p()
+        st = self._lib.nmfamd_local_group_create(int(world), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_local_group_create")
+        self._h, self.world = h, int(world)
+
+    def abort(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_local_group_abort(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_local_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LocalComm:
+    """One rank of the in-process transport: the ranks' kernels read each other's buffers where they lie (same device, or peer-mapped devices over xGMI).
+    The constructor blocks until every rank of the group has joined."""
+
+    def __init__(self, group: LocalGroup, rank: int):
+        self._lib = library()
+        self.group = group                       # keep it alive
+        h = C.c_void_p()
+        st = self._lib.nmfamd_comm_create_local(group._h, int(rank), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "nmfamd_comm_create_local", "the devices of two ranks cannot map each other's memory, or a rank failed")
+        self._h = h
+        self.world, self.rank = group.world, int(rank)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nmfamd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 SHARD_ROW_BLOCKS, SHARD_REPLICATED = 0, 1
 
 

@@ -40,12 +40,12 @@ def test_default_bench_line_has_the_contract_fields():
 
 def test_gpus_n_without_torchrun_refuses_or_rehearses():
     """`python bench.py --gpus 2` outside torchrun on a box with ONE device: no line at all and a non-zero exit (never an n_gpus = 1
-    line under a --gpus 2 command); with --allow-shared-device it starts two rank processes itself (gloo, ranks share the device) and
-    the line says n_gpus = 2 and that it is a rehearsal."""
+    line under a --gpus 2 command); with --allow-shared-device it runs the in-library team itself (two rank threads share the device) and the
+    line is the north_star's series -- the ONE 10000 x 5000 problem, "scaling": "strong", n_gpus = 2 -- and says that it is a rehearsal."""
     import torch
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a one-device box")
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
     out = subprocess.run(base, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "--gpus 2" in out.stderr and "1 HIP device" in out.stderr
@@ -54,5 +54,27 @@ def test_gpus_n_without_torchrun_refuses_or_rehearses():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and "REHEARSAL" in d["config"]["parallelism"]
-    assert d["value"] == pytest.approx(2 * 1e3 / d["ms_per_step"], rel=1e-6)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and "REHEARSAL" in d["config"]["parallelism"] and "team" in d["config"]["parallelism"]
+    assert d["scaling"] == "strong" and d["unit"] == "iterations/s" and d["config"]["total_columns"] == 5000 and d["config"]["columns_per_gpu"] == 2500
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-6)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"            # rank 0 reports it for every N
+    assert 2000 < d["frobenius_last"] < 2200                                                # the same problem as the N = 1 line (7 iterations in)
+    # --scaling weak is the explicit other series: one 10000 x 5000 shard per rank
+    out = subprocess.run(base + ["--allow-shared-device", "--scaling", "weak", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["config"]["total_columns"] == 10000 and d["value"] == pytest.approx(2 * 1e3 / d["ms_per_step"], rel=1e-6)
+
+
+def test_a_hung_rank_ends_the_bench_inside_the_deadline_with_the_phase():
+    """First contact with a node nobody has run on: a rank that never joins must not hang the bench until the driver's timeout.  NMFAMD_BENCH_TEST_HANG=1 makes
+    the last rank thread of the team sleep instead of joining; the launcher kills the child process group at the deadline, names the phase, exits non-zero."""
+    import time
+    env = dict(os.environ, NMFAMD_BENCH_TEST_HANG="1", NMFAMD_BENCH_DEADLINE="45")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--allow-shared-device", "--no-cpu-baseline",
+                          "--transport", "team"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    took = time.monotonic() - t0
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "deadline" in out.stderr and "phase" in out.stderr and "joining the group" in out.stderr, out.stderr[-2000:]
+    assert took < 120

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmfgpu_amd._lib import library
 
 lib = library()
-X, Y = 10000, 5000
+X, Y = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10000, 5000)
 cap = 8 * 4 * 400 * 8
 buf = np.zeros(cap, dtype=np.uint64)
 waves = C.c_long(0)

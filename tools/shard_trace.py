@@ -27,7 +27,12 @@ if MODE == "fused":
     geo = e.geometry()
     e.close()
 else:
-    comm = na.RcclComm(na.RcclComm.unique_id(), 1, 0)
+    # SHARD_TRACE_COMM=rccl: a one-rank RCCL clique (its proxy thread and streams exist beside the loop); default: the in-process transport a team uses
+    if os.environ.get("SHARD_TRACE_COMM", "local") == "rccl":
+        comm = na.RcclComm(na.RcclComm.unique_id(), 1, 0)
+    else:
+        group = na.LocalGroup(1)
+        comm = na.LocalComm(group, 0)
     e = na.Engine(M, NC, R, "mu", row_blocks=1)
     e.upload(V); e.set_factors(W, H)
     run = na.ShardedRun(e, comm, M, NC, int(MODE))

@@ -22,12 +22,13 @@ def run(nc, mode, **env):
 M, N, R = 10000, 5000, 64
 fused = run(N, "fused")
 one = run(N, 1)
-print(f"fused single-GPU loop, n = {N}: {fused:.1f} us/iteration; sharded loop of a team of one (replicated mode): {one:.1f}; row-block mode: {run(N, 0):.1f}", flush=True)
+print(f"fused single-GPU loop, n = {N}: {fused:.1f} us/iteration; sharded loop of a team of one (replicated mode, in-process transport): {one:.1f}; "
+      f"the same beside a one-rank RCCL clique: {run(N, 1, SHARD_TRACE_COMM='rccl'):.1f}; row-block mode: {run(N, 0):.1f}", flush=True)
 rows = []
 for world in (1, 2, 4, 8):
     nc = N // world
     a = run(nc, 1, NMFAMD_SHARD_REHEARSE=1)
-    b = run(nc, 1, NMFAMD_SHARD_NO_DIRECT=1)
+    b = run(nc, 1, NMFAMD_SHARD_NO_DIRECT=1, SHARD_TRACE_COMM="rccl")
     c = run(nc, 0)
     rows.append((world, nc, a, b, c))
     print(f"shard of a {world}-GPU run, n = {nc}: rank-of-N rehearsal (direct exchange) {a:.1f} us, round-3 path (reduce + RCCL call) {b:.1f} us, row-block mode {c:.1f} us", flush=True)

@@ -133,6 +133,9 @@ typedef struct nmfamd_geometry {
 	                          gave up (it could not keep its workgroups resident) and the engine reported the error */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
+/* The same for a caller compiled against an older (shorter) or newer (longer) nmfamd_geometry: writes min(struct_size, sizeof(nmfamd_geometry)) bytes, never
+ * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
+NMFAMD_API int nmfamd_engine_geometry_sized(const nmfamd_engine* e, void* out, unsigned long struct_size);
 
 /* ---- column-sharded multi-GPU form of the multiplicative update ------------------------------
  * Rank g holds V(:, J_g), H(:, J_g) and a full replica of W.  Per iteration:

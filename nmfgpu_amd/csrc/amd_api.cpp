@@ -318,6 +318,16 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 	return NMFAMD_OK;
 }
 
+int nmfamd_engine_geometry_sized(const nmfamd_engine* e, void* out, unsigned long struct_size) {
+	if (!out || struct_size < 8) return NMFAMD_INVALID_ARGUMENT;
+	nmfamd_geometry g;
+	std::memset(&g, 0, sizeof(g));
+	const int st = nmfamd_engine_geometry(e, &g);
+	if (st != NMFAMD_OK) return st;
+	std::memcpy(out, &g, struct_size < sizeof(g) ? (size_t)struct_size : sizeof(g));
+	return NMFAMD_OK;
+}
+
 int nmfamd_engine_h_step(nmfamd_engine* e, int compute_error) {
 	return dispatch(e, [&](Engine<float>& g) { return g.h_step(compute_error != 0); },
 	                   [&](Engine<double>& g) { return g.h_step(compute_error != 0); });

@@ -431,7 +431,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
 		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
-		tri_scale_pending_ = false; tri_scale_from_gram_ = false;
+		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -476,7 +476,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; }
+	if (w) { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -1023,14 +1023,17 @@ Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long
 	if (alg_ != ALG_MU && alg_ != ALG_NSNMF) return ST_INVALID;
 	if (rows <= 0 || rows % 128 != 0 || row0 < 0 || row0 % 128 != 0 || row0 + rows > mpad_) return ST_INVALID;
 	const T eps = std::numeric_limits<T>::epsilon();
+	// Gw_raw_ is the Gram matrix of the panel WITHOUT its pending column scale: the trace below needs that scale even when materialize_w() is about to
+	// fold it into the panel (a caller that used w_finish() before: ADVICE r3) -- the staged sums stay where they are
+	const T* trace_scale = tri_trace_scale();
 	if (Status s = materialize_w()) return s;           // (a pending column scale belongs to the old W; fold it in first)
 	if (compute_error) {
-		const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
+		const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + its scale)
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 			if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
 			else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 		}
-		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_, tri_trace_scale()));
+		HIPX(launch_trace_small<T>(hht, wtw, RP_, r_, psR_, stream_, trace_scale));
 		if (Status s = fetch_error_terms(n_)) return s;
 	}
 	const long valid = std::max<long>(0, std::min<long>(rows, (long)m_ - row0));
@@ -1494,6 +1497,15 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 			const long rows_per_block = std::max<long>(64, block_bytes / ((long)RP_ * (long)sizeof(T)));
 			auto cut = [&](long range) { return (range * RP_ * (long)sizeof(T) > 3l * 1024 * 1024) ? (int)std::min<long>(64, (range + rows_per_block - 1) / rows_per_block) : 1; };
 			kl_blocks_w_ = cut(n_); kl_blocks_h_ = cut(m_);
+			// five blocks or more: a multiple of eight, so that every XCD gathers from its OWN blocks (k_kl_fused) and fetches 1 / 8 of the factor per launch
+			auto by_xcd = [](int b) { return b >= 5 ? ((b + 7) / 8) * 8 : b; };
+			kl_blocks_w_ = by_xcd(kl_blocks_w_); kl_blocks_h_ = by_xcd(kl_blocks_h_);
+			// every block writes its own partial numerator panel (and k_kl_update reads them all): keep that scratch within a quarter of the free memory
+			// (64 blocks of a 1M-row factor were 32 GB), halving the block count until it fits
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)1 << 62; }
+			auto fit = [&](int b, long panel_rows) { while (b > 1 && (double)b * RP_ * (double)panel_rows * sizeof(T) > 0.25 * (double)free_b) b = b > 8 ? ((b / 2 + 7) / 8) * 8 : b / 2; return b; };
+			kl_blocks_w_ = fit(kl_blocks_w_, mpad_); kl_blocks_h_ = fit(kl_blocks_h_, npad_);
 			auto boundaries = [&](const std::vector<int>& ptr, const std::vector<int>& idx, int rows, long range, int blocks, int** dev) -> hipError_t {
 				if (blocks <= 1) return hipSuccess;
 				const long per = (range + blocks - 1) / blocks;
@@ -1513,8 +1525,14 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 			HIPX(boundaries(csr_ptr, csr_idx, m_, n_, kl_blocks_w_, &csr_bptr_));
 			HIPX(boundaries(csc_ptr, csc_idx, n_, m_, kl_blocks_h_, &csc_bptr_));
 			const long pe = std::max<long>(kl_blocks_w_ > 1 ? (long)kl_blocks_w_ * RP_ * mpad_ : 0, kl_blocks_h_ > 1 ? (long)kl_blocks_h_ * RP_ * npad_ : 0);
-			if (pe > 0) HIPX(hipMalloc((void**)&kl_part_, sizeof(T) * (size_t)pe));
-			if (kl_blocks_w_ > 1) HIPX(hipMalloc((void**)&kl_tpart_, sizeof(T) * 2 * (size_t)kl_blocks_w_ * mpad_));
+			// (no room for the partial panels after all: the unblocked gather needs none)
+			bool ok = pe == 0 || hipMalloc((void**)&kl_part_, sizeof(T) * (size_t)pe) == hipSuccess;
+			if (ok && kl_blocks_w_ > 1) ok = hipMalloc((void**)&kl_tpart_, sizeof(T) * 2 * (size_t)kl_blocks_w_ * mpad_) == hipSuccess;
+			if (!ok) {
+				(void)hipGetLastError();
+				for (void** b : oldb) { if (*b) (void)hipFree(*b); *b = nullptr; }
+				kl_blocks_w_ = kl_blocks_h_ = 1;
+			}
 		}
 	}
 	HIPX(hipStreamSynchronize(stream_));
@@ -1546,9 +1564,12 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		else HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
 	}
 	record_end();
-	HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
-	if (!two_pass && kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_));
-	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_));
+	// the column sums of W: from the partial sums its last update left (round 4), or by a pass over the panel when W was set from outside
+	if (!kl_sw_ready_) HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
+	// ... and the update of H leaves the partial row sums of the NEW H (the W step's denominators) in rowsum_part_: one small launch instead of a pass over H
+	if (!two_pass && kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_, rowsum_part_));
+	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_, 1, 0, rowsum_part_));
+	HIPX(launch_kl_sums<T>(rowsum_part_, nullptr, (int)(npad_ / 128), RP_, sH_, stream_));
 	// W step (the quotient is re-evaluated with the new H), over the CSR image; per-row error terms on error iterations only
 	record_begin();
 	if (two_pass) {
@@ -1568,7 +1589,6 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		                        m_, (int)mpad_, stream_));
 	}
 	record_end();
-	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sH_, stream_));
 	if (compute_error) {
 		// Frobenius error by the reference's trace formula with (W_{k-1}, H_k); KL divergence next to it
 		HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G_, stream_));
@@ -1586,8 +1606,11 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		HIPX(hipEventRecord(err_event_, stream_));
 		kl_pending_ = true;
 	}
-	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
-	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_));
+	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_, rowsum_part_));
+	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, 1, 0, rowsum_part_));
+	// colsum of the NORMALISED W = (sum of the new column) / (its norm), both from the update's per-workgroup partials (norm_parts = mpad / 128 of each)
+	HIPX(launch_kl_sums<T>(rowsum_part_, sumsq_part_, norm_parts, RP_, sW_, stream_));
+	kl_sw_ready_ = true;
 	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
 	return ST_OK;
 }
@@ -1636,12 +1659,21 @@ Status Engine<T>::kl_w_products(T* exchange, bool compute_error) {
 	record_end();
 	HIPX(launch_panel_rowsum<T>(H_, RP_, (int)npad_, rowsum_part_, sh, stream_));
 	if (compute_error) HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, hht, stream_));
+	else {
+		// the regions nobody reads on this iteration still ride the all-reduce: keep them finite (left alone they grow by the rank count per iteration)
+		HIPX(hipMemsetAsync(hht, 0, sizeof(T) * (size_t)RP_ * RP_, stream_));
+		HIPX(hipMemsetAsync(tv, 0, sizeof(T) * 2 * (size_t)mpad_, stream_));
+	}
 	return ST_OK;
 }
 
 template <typename T>
 Status Engine<T>::kl_w_finish(const T* exchange, bool compute_error) {
 	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	// the error terms in the exchange buffer were (or were not) produced by w_products() under the flag h_step() latched: a caller asking for the
+	// other thing here would read terms that are not there
+	if (compute_error != kl_err_iter_) { last_error_ = "kl: w_finish(compute_error) differs from the h_step(compute_error) of the same iteration"; return ST_INVALID; }
+	kl_sw_ready_ = false;
 	const T eps = std::numeric_limits<T>::epsilon();
 	const int norm_parts = (int)(mpad_ / 128);
 	const T* num = exchange;

@@ -89,7 +89,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
@@ -238,6 +238,7 @@ private:
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
 	bool sole_rank_ = false;
+	bool kl_sw_ready_ = false;       // sW_ holds the column sums of the current W (left by its last KL update; a W set from outside needs the pass over the panel)
 	bool kl_err_iter_ = false;       // sharded KL: h_step's compute_error, for the W-side evaluation in w_products
 	long err_total_columns_ = 0;     // sharded runs: columns of the whole matrix (0: this engine's own n)
 	Status kl_h_step();

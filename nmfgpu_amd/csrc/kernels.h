@@ -376,6 +376,11 @@ hipError_t launch_panel_rowsum(const T* P, int RP, int len_pad, T* partial, T* s
 // P(c, y) <- P(c, y) num(c, y) / (den(c) + eps); sumsq_part (optional): (len_pad / 128) * RP partial sums of squares
 template <typename T>
 // num: `parts` partial numerator panels part_stride apart, added in order
-hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts = 1, long part_stride = 0);
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts = 1, long part_stride = 0,
+                            T* sum_part = nullptr);      // sum_part (optional): (len_pad / 128) * RP partial sums of the new values
+// sums(c) = sum of the len_pad / 128 vectors of sum_part, divided by sqrt(sum of sumsq_part) where sumsq_part is given and that is > 0 (the column sums of a panel
+// AFTER its column normalisation, from what its update left behind); RP in {64, 128, 256}
+template <typename T>
+hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream);
 
 } // namespace nmfamd

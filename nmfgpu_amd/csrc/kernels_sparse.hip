@@ -193,6 +193,9 @@ template hipError_t launch_sddmm_quotient<double>(const int*, const int*, const 
 // of block 0, then block 1, ... -- so that at any time the workgroups in flight gather from one or two blocks; a row's entries are
 // sorted by index, hence its entries of block b are the range [bptr[row * (blocks + 1) + b], bptr[row * (blocks + 1) + b + 1]).
 // One partial numerator panel (and one vector of error terms) per block, added in block order by the update kernel: deterministic.
+__device__ inline float kl_log(float x) { return logf(x); }
+__device__ inline double kl_log(double x) { return log(x); }
+
 template <typename T, int VEC, bool TERMS>
 __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                                   const T* __restrict__ A, const T* __restrict__ B, T eps,
@@ -200,8 +203,22 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
                                                   int blocks, long out_stride) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int per_block = (rows_pad + 3) >> 2;            // workgroups per block
-	const int blk = blocks > 1 ? (int)(blockIdx.x / per_block) : 0;
-	const int row = (int)(blockIdx.x - (unsigned)blk * per_block) * 4 + wave;
+	// Which (block, row group) this workgroup is.  blocks % 8 == 0 (the engine cuts long factors that way): workgroup i runs on XCD i % 8, and XCD x takes
+	// the blocks x, x + 8, ... one after the other for all rows -- every L2 then holds ONE block at a time and fetches only ITS blocks (1 / 8 of the
+	// gathered factor per launch instead of all of it: the factor left the memory-side cache eight times per launch in block-major order).
+	// Otherwise block-major: all XCDs gather from the same block at a time.
+	int blk = 0, rg = (int)blockIdx.x;
+	if (blocks > 1) {
+		if ((blocks & 7) == 0) {
+			const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+			blk = xcd + 8 * (j / per_block);
+			rg = j % per_block;
+		} else {
+			blk = (int)(blockIdx.x / per_block);
+			rg = (int)(blockIdx.x - (unsigned)blk * per_block);
+		}
+	}
+	const int row = rg * 4 + wave;
 	if (row >= rows_pad) return;
 	out += (long)blk * out_stride;
 	if (TERMS) { t_vwh += (long)blk * rows_pad; t_kl += (long)blk * rows_pad; }
@@ -239,8 +256,10 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
 #pragma unroll
 			for (int e = 0; e < SEG; ++e) acc[e] += qb * rb[e];
 			if (TERMS && sl == 0) {
-				if (va) { s_vwh += xa * da; if (xa > T(0)) s_kl += xa * (T)log((double)xa / (double)(da + eps)); }
-				if (vb) { s_vwh += xb * db; if (xb > T(0)) s_kl += xb * (T)log((double)xb / (double)(db + eps)); }
+				// (the logarithm in T: round 3 took it in double for float entries too -- a software routine on a quarter-rate pipe, run by four lanes of a
+				//  divergent wave per pair of entries: the error-term form of this launch took 1.31 ms against 0.61; the term is rounded to T anyway)
+				if (va) { s_vwh += xa * da; if (xa > T(0)) s_kl += xa * kl_log(xa / (da + eps)); }
+				if (vb) { s_vwh += xb * db; if (xb > T(0)) s_kl += xb * kl_log(xb / (db + eps)); }
 			}
 		}
 	}
@@ -332,14 +351,14 @@ template hipError_t launch_panel_rowsum<double>(const double*, int, int, double*
 // panel column; the `parts` partial numerators (the blocks of the blocked KL step) are added in block order, eight loads in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* __restrict__ num, const T* __restrict__ den, int RP, T eps,
-                                                   T* __restrict__ sumsq_part, int parts, long part_stride) {
+                                                   T* __restrict__ sumsq_part, int parts, long part_stride, T* __restrict__ sum_part) {
 	typedef T T4 __attribute__((ext_vector_type(4)));
-	__shared__ T s_ss[256 * 4];
+	__shared__ T s_ss[256 * 4], s_sv[256 * 4];
 	const long base = (long)blockIdx.x * 128 * RP;
 	const int per_row = RP / 4, c4 = threadIdx.x % per_row, yy = threadIdx.x / per_row, ystep = 256 / per_row;
 	T4 d = *reinterpret_cast<const T4*>(den + 4 * c4);
 	d += in_vgpr(eps);      // (a scalar operand of a packed add otherwise: split3.h)
-	T4 ss = {0, 0, 0, 0};
+	T4 ss = {0, 0, 0, 0}, sv = {0, 0, 0, 0};
 	for (int y = yy; y < 128; y += ystep) {
 		const long e = base + (long)y * RP + 4 * c4;
 		T4 nm = *reinterpret_cast<const T4*>(num + e);
@@ -356,28 +375,69 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 		const T4 v = p * nm / d;
 		*reinterpret_cast<T4*>(P + e) = v;
 		ss += v * v;
+		sv += v;
 	}
-	if (sumsq_part) {
-		// the panel columns of one factor row in ascending order of the thread's start column (fixed order)
+	if (sumsq_part || sum_part) {
+		// the panel columns of one factor row in ascending order of the thread's start column (fixed order); sums of squares (the column normalisation of W)
+		// and plain sums (the row sums of the factor matrix: the other half-step's denominators -- round 3 read the panel again for them) in one exchange
 #pragma unroll
-		for (int i = 0; i < 4; ++i) s_ss[threadIdx.x * 4 + i] = ss[i];
+		for (int i = 0; i < 4; ++i) { s_ss[threadIdx.x * 4 + i] = ss[i]; s_sv[threadIdx.x * 4 + i] = sv[i]; }
 		__syncthreads();
 		if ((int)threadIdx.x < RP) {
 			const int c = threadIdx.x;
-			T acc = 0;
-			for (int g = 0; g < ystep; ++g) acc += s_ss[(g * per_row + c / 4) * 4 + (c & 3)];
-			sumsq_part[(long)blockIdx.x * RP + c] = acc;
+			T acc = 0, acv = 0;
+			for (int g = 0; g < ystep; ++g) { acc += s_ss[(g * per_row + c / 4) * 4 + (c & 3)]; acv += s_sv[(g * per_row + c / 4) * 4 + (c & 3)]; }
+			if (sumsq_part) sumsq_part[(long)blockIdx.x * RP + c] = acc;
+			if (sum_part) sum_part[(long)blockIdx.x * RP + c] = acv;
 		}
 	}
 }
 
+// sums(c) = (sum over parts of sum_part(., c)) * (1 / sqrt(sum over parts of sumsq_part(., c)), or 1 where that is 0: kernel::normalizeColumns' guard) -- the
+// column sums of the panel AFTER its column normalisation, from the two vectors of per-workgroup partials its update left (sumsq_part == nullptr: plain sums).
+// One workgroup of 1024 threads per 16 columns (16 columns x 64 groups of parts, eight loads in flight, groups added in order): a single workgroup pulled the
+// 800 KB of config 3's W-side partials through one CU in 8.4 us.
 template <typename T>
-hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts, long part_stride) {
-	if (RP % 64 != 0 || RP > 256 || parts < 1) return hipErrorInvalidValue;
-	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part, parts, part_stride);
+__global__ __launch_bounds__(1024) void k_kl_sums(const T* __restrict__ sum_part, const T* __restrict__ sumsq_part, int parts, int RP, T* __restrict__ sums) {
+	__shared__ T s_a[1024], s_b[1024];
+	const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+	T a = 0, b = 0;
+	for (int p = g; p < parts; p += 8 * 64) {
+		T va[8], vb[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int q = p + u * 64;
+			va[u] = q < parts ? sum_part[(long)q * RP + c] : T(0);
+			vb[u] = (sumsq_part != nullptr && q < parts) ? sumsq_part[(long)q * RP + c] : T(0);
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+	}
+	s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+	__syncthreads();
+	if (threadIdx.x < 16) {
+		T sa = 0, sb = 0;
+		for (int k = 0; k < 64; ++k) { sa += s_a[k * 16 + cl]; sb += s_b[k * 16 + cl]; }
+		sums[c] = sumsq_part == nullptr ? sa : (sb > T(0) ? sa / (T)sqrt((double)sb) : sa);
+	}
+}
+
+template <typename T>
+hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream) {
+	if (RP < 64 || RP > 256 || RP % 16 != 0) return hipErrorInvalidValue;
+	hipLaunchKernelGGL((k_kl_sums<T>), dim3(RP / 16), dim3(1024), 0, stream, sum_part, sumsq_part, parts, RP, sums);
 	return hipGetLastError();
 }
-template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t, int, long);
-template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t, int, long);
+template hipError_t launch_kl_sums<float>(const float*, const float*, int, int, float*, hipStream_t);
+template hipError_t launch_kl_sums<double>(const double*, const double*, int, int, double*, hipStream_t);
+
+template <typename T>
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts, long part_stride, T* sum_part) {
+	if (RP % 64 != 0 || RP > 256 || parts < 1) return hipErrorInvalidValue;
+	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part, parts, part_stride, sum_part);
+	return hipGetLastError();
+}
+template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t, int, long, float*);
+template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t, int, long, double*);
 
 } // namespace nmfamd

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 M, N_COLS, R = 10000, 5000, 64
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS spec"
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s spec (6.29 TB/s measured copy rate)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense" (the 5 PF figure counts 2:1 sparsity)
 
 # --workload c4 (NOT the default and not the BASELINE metric line): one column shard of BASELINE config 4 per GPU
 C4 = {"rows": 50000, "columns_per_gpu": 6250, "features": 256, "theta": 0.5}
@@ -368,6 +369,7 @@ def main():
         torch.cuda.synchronize()
 
     kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
+    form_ms, form_launches, resident_images = (0.0, 0.0), (0, 0), 2
     world = 1
     if not args.sharded:
         eng = na.Engine(M, N_COLS, R, algorithm, dtype=np.float32, stream=engine_stream(torch), **alg_kw)
@@ -384,10 +386,11 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if not args.no_kernel_events:
-            kernel_ms, kernel_launches, pair_overhead_ms = eng.kernel_timing_read2()
+            kernel_ms, kernel_launches, pair_overhead_ms, form_ms, form_launches = eng.kernel_timing_read3()
             eng.kernel_timing(0)
         frob = eng.frobenius
         product_kernel = eng.geometry()["product_kernel"]
+        resident_images = eng.geometry()["resident_images"]
         parallelism = "single GPU"
     else:
         from nmfgpu_amd.distributed import EngineShard, ShardedMU
@@ -415,7 +418,7 @@ def main():
     if rank == 0:
         flops_per_launch = 2.0 * M * N_COLS * R               # one product against V (algorithmic, unpadded)
         bytes_per_launch = 4.0 * M * N_COLS                   # the fp32 image of V (or V^T) one product streams
-        roofline = None
+        roofline = roofline_mfma = None
         if kernel_launches > 0:
             # Event pairs over-report a launch by a few us (an EMPTY pair on the idle stream reports idle_event_pair_us; the
             # rocprofv3 trace of the same run averages ~2 us less per launch than the events).  No correction is applied:
@@ -434,6 +437,26 @@ def main():
                             "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                             "achieved_is": "effective bandwidth: algorithmic bytes of V per launch / launch time (memory-side cache hits included)",
                             "kernel": "k_factor_product_x3", "fp32_equivalent_tflops": flops_per_launch / avg_s / 1e12, **common}
+                # "hbm" is the nearest of the contract's two labels, not a saturated resource: ONE image of V (207 MB) is resident and the second product of
+                # an iteration finds most of it in the 256 MiB memory-side cache; the matrix pipe is the other candidate -- see roofline_mfma below
+                roofline["streams_from"] = ("HBM + the 256 MiB memory-side cache (one resident fp32 image of V: the product that runs second in an iteration reads most of it from that cache)"
+                                            if resident_images == 1 else "HBM (two resident images of V, each streamed along its output index)")
+                # the two launches of an iteration are two FORMS of the kernel on the same image: W^T V reads it along the reduction index
+                # (y-tiled form, staged through LDS), V H^T along its output index (x-tiled form)
+                if form_launches[0] > 0 and form_launches[1] > 0:
+                    forms = {}
+                    for key, what, ms, cnt in (("wt_v", "W^T V: y-tiled form (reads the one image along the reduction index, parked in LDS)" if resident_images == 1 else "W^T V: x-tiled form on the image of V^T", form_ms[0], form_launches[0]),
+                                               ("v_ht", "V H^T: x-tiled form (reads the image along its output index)", form_ms[1], form_launches[1])):
+                        a = ms / 1e3 / cnt
+                        forms[key] = {"form": what, "avg_launch_us": a * 1e6, "launches": cnt, "achieved": bytes_per_launch / a / 1e9, "frac": bytes_per_launch / a / 1e9 / PEAK_HBM_GBS}
+                    roofline["forms"] = forms
+                # the same launches against the matrix pipe: six bf16 MFMAs per fp32 product term are what the kernel issues (12 mnr flops per launch); the share of
+                # the pipe's cycles they occupy, measured with SQ counters: profiles/r03_pmc_sq.md (43 - 48 % busy)
+                mfma_tflops = 6.0 * flops_per_launch / avg_s / 1e12
+                roofline_mfma = {"bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": mfma_tflops / PEAK_BF16_MFMA_TFLOPS,
+                                 "kernel": "k_factor_product_x3", "flops_per_launch": 6.0 * flops_per_launch,
+                                 "achieved_is": "bf16 MFMA work issued (six exact cross terms per fp32 product) / launch time, against the dense bf16 peak",
+                                 "pipe_busy_measured": "43-48 % of cycles (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_pmc_sq.md)"}
             else:
                 achieved = flops_per_launch / avg_s / 1e12
                 traffic, traffic_source = measured_traffic("factor_product", "nmfgpu_amd/csrc/kernels.hip")
@@ -461,6 +484,8 @@ def main():
                          if roofline is not None and roofline["bound"] == "hbm" else
                          whole_iteration(roofline, elapsed / K, floor_flops=2.0 * flops_per_launch, basis="the two products against V (2 x 6.4 GFLOP) at the fp32 MFMA peak")),
         }
+        if roofline_mfma is not None:
+            out["roofline_mfma"] = roofline_mfma
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, W, H, algorithm=algorithm, **alg_kw)
             if algorithm == "mu":

@@ -116,6 +116,8 @@ NMFAMD_API int nmfamd_engine_kernel_timing(nmfamd_engine* e, int enable);
 NMFAMD_API int nmfamd_engine_kernel_timing_read(nmfamd_engine* e, double* total_ms, long* launches);
 /* The same, plus what an EMPTY event pair reports on the idle stream (ms): the share of each sample that is not kernel time. */
 NMFAMD_API int nmfamd_engine_kernel_timing_read2(nmfamd_engine* e, double* total_ms, long* launches, double* pair_overhead_ms);
+/* ... and split by product: kind_ms[2] / kind_launches[2] = {H-side product (W^T V; y-tiled form when one image of V is resident), W-side product (V H^T)} */
+NMFAMD_API int nmfamd_engine_kernel_timing_read3(nmfamd_engine* e, double* total_ms, long* launches, double* pair_overhead_ms, double* kind_ms, long* kind_launches);
 
 /* Geometry the harness needs for its roofline arithmetic. */
 typedef struct nmfamd_geometry {

@@ -306,6 +306,13 @@ int nmfamd_engine_kernel_timing_read2(nmfamd_engine* e, double* total_ms, long* 
 	return NMFAMD_OK;
 }
 
+int nmfamd_engine_kernel_timing_read3(nmfamd_engine* e, double* total_ms, long* launches, double* pair_overhead_ms, double* kind_ms, long* kind_launches) {
+	if (!e) return NMFAMD_INVALID_ARGUMENT;
+	if (e->elem_bytes == 4) e->f->dominant_stats(total_ms, launches, pair_overhead_ms, kind_ms, kind_launches);
+	else e->d->dominant_stats(total_ms, launches, pair_overhead_ms, kind_ms, kind_launches);
+	return NMFAMD_OK;
+}
+
 int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 	if (!e || !out) return NMFAMD_INVALID_ARGUMENT;
 	auto fill = [&](const auto& g) {

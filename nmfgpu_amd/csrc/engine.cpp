@@ -486,11 +486,13 @@ Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_
 // ---- the two big products ------------------------------------------------------------------
 
 template <typename T>
-void Engine<T>::record_begin() {
+void Engine<T>::record_begin(int kind) {
 	if (!timing_ || !timing_now_) return;
 	if (ev_used_ + 2 > ev_.size()) {
 		for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev_.push_back(e); }
 	}
+	if (ev_kind_.size() < ev_.size() / 2) ev_kind_.resize(ev_.size() / 2, 0);
+	ev_kind_[ev_used_ / 2] = (char)kind;
 	(void)hipEventRecord(ev_[ev_used_], stream_);
 }
 
@@ -502,16 +504,23 @@ void Engine<T>::record_end() {
 }
 
 template <typename T>
-void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms) {
+void Engine<T>::dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms, double* kind_ms, long* kind_launches) {
 	double tot = 0; long cnt = 0;
+	double km[2] = {0, 0}; long kc[2] = {0, 0};
 	(void)hipStreamSynchronize(stream_);
 	for (size_t i = 0; i + 1 < ev_used_; i += 2) {
 		float ms = 0;
-		if (hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+		if (hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]) == hipSuccess) {
+			tot += ms; ++cnt;
+			const int k = (i / 2 < ev_kind_.size() && ev_kind_[i / 2] != 0) ? 1 : 0;
+			km[k] += ms; ++kc[k];
+		}
 	}
 	ev_used_ = 0;
 	if (total_ms) *total_ms = tot;
 	if (launches) *launches = cnt;
+	if (kind_ms) { kind_ms[0] = km[0]; kind_ms[1] = km[1]; }
+	if (kind_launches) { kind_launches[0] = kc[0]; kind_launches[1] = kc[1]; }
 	if (pair_overhead_ms) {
 		// what an event pair reports with NOTHING between the two records (idle stream, smallest of eight):
 		// the part of every sample above that is not kernel time
@@ -627,7 +636,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
 		if (rg) { if (Status st = standalone_gram(*rg)) return st; }
-		record_begin();
+		record_begin(1);
 		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, csr_val_, F, RP_, dest, m_, (int)mpad_, stream_));
 		record_end();
 		return ST_OK;
@@ -636,7 +645,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		if (bf16_) {
 			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
 			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
-			record_begin();
+			record_begin(1);
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
@@ -644,14 +653,14 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
 			if (rg && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
-			record_begin();
+			record_begin(1);
 			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_));
 			record_end();
 			return ST_OK;
 		}
 		if (tiled_) {
 			if (rg && planW_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
-			record_begin();
+			record_begin(1);
 			HIPX(launch_factor_product_f32(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
@@ -659,13 +668,13 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	}
 	if constexpr (std::is_same<T, double>::value) {
 		if (tiled_) {
-			record_begin();
+			record_begin(1);
 			HIPX(launch_factor_product_f64(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_));
 			record_end();
 			return ST_OK;
 		}
 	}
-	record_begin();
+	record_begin(1);
 	HIPX(launch_factor_product_valu<T>(V_, mpad_, (int)mpad_, n_, F, RP_, dest, stream_));
 	record_end();
 	return ST_OK;
@@ -1571,7 +1580,7 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_, 1, 0, rowsum_part_));
 	HIPX(launch_kl_sums<T>(rowsum_part_, nullptr, (int)(npad_ / 128), RP_, sH_, stream_));
 	// W step (the quotient is re-evaluated with the new H), over the CSR image; per-row error terms on error iterations only
-	record_begin();
+	record_begin(1);
 	if (two_pass) {
 		HIPX(launch_sddmm_quotient<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, q_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr, m_, stream_));
 		HIPX(launch_spmm_rows<T>(csr_ptr_, csr_idx_, q_, H_, RP_, slabs_, m_, (int)mpad_, stream_));
@@ -1642,7 +1651,7 @@ Status Engine<T>::kl_w_products(T* exchange, bool compute_error) {
 	T* sh = hht + (long)RP_ * RP_;
 	T* tv = sh + RP_;
 	T* tk = tv + mpad_;
-	record_begin();
+	record_begin(1);
 	if (kl_blocks_w_ > 1) {
 		HIPX(launch_kl_fused<T>(csr_bptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, kl_part_, compute_error ? kl_tpart_ : (T*)nullptr,
 		                        compute_error ? kl_tpart_ + (long)kl_blocks_w_ * mpad_ : (T*)nullptr, m_, (int)mpad_, stream_, kl_blocks_w_, (long)RP_ * mpad_));

@@ -113,7 +113,8 @@ public:
 	// by HIP events on the engine's stream; dominant_stats reads them back (host sync).
 	// stride: time the launches of every stride-th iteration only (1 = all)
 	void enable_kernel_timing(bool on, int stride = 1) { timing_ = on; timing_stride_ = stride > 0 ? stride : 1; timing_iter_ = 0; }
-	void dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms = nullptr);
+	// kind_ms / kind_launches (optional, two entries each): the same split by product -- [0] the H-side product (W^T V, or the KL H half-step's gather), [1] the W side
+	void dominant_stats(double* total_ms, long* launches, double* pair_overhead_ms = nullptr, double* kind_ms = nullptr, long* kind_launches = nullptr);
 
 	int m() const { return m_; }
 	int n() const { return n_; }
@@ -158,7 +159,7 @@ private:
 	Status iterate_kl(bool compute_error);            // KL-divergence multiplicative update (sparse mode)
 	Status fetch_error_terms(int count_n);            // enqueue the copies, do not wait
 	void finalize_error(bool resolve);
-	void record_begin();
+	void record_begin(int kind = 0);
 	void record_end();
 
 	int m_, n_, r_, RP_, alg_;
@@ -289,6 +290,7 @@ private:
 	long timing_iter_ = 0;
 	bool timing_now_ = false;
 	std::vector<hipEvent_t> ev_;
+	std::vector<char> ev_kind_;              // per event pair: which product it brackets (record_begin)
 	size_t ev_used_ = 0;
 };
 

@@ -178,6 +178,13 @@ class Engine:
         self._check(self._lib.nmfamd_engine_kernel_timing_read2(self._h, C.byref(ms), C.byref(cnt), C.byref(ov)), "kernel_timing_read2")
         return ms.value, cnt.value, ov.value
 
+    def kernel_timing_read3(self):
+        """(total_ms, launches, idle_pair_ms, (ms_h, ms_w), (launches_h, launches_w)): the product launches split into the H side (W^T V) and the W side (V H^T)."""
+        ms, cnt, ov = C.c_double(0), C.c_long(0), C.c_double(0)
+        km, kc = (C.c_double * 2)(), (C.c_long * 2)()
+        self._check(self._lib.nmfamd_engine_kernel_timing_read3(self._h, C.byref(ms), C.byref(cnt), C.byref(ov), km, kc), "kernel_timing_read3")
+        return ms.value, cnt.value, ov.value, (km[0], km[1]), (kc[0], kc[1])
+
     def geometry(self) -> dict:
         g = _Geometry()
         self._check(self._lib.nmfamd_engine_geometry(self._h, C.byref(g)), "geometry")

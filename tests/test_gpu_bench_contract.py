@@ -30,6 +30,15 @@ def test_default_bench_line_has_the_contract_fields():
     assert r["launches"] > 0 and r["avg_launch_us"] > 10
     if r["bound"] == "hbm":
         assert r["achieved"] == pytest.approx(r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=1e-6)
+    if r["kernel"] == "k_factor_product_x3":
+        # the two forms of the kernel are stamped apart (W^T V reads the one image along the reduction index, V H^T along its output index), and the same
+        # launches are priced against the bf16 matrix pipe as well: neither resource is saturated, the line says so instead of implying an HBM-bound kernel
+        f = r["forms"]
+        assert set(f) == {"wt_v", "v_ht"} and all(v["launches"] > 0 and v["frac"] == pytest.approx(v["achieved"] / r["peak"], rel=1e-9) for v in f.values())
+        assert f["wt_v"]["launches"] + f["v_ht"]["launches"] == r["launches"] and "memory-side cache" in r["streams_from"]
+        m2 = d["roofline_mfma"]
+        assert m2["bound"] == "mfma" and m2["unit"] == "TFLOP/s" and m2["peak"] == 2500.0 and m2["frac"] == pytest.approx(m2["achieved"] / m2["peak"], rel=1e-9)
+        assert m2["achieved"] == pytest.approx(6.0 * r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12, rel=1e-6) and 0.1 < m2["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
     # the iteration converged to the same error as every other path on this input (oracle: 2022.63 after 220 iterations;

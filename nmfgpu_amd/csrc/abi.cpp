@@ -213,8 +213,11 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 	}
 
 	// Parameter "numGpus" = N > 1 (extension; the reference is single-GPU, SingleGpuDispatcher.h:36): column shards of V on N
-	// rank threads inside this one call.  "shardMode": 0 (default) reduce-scatter by row blocks of W, 1 replicated W update.
-	int num_gpus = 1, shard_mode = nmfamd::SHARD_ROW_BLOCKS;
+	// rank threads inside this one call.  "shardMode": 0 reduce-scatter by row blocks of W, 1 replicated W update; absent: by the size of the m x r
+	// exchange panel, as bench.py chooses -- 8 MB or more (config 4's 51 MB): row blocks; less (config 2's 2.6 MB): the replicated update, which at padded
+	// rank 64 reads the ranks' panels in place and needs one rendezvous per iteration (sharded.cpp)
+	int num_gpus = 1;
+	int shard_mode = (double)sizeof(T) * (double)d.inputMatrix.rows * (double)nmfamd::padded_rank((int)d.features) >= 8e6 ? nmfamd::SHARD_ROW_BLOCKS : nmfamd::SHARD_REPLICATED;
 	{
 		int idx = parameter_index(d.parameters, d.numParameters, "numGpus");
 		if (idx >= 0) num_gpus = (int)d.parameters[idx].value;

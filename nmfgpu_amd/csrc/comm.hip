@@ -212,6 +212,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_local_sum(PeerPtrs peers, int world, long offset, T* __restrict__ out, long count) {
 	constexpr int V = 16 / sizeof(T);
 	typedef T vec __attribute__((ext_vector_type(V)));
+	// buffers in other devices' memory, re-read at the same addresses every iteration: a system-scope acquire before the first read, whatever fence scope the
+	// runtime gave the launch
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 	const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
 	if (i + V <= count) {
 		vec s = *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[0]) + offset + i);
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(256) void k_local_gather(PeerPtrs peers, int world,
 	typedef T vec __attribute__((ext_vector_type(V)));
 	const int p = blockIdx.y;
 	if (p == rank) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (as in k_local_sum)
 	const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
 	const T* src = static_cast<const T*>(peers.p[p]) + (long)p * count;
 	T* dst = mine + (long)p * count;

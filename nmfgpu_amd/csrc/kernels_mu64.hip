@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 	// peers.count > 0: the "slabs" are the exchange panels of the ranks of a column-sharded run, read where they lie (this device or a peer's memory,
 	// comm.h exchange_publish) and added in rank order -- the all-reduce of SURVEY 8(e) happens in this kernel's prologue
 	if (peers.count > 0) S = peers.count;
+	// panels in OTHER devices' memory: a system-scope acquire before the first read of them -- whatever fence scope the runtime gave this launch, lines of a
+	// peer's buffer this device cached two iterations ago (the exchange slots alternate) must not be served again.  Never executed by a single-GPU run.
+	if (peers.count > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 	auto slab_at = [&](int k) -> const float* { return peers.count > 0 ? peers.p[k] : slabs + (long)k * slab_stride; };
 	f32x4v qa[4];
 	f32x4v qs[QS > 1 ? QS - 1 : 1][4];
@@ -431,6 +434,7 @@ hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, l
 
 // out[i] = sum over k (ascending) of src.p[k][i], i < count (a multiple of 4): the r x r part of the exchange (H_g H_g^T of every rank) before the W update
 __global__ __launch_bounds__(256) void k_sum_peers(PeerSlabs src, float* __restrict__ out, int count) {
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (peers' memory: see k_mu64_update32)
 	const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
 	if (i >= count) return;
 	f32x4 s = *reinterpret_cast<const f32x4*>(src.p[0] + i);

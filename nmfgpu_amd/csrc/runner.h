@@ -175,10 +175,15 @@ public:
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return nmfamd::ST_NO_DEVICE; }
 		if (world_ < 2 || world_ > 16 || (long)world_ > (long)n_) return nmfamd::ST_INVALID;
+		// Transport: the in-process one (the ranks are threads of this process: every rank's kernels read the peers' buffers in place, over xGMI when the
+		// devices differ) unless NMFAMD_COMM=rccl asks for RCCL; when two devices cannot map each other's memory the set-up falls back to RCCL (do_setup).
+		// Round 4: RCCL was the default for ranks with a device each -- its mere presence costs ~11 us per iteration at config 2's size, and the
+		// small-message form of the W step (sharded.cpp) needs peer reads.
 		const char* force = std::getenv("NMFAMD_COMM");
 		const bool shared = world_ > ndev;
-		local_ = shared || (force != nullptr && (std::strcmp(force, "p2p") == 0 || std::strcmp(force, "local") == 0)) || !nmfamd::rccl_available();
+		local_ = true;
 		if (force != nullptr && std::strcmp(force, "rccl") == 0) { if (shared || !nmfamd::rccl_available()) return nmfamd::ST_INVALID; local_ = false; }
+		rccl_fallback_ = local_ && !shared && nmfamd::rccl_available() && !(force != nullptr && (std::strcmp(force, "p2p") == 0 || std::strcmp(force, "local") == 0));
 		for (int g = 0; g < world_; ++g) {
 			ranks_.emplace_back(new Rank());
 			ranks_[g]->device = (first_device_ + g) % ndev;
@@ -346,8 +351,22 @@ private:
 		nmfamd::local_group_barrier(*rendezvous_);
 		if (setup_failed_.load(std::memory_order_acquire)) return st;          // (a healthy rank reports ST_OK: the caller sees the failed one's status)
 		Status ct = local_ ? nmfamd::local_comm_create(transport_group_, g, &rk.comm) : nmfamd::rccl_comm_create(unique_id_, world_, g, &rk.comm);
-		if (ct != nmfamd::ST_OK) { setup_failed_.store(true, std::memory_order_release); if (transport_group_) nmfamd::local_group_abort(*transport_group_); }
+		if (ct != nmfamd::ST_OK) { comm_failed_.store(true, std::memory_order_release); if (transport_group_) nmfamd::local_group_abort(*transport_group_); }
 		nmfamd::local_group_barrier(*rendezvous_);
+		if (comm_failed_.load(std::memory_order_acquire) && local_ && rccl_fallback_) {
+			// the in-process transport could not be set up (a pair of devices without peer access): every rank agrees (the failure aborted the group for
+			// all), rank 0 fetches an RCCL id, and the ranks form an RCCL clique instead
+			rk.comm.reset();
+			if (g == 0) { fallback_id_ok_ = nmfamd::rccl_unique_id(unique_id_) == nmfamd::ST_OK; }
+			nmfamd::local_group_barrier(*rendezvous_);
+			ct = fallback_id_ok_ ? nmfamd::rccl_comm_create(unique_id_, world_, g, &rk.comm) : nmfamd::ST_HIP_ERROR;
+			if (ct != nmfamd::ST_OK) setup_failed_.store(true, std::memory_order_release);
+			nmfamd::local_group_barrier(*rendezvous_);
+			if (g == 0 && !setup_failed_.load(std::memory_order_acquire)) { local_ = false; transport_group_.reset(); }
+			nmfamd::local_group_barrier(*rendezvous_);
+		} else if (comm_failed_.load(std::memory_order_acquire)) {
+			setup_failed_.store(true, std::memory_order_release);
+		}
 		if (setup_failed_.load(std::memory_order_acquire)) return ct;
 		rk.sh.reset(new nmfamd::ShardedRank<T>(rk.eng.get(), rk.comm.get(), mode_, (long)m_, (long)n_));
 		return rk.sh->prepare();
@@ -365,7 +384,8 @@ private:
 	unsigned m_, n_, r_;
 	int alg_;
 	bool local_ = true;
-	std::atomic<bool> odd_values_{false}, setup_failed_{false};
+	std::atomic<bool> odd_values_{false}, setup_failed_{false}, comm_failed_{false};
+	bool rccl_fallback_ = false, fallback_id_ok_ = false;
 	std::vector<std::unique_ptr<Rank>> ranks_;
 	std::string error_;
 	std::vector<std::thread> workers_;

@@ -186,8 +186,9 @@ class Engine:
         return ms.value, cnt.value, ov.value, (km[0], km[1]), (kc[0], kc[1])
 
     def geometry(self) -> dict:
+        # (the sized getter: a library older or newer than this mirror never writes past the struct, include/nmfgpu_amd.h)
         g = _Geometry()
-        self._check(self._lib.nmfamd_engine_geometry(self._h, C.byref(g)), "geometry")
+        self._check(self._lib.nmfamd_engine_geometry_sized(self._h, C.byref(g), C.c_ulong(C.sizeof(g))), "geometry")
         return {k: getattr(g, k) for k, _ in _Geometry._fields_}
 
     # ---- column-sharded form ----

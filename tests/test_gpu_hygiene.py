@@ -143,3 +143,18 @@ def test_round1_update_path_with_partial_gram_matrices_still_agrees(monkeypatch)
     eng.iterate(30, last_iteration=30)
     Wg, Hg = eng.get_factors()
     assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4 and eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
+
+
+def test_geometry_getter_never_writes_past_the_callers_struct():
+    """nmfamd_geometry grew at its end (one_pass); nmfamd_engine_geometry_sized writes min(struct_size, sizeof) bytes."""
+    import ctypes as C
+    from nmfgpu_amd._lib import library
+    eng = na.Engine(300, 200, 8, "mu")
+    lib = library()
+    buf = (C.c_ubyte * 96)(*([0xAB] * 96))
+    assert lib.nmfamd_engine_geometry_sized(eng._h, buf, C.c_ulong(56)) == 0          # a caller compiled against round 2's 56-byte struct
+    assert all(b == 0xAB for b in bytes(buf)[56:]) and bytes(buf)[:4] == (300).to_bytes(4, "little")
+    assert lib.nmfamd_engine_geometry_sized(eng._h, buf, C.c_ulong(4)) != 0
+    g = eng.geometry()
+    assert g["m"] == 300 and g["n"] == 200 and g["padded_rank"] == 64
+    eng.close()

@@ -64,6 +64,28 @@ def test_compute_with_numgpus_matches_oracle_and_single_gpu(alg, r, params, dtyp
     assert sn.record(0).numIterations == iters
 
 
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_direct_exchange_gives_the_bits_of_the_reduced_exchange(ranks, monkeypatch):
+    """Round 4's small-message form of the W step (replicated mode at padded rank 64: the W update reads the ranks' exchange panels in place and adds them
+    in rank order in its prologue, two alternating buffers, one rendezvous per iteration) against round 3's form of the same step (the panels summed by the
+    transport's reduction kernel in rank order, the sum copied back, the W update on the one reduced panel; NMFAMD_SHARD_NO_DIRECT=1): the same values are
+    added in the same order, so the factors and the reported error must agree BIT FOR BIT -- on ragged shards, across an odd rank count, error iterations included."""
+    m, n, r, iters = 700, 530, 48, 31
+    V, W0, H0 = problem(m, n, r, np.float32, seed=40 + ranks)
+    out = []
+    for no_direct in ("0", "1"):
+        monkeypatch.setenv("NMFAMD_SHARD_NO_DIRECT", no_direct)
+        W, H = W0.copy(order="F"), H0.copy(order="F")
+        s = na.Summary()
+        assert na.compute(V, W, H, iterations=iters, parameters={"numGpus": ranks, "shardMode": 1}, summary=s) == na.ResultType.Success
+        out.append((W, H, s.record(0).frobenius))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    # ... and both are the single-GPU run up to the summation order of the column shards
+    W1, H1 = W0.copy(order="F"), H0.copy(order="F")
+    assert na.compute(V, W1, H1, iterations=iters) == na.ResultType.Success
+    assert rel(out[0][0], W1) < 2e-5 and rel(out[0][1], H1) < 2e-5
+
+
 def test_compute_with_numgpus_random_init_draws_one_stream_for_all_shards():
     """AllRandomValues on N ranks: every rank fills its columns of H from the position those columns have in the ONE stream,
     so the start -- and with it the whole run -- is the single-GPU run's up to rounding."""

@@ -174,13 +174,13 @@ def cpu_baseline_blas(V, W, H, threads: int, budget_s: float = 6.0):
 #   rccl  -- one process per GPU (torch.distributed.run), RCCL through its C API on the engine's stream; torch.distributed (gloo) only carries the unique id,
 #            the barriers and the MAX of the timings.
 # `--transport auto` (default): team first, rccl when the team could not be set up (devices that cannot map each other's memory, a failed rank).  Every
-# phase runs under ONE deadline (NMFAMD_BENCH_DEADLINE seconds, default 900): a run that passes it is killed -- child ranks included, which are fresh
+# phase runs under ONE deadline (NMFAMD_BENCH_DEADLINE seconds, default 480): a run that passes it is killed -- child ranks included, which are fresh
 # processes, never a re-exec of a process that touched the GPU -- and bench.py exits non-zero naming the phase that hung.
 _PHASE = {"name": "start", "file": os.environ.get("NMFAMD_BENCH_PHASE_FILE")}
 
 
 def deadline_seconds() -> float:
-    return float(os.environ.get("NMFAMD_BENCH_DEADLINE", "900"))
+    return float(os.environ.get("NMFAMD_BENCH_DEADLINE", "480"))
 
 
 def phase(name: str):

@@ -29,3 +29,32 @@ def test_gpus_n_refuses_without_devices():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
     assert out.returncode == 2 and not out.stdout.strip() and "--gpus 2" in out.stderr
+
+
+def _torchrun(extra, timeout=240):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", NMFAMD_BENCH_DEADLINE="120", GLOO_SOCKET_IFNAME="lo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra]
+    t0 = time.monotonic()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    return out, time.monotonic() - t0
+
+
+def test_ranks_under_torchrun_without_devices_agree_and_leave_nonzero():
+    """The driver's launch (one rank per GPU under torch.distributed.run) on a box with NO usable device: the control plane (gloo) comes up, rank 0's team
+    child refuses, every rank hears about it and leaves non-zero -- no line, no hang.  (world_size 2, gloo, CPU only.)"""
+    out, took = _torchrun([])
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert took < 200
+
+
+def test_rccl_ranks_without_devices_leave_nonzero():
+    out, took = _torchrun(["--transport", "rccl"])
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "HIP device" in out.stderr or "RCCL" in out.stderr or "librccl" in out.stderr
+    assert took < 200

@@ -207,6 +207,8 @@ NMFAMD_API int nmfamd_local_group_create(int world, nmfamd_local_group** out);
 NMFAMD_API void nmfamd_local_group_destroy(nmfamd_local_group* g);
 NMFAMD_API void nmfamd_local_group_abort(nmfamd_local_group* g);
 NMFAMD_API int nmfamd_comm_create_local(nmfamd_local_group* g, int rank, nmfamd_comm** out);
+/* why nmfamd_comm_create_local failed: names the pair of devices that cannot map each other's memory (valid until the calling thread's next call) */
+NMFAMD_API const char* nmfamd_local_group_last_error(nmfamd_local_group* g);
 /* "rccl" / "in-process (peer reads)" */
 NMFAMD_API const char* nmfamd_comm_transport(const nmfamd_comm* c);
 /* nmfamd_engine_create with the padded row count rounded up to a multiple of 128 * row_blocks (equal row blocks of W) */

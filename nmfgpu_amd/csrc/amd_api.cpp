@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <memory>
 #include <new>
 #include <vector>
@@ -212,6 +213,12 @@ int nmfamd_comm_create_local(nmfamd_local_group* g, int rank, nmfamd_comm** out)
 	if (st != ST_OK) { delete c; return (int)st; }
 	*out = c;
 	return NMFAMD_OK;
+}
+
+const char* nmfamd_local_group_last_error(nmfamd_local_group* g) {
+	static thread_local std::string text;
+	text = (g && g->g) ? local_group_failure(*g->g) : std::string();
+	return text.c_str();
 }
 
 const char* nmfamd_comm_transport(const nmfamd_comm* c) { return (c && c->c) ? c->c->transport() : ""; }

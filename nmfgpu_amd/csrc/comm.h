@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -75,5 +76,7 @@ Status local_comm_create(const std::shared_ptr<LocalGroup>& group, int rank, std
 void local_group_barrier(LocalGroup& g);
 // every rank waiting in (or arriving at) a collective of this group returns an error instead of waiting on
 void local_group_abort(LocalGroup& g);
+// why a set-up on this group failed (which pair of devices could not map each other's memory); empty when nothing failed
+std::string local_group_failure(LocalGroup& g);
 
 } // namespace nmfamd

@@ -157,6 +157,9 @@ struct LocalGroup {
 	std::atomic<int> arrived{0};
 	std::atomic<unsigned> generation{0};
 	std::atomic<bool> aborted{false};
+	std::mutex failure_lock;
+	std::string failure;                 // why the set-up failed (the first rank to fail says which pair of devices): local_group_failure()
+	void fail(const std::string& what) { std::lock_guard<std::mutex> g(failure_lock); if (failure.empty()) failure = what; }
 	struct Slot {
 		const void* buf = nullptr;
 		hipEvent_t ready = nullptr, done = nullptr;
@@ -201,6 +204,7 @@ static bool barrier(LocalGroup& g) {
 }
 
 void local_group_barrier(LocalGroup& g) { (void)barrier(g); }
+std::string local_group_failure(LocalGroup& g) { std::lock_guard<std::mutex> l(g.failure_lock); return g.failure; }
 void local_group_abort(LocalGroup& g) { g.aborted.store(true, std::memory_order_release); }
 
 namespace {
@@ -368,16 +372,23 @@ Status local_comm_create(const std::shared_ptr<LocalGroup>& group, int rank, std
 	bool ok = hipGetDevice(&me.device) == hipSuccess &&
 	          hipEventCreateWithFlags(&me.ready, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&me.done, hipEventDisableTiming) == hipSuccess;
-	if (!ok) group->aborted.store(true, std::memory_order_release);
+	if (!ok) { group->fail("rank " + std::to_string(rank) + ": no current device or no events"); group->aborted.store(true, std::memory_order_release); }
 	if (!barrier(*group)) return ST_HIP_ERROR;
 	// peers on other devices: map their memory into this device's address space (reads go over xGMI)
 	for (int p = 0; p < group->world; ++p) {
 		const int dev = group->slots[p].device;
 		if (dev == me.device) continue;
 		int can = 0;
-		if (hipDeviceCanAccessPeer(&can, me.device, dev) != hipSuccess || !can) { group->aborted.store(true, std::memory_order_release); break; }
+		if (hipDeviceCanAccessPeer(&can, me.device, dev) != hipSuccess || !can) {
+			group->fail("rank " + std::to_string(rank) + " (device " + std::to_string(me.device) + ") cannot map the memory of rank " + std::to_string(p) + " (device " + std::to_string(dev) +
+			            "): hipDeviceCanAccessPeer says no");
+			group->aborted.store(true, std::memory_order_release); break;
+		}
 		const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
-		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { group->aborted.store(true, std::memory_order_release); break; }
+		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+			group->fail("rank " + std::to_string(rank) + " (device " + std::to_string(me.device) + "): hipDeviceEnablePeerAccess(device " + std::to_string(dev) + ") failed: " + hipGetErrorString(e));
+			group->aborted.store(true, std::memory_order_release); break;
+		}
 		(void)hipGetLastError();
 	}
 	if (!barrier(*group)) return ST_HIP_ERROR;

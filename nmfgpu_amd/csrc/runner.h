@@ -275,6 +275,7 @@ private:
 				const char* b = rk->eng ? rk->eng->last_error() : "";
 				const char* c2 = rk->comm ? rk->comm->last_error() : "";
 				error_ = std::string(a && *a ? a : (b && *b ? b : c2));
+				if (error_.empty() && transport_group_) error_ = nmfamd::local_group_failure(*transport_group_);
 				return rk->status;
 			}
 		return nmfamd::ST_OK;

@@ -322,7 +322,9 @@ class LocalComm:
         h = C.c_void_p()
         st = self._lib.nmfamd_comm_create_local(group._h, int(rank), C.byref(h))
         if st != 0:
-            raise EngineError(st, "nmfamd_comm_create_local", "the devices of two ranks cannot map each other's memory, or a rank failed")
+            self._lib.nmfamd_local_group_last_error.restype = C.c_char_p
+            why = (self._lib.nmfamd_local_group_last_error(group._h) or b"").decode()
+            raise EngineError(st, "nmfamd_comm_create_local", why or "a rank of the group failed or the group was aborted")
         self._h = h
         self.world, self.rank = group.world, int(rank)
 

@@ -164,7 +164,8 @@ Status Engine<T>::allocate() {
 			const double product_us = 6.0 + (double)sizeof(T) * (double)pad128(m_) * (double)pad128(n_) / 5.0e6;       // (bytes at ~5 TB/s + launch and fill)
 			const double pairs = (ksH_ + 2) / 2;
 			while (gram_ksplit_ < GRAM_KSPLIT_MAX && 24.0 * (pairs / 317.0) / gram_ksplit_ > 0.55 * product_us) gram_ksplit_ *= 2;      // (24 us for config 2's 317 pairs in one slice: one CU's L2 rate, gram_image.h)
-			if (const char* e = tuning_env("NMFAMD_GRAM_KSPLIT")) gram_ksplit_ = std::max(1, std::min(GRAM_KSPLIT_MAX, std::atoi(e)));
+			// (NMFAMD_GRAM_KSPLIT = 1 / 2 / 4 / 8 forces the slice count: the parity tests run every form at shapes the oracle covers)
+			if (const char* e = std::getenv("NMFAMD_GRAM_KSPLIT")) { const int k = std::atoi(e); if (k == 1 || k == 2 || k == 4 || k == 8) gram_ksplit_ = k; }
 		}
 		planH_.splits = plan_splits_x3(planH_.xtiles, ksH_, num_cus_, gram_ksplit_ > 1 ? GRAM_IMAGE_TILES * gram_ksplit_ : 0);
 		planW_.splits = plan_splits_x3(planW_.xtiles, ksW_, num_cus_);

@@ -284,28 +284,36 @@ __global__ __launch_bounds__(256) void k_normalize_panel_v2(T* __restrict__ P, i
 		s_norm[c] = s > T(0) ? (T)sqrt(s) : T(0);
 	}
 	__syncthreads();
-	// `rows` panel rows x RP values, four elements per thread and step, eight steps in flight
+	// `rows` panel rows x RP values, one 16-byte (fp32) / 32-byte (fp64) vector per thread and step, eight steps in flight.  (Round 4: the scalar form of this loop --
+	// four element loads and four guarded element stores per step -- ran config 3's 51 MB panel at 3.2 TB/s.)  RP is a multiple of 64 and a thread's column quad
+	// (4 e) % RP stays the same for all its steps when RP divides 1 024 (64 ... 512): its four norms then live in registers; other ranks look them up per step.
+	typedef T T4 __attribute__((ext_vector_type(4)));
 	const long base = (long)blockIdx.x * rows * RP;
 	const int quads = rows * RP / 4;
+	const int cq = (4 * (int)threadIdx.x) % RP;
+	const bool fixed_quad = (1024 % RP) == 0;
+	T4 nr;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nr[k] = s_norm[cq + k];
 	for (int e0 = threadIdx.x; e0 < quads; e0 += 256 * 8) {
-		T v[8][4];
+		T4 v[8];
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
 			const int e = e0 + u * 256;
-			if (e < quads) {
-#pragma unroll
-				for (int k = 0; k < 4; ++k) v[u][k] = P[base + 4 * (long)e + k];
-			}
+			if (e < quads) v[u] = *reinterpret_cast<const T4*>(P + base + 4 * (long)e);
 		}
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
 			const int e = e0 + u * 256;
 			if (e < quads) {
+				if (!fixed_quad) {
 #pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const T nrm = s_norm[(4 * e + k) % RP];
-					if (nrm > T(0)) P[base + 4 * (long)e + k] = v[u][k] / nrm;
+					for (int k = 0; k < 4; ++k) nr[k] = s_norm[(4 * e) % RP + k];
 				}
+				T4 o;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) o[k] = nr[k] > T(0) ? v[u][k] / nr[k] : v[u][k];
+				*reinterpret_cast<T4*>(P + base + 4 * (long)e) = o;
 			}
 		}
 	}

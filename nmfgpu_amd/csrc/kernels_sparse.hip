@@ -362,6 +362,8 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 	for (int y = yy; y < 128; y += ystep) {
 		const long e = base + (long)y * RP + 4 * c4;
 		T4 nm = *reinterpret_cast<const T4*>(num + e);
+		// batches of eight requested together; the remainder as ONE batch of its own size (round 3's tail loop took the last parts % 8 panels one dependent
+		// load at a time -- seven of config 3's sixteen H-side panels; clamped duplicates instead re-read whole panels: 56 -> 71 us)
 		int b = 1;
 		for (; b + 8 <= parts; b += 8) {
 			T4 t[8];
@@ -370,7 +372,13 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 #pragma unroll
 			for (int u = 0; u < 8; ++u) nm += t[u];
 		}
-		for (; b < parts; ++b) nm += *reinterpret_cast<const T4*>(num + (long)b * part_stride + e);
+#define NMFAMD_KL_TAIL(N) case N: { T4 t[N]; _Pragma("unroll") for (int u = 0; u < N; ++u) t[u] = *reinterpret_cast<const T4*>(num + (long)(b + u) * part_stride + e); \
+                                   _Pragma("unroll") for (int u = 0; u < N; ++u) nm += t[u]; break; }
+		switch (parts - b) {
+			NMFAMD_KL_TAIL(1) NMFAMD_KL_TAIL(2) NMFAMD_KL_TAIL(3) NMFAMD_KL_TAIL(4) NMFAMD_KL_TAIL(5) NMFAMD_KL_TAIL(6) NMFAMD_KL_TAIL(7)
+			default: break;
+		}
+#undef NMFAMD_KL_TAIL
 		const T4 p = *reinterpret_cast<const T4*>(P + e);
 		const T4 v = p * nm / d;
 		*reinterpret_cast<T4*>(P + e) = v;

@@ -1110,3 +1110,31 @@ def test_long_horizon_fused_mu_stays_on_the_oracle_trajectory():
     R_ref = W64 @ H64
     assert np.linalg.norm(R_gpu - R_ref) / np.linalg.norm(R_ref) < 2e-3
     np.testing.assert_allclose(np.linalg.norm(Wg.astype(np.float64), axis=0), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,n", [(4000, 200), (1500, 900)])
+def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m, n, monkeypatch):
+    """Round 4 (column shards): W^T W rides in the W^T V launch cut into K slices -- 10 passenger workgroups per slice write UNSCALED partial matrices, the H update
+    adds them in order and scales them by the pending column scale, which comes from the W update's per-workgroup sums of squares (gram_image.h, k_mu64_update32).
+    The engine picks the slice count from the shard's shape; here every count is forced (NMFAMD_GRAM_KSPLIT) at shapes the fp64 oracle covers: same factors and
+    reported errors as the one-slice form up to summation order, all within the fp32 tolerance of the oracle.  4 000 x 200 also gives W^T V ten K slices: the H update's
+    13-slab batches (k_mu64_update32<false, 13, QS>)."""
+    r, iters = 64, 40
+    V, W0, H0 = problem(m, n, r, np.float32, seed=77)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    got = {}
+    for ks in (1, 2, 4, 8):
+        monkeypatch.setenv("NMFAMD_GRAM_KSPLIT", str(ks))
+        eng = na.Engine(m, n, r, "mu")
+        eng.upload(V); eng.set_factors(W0, H0)
+        eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+        Wg, Hg = eng.get_factors()
+        got[ks] = (Wg, Hg, eng.frobenius, eng.geometry()["slabs_h"])
+        eng.close()
+        assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4, (ks, rel(Wg, W64), rel(Hg, H64))
+        assert got[ks][2] == pytest.approx(ref["frobenius"], rel=1e-5)
+    if (m, n) == (4000, 200):
+        assert got[1][3] > 8                                  # more slabs than one batch of eight
+    for ks in (2, 4, 8):
+        assert rel(got[ks][0], got[1][0]) < 5e-6 and rel(got[ks][1], got[1][1]) < 5e-6

@@ -222,6 +222,9 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 // Workgroup = 4 waves = 32 panel columns.  Wave w owns result rows c = 16 w .. 16 w + 15 for both 16-column halves.
 // U: further slabs requested together with the first one (and per later batch): 7 for the few slabs of a whole problem, 13 for the many a short
 // column shard's W^T V is cut into (26 slabs at n = 625: two round trips instead of four)
+#ifndef U32_Q_EARLY
+#define U32_Q_EARLY 0               // (A/B switch, tools/build_variant.sh: 1 = request the finished r x r operand behind the slabs' first batch as the K-slice forms do)
+#endif
 // QS: K slices the r x r operand arrives in (H update; 1: the finished matrix)
 template <bool IS_W, int U = 7, int QS = 1>
 __global__ __launch_bounds__(256) void k_mu64_update32(
@@ -264,20 +267,19 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 				t[u][j] = *reinterpret_cast<const f32x4v*>(slab_at(k) + e);
 			}
 		}
-		__builtin_amdgcn_sched_barrier(0);
-		// A operand of the r x r product: Q(c = 16 wave + l15, c' = 16 q + t), t = 0 .. 15 (Q is symmetric: a row is a column).  Requested right BEHIND the slabs' first
-		// batch: the wait for that batch then leaves these in flight, and they arrive while the slabs are summed and parked in LDS (in front of the batch they
-		// made every workgroup of the launch wait for the same few lines first: 7.4 -> 10 us with four K slices)
-	#pragma unroll
-		for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
-		if (!IS_W && QS > 1) {
-			// Q arrives as QS unscaled K slices of Wu^T Wu (gram_image.h, K-split form): all requested together, added in order below
-	#pragma unroll
+		if (QS > 1 || U32_Q_EARLY) {
+			// Q arrives as QS unscaled K slices of Wu^T Wu (gram_image.h, K-split form): requested right BEHIND the slabs' first batch -- the wait for that batch then
+			// leaves these in flight and they arrive while the slabs are summed and parked in LDS (in front of the batch they made every workgroup of the launch wait
+			// for the same few lines first: 7.4 -> 10 us with four slices; behind the slab loop they cost a round trip of their own)
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+#pragma unroll
 			for (int k = 1; k < QS; ++k)
-	#pragma unroll
+#pragma unroll
 				for (int u = 0; u < 4; ++u) qs[k - 1][u] = *reinterpret_cast<const f32x4v*>(Q + (long)k * 4096 + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+			__builtin_amdgcn_sched_barrier(0);
 		}
-		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int u = 0; u < U; ++u)
 			if (1 + u < S) {
@@ -301,6 +303,11 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		}
 	}
 	const f32x4v sc = *reinterpret_cast<const f32x4v*>(scale + c4);
+	// A operand of the r x r product: Q(c = 16 wave + l15, c' = 16 q + t), t = 0 .. 15 (Q is symmetric: a row is a column); one finished matrix: in flight during the LDS pass
+	if (QS == 1 && !U32_Q_EARLY) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4v*>(Q + (long)(16 * wave + l15) * 64 + 16 * q + 4 * u);
+	}
 	if (!IS_W && QS > 1) {
 		// ... then D (.) D as the one-slice passengers do: (v * d(column)) * d(row)
 #pragma unroll
@@ -372,9 +379,10 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		}
 		if (l15 == 0) *reinterpret_cast<f32x4v*>(colsq_part + (long)blockIdx.x * 64 + 16 * wave + 4 * q) = sq;
 	}
-	if (IS_W && compute_error && blockIdx.x == 0) {
-		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (AlgorithmMultiplicativeFrobenius.h:212)
-		for (int d = wave * 16; d < wave * 16 + 16; ++d) {
+	if (IS_W && compute_error && wave == 0) {
+		// r terms of tr(H H^T W^T W): ps(d) = sum_i (H H^T)(d, i) (W^T W)(i, d)   (AlgorithmMultiplicativeFrobenius.h:212) -- one term per workgroup (round 3:
+		// all 64 in workgroup 0, sixteen dependent round trips per wave: that workgroup ran 16 us on every error iteration while the others took 6)
+		for (int d = blockIdx.x; d < 64; d += gridDim.x) {
 			float v = Q[(long)lane * 64 + d] * Gprev[(long)d * 64 + lane];
 			for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w);
 			if (lane == 0) ps[d] = v;

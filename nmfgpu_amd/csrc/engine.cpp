@@ -83,6 +83,7 @@ Engine<T>::~Engine() {
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
+	if (rowdot_part_) (void)hipFree(rowdot_part_);
 	if (Gpart_) (void)hipFree(Gpart_);
 	if (Graw64_) (void)hipFree(Graw64_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
@@ -272,6 +273,7 @@ Status Engine<T>::allocate() {
 	}
 	if (alg_ >= ALG_GDCLS && alg_ <= ALG_AHCLS) {
 		HIPX(dalloc(&Wold_, panelW));
+		HIPX(dalloc(&rowdot_part_, (long)ROW_DOT_GROUPS * RP_));
 		HIPX(hipMalloc((void**)&inv_work_, sizeof(double) * 2 * (size_t)r_ * r_));
 		if (tuning_env("NMFAMD_NO_OVERLAP") == nullptr) {
 			HIPX(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
@@ -955,7 +957,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 			                            wpart, nullptr, 0, qx3_));
 			if (Status st = normalize_w(wpart != nullptr, norm_parts)) return st;
 			// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
-			if (compute_error) HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+			if (compute_error) HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 		} else {
 			T offW = 0, diagW = 0;
 			if (alg_ == ALG_ACLS) diagW = (T)prm_.lambdaW;
@@ -972,7 +974,7 @@ Status Engine<T>::w_finish(const T* exchange, bool compute_error) {
 			HIPX(launch_panel_update<T>(PANEL_LS, Wt_, exchange, 1, 0, Qinv_, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_,
 			                            wpart, nullptr, 0, qx3_));
 			// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
-			if (compute_error) HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));
+			if (compute_error) HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 			if (Status st = normalize_w(wpart != nullptr, norm_parts)) return st;
 		}
 		if (compute_error) { if (Status st = fetch_error_terms(r_)) return st; }
@@ -1395,7 +1397,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				}
 				if (gd_err) {
 					// tr(H^T W^T V) as diag((V H^T)^T W) with the UPDATED W (GDCLS :259-264)
-					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+					HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 					error_terms_n = r_;
 				}
 			} else {
@@ -1408,7 +1410,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				                            nullptr, m_, sumsq_part_, compute_error ? numW_ : nullptr, stream_, wpart, nullptr, 0, qx3_));
 				if (compute_error) {
 					// tr(W_old^T (V H^T)) over r diagonals (ALS :199-205)
-					HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_));
+					HIPX(launch_row_dot<T>(Wold_, numW_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 					error_terms_n = r_;
 				}
 				if (Status s = normalize_w(wpart != nullptr, norm_parts)) return s;
@@ -1418,12 +1420,12 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			// (ALS/ACLS/AHCLS :199-205 with W never overwritten) or a stale buffer (GDCLS); here:
 			// ALS family as the reference, GDCLS the product the formula names.
 			if (ls_family) {
-				HIPX(launch_row_dot<T>(Wt_, Wt_, RP_, r_, mpad_, psN_, stream_));
+				HIPX(launch_row_dot<T>(Wt_, Wt_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 			} else {
 				if (Status s = product_w(Fh)) return s;
 				HIPX(launch_panel_update<T>(PANEL_SET, numW_, slabs_, planW_.splits, slab_stride_, HHt_, RP_, (int)mpad_, eps,
 				                            nullptr, m_, nullptr, nullptr, stream_));
-				HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_));
+				HIPX(launch_row_dot<T>(numW_, Wt_, RP_, r_, mpad_, psN_, stream_, rowdot_part_));
 			}
 			error_terms_n = r_;
 		}

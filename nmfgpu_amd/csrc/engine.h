@@ -183,6 +183,7 @@ private:
 	T *slabs_ = nullptr;
 	T *numW_ = nullptr;                       // reduced (V H^T)^T panel (LS family error terms, sharded runs)
 	T *Wold_ = nullptr;                       // LS family: W before the update
+	T *rowdot_part_ = nullptr;                // ... and the per-workgroup partial vectors of launch_row_dot's coalesced form
 	T *G_ = nullptr, *G2_ = nullptr, *HHt_ = nullptr, *Qinv_ = nullptr, *gram_part_ = nullptr;
 	T *sumsq_part_ = nullptr;
 	// bf16-operand products (kernels_bf16.hip): fragment-ordered bf16 images of V, Vt and of the two factor panels

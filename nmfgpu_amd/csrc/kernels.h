@@ -220,7 +220,8 @@ template <typename T>
 hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq = nullptr);
 
 template <typename T>
-hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream);
+hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream, T* part = nullptr);      // part: ROW_DOT_GROUPS * RP scratch -> coalesced form
+constexpr int ROW_DOT_GROUPS = 128;
 
 template <typename T>
 hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, hipStream_t stream);

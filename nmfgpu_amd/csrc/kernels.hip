@@ -818,13 +818,52 @@ __global__ __launch_bounds__(256) void k_row_dot(const T* __restrict__ A, const 
 	if (threadIdx.x == 0) ps[d] = red[0];
 }
 
+// The same sums with coalesced reads (round 4: the kernel above walks a panel column with one 4-byte load per 256-byte row -- every workgroup touches every cache
+// line of both panels: 25 us at config 5 on every error iteration).  Workgroup g takes a contiguous range of panel rows, a thread four consecutive d (16-byte
+// loads) of every (1024 / RP)-th row of the range; per-workgroup partial vectors, summed in order by launch_reduce_partials.
 template <typename T>
-hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream) {
+__global__ __launch_bounds__(256) void k_row_dot_part(const T* __restrict__ A, const T* __restrict__ B, int RP, long len, int groups, T* __restrict__ part) {
+	typedef T T4 __attribute__((ext_vector_type(4)));
+	__shared__ T s_p[256 * 4];
+	const int per_row = RP / 4, c4 = threadIdx.x % per_row, yy = threadIdx.x / per_row, ystep = 256 / per_row;
+	const long y0 = (len * blockIdx.x) / groups, y1 = (len * (blockIdx.x + 1)) / groups;
+	T4 acc = {0, 0, 0, 0};
+	for (long y = y0 + yy; y < y1; y += 4l * ystep) {
+		T4 a[4], b[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const long yu = y + (long)u * ystep;
+			const long e = (yu < y1 ? yu : y0) * RP + 4 * c4;
+			a[u] = *reinterpret_cast<const T4*>(A + e); b[u] = *reinterpret_cast<const T4*>(B + e);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (y + (long)u * ystep < y1) acc += a[u] * b[u];
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) s_p[threadIdx.x * 4 + i] = acc[i];
+	__syncthreads();
+	if ((int)threadIdx.x < RP) {
+		const int c = threadIdx.x;
+		T v = 0;
+		for (int g = 0; g < ystep; ++g) v += s_p[(g * per_row + c / 4) * 4 + (c & 3)];
+		part[(long)blockIdx.x * RP + c] = v;
+	}
+}
+
+// part (optional): ROW_DOT_GROUPS * RP elements of scratch -- with it the coalesced two-launch form runs (RP <= 256)
+template <typename T>
+hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream, T* part) {
+	if (part != nullptr && RP <= 256 && RP % 64 == 0 && len >= 4096) {
+		hipLaunchKernelGGL((k_row_dot_part<T>), dim3(ROW_DOT_GROUPS), dim3(256), 0, stream, A, B, RP, len, ROW_DOT_GROUPS, part);
+		if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+		return launch_reduce_partials<T>(part, ROW_DOT_GROUPS, RP, ps, r, stream);
+	}
 	hipLaunchKernelGGL((k_row_dot<T>), dim3(r), dim3(256), 0, stream, A, B, RP, len, ps);
 	return hipGetLastError();
 }
-template hipError_t launch_row_dot<float>(const float*, const float*, int, int, long, float*, hipStream_t);
-template hipError_t launch_row_dot<double>(const double*, const double*, int, int, long, double*, hipStream_t);
+template hipError_t launch_row_dot<float>(const float*, const float*, int, int, long, float*, hipStream_t, float*);
+template hipError_t launch_row_dot<double>(const double*, const double*, int, int, long, double*, hipStream_t, double*);
 
 // A(i, j) = [reuse] A(i, j) + (i == j ? diag : offdiag) on the r x r block
 // (kernel::fillMatrix / addConstantToMatrix, KernelFillMatrix.cu:29-45)

@@ -625,12 +625,22 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_lds_f32(
 				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = *reinterpret_cast<const f32x4*>(P + base + 4l * e);
 			}
 		}
-		for (int k = 1; k < S; ++k) {
-			f32x4 t[4];
+		// the K slices in batches of up to five, requested together and added in slice order (round 4: one slice per turn of a loop was one dependent round
+		// trip per slice -- five of them for the six slices of config 5's W^T V)
+		for (int k0 = 1; k0 < S; k0 += 5) {
+			f32x4 t[5][4];
 #pragma unroll
-			for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));
+			for (int u = 0; u < 5; ++u) {
+				const int k = k0 + u < S ? k0 + u : 0;      // clamped duplicate, discarded below
 #pragma unroll
-			for (int i = 0; i < 4; ++i) num[i] += t[i];
+				for (int i = 0; i < 4; ++i) t[u][i] = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab_stride + base + 4l * (tid + 256 * i));
+			}
+#pragma unroll
+			for (int u = 0; u < 5; ++u)
+				if (k0 + u < S) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) num[i] += t[u][i];
+				}
 		}
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {

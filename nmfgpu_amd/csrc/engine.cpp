@@ -886,9 +886,11 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			if (Status s = product_h(F, nullptr, x3_ && wx3_valid_ && F == Wt_)) return s;
 			if (Status s = normal_inverse_join()) return s;
 		}
-		T* hpart = nullptr;
-		if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) hpart = gramH_part_; }
 		const bool emit = x3_ && panel_update_delivers_gram(RP_, sizeof(T));
+		T* hpart = nullptr;
+		// (GDCLS on the split-operand path at padded rank 64: the fused iteration takes H H^T from the split image beside the product, Engine::iterate -- the
+		//  sharded form, w_products(), makes its own Gram pass over H)
+		if constexpr (std::is_same<T, float>::value) { if (gram_from_update() && !(alg_ == ALG_GDCLS && emit && RP_ == 64 && passengers_ride(planWx_) && h_partials_unneeded_)) hpart = gramH_part_; }
 		HIPX(launch_panel_update<T>(PANEL_LS, H_, slabs_, S, slab_stride_, Qinv_, RP_, (int)npad_, eps,
 		                            nullptr, n_, nullptr, nullptr, stream_, hpart, emit ? Hx3_ : nullptr, ksW_, qx3_));
 		hx3_valid_ = emit;
@@ -1327,7 +1329,10 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	if (prm_.divergence != 0) return constant_w ? ST_INVALID : iterate_kl(compute_error);
 	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
-	if (Status s = h_step_impl(compute_error)) return s;
+	h_partials_unneeded_ = !constant_w;              // (the fused iteration: H H^T rides the product where it can)
+	const Status hs = h_step_impl(compute_error);
+	h_partials_unneeded_ = false;
+	if (hs != ST_OK) return hs;
 
 	const bool ls_family = alg_ == ALG_ALS || alg_ == ALG_ACLS || alg_ == ALG_AHCLS;
 	int error_terms_n = n_;   // length of the tr(H^T W^T V) term vector
@@ -1344,15 +1349,20 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, diag, stream_));
 			Fh = Hs_;
 		}
+		// GDCLS at padded rank 64 on the split-operand path (round 4): H H^T only feeds the W update, which runs AFTER the product against V -- so it is taken from
+		// the split image of H by the passenger workgroups of that launch, as the multiplicative update does (gram_image.h): no reduction launch, no partial Gram
+		// matrices out of the H update.  (The ALS family inverts H H^T beside the product and needs it before.)
+		bool hht_rides = false;
 		if constexpr (std::is_same<T, float>::value) {
-			if (gram_h_partials_ && Fh == H_) {
+			hht_rides = !constant_w && alg_ == ALG_GDCLS && x3_ && hx3_valid_ && Fh == H_ && RP_ == 64 && !gram_h_partials_ && passengers_ride(planWx_);
+			if (!hht_rides && gram_h_partials_ && Fh == H_) {
 				// H H^T from the partial Gram matrices the H update left behind
 				HIPX(launch_gram64_from_partials(gramH_part_, (int)(npad_ / 64), HHt_, nullptr, stream_));
 				hht_done = true;
 			}
 		}
-		if (!hht_done) HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
-		if (compute_error) {
+		if (!hht_done && !hht_rides) HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
+		if (compute_error && !hht_rides) {
 			const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 				if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
@@ -1379,6 +1389,14 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
 					rg.inv_a = HHt_; rg.inv_out = Qinv_; rg.inv_offdiag = offW; rg.inv_diag = diagW; rg.inv_r = r_;
 					if (Status s = product_w(Fh, &rg, nullptr, x3_ && hx3_valid_ && Fh == H_)) return s;
+				}
+			} else if (hht_rides) {
+				if constexpr (std::is_same<T, float>::value) {
+					GramReduceArgs rg = {nullptr, 0, HHt_, nullptr, 0};
+					rg.image = Hx3_; rg.image_ks = ksW_;
+					if (Status s = product_w(Fh, &rg, nullptr, true)) return s;
+					// (the error term's trace reads the finished H H^T: behind the launch that made it)
+					if (compute_error) HIPX(launch_trace_small<T>(HHt_, G2_, RP_, r_, psR_, stream_, tri_trace_scale()));
 				}
 			} else {
 				if (Status s = product_w(Fh, nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;

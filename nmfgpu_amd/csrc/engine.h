@@ -260,6 +260,7 @@ private:
 	Status tri_prepare_h(T* hht, bool local_q);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
 	Status tri_update_w(const T* num, int S, long stride, const T* hht);   // W update + normalisation + everything tri_prepare_w() would do
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
+	bool h_partials_unneeded_ = false; // set by iterate() around its H step: GDCLS takes H H^T from the split image beside the product against V
 	int normalize_next_ = 0;
 	T *psN_ = nullptr, *psR_ = nullptr;
 	long ps_stride_ = 0;

@@ -103,15 +103,16 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const T* __restrict__ p
 	const int p0 = (parts * g) / 4, p1 = (parts * (g + 1)) / 4;
 	T s = 0;
 	if (e < count) {
-		int p = p0;
-		for (; p + 8 <= p1; p += 8) {
+		// batches of eight requested together, the last one clamped (the duplicates are this thread's own first line again): round 3's tail loop took the last
+		// (p1 - p0) % 8 partials one dependent load at a time -- seven of the forty per group at config 5's W side
+		for (int p = p0; p < p1; p += 8) {
 			T v[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) v[u] = partial[(long)(p + u) * stride + e];
+			for (int u = 0; u < 8; ++u) v[u] = partial[(long)(p + u < p1 ? p + u : p0) * stride + e];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) s += v[u];
+			for (int u = 0; u < 8; ++u)
+				if (p + u < p1) s += v[u];
 		}
-		for (; p < p1; ++p) s += partial[(long)p * stride + e];
 	}
 	red[g][tx] = s;
 	__syncthreads();

@@ -1190,7 +1190,10 @@ template <typename T>
 Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (from_gram_partials) {
-			if (x3_ && Graw64_ != nullptr) {
+			if (x3_ && Graw64_ != nullptr && std::getenv("NMFAMD_NORMALIZE_TWO_LAUNCHES") == nullptr) {
+				// ONE launch (round 4): column scales from the update's sums of squares, G = D (sum of the partial Gram matrices) D, W <- W D and its split image
+				HIPX(launch_gram64_reduce_scale_all(gramW_part_, (int)(mpad_ / 64), sumsq_part_, norm_parts, G_, scale_, Wt_, (int)mpad_, Wx3_, ksH_, stream_));
+			} else if (x3_ && Graw64_ != nullptr) {
 				// reduction, then ONE launch: scales from the raw diagonal, G = D Graw D, W <- W D and its split image for the next W^T V
 				HIPX(launch_gram64_normalize_all(gramW_part_, (int)(mpad_ / 64), Graw64_, G_, scale_, Wt_, (int)mpad_, Wx3_, ksH_, stream_));
 			} else {

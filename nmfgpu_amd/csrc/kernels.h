@@ -120,6 +120,10 @@ hipError_t launch_mu64_apply_scale(float* P, int len_pad, const float* scale, hi
 // G <- diag(scale) G diag(scale): the stand-alone (not passenger) form of the Gram reduction
 hipError_t launch_gram64_from_partials(const float* partials, int parts, float* G, float* scale, hipStream_t stream);
 hipError_t launch_gram64_normalize_all(const float* partials, int parts, float* Graw, float* G, float* scale, float* P, int len_pad, void* x3_out, int x3_ks, hipStream_t stream);
+// the same in ONE launch: column scales from the update kernel's sums of squares (sq_parts vectors of 64) instead of the reduced diagonal; G = D (sum of the partial
+// matrices) D; P <- P D and its split image
+hipError_t launch_gram64_reduce_scale_all(const float* gram_part, int parts, const float* sumsq_part, int sq_parts, float* G, float* scale, float* P, int len_pad,
+                                          void* x3_out, int x3_ks, hipStream_t stream);
 
 // Generic (VALU) form, writes the finished panel (no slabs).  Xpad multiple of 64, RP multiple of 32.
 template <typename T>

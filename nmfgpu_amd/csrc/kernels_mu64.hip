@@ -637,6 +637,83 @@ __global__ __launch_bounds__(256) void k_mu64_scale_all_x3(float* __restrict__ P
 	}
 }
 
+// Round 4: the reduction of the partial Gram matrices AND the scaling pass in ONE launch (every launch costs ~5 us whatever it does).  What made round 3's attempt
+// slow (13 us) was the diagonal: every workgroup gathered it from the partial matrices, one cache line per element and part.  Here the column scales come from the
+// per-workgroup sums of squares the update kernel writes anyway (`sq_parts` vectors of 64, contiguous): every workgroup adds them in ONE batch of loads (four groups
+// of parts, added in order: the same bits everywhere).  Grid: row_blocks workgroups scale 16 panel rows each and write their split image; 64 more reduce one row of
+// the Gram matrix each over `parts` partial matrices (four groups of parts) and scale it, D (sum) D; the first of them publishes the scales.
+__global__ __launch_bounds__(256) void k_mu64_reduce_scale_all_x3(float* __restrict__ P, const float* __restrict__ gram_part, int parts, const float* __restrict__ sumsq_part, int sq_parts,
+                                                                 float* __restrict__ G, float* __restrict__ scale, bf16x8* __restrict__ x3_out, int x3_ks, int row_blocks) {
+	__shared__ __attribute__((aligned(16))) float s_v[16][68];
+	__shared__ __attribute__((aligned(16))) float s_scale[64];
+	__shared__ float s_grp[4][64];
+	const int tid = threadIdx.x;
+	{
+		// sums of squares of the 64 columns: thread (c, g) takes the parts g, g + 4, ... -- up to 48 of them in flight (config 5: 158 parts, 40 per thread)
+		const int c = tid & 63, g = tid >> 6;
+		float sum = 0.f;
+		for (int p = g; p < sq_parts; p += 4 * 48) {
+			float v[48];
+#pragma unroll
+			for (int u = 0; u < 48; ++u) v[u] = p + 4 * u < sq_parts ? sumsq_part[(long)(p + 4 * u) * 64 + c] : 0.f;
+#pragma unroll
+			for (int u = 0; u < 48; ++u) sum += v[u];
+		}
+		s_grp[g][c] = sum;
+	}
+	__syncthreads();
+	if (tid < 64) {
+		const float d = ((s_grp[0][tid] + s_grp[1][tid]) + s_grp[2][tid]) + s_grp[3][tid];
+		s_scale[tid] = d > 0.f ? 1.0f / sqrtf(d) : 1.0f;
+	}
+	__syncthreads();
+	if ((int)blockIdx.x >= row_blocks) {
+		// one row of G: element (row, c) = sum over the partial matrices, four groups of parts, groups added in order
+		const int row = (int)blockIdx.x - row_blocks, c = tid & 63, g = tid >> 6;
+		const int p0 = (parts * g) / 4, p1 = (parts * (g + 1)) / 4;
+		const float* src = gram_part + (long)row * 64 + c;
+		float sum = 0.f;
+		for (int p = p0; p < p1; p += 48) {
+			float v[48];
+#pragma unroll
+			for (int u = 0; u < 48; ++u) v[u] = p + u < p1 ? src[(long)(p + u) * 4096] : 0.f;
+#pragma unroll
+			for (int u = 0; u < 48; ++u) sum += v[u];
+		}
+		__syncthreads();
+		s_grp[g][c] = sum;
+		__syncthreads();
+		if (tid < 64) {
+			const float v = ((s_grp[0][tid] + s_grp[1][tid]) + s_grp[2][tid]) + s_grp[3][tid];
+			G[(long)row * 64 + tid] = (v * s_scale[tid]) * s_scale[row];
+			if (row == 0) scale[tid] = s_scale[tid];
+		}
+		return;
+	}
+	const long e = (long)blockIdx.x * 256 + tid;
+	f32x4 v = *reinterpret_cast<f32x4*>(P + 4 * e);
+	v *= *reinterpret_cast<const f32x4*>(s_scale + (4 * tid) % 64);
+	*reinterpret_cast<f32x4*>(P + 4 * e) = v;
+	*reinterpret_cast<f32x4*>(&s_v[tid >> 4][4 * (tid & 15)]) = v;
+	__syncthreads();
+	if (tid < 128 && (int)blockIdx.x < x3_ks) {
+		const int r = tid & 31, h = (tid >> 5) & 1, nb = tid >> 6;
+		float w[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) w[j] = s_v[8 * h + j][32 * nb + r];
+		store_split3(x3_out, blockIdx.x, 2, nb, h, r, w);
+	}
+}
+
+hipError_t launch_gram64_reduce_scale_all(const float* gram_part, int parts, const float* sumsq_part, int sq_parts, float* G, float* scale, float* P, int len_pad,
+                                          void* x3_out, int x3_ks, hipStream_t stream) {
+	if (parts < 1 || sq_parts < 1 || len_pad % 16 != 0) return hipErrorInvalidValue;
+	const int row_blocks = len_pad / 16;
+	hipLaunchKernelGGL(k_mu64_reduce_scale_all_x3, dim3((unsigned)row_blocks + 64), dim3(256), 0, stream, P, gram_part, parts, sumsq_part, sq_parts, G, scale,
+	                   reinterpret_cast<bf16x8*>(x3_out), x3_ks, row_blocks);
+	return hipGetLastError();
+}
+
 // partials -> Graw (unscaled sum), then the launch above: G, scale, the scaled panel and its split image
 hipError_t launch_gram64_normalize_all(const float* partials, int parts, float* Graw, float* G, float* scale, float* P, int len_pad, void* x3_out, int x3_ks, hipStream_t stream) {
 	hipError_t e = launch_reduce_partials<float>(partials, parts, 4096, Graw, 4096, stream);

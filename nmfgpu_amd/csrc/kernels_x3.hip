@@ -142,7 +142,9 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // DIAG (measurement builds only, NMFAMD_X3_VARIANT 10..12): 1 = no ring refill (issue rate of the split + MFMA
 // stream alone), 2 = refill A only, 3 = refill F only, 4 = the production loop; all of them stamp the main loop
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false>
+// R32 (y-tiled form on 16-row tiles, loads straight to registers): MFMA row r of M-block b is tile row 32 b + r (as in the YLDS form) instead of 4 r + b: consecutive lanes read
+// consecutive 64-byte column chunks -- 16 cache lines per wave instruction instead of 32
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
 __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -210,13 +212,13 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		//   are eight tiles, a lane quartet (l31 >> 2) per tile, 1 KiB contiguous per tile and K-step; y-tiled: a K-step IS a
 		//   tile, the 16 k of a row are 64 contiguous bytes and the 128 rows of the wave 8 KiB contiguous (with 128-row tiles
 		//   a K-step takes 64 bytes out of each of 128 rows 512 bytes apart and every row is revisited eight times).
-		const float* ap = IMG == 16 ? (TR ? A + ((long)xt * TH + 4 * l31) * 16 + 8 * half
+		const float* ap = IMG == 16 ? (TR ? A + ((long)xt * TH + (R32 ? l31 : 4 * l31)) * 16 + 8 * half
 		                                  : A + ((long)xt * 8 + (l31 >> 2)) * tile_stride + (8 * half) * 16 + 4 * (l31 & 3))
 		                            : (TR ? A + ((long)xt * TH + 4 * l31) * TH + 8 * half
 		                                  : A + (long)xt * tile_stride + (8 * half) * TH + 4 * l31);
 		auto a_addr = [&](int step, int i) -> const float* {
 			if (IMG == 16) {
-				if (TR) return ap + (long)step * tile_stride + (i >> 1) * 16 + 4 * (i & 1);
+				if (TR) return ap + (long)step * tile_stride + (i >> 1) * (R32 ? 32 * 16 : 16) + 4 * (i & 1);
 				return ap + ((long)step * 16 + i) * 16;
 			}
 			if (TR) return ap + (long)(step >> 3) * tile_stride + (step & 7) * 16 + (i >> 1) * TH + 4 * (i & 1);
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) {
 				const int mi = gi + 8 * q + 4 * half;
-				const int x = xt * TH + (YLDS ? 32 * b + mi : 4 * mi + b);
+				const int x = xt * TH + ((YLDS || R32) ? 32 * b + mi : 4 * mi + b);
 				slab[(long)x * RP + coff + 32 * nb + l31] = s[gi];
 			}
 		}
@@ -438,7 +440,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
-template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -451,8 +453,8 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS>), grid, block, lds_bytes, stream,
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
 }
@@ -484,12 +486,20 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	if (stamps != nullptr) return hipErrorNotSupported;      // stamped kernels exist in the diagnostic build only (tuning.h)
 #endif
 	if (image_tile == 16) {
-		if (RP % 128 == 0) return y_tiled ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
-		                                  : launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		static const bool ydirect = tuning_env("NMFAMD_X3_YDIRECT") != nullptr;          // A/B switch: row-per-lane global loads
-		if (y_tiled && !ydirect) return launch_fp_x3<X3_RING_Y, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return y_tiled ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
-		               : launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		// y-tiled form on 16-row tiles (one resident image, config 2's W^T V).  Round 4: loads straight to registers with MFMA row r of M-block b = tile row 32 b + r, so that
+		// consecutive lanes read consecutive 64-byte column chunks (16 cache lines per wave instruction): 42.5 us per launch against 46.3 for the LDS-staged form (rounds 2-3's
+		// default) and 47.4 for direct loads with the x-tiled form's interleaved rows (4 r + b: 32 lines per instruction) on the same box; results bit-identical.
+		// NMFAMD_X3_YLDS / NMFAMD_X3_YDIRECT (measurement builds) select the older forms.
+		static const bool ylds = tuning_env("NMFAMD_X3_YLDS") != nullptr, ydirect = tuning_env("NMFAMD_X3_YDIRECT") != nullptr;
+		if (RP % 128 == 0) {
+			if (!y_tiled) return launch_fp_x3<2, 4, 0, 4, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+			return ydirect ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
+			               : launch_fp_x3<2, 4, 0, 4, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		}
+		if (!y_tiled) return launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (ylds) return launch_fp_x3<X3_RING_Y, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (ydirect) return launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
 	if (y_tiled) {
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);

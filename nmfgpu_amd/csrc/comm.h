@@ -50,7 +50,8 @@ public:
 	virtual const char* last_error() const { return ""; }
 
 protected:
-	std::vector<void*> xbuf_;          // exchange buffers of the default (one-rank) implementation
+	std::vector<void*> xbuf_;          // exchange buffers (this rank's)
+	size_t xbuf_bytes_ = 0;
 public:
 	Comm() = default;
 	Comm(const Comm&) = delete;

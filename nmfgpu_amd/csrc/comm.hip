@@ -14,13 +14,21 @@ namespace nmfamd {
 
 // ---- exchange buffers: the part every transport shares (a team of one reads its own buffer) ---------------------------
 Status Comm::exchange_alloc(size_t bytes, int slots, void** mine) {
-	if (bytes == 0 || slots < 1 || slots > 2 || mine == nullptr || !xbuf_.empty()) return ST_INVALID;
+	if (bytes == 0 || slots < 1 || slots > 2 || mine == nullptr) return ST_INVALID;
+	// (a second sharded run on the same communicator reuses the buffers when they are large enough)
+	if ((int)xbuf_.size() != slots || bytes > xbuf_bytes_) {
+		for (void* p : xbuf_) if (p) (void)hipFree(p);
+		xbuf_.clear(); xbuf_bytes_ = 0;
+		for (int i = 0; i < slots; ++i) {
+			void* p = nullptr;
+			if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_NO_DEVICE_MEMORY; }
+			xbuf_.push_back(p);
+		}
+		xbuf_bytes_ = bytes;
+	}
 	for (int i = 0; i < slots; ++i) {
-		void* p = nullptr;
-		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_NO_DEVICE_MEMORY; }
-		xbuf_.push_back(p);
-		if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_HIP_ERROR; }
-		mine[i] = p;
+		if (hipMemset(xbuf_[i], 0, bytes) != hipSuccess) { (void)hipGetLastError(); return ST_HIP_ERROR; }
+		mine[i] = xbuf_[i];
 	}
 	return ST_OK;
 }
@@ -300,7 +308,7 @@ public:
 		LocalGroup::Slot& me = g_->slots[rank_];
 		for (int i = 0; i < slots && st == ST_OK; ++i) {
 			me.xbuf[i] = mine[i];
-			if (hipEventCreateWithFlags(&me.xready[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st = ST_HIP_ERROR; }
+			if (me.xready[i] == nullptr && hipEventCreateWithFlags(&me.xready[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st = ST_HIP_ERROR; }
 		}
 		if (st != ST_OK) g_->aborted.store(true, std::memory_order_release);
 		if (!barrier(*g_)) return st != ST_OK ? st : ST_HIP_ERROR;          // every rank's buffers and events exist from here on

@@ -371,3 +371,65 @@ def test_config4_as_stated_eight_shards_on_one_device():
         W, H = W0.copy(order="F"), H0.copy(order="F")
         assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.nsNMF, iterations=iters, parameters=dict(base, numGpus=8, shardMode=1)) == na.ResultType.Success
         assert np.array_equal(W, out["repl"][0]) and np.array_equal(H, out["repl"][1])
+
+
+def test_team_of_rank_threads_through_the_c_abi_runs_twice_on_one_communicator():
+    """The in-process team below the boundary (include/nmfgpu_amd.h: nmfamd_local_group_*, nmfamd_comm_create_local, nmfamd_sharded_*), as bench.py --gpus N drives it:
+    three rank threads on one device, rank-64 multiplicative update (the direct exchange), TWO sharded runs after each other on the same communicators (the exchange
+    buffers are reused), both W-step modes.  Every rank holds the same bits of W, the replicated mode repeats bit for bit, and the result is the single-engine run's."""
+    import threading
+    import torch
+    m, n, r, world, iters = 900, 610, 40, 3, 25
+    V, W0, H0 = problem(m, n, r, np.float32, seed=91)
+    group = na.LocalGroup(world)
+    gate = threading.Barrier(world)
+    results, errors = {}, []
+
+    def rank_thread(g):
+        eng = comm = run = None
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            comm = na.LocalComm(group, g)
+            c0, nc = na.shard_columns(n, world, g)
+            eng = na.Engine(m, nc, r, "mu", row_blocks=world, stream=stream.cuda_stream)
+            eng.upload(F(V[:, c0:c0 + nc]))
+            for name, mode in (("repl", na.SHARD_REPLICATED), ("repl again", na.SHARD_REPLICATED), ("rows", na.SHARD_ROW_BLOCKS)):
+                eng.set_factors(W0, F(H0[:, c0:c0 + nc]))
+                gate.wait()
+                run = na.ShardedRun(eng, comm, m, n, mode)
+                run.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+                Wg, Hg = eng.get_factors()
+                results[(name, g)] = (Wg, Hg, run.frobenius)
+                run.close(); run = None
+                gate.wait()
+        except BaseException as e:          # noqa: BLE001
+            errors.append((g, e)); group.abort(); gate.abort()
+        finally:
+            for obj in (run, eng, comm):
+                if obj is not None:
+                    try:
+                        obj.close()
+                    except Exception:       # noqa: BLE001
+                        pass
+
+    threads = [threading.Thread(target=rank_thread, args=(g,), daemon=True) for g in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)][:2] or errors[:1]
+    eng1 = na.Engine(m, n, r, "mu")
+    eng1.upload(V); eng1.set_factors(W0, H0)
+    eng1.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    W1, H1 = eng1.get_factors(); f1 = eng1.frobenius
+    eng1.close()
+    for name in ("repl", "repl again", "rows"):
+        Wg = results[(name, 0)][0]
+        Hg = np.concatenate([results[(name, g)][1] for g in range(world)], axis=1)
+        for g in range(1, world):
+            assert np.array_equal(results[(name, g)][0], Wg) and results[(name, g)][2] == results[(name, 0)][2]
+        assert rel(Wg, W1) < 2e-5 and rel(Hg, H1) < 2e-5 and results[(name, 0)][2] == pytest.approx(f1, rel=1e-6)
+    assert np.array_equal(results[("repl", 0)][0], results[("repl again", 0)][0])
+    for g in range(world):
+        assert np.array_equal(results[("repl", g)][1], results[("repl again", g)][1])

@@ -640,7 +640,7 @@ def team_worker(args):
         raise SystemExit(4)
     elapsed = max(r[0] for r in res)
     out = multi_line(args, problems[0], N, elapsed, res[0][1], res[0][2],
-                     "in-library team (one process, one rank thread per GPU; the W update reads the ranks' exchange panels in place: peer access over xGMI)",
+                     "in-library team (one process, one rank thread per GPU; in-process transport: the ranks' kernels read each other's buffers in place, peer access over xGMI)",
                      shared_devices=devices if devices < N else 0)
     print(json.dumps(out), flush=True)
 

@@ -190,6 +190,17 @@ Status Engine<T>::allocate() {
 		else if (force != nullptr) one_image_ = std::atoi(force) != 0;
 		else if (cache_window) one_image_ = true;
 		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 3 * image_b + (image_b >> 3) > free_b) one_image_ = true;
+		// V H^T of a narrow column shard (short reduction range, x-tiles for a third of the chip): ONE slab from 128 x 32 workgroups, two per x-tile, (79 of 256 CUs busy
+		// with 128 x 64 workgroups, each wave bound by its own MFMA issue).  Same bits as the 128 x 64 form with one slice.
+		w_col_split_ = false;
+		if (RP_ == 64 && fused_capable() && !one_image_ && 2 * planW_.xtiles + GRAM_REDUCE_BLOCKS <= num_cus_) {
+			// measured, rank-of-N iteration of config 2's column shards: n = 625 (one slice either way) 40.5 -> 39.3 us; n = 1 250 (instead of 3 slices + k_reduce_slabs) 48.2 -> 49.0;
+			// n = 2 500 62.9 -> 69.1 -- the operand split (44 VALU per 32 rows and K-step) is done twice, so a wave gains far less than the halved MFMAs: only where the
+			// plan has one slice anyway.  NMFAMD_X3_COLSPLIT = 0 / 1 forces the choice (parity test, measurements).
+			w_col_split_ = planW_.splits == 1;
+			if (const char* e = std::getenv("NMFAMD_X3_COLSPLIT")) w_col_split_ = std::atoi(e) != 0;
+			if (w_col_split_) { planW_.splits = planWx_.splits = 1; planWx_.col_split = 2; }
+		}
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));

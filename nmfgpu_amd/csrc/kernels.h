@@ -17,6 +17,8 @@ struct FactorProductPlan {
 	int splits;       // workgroup slices of the reduction range = number of output slabs
 	int nb;           // 32-wide N-blocks per wave tile: 2, or 1 when only the first 32 panel columns are needed (rank <= 32)
 	int chunks;       // launches needed to cover RP = chunks * 64 factor rows
+	int col_split = 0; // split-operand product, RP = 64 only: 2 = a workgroup takes 32 of the 64 panel columns (twice the workgroups, half the MFMAs per K-step and
+	                   // wave; the operand is split twice) -- for small reduction ranges, where the 128 x 64 form leaves most of the chip idle; same bits
 };
 
 FactorProductPlan plan_factor_product(int X, int Y, int RP, int num_cus);

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	// still wait for a CU to drain and be launched there before the kernel can end
 	const int pblocks = xtiles * splits;
 	if (blockIdx.x >= (unsigned)pblocks) {
+		if (blockIdx.y != 0) return;                            // (one set of passengers, whatever the number of column chunks)
 		// the 64 x 64 inverse of the least-squares algorithms rides as ONE block right behind the product's last one
 		if (rg.inv_a != nullptr) inverse_gj64_body<float, X3_WAVES>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
 		else if (rg.image != nullptr) { if (X3_WAVES == 4) gram_image_block(rg, blockIdx.x - pblocks, lds); }
@@ -506,6 +507,8 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		return launch_fp_x3<X3_RING_X, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
 	static const int variant = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
+	// short reduction ranges (a column shard's V H^T): 128 x 32 per workgroup, two workgroups per x-tile (FactorProductPlan::col_split)
+	if (RP == 64 && p.col_split == 2) return launch_fp_x3<X3_RING_X, 4, 0, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
 	if (RP % 128 == 0 && variant != 20) return launch_fp_x3<2, 4, 0, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 #ifdef NMFAMD_DIAG_BUILD

@@ -1138,3 +1138,24 @@ def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m
         assert got[1][3] > 8                                  # more slabs than one batch of eight
     for ks in (2, 4, 8):
         assert rel(got[ks][0], got[1][0]) < 5e-6 and rel(got[ks][1], got[1][1]) < 5e-6
+
+
+def test_column_split_product_gives_the_bits_of_the_whole_panel_form(monkeypatch):
+    """Round 4 (narrow column shards): V H^T with a short reduction range runs as 128 x 32 workgroups, two per x-tile (FactorProductPlan::col_split, kernels_x3.hip NBW = 1),
+    when the plan has one K slice.  Every output element sees the same MFMAs in the same order as in the 128 x 64 form: same bits, both against the fp64 oracle."""
+    m, n, r, iters = 4000, 200, 64, 30
+    V, W0, H0 = problem(m, n, r, np.float32, seed=78)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
+    ref = oracle.run("mu", V64, W64, H64, iters)
+    got = {}
+    for cs in ("0", "1"):
+        monkeypatch.setenv("NMFAMD_X3_COLSPLIT", cs)
+        eng = na.Engine(m, n, r, "mu")
+        eng.upload(V); eng.set_factors(W0, H0)
+        eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+        got[cs] = (*eng.get_factors(), eng.frobenius, eng.geometry()["slabs_w"])
+        eng.close()
+        assert got[cs][3] == 1
+        assert rel(got[cs][0], W64) < 2e-4 and rel(got[cs][1], H64) < 2e-4
+        assert got[cs][2] == pytest.approx(ref["frobenius"], rel=1e-5)
+    assert np.array_equal(got["0"][0], got["1"][0]) and np.array_equal(got["0"][1], got["1"][1]) and got["0"][2] == got["1"][2]

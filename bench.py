@@ -445,7 +445,7 @@ def main():
                 # (y-tiled form, staged through LDS), V H^T along its output index (x-tiled form)
                 if form_launches[0] > 0 and form_launches[1] > 0:
                     forms = {}
-                    for key, what, ms, cnt in (("wt_v", "W^T V: y-tiled form (reads the one image along the reduction index, parked in LDS)" if resident_images == 1 else "W^T V: x-tiled form on the image of V^T", form_ms[0], form_launches[0]),
+                    for key, what, ms, cnt in (("wt_v", "W^T V: y-tiled form (reads the one image along the reduction index, straight to registers)" if resident_images == 1 else "W^T V: x-tiled form on the image of V^T", form_ms[0], form_launches[0]),
                                                ("v_ht", "V H^T: x-tiled form (reads the image along its output index)", form_ms[1], form_launches[1])):
                         a = ms / 1e3 / cnt
                         forms[key] = {"form": what, "avg_launch_us": a * 1e6, "launches": cnt, "achieved": bytes_per_launch / a / 1e9, "frac": bytes_per_launch / a / 1e9 / PEAK_HBM_GBS}

@@ -190,17 +190,21 @@ Status Engine<T>::allocate() {
 		else if (force != nullptr) one_image_ = std::atoi(force) != 0;
 		else if (cache_window) one_image_ = true;
 		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 3 * image_b + (image_b >> 3) > free_b) one_image_ = true;
-		// V H^T of a narrow column shard (short reduction range, x-tiles for a third of the chip): ONE slab from 128 x 32 workgroups, two per x-tile, (79 of 256 CUs busy
-		// with 128 x 64 workgroups, each wave bound by its own MFMA issue).  Same bits as the 128 x 64 form with one slice.
+		// V H^T of a narrow column shard (short reduction range: at most 20 K-steps per wave without K slices): ONE slab from 128 x 32 workgroups, two per x-tile and two to a
+		// CU (kernels_x3.hip, NBW = 1), instead of up to three K slices of 128 x 64 ones.  Per wave the 128 x 64 form is bound by its own MFMA issue (35 cycles each) while
+		// a third of the chip's SIMDs work; the narrow form puts a second wave on every SIMD (the operand split is done twice, so it pays only while the range is short).
+		// Same bits as the 128 x 64 form with one slice; and one slab is the exchange panel of the sharded loop as it stands (no k_reduce_slabs launch).
+		// Measured at m = 10 000 (tools/shard_trace.py; fused loop / rank-of-N rehearsal, us per iteration): n = 625: 39.4 -> 36.6 / 40.4 -> 37.5; n = 1 250: 44.4 -> 44.3 /
+		// 48.5 -> 45.3; n = 1 900: 50.8 -> 52.9 / 54.8 -> 54.0; n = 2 500: 58.5 -> 61.7 / 63.4 -> 62.5 -- hence the limit of 80 K-steps.  Both products in this form at
+		// config 2: 92.7 -> 106.7 us (NMFAMD_X3_COLSPLIT = 2).  NMFAMD_X3_COLSPLIT = 0 / 1 forces the choice (parity test, measurements).
 		w_col_split_ = false;
-		if (RP_ == 64 && fused_capable() && !one_image_ && 2 * planW_.xtiles + GRAM_REDUCE_BLOCKS <= num_cus_) {
-			// measured, rank-of-N iteration of config 2's column shards: n = 625 (one slice either way) 40.5 -> 39.3 us; n = 1 250 (instead of 3 slices + k_reduce_slabs) 48.2 -> 49.0;
-			// n = 2 500 62.9 -> 69.1 -- the operand split (44 VALU per 32 rows and K-step) is done twice, so a wave gains far less than the halved MFMAs: only where the
-			// plan has one slice anyway.  NMFAMD_X3_COLSPLIT = 0 / 1 forces the choice (parity test, measurements).
-			w_col_split_ = planW_.splits == 1;
-			if (const char* e = std::getenv("NMFAMD_X3_COLSPLIT")) w_col_split_ = std::atoi(e) != 0;
+		if (RP_ == 64 && fused_capable() && !one_image_ && 2 * planW_.xtiles + GRAM_REDUCE_BLOCKS <= 2 * num_cus_) {
+			w_col_split_ = ksW_ <= 80 && 4 * planW_.xtiles >= num_cus_;
+			if (const char* e = std::getenv("NMFAMD_X3_COLSPLIT")) { const int v = std::atoi(e); if (v == 0) w_col_split_ = false; else if (v == 1) w_col_split_ = true; }
 			if (w_col_split_) { planW_.splits = planWx_.splits = 1; planWx_.col_split = 2; }
 		}
+		// (measurement builds, NMFAMD_X3_COLSPLIT = 2: both products from 128 x 32 workgroups, two per CU, with the plan's K slices)
+		if (const char* e = tuning_env("NMFAMD_X3_COLSPLIT")) { if (std::atoi(e) == 2 && RP_ == 64 && fused_capable()) { planHx_.col_split = planWx_.col_split = 2; w_col_split_ = true; } }
 	}
 	// panels (and the slabs the products write) cover whole x-tiles and whole 128-column update tiles
 	mpad_ = pad128(std::max<long>(m_, (long)planW_.xtiles * planW_.th));
@@ -720,7 +724,8 @@ Status Engine<T>::normal_inverse_fork(T* A, T offdiag, T diag) {
 template <typename T>
 bool Engine<T>::passengers_ride(const FactorProductPlan& plan) const {
 	const int passengers = (&plan == &planHx_ && gram_ksplit_ > 1) ? GRAM_IMAGE_TILES * gram_ksplit_ : GRAM_REDUCE_BLOCKS;
-	return RP_ == 64 && ((plan.xtiles >= GRAM_REDUCE_BLOCKS && passengers == GRAM_REDUCE_BLOCKS) || plan.xtiles * plan.splits + passengers <= num_cus_);
+	const int per_cu = plan.col_split == 2 ? 2 : 1;       // (128 x 32 workgroups: two to a CU)
+	return RP_ == 64 && ((plan.xtiles >= GRAM_REDUCE_BLOCKS && passengers == GRAM_REDUCE_BLOCKS) || per_cu * plan.xtiles * plan.splits + passengers <= per_cu * num_cus_);
 }
 
 // fp32 product (native MFMA or split-operand kernel) at padded rank 64 with passenger blocks in its grid

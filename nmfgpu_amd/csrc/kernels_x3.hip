@@ -145,7 +145,7 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // R32 (y-tiled form on 16-row tiles, loads straight to registers): MFMA row r of M-block b is tile row 32 b + r (as in the YLDS form) instead of 4 r + b: consecutive lanes read
 // consecutive 64-byte column chunks -- 16 cache lines per wave instruction instead of 32
 template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
-__global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
+__global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
 	float* __restrict__ slabs, long slab_stride, int RP,
@@ -157,7 +157,10 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 	// grid.x = xtiles * splits product blocks (x-tile fastest) followed by the GRAM_REDUCE_BLOCKS passenger blocks,
 	// and no more: every block of this kernel claims a whole CU (512 registers per lane), so an idle block would
 	// still wait for a CU to drain and be launched there before the kernel can end
-	const int pblocks = xtiles * splits;
+	// NBW = 1 (padded rank 64 only): the two 32-column chunks of an x-tile are NEIGHBOURS in grid.x (same XCD: the tile of A is fetched into one L2) and two workgroups share
+	// a CU (180 registers per lane): two waves per SIMD, one splitting operands or waiting for memory while the other feeds the matrix pipe
+	constexpr bool FOLD = NBW == 1;
+	const int pblocks = xtiles * splits * (FOLD ? 2 : 1);
 	if (blockIdx.x >= (unsigned)pblocks) {
 		if (blockIdx.y != 0) return;                            // (one set of passengers, whatever the number of column chunks)
 		// the 64 x 64 inverse of the least-squares algorithms rides as ONE block right behind the product's last one
@@ -174,8 +177,10 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		const int q8 = pblocks / 8, r8 = pblocks % 8, xcd = vb % 8, idx = vb / 8;
 		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
 	}
+	const int chunk = FOLD ? (vb & 1) : (int)blockIdx.y;
+	if (FOLD) vb >>= 1;
 	const int xt = vb % xtiles, sp = vb / xtiles;
-	const int coff = 32 * NBW * blockIdx.y;
+	const int coff = 32 * NBW * chunk;
 	const long fstep = (long)NBT * 192;                 // factor fragments per K-step
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(64 * X3_WAVES, 1) void k_factor_product_x3(
 		float* lw = lds + wave * (2 * 128 * 20);                                           // two slots of 128 x 20 floats
 		const int wofs = (lane >> 2) * 20 + 4 * (lane & 3);                                // + i * 320, + slot * 2560
 		const int rofs = l31 * 20 + 8 * half;                                              // + b * 640, + slot * 2560
-		const bf16x8* fp = F + (long)blockIdx.y * (NBW * 192) + lane;                      // + step * fstep + (nb * 3 + plane) * 64
+		const bf16x8* fp = F + (long)chunk * (NBW * 192) + lane;                      // + step * fstep + (nb * 3 + plane) * 64
 		const int last = s1 - 1, kend = steps_total - 1;
 		f32x4 va[D][8];
 		bf16x8 fb[D][NBW][3];
@@ -451,7 +456,8 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	const bool with_reduce = wanted && RP == 64;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
-	dim3 grid(p.xtiles * p.splits + passengers, RP / (32 * NBW), 1), block(64 * WAVES);
+	if (NBW == 1 && RP != 64) return hipErrorInvalidValue;
+	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
@@ -497,6 +503,12 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 			return ydirect ? launch_fp_x3<2, 4, 0, 4, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
 			               : launch_fp_x3<2, 4, 0, 4, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		}
+#ifdef NMFAMD_DIAG_BUILD
+		if (RP == 64 && p.col_split == 2) {       // (measured slower at config 2: 41.9 -> 51.0 and 40.8 -> 45.4 us per launch; Engine::init)
+			if (!y_tiled) return launch_fp_x3<X3_RING_X, 4, 0, 1, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+			return launch_fp_x3<X3_RING_X, 4, 0, 1, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		}
+#endif
 		if (!y_tiled) return launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		if (ylds) return launch_fp_x3<X3_RING_Y, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 		if (ydirect) return launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
@@ -504,6 +516,9 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	}
 	if (y_tiled) {
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+#ifdef NMFAMD_DIAG_BUILD
+		if (RP == 64 && p.col_split == 2) return launch_fp_x3<X3_RING_X, 4, 0, 1, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+#endif
 		return launch_fp_x3<X3_RING_X, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 	}
 	static const int variant = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements

@@ -11,6 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(nc, mode, **env):
+    # (the better of two processes: the placement of the 207 MB image differs from process to process and moves an iteration by up to ~8 us)
+    return min(run_once(nc, mode, **env), run_once(nc, mode, **env))
+
+
+def run_once(nc, mode, **env):
     e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_trace.py"), str(nc), str(mode), "600"], env=e, capture_output=True, text=True)
     for line in out.stdout.splitlines():

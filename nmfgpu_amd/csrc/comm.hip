@@ -1,6 +1,7 @@
 // comm.hip -- RCCL (C API, loaded at run time) and in-process transports of comm.h.
 #include "comm.h"
 
+#include <algorithm>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -219,41 +220,71 @@ namespace {
 
 struct PeerPtrs { const void* p[LOCAL_MAX_WORLD]; };
 
-// out[i] = sum over ranks (ascending) of peer_p[offset + i]; 16 bytes per lane and load
+// out[i] = sum over ranks (ascending) of peer_p[offset + i]; 16 bytes per lane and load.
+// A BOUNDED grid (LOCAL_COPY_BLOCKS workgroups, grid-stride, four independent vectors per lane and turn): the kernels open with a system-scope acquire -- buffers in other
+// devices' memory are re-read at the same addresses every iteration, and whatever fence scope the runtime gave the launch, lines cached two iterations ago must not be served
+// again -- and that fence is paid per WAVE: with one workgroup per 4 KiB (round 4's first form) the 51 MB reduce-scatter of a config-4 shard took 358 us instead of ~25
+// (200 000 fences; tools/c4_shard_modes.py).  A team of one has no peer memory and skips it.
+constexpr int LOCAL_COPY_BLOCKS = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void k_local_sum(PeerPtrs peers, int world, long offset, T* __restrict__ out, long count) {
 	constexpr int V = 16 / sizeof(T);
 	typedef T vec __attribute__((ext_vector_type(V)));
-	// buffers in other devices' memory, re-read at the same addresses every iteration: a system-scope acquire before the first read, whatever fence scope the
-	// runtime gave the launch
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-	const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
-	if (i + V <= count) {
-		vec s = *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[0]) + offset + i);
-		for (int p = 1; p < world; ++p) s += *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[p]) + offset + i);
-		*reinterpret_cast<vec*>(out + i) = s;
-	} else {
-		for (long k = i; k < count; ++k) {
-			T s = static_cast<const T*>(peers.p[0])[offset + k];
-			for (int p = 1; p < world; ++p) s += static_cast<const T*>(peers.p[p])[offset + k];
-			out[k] = s;
+	if (world > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+	const long stride = (long)gridDim.x * 256 * V;
+	long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+	for (; i + 3 * stride + V <= count; i += 4 * stride) {
+		vec s[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) s[u] = *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[0]) + offset + i + u * stride);
+		for (int p = 1; p < world; ++p) {
+			vec t[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[p]) + offset + i + u * stride);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) s[u] += t[u];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) *reinterpret_cast<vec*>(out + i + u * stride) = s[u];
+	}
+	for (; i < count; i += stride) {
+		if (i + V <= count) {
+			vec s = *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[0]) + offset + i);
+			for (int p = 1; p < world; ++p) s += *reinterpret_cast<const vec*>(static_cast<const T*>(peers.p[p]) + offset + i);
+			*reinterpret_cast<vec*>(out + i) = s;
+		} else {
+			for (long k = i; k < count; ++k) {
+				T s = static_cast<const T*>(peers.p[0])[offset + k];
+				for (int p = 1; p < world; ++p) s += static_cast<const T*>(peers.p[p])[offset + k];
+				out[k] = s;
+			}
 		}
 	}
 }
 
-// mine[p * count + i] = peer_p[p * count + i] for every peer p != rank
+// mine[p * count + i] = peer_p[p * count + i] for every peer p != rank (grid.y = peer; grid.x bounded as above)
 template <typename T>
 __global__ __launch_bounds__(256) void k_local_gather(PeerPtrs peers, int world, int rank, T* __restrict__ mine, long count) {
 	constexpr int V = 16 / sizeof(T);
 	typedef T vec __attribute__((ext_vector_type(V)));
 	const int p = blockIdx.y;
 	if (p == rank) return;
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (as in k_local_sum)
-	const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (as in k_local_sum; a team of one never launches this kernel)
 	const T* src = static_cast<const T*>(peers.p[p]) + (long)p * count;
 	T* dst = mine + (long)p * count;
-	if (i + V <= count) *reinterpret_cast<vec*>(dst + i) = *reinterpret_cast<const vec*>(src + i);
-	else for (long k = i; k < count; ++k) dst[k] = src[k];
+	const long stride = (long)gridDim.x * 256 * V;
+	long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
+	for (; i + 3 * stride + V <= count; i += 4 * stride) {
+		vec t[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec*>(src + i + u * stride);
+#pragma unroll
+		for (int u = 0; u < 4; ++u) *reinterpret_cast<vec*>(dst + i + u * stride) = t[u];
+	}
+	for (; i < count; i += stride) {
+		if (i + V <= count) *reinterpret_cast<vec*>(dst + i) = *reinterpret_cast<const vec*>(src + i);
+		else for (long k = i; k < count; ++k) dst[k] = src[k];
+	}
 }
 
 class LocalComm : public Comm {
@@ -331,8 +362,8 @@ public:
 
 private:
 	static bool aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-	static dim3 blocks(long count, int eb) { const long per = 256l * (16 / eb); return dim3((unsigned)((count + per - 1) / per)); }
-	dim3 blocks2(long count, int eb) const { const long per = 256l * (16 / eb); return dim3((unsigned)((count + per - 1) / per), (unsigned)g_->world); }
+	static dim3 blocks(long count, int eb) { const long per = 256l * (16 / eb); return dim3((unsigned)std::min<long>(LOCAL_COPY_BLOCKS, (count + per - 1) / per)); }
+	dim3 blocks2(long count, int eb) const { const long per = 256l * (16 / eb); return dim3((unsigned)std::min<long>(std::max(64, LOCAL_COPY_BLOCKS / g_->world), (count + per - 1) / per), (unsigned)g_->world); }
 	Status fail(const char* what) { error_ = what; g_->aborted.store(true, std::memory_order_release); (void)hipGetLastError(); return ST_HIP_ERROR; }
 
 	// This rank's buffer becomes readable by the peers once the work enqueued so far has run; returns every rank's

@@ -53,8 +53,11 @@ Status ShardedRank<T>::prepare() {
 		xslot_[0] = static_cast<T*>(mine[0]); xslot_[1] = static_cast<T*>(mine[1]);
 	} else if (!dalloc(&exchange_, eng_->exchange_count())) return fail("hipMalloc(exchange)");
 	if (mode_ == SHARD_ROW_BLOCKS) {
-		if (mpad % (128l * world) != 0) { last_error_ = "engine was not created with set_row_blocks(world)"; return ST_INVALID; }
-		blk_rows_ = mpad / world;
+		// (measurements: NMFAMD_SHARD_REHEARSE = N > 1 on a team of one in this mode makes the rank run the row-block W step on 1 / N of the rows, as a rank of N would:
+		//  timing only -- the other row blocks are never updated, the factors mean nothing.  tools/c4_shard_modes.py)
+		const int pretend = (world == 1 && rehearse != nullptr && std::atoi(rehearse) > 1) ? std::atoi(rehearse) : world;
+		if (mpad % (128l * pretend) != 0) { last_error_ = "engine was not created with set_row_blocks(world)"; return ST_INVALID; }
+		blk_rows_ = mpad / pretend;
 		if (!dalloc(&blk_, RP * blk_rows_) || !dalloc(&colsq_, RP)) return fail("hipMalloc(row block)");
 	}
 	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); nloc_max_ = std::max(nloc_max_, c); }

@@ -33,4 +33,17 @@ for mode in (1, 0):
     us = timed(lambda k, f: run.iterate(k, first_iteration=f, error_every=10), e.synchronize)
     print(f"team of one, mode {mode} ({'replicated' if mode else 'row blocks'}): {us:.1f} us/iteration", flush=True)
     run.close()
-e.close(); comm.close()
+e.close()
+# what a rank of eight enqueues in the row-block form (an eighth of the rows updated, normalised, re-packed; no link time, no peer reads): timing only
+os.environ["NMFAMD_SHARD_REHEARSE"] = "8"
+e = na.Engine(M, NC, R, "nsnmf", theta=0.5, precision="bf16", row_blocks=8)
+rs = np.random.RandomState(1)
+V = np.empty((M, NC), dtype=np.float32, order="F")
+for j0 in range(0, NC, 625):
+    V[:, j0:j0 + 625] = rs.random_sample((625, M)).astype(np.float32).T
+e.upload(V); del V
+e.set_factors(W, H)
+run = na.ShardedRun(e, comm, M, NC, 0)
+us = timed(lambda k, f: run.iterate(k, first_iteration=f, error_every=0), e.synchronize)
+print(f"rank-of-8 rehearsal, row blocks (1/8 of the rows in the W step): {us:.1f} us/iteration", flush=True)
+run.close(); e.close(); comm.close()

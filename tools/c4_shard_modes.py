@@ -24,6 +24,8 @@ def timed(fn, sync, warm=10):
 e = na.Engine(M, NC, R, "nsnmf", theta=0.5, precision="bf16", row_blocks=1)
 e.upload(V); del V
 e.set_factors(W, H)
+timed(lambda k, f: e.iterate(k, first_iteration=f, error_every=10), e.synchronize)      # (the first timed loop of a process runs ~13 us per iteration slow: discarded)
+e.set_factors(W, H)
 print(f"fused loop: {timed(lambda k, f: e.iterate(k, first_iteration=f, error_every=10), e.synchronize):.1f} us/iteration", flush=True)
 group = na.LocalGroup(1)
 comm = na.LocalComm(group, 0)

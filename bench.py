@@ -112,6 +112,11 @@ def engine_stream(torch) -> int:
     return _ENGINE_STREAM[0].cuda_stream
 
 
+# Untimed set-up iterations before the W warm-up steps of a single-GPU line (config 2's shape; a third of it for config 4's 0.44 ms iteration, a tenth for config 3's 1.3 ms):
+# ~25 ms of the hot path, after which the factors go back to W0, H0.  The line reports it as config.setup_iterations.
+SETUP_ITERATIONS = 240
+
+
 def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
     """The oracle (our CPU port of the reference's iteration) timed on this box's host cores.  A run's one-off work (the sorted
     tr(V^T V) vector of allocateMemory, workspace allocation) is timed by a zero-iteration run and taken out: the metric counts
@@ -375,6 +380,11 @@ def main():
         eng = na.Engine(M, N_COLS, R, algorithm, dtype=np.float32, stream=engine_stream(torch), **alg_kw)
         eng.upload(V)
         eng.set_factors(W, H)
+        # set-up, not steps (as in the multi-GPU paths below): the first launches of every kernel and the device's ramp from idle -- measured, iterations 26-75 of a
+        # process run at 101 us, 76-100 at 96, from ~125 on at 91-92 (profiles/r04_warmup_timeline.txt; the same ramp follows 2 s of idling) -- then back to W0, H0
+        eng.iterate(SETUP_ITERATIONS, first_iteration=1, error_every=10)
+        eng.synchronize()
+        eng.set_factors(W, H)
         eng.iterate(Wm, first_iteration=1, error_every=10)
         eng.synchronize()
         if not args.no_kernel_events:
@@ -471,7 +481,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32" if algorithm == "mu" else
                                    f"configs[4]: {names[algorithm]} at dense random V 10000x5000, r=64, fp32, parameters {alg_kw}",
-                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "parallelism": parallelism,
+                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "setup_iterations": 0 if args.sharded else SETUP_ITERATIONS, "parallelism": parallelism,
                        "arithmetic": ("fp32 operands and fp32 accumulation; the two big products run on the bf16 matrix pipe with every operand "
                                       "split EXACTLY into three bf16 terms (six cross products kept, dropped terms <= 2^-23 relative): measured "
                                       "error against fp64 equals the native fp32 MFMA kernel's (tests/test_gpu_parity.py)") if product_kernel == 2
@@ -544,7 +554,8 @@ def multi_line(args, pb, world, elapsed, kernel, frob, transport: str, shared_de
            "config": {"workload": ("configs[3]: dense random V 50000 x (6250 per GPU) column shards, r=256, nsNMF theta=0.5, bf16 MFMA operands" if c4 else
                                    "configs[1]: the ONE dense random V 10000x5000, r=64, MU Frobenius, fp32, column-sharded over the GPUs" if strong else
                                    "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32"),
-                      "rows": rows, "columns_per_gpu": nc, "total_columns": pb["total"], "features": feats, "error_every": 10, "parallelism": parallelism},
+                      "rows": rows, "columns_per_gpu": nc, "total_columns": pb["total"], "features": feats, "error_every": 10,
+                      "setup_iterations": SETUP_ITERATIONS // 3 if pb["c4"] else SETUP_ITERATIONS, "parallelism": parallelism},
            "frobenius_last": frob,
            "roofline": whole_iteration(roofline, elapsed / K, floor_bytes=2.0 * bytes_per_launch, basis="rank 0's two passes over its image of V per iteration at the HBM peak")}
     if not args.no_cpu_baseline and pb["full"] is not None:
@@ -595,7 +606,7 @@ def team_worker(args):
             gate.wait()                                     # (every rank holds its engine before anybody enters the run's set-up, which is a collective)
             run = na.ShardedRun(eng, comm, pb["rows"], pb["total"], pb["mode"])
             phase(f"team: rank {g} first iterations (set-up)")
-            run.iterate(30 if not pb["c4"] else 12, first_iteration=1, error_every=10)
+            run.iterate(SETUP_ITERATIONS if not pb["c4"] else SETUP_ITERATIONS // 3, first_iteration=1, error_every=10)
             eng.synchronize()
             eng.set_factors(pb["W"], pb["H"])
             phase(f"team: rank {g} warm-up")
@@ -736,7 +747,7 @@ def rccl_ranks(args):
 
     # set-up, not steps: the first collectives of a communicator and the first launches of every kernel
     phase("RCCL: first iterations (set-up)")
-    run.iterate(240 if not pb["c4"] else 12, first_iteration=1, error_every=10)
+    run.iterate(SETUP_ITERATIONS if not pb["c4"] else SETUP_ITERATIONS // 3, first_iteration=1, error_every=10)
     eng.synchronize()
     eng.set_factors(pb["W"], pb["H"])
     phase("RCCL: warm-up")
@@ -780,6 +791,9 @@ def main_c3(args):
     eng = na.Engine(m, n, r, "mu", dtype=np.float32, stream=engine_stream(torch), divergence="kl")
     eng.upload_sparse(1, val, ptr, idx, 0)
     eng.set_factors(W, H)
+    eng.iterate(SETUP_ITERATIONS // 10, first_iteration=1, error_every=10)      # set-up (first launches, the device's ramp from idle: see main()), then back to W0, H0
+    eng.synchronize()
+    eng.set_factors(W, H)
     eng.iterate(Wm, first_iteration=1, error_every=10)
     eng.synchronize()
     if not args.no_kernel_events:
@@ -811,7 +825,7 @@ def main_c3(args):
            "value": K / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[2]: sparse CSR V 100000x20000 at 1% (Poisson(200) entries per row, values 1..5), r=128, MU on the KL divergence, fp32",
-                      "rows": m, "columns": n, "features": r, "stored_entries": nnz, "error_every": 10, "parallelism": "single GPU"},
+                      "rows": m, "columns": n, "features": r, "stored_entries": nnz, "error_every": 10, "setup_iterations": SETUP_ITERATIONS // 10, "parallelism": "single GPU"},
            "frobenius_last": eng.frobenius, "kl_divergence_last": eng.kl_divergence,
            "iter_flops": 8.0 * nnz * r, "achieved_tflops_whole_iteration": 8.0 * nnz * r * (K / elapsed) / 1e12,
            "gather_gbs_whole_iteration": 2.0 * gather_bytes * (K / elapsed) / 1e9, "roofline": roofline}
@@ -848,7 +862,7 @@ def main_c4(args):
     K, Wm = args.steps, args.warmup
     shard = EngineShard(V, W, H, algorithm="nsnmf", theta=theta, precision="bf16")
     drv = ShardedMU(shard, total_columns=n * world, rows=m)
-    drv.run(12, first_iteration=1, error_every=10)      # set-up (one-time costs), then back to W0, H0
+    drv.run(SETUP_ITERATIONS // 3, first_iteration=1, error_every=10)      # set-up (one-time costs, the device's ramp from idle: see main()), then back to W0, H0
     shard.synchronize()
     shard.engine.set_factors(W, H)
 
@@ -881,7 +895,7 @@ def main_c4(args):
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "configs[3] per GPU: dense random V 50000x6250 column shard, r=256, nsNMF theta=0.5, bf16 MFMA operands",
-                       "rows": m, "columns_per_gpu": n, "features": r, "error_every": 10,
+                       "rows": m, "columns_per_gpu": n, "features": r, "error_every": 10, "setup_iterations": SETUP_ITERATIONS // 3,
                        "parallelism": f"column shards x{world}, W replicated, all-reduce of (V (SH)^T | (SH)(SH)^T) per iteration"},
             "frobenius_last": drv.frobenius, "iter_flops": iter_flops,
             "achieved_tflops_whole_iteration": iter_flops * (K / elapsed) / 1e12,

@@ -84,6 +84,7 @@ Engine<T>::~Engine() {
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
 	if (rowdot_part_) (void)hipFree(rowdot_part_);
+	if (tri_ride_counters_) (void)hipFree(tri_ride_counters_);
 	if (Gpart_) (void)hipFree(Gpart_);
 	if (Graw64_) (void)hipFree(Graw64_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
@@ -134,6 +135,19 @@ Status Engine<T>::allocate() {
 		ksW_ = (n_ + 15) / 16; ksH_ = (m_ + 15) / 16;
 		planH_.splits = plan_splits_bf16(planH_.xtiles, ksH_, RP_, num_cus_);
 		planW_.splits = plan_splits_bf16(planW_.xtiles, ksW_, RP_, num_cus_);
+		// Padded rank 256 (the kernels_tri.hip iteration): the Gram matrix of the operand a product multiplies V with rides in that product's launch as TRI_PASSENGERS
+		// workgroups (tri_gram_tile.h) -- its consumer is the update kernel behind the launch.  V (S H)^T leaves the CUs free as it is (config 4: 224 workgroups);
+		// W^T V is planned with one K slice fewer (9 -> 8: 252 -> 224 workgroups).  NMFAMD_TRI_RIDE = 0 / h / w: none / only (S H)(S H)^T / only W^T W.
+		if (RP_ == 256 && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && tri_kernels_available(RP_)) {
+			const char* e = std::getenv("NMFAMD_TRI_RIDE");
+			const bool want_w = e == nullptr || (e[0] != '0' && e[0] != 'h'), want_h = e == nullptr || (e[0] != '0' && e[0] != 'w');
+			if (want_w && num_cus_ > 2 * TRI_PASSENGERS) {
+				FactorProductPlan t = planH_;
+				t.splits = plan_splits_bf16(planH_.xtiles, ksH_, RP_, num_cus_ - TRI_PASSENGERS);
+				if (bf16_product_workgroups(t) + TRI_PASSENGERS <= num_cus_) { planH_.splits = t.splits; tri_ride_w_ = true; }
+			}
+			tri_ride_h_ = want_h && bf16_product_workgroups(planW_) + TRI_PASSENGERS <= num_cus_;
+		}
 		planHb_ = planH_; planWb_ = planW_;
 	}
 	// fp32, dense, MFMA path: both products run on the bf16 matrix pipe with every operand split exactly into
@@ -275,7 +289,9 @@ Status Engine<T>::allocate() {
 	if constexpr (std::is_same<T, float>::value) {
 		tri_ = bf16_ && tri_kernels_available(RP_) && (alg_ == ALG_MU || alg_ == ALG_NSNMF);
 		if (tri_) {
-			HIPX(hipMalloc((void**)&gram_tri_part_, sizeof(float) * (size_t)gram_tri_partial_elems(num_cus_)));
+			HIPX(hipMalloc((void**)&gram_tri_part_, sizeof(float) * (size_t)std::max<long>(gram_tri_partial_elems(num_cus_), (long)(TRI_PASSENGERS / 2) * 36 * 1024)));
+			HIPX(hipMalloc((void**)&tri_ride_counters_, 64));
+			HIPX(hipMemsetAsync(tri_ride_counters_, 0, 64, stream_));
 			HIPX(dalloc(&Gw_raw_, rr));
 			HIPX(dalloc(&Gh_raw_, rr));
 			HIPX(dalloc(&colsq_, (long)RP_ * colsq_stage_parts()));
@@ -611,7 +627,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		if (bf16_) {
 			// bf16 operands: the factor panel is re-rounded and re-ordered for every product
 			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
-			if (rg && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && rg->tri_frags == nullptr && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
 			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
@@ -662,7 +678,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	if constexpr (std::is_same<T, float>::value) {
 		if (bf16_) {
 			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
-			if (rg && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && rg->tri_frags == nullptr && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin(1);
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
@@ -837,8 +853,9 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 		if (tri_) {
 			// The fragments hold bf16(W) as the panel stores it -- unsmoothed, without the pending column scale D; the product's output gets both:
 			// (W D S)^T V = S D (W^T V), applied by the H update to the summed slabs (PanelTriExtras).
-			if (Status s = tri_prepare_w()) return s;
-			if (Status s = product_h(Wt_, nullptr, true)) return s;
+			GramReduceArgs ride = {nullptr, 0, nullptr, nullptr, 0};
+			if (Status s = tri_prepare_w(&ride)) return s;
+			if (Status s = product_h(Wt_, ride.tri_frags != nullptr ? &ride : nullptr, true)) return s;
 			T off, diag;
 			tri_smoothing(&off, &diag);
 			PanelTriExtras ex;
@@ -934,8 +951,9 @@ Status Engine<T>::w_products(T* exchange) {
 	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (tri_) {
-			if (Status s = tri_prepare_h(ex_hht, sole_rank_)) return s;      // (a team of one: nothing is added to ex_hht before the W update reads it)
-			if (Status s = product_w(H_, nullptr, exchange, true)) return s;
+			GramReduceArgs ride = {nullptr, 0, nullptr, nullptr, 0};
+			if (Status s = tri_prepare_h(ex_hht, sole_rank_, sole_rank_ ? &ride : nullptr)) return s;      // (a team of one: nothing is added to ex_hht before the W update reads it)
+			if (Status s = product_w(H_, ride.tri_frags != nullptr ? &ride : nullptr, exchange, true)) return s;
 			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
 		}
@@ -1107,7 +1125,7 @@ void Engine<T>::tri_smoothing(T* offdiag, T* diag) const {
 }
 
 template <typename T>
-Status Engine<T>::tri_prepare_w() {
+Status Engine<T>::tri_prepare_w(GramReduceArgs* ride) {
 	if constexpr (std::is_same<T, float>::value) {
 		const bool wide = qx3_ != nullptr && panel_update_wide_available(RP_);
 		if (!wtb_valid_) {
@@ -1120,7 +1138,10 @@ Status Engine<T>::tri_prepare_w() {
 			// and not smoothed -- the H update applies D and S around its r x r product (PanelTriExtras::den_transform), the error term's trace applies D
 			// (AlgorithmNonSmoothNMF.h:201-202 wants the unsmoothed W^T W).  Round 3 first ran k_smooth_gram here (6.5 us) and a staging launch for D (4.7 us).
 			// The diagonal of the matrix IS the new pending scale: sums of squares of the rounded columns (one "staged" vector).
-			HIPX(launch_gram_tri_bf16_image(Wtb_, RP_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, wide ? qx3_ : nullptr, tri_scale_from_gram_ ? colsq_ : nullptr, num_cus_, stream_));
+			if (ride != nullptr && tri_ride_w_) {
+				// as passengers of the W^T V launch the caller is about to make: every consumer (H update, error trace, the next W update's pending scale) runs behind it
+				ride->tri_frags = Wtb_; ride->tri_ks = ksH_; ride->tri_partial = gram_tri_part_; ride->tri_counters = tri_ride_counters_; ride->G = Gw_raw_; ride->tri_x3 = wide ? qx3_ : nullptr; ride->tri_diag = tri_scale_from_gram_ ? colsq_ : nullptr;
+			} else HIPX(launch_gram_tri_bf16_image(Wtb_, RP_, ksH_, num_cus_, gram_tri_part_, Gw_raw_, wide ? qx3_ : nullptr, tri_scale_from_gram_ ? colsq_ : nullptr, num_cus_, stream_));
 			if (tri_scale_from_gram_) { colsq_parts_ = 1; tri_scale_from_gram_ = false; }
 			tri_gw_ready_ = true;
 			qx3_holds_g_ = wide;
@@ -1133,7 +1154,7 @@ Status Engine<T>::tri_prepare_w() {
 // V is multiplied with.  local_q: hht stays what the W update multiplies with (no reduction over ranks in between), so the reduction also leaves its split
 // image in qx3_ and the update's launcher need not pack it (k_pack_panel_x3, 4.9 us).
 template <typename T>
-Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
+Status Engine<T>::tri_prepare_h(T* hht, bool local_q, GramReduceArgs* ride) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (!hb_valid_) {
 			// H did not come from this engine's H update (set_factors / randomize between the two half-steps): one finishing pass makes the fragments
@@ -1143,7 +1164,8 @@ Status Engine<T>::tri_prepare_h(T* hht, bool local_q) {
 			hb_valid_ = true;
 		}
 		const bool image = local_q && qx3_ != nullptr && panel_update_wide_available(RP_);
-		if (image) HIPX(launch_gram_tri_bf16_image(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, qx3_, nullptr, num_cus_, stream_));
+		if (image && ride != nullptr && tri_ride_h_) { ride->tri_frags = Hb_; ride->tri_ks = ksW_; ride->tri_partial = gram_tri_part_; ride->tri_counters = tri_ride_counters_; ride->G = hht; ride->tri_x3 = qx3_; ride->tri_diag = nullptr; }      // (rides in the V (S H)^T launch)
+		else if (image) HIPX(launch_gram_tri_bf16_image(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, qx3_, nullptr, num_cus_, stream_));
 		else HIPX(launch_gram_tri_bf16(Hb_, RP_, ksW_, num_cus_, gram_tri_part_, hht, nullptr, 0, num_cus_, stream_));
 		qx3_holds_g_ = false;
 		qx3_holds_hht_ = image;
@@ -1359,8 +1381,10 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	if (!(constant_w && !compute_error)) {
 		const T* Fh = H_;
 		bool hht_done = false;
+		GramReduceArgs tri_ride = {nullptr, 0, nullptr, nullptr, 0};
 		if (tri_) {
-			if (Status s = tri_prepare_h(HHt_, true)) return s;
+			// (error iterations: the trace below reads H H^T before the product is launched -- the Gram matrix by its own launches then)
+			if (Status s = tri_prepare_h(HHt_, true, (!compute_error && !constant_w) ? &tri_ride : nullptr)) return s;
 			hht_done = true;
 		} else if (alg_ == ALG_NSNMF) {
 			const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -1418,7 +1442,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					if (compute_error) HIPX(launch_trace_small<T>(HHt_, G2_, RP_, r_, psR_, stream_, tri_trace_scale()));
 				}
 			} else {
-				if (Status s = product_w(Fh, nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;
+				if (Status s = product_w(Fh, tri_ride.tri_frags != nullptr ? &tri_ride : nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;
 			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;

@@ -237,6 +237,8 @@ private:
 	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams
 	// it (normalise + smooth + bf16 fragments), Gram matrices of the smoothed panels from the unsmoothed ones (S G S)
 	bool tri_ = false;
+	unsigned* tri_ride_counters_ = nullptr;          // arrival counters of the Gram passengers (tri_gram_tile.h): zero between launches
+	bool tri_ride_w_ = false, tri_ride_h_ = false;   // the Gram matrix of W / of S H rides in the W^T V / V (S H)^T launch (Engine::init leaves TRI_PASSENGERS CUs free)
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel
 	bool tri_scale_from_gram_ = false; // ... and its sums of squares are still to come out of the next Gram reduction (tri_prepare_w), into colsq_
@@ -257,8 +259,8 @@ private:
 	float *gram_tri_part_ = nullptr, *Gw_raw_ = nullptr, *Gh_raw_ = nullptr, *colsq_ = nullptr;
 	bool qx3_holds_g_ = false, qx3_holds_hht_ = false;   // qx3_ holds the split image of G_ / of the smoothed H H^T (k_smooth_gram)
 	void tri_smoothing(T* offdiag, T* diag) const;
-	Status tri_prepare_w();          // Wtb_, Gw_raw_, G_ for the H step
-	Status tri_prepare_h(T* hht, bool local_q);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
+	Status tri_prepare_w(GramReduceArgs* ride = nullptr);          // Wtb_, Gw_raw_, G_ for the H step (ride: the Gram matrix as passengers of the product launch that follows, tri_gram_tile.h)
+	Status tri_prepare_h(T* hht, bool local_q, GramReduceArgs* ride = nullptr);    // Hb_, Gh_raw_, hht (= the Gram matrix of the smoothed H) for the W step
 	Status tri_update_w(const T* num, int S, long stride, const T* hht);   // W update + normalisation + everything tri_prepare_w() would do
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	bool h_partials_unneeded_ = false; // set by iterate() around its H step: GDCLS takes H H^T from the split image beside the product against V

@@ -62,8 +62,17 @@ struct GramReduceArgs {
 	// ... cut into ksplit slices of the K range (gram_image.h): 10 * ksplit passenger blocks, G then receives ksplit UNSCALED partial matrices ([ksplit][4096])
 	// that the consumer adds and scales (launch_mu64_update32, qsplit); with normalize the scales must come from colsq_part
 	int ksplit = 0;
+	// fourth kind (bf16 factor product at padded rank 256 only, tri_gram_tile.h): the 256 x 256 Gram matrix of a panel from its bf16 fragments (tri_frags, tri_ks K-steps
+	// of 16 panel rows) by TRI_PASSENGERS workgroups (K slices, the last one of a half reduces): G (fp32, both triangles), tri_diag (its diagonal, or nullptr), tri_x3 (its split image, or nullptr)
+	const void* tri_frags = nullptr;
+	int tri_ks = 0;
+	void* tri_x3 = nullptr;
+	float* tri_diag = nullptr;
+	float* tri_partial = nullptr;       // [TRI_PASSENGERS / 2][36][1024] partial tiles
+	unsigned* tri_counters = nullptr;   // two counters, zero between launches
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
+constexpr int TRI_PASSENGERS = 32;                 // tri_gram_tile.h: 16 K slices x 2 halves of the 36 upper-triangle tiles
 constexpr int GRAM_IMAGE_TILES = 10;               // gram_image.h: upper triangle of the 4 x 4 grid of 16 x 16 tiles
 constexpr int GRAM_KSPLIT_MAX = 8;                 // ... and the most K slices its K-split form is cut into
 
@@ -312,6 +321,8 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
                                       float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 // K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP
 int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
+// workgroups the bf16 product launches for a plan at padded rank 256 (what is left of the chip can carry TRI_PASSENGERS)
+int bf16_product_workgroups(const FactorProductPlan& p);
 
 // ---- fp32 product by exact 3 x bf16 operand splitting (kernels_x3.hip), padded rank 64 ------------
 // The streamed matrix is the x-tiled fp32 image (tile height 128); the factor panel is split into

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "tri_gram_tile.h"
 #include "tuning.h"
 
 namespace nmfamd {
@@ -463,7 +464,7 @@ __device__ bf16x8 g_bf_zero_block[64];      // one all-zero fragment block: the 
 template <int NRB, int D, int DF>
 __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
+	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg) {
 	static_assert(D % 2 == 0 && D % DF == 0 && DF >= 2 && NRB <= 8, "ring depth even (two operand sets) and a multiple of the factor ring's, at most eight row blocks");
 #ifndef BFD_PAIR
 #define BFD_PAIR 0
@@ -478,6 +479,14 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	constexpr int AHEAD = BFD_PAIR ? 4 : 2, SLOTS = BFD_PAIR ? 6 : 3;
 	__shared__ __attribute__((aligned(16))) bf16x8 l8[SLOTS * 512];      // [slot][block 0..7][lane]
 	const int nblk = tiles * splits;
+	if (blockIdx.x >= (unsigned)nblk) {
+		// passengers behind the product's workgroups: the Gram matrix of a factor panel, one tile per workgroup (tri_gram_tile.h)
+		static_assert(sizeof(l8) >= TRI_RIDE_LDS_BYTES, "the passengers' LDS overlays the product's ring");
+		if (blockIdx.y == 0 && rg.tri_frags != nullptr)
+			tri_gram_passenger(reinterpret_cast<const bf16x8*>(rg.tri_frags), rg.tri_ks, (int)blockIdx.x - nblk, rg.tri_partial, rg.tri_counters, rg.G,
+			                   reinterpret_cast<bf16x8*>(rg.tri_x3), rg.tri_diag, l8);
+		return;
+	}
 	int vb = blockIdx.x;
 	{
 		const int q8 = nblk / 8, r8 = nblk % 8, xcd = vb % 8, idx = vb / 8;      // XCD-aware placement, as in kernels_x3.hip
@@ -925,15 +934,18 @@ static void plan_bf16_dma(int xtiles, int KS, int num_cus, int* tiles, int* spli
 }
 
 static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
-                                     float* slabs, long slab_stride, hipStream_t stream) {
+                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr) {
 	// (the K slices are the caller's plan -- plan_splits_bf16 from the engine's CU count, which also sized the slabs; the workgroups
 	//  along x follow from the tile count alone: no device query per launch)
 	const int tiles = (4 * p.xtiles + BFD_NRB - 1) / BFD_NRB, splits = p.splits;
 	if (splits < 1 || KS < 1) return hipErrorInvalidValue;
-	dim3 grid(tiles * splits, RP / 256), block(256);
+	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
+	const bool ride = rg != nullptr && rg->tri_frags != nullptr;
+	if (ride && (RP != 256 || rg->G == nullptr || rg->tri_ks < 1 || rg->tri_partial == nullptr || rg->tri_counters == nullptr)) return hipErrorInvalidValue;
+	dim3 grid(tiles * splits + (ride ? TRI_PASSENGERS : 0), RP / 256), block(256);
 	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-	                   slabs, slab_stride, RP, KS, splits, tiles);
+	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none);
 	return hipGetLastError();
 }
 
@@ -979,6 +991,8 @@ int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
+int bf16_product_workgroups(const FactorProductPlan& p) { return ((4 * p.xtiles + BFD_NRB - 1) / BFD_NRB) * p.splits; }
+
 // RP: padded rank of the panel (64, or a multiple of 128).  256 columns per pass over A when RP is a
 // multiple of 256, else 128 (64 for RP = 64); wider panels take RP / 256 (RP / 128) passes (grid.z).
 hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
@@ -989,7 +1003,9 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 		static const bool unstaged = tuning_env("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
 		if (unstaged) return launch_fp_bf16<D, 4>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 		if (rg != nullptr && rg->partials != nullptr) return hipErrorInvalidValue;
+		const bool tri_ride = rg != nullptr && rg->tri_frags != nullptr;
 		static const bool staged = tuning_env("NMFAMD_BF_STAGED") != nullptr;          // A/B switch: the round-1 kernel
+		if (tri_ride && (staged || tuning_env("NMFAMD_BF_R3") != nullptr)) return hipErrorInvalidValue;      // (only the shipped kernel carries passengers)
 		if (staged) return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
 		// Round 4 built the role swap VERDICT r3 asked for (k_factor_product_bf16_r3: the HBM stream straight into the MFMA operand registers, the factor fragments
 		// through LDS) and its form with hand-written loads and counted waits (r3a): 158.5 / 157.7 us per launch against this kernel's 159.6 on the same box
@@ -997,7 +1013,7 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 		// builds) selects the new one, NMFAMD_BF_R3_PLAIN=1 its compiler-scheduled form.
 		static const bool r3 = tuning_env("NMFAMD_BF_R3") != nullptr;
 		if (r3) return launch_fp_bf16_r3(p, A, KS, F, RP, slabs, slab_stride, stream);
-		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream);
+		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	}
 	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	return hipErrorInvalidValue;

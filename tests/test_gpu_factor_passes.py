@@ -189,6 +189,45 @@ def test_rank256_bf16_path_tracks_fp32(m, n):
     assert np.array_equal(Wg, W2) and np.array_equal(Hg, H2)
 
 
+@pytest.mark.parametrize("m,n", [(33000, 140), (700, 1900)])
+def test_rank256_gram_matrices_as_passengers_of_the_products(m, n, monkeypatch):
+    """Round 4: at padded rank 256 the Gram matrix of the operand a product multiplies V with (W^T W from W's fragments, (S H)(S H)^T from the smoothed H's) rides in
+    that product's launch as 32 passenger workgroups -- 16 K slices x 2 halves of the tiles; the last workgroup of a half to arrive adds the slices in slice order and
+    writes the matrix, its diagonal and its split image (tri_gram_tile.h).  NMFAMD_TRI_RIDE = 0 / h / w keeps both / one of them on their own launches
+    (k_gram_tri_bf16 + k_gram_tri_reduce_image): same factors and reported errors up to the summation order of the K slices, every form within the bf16 mode's 2e-2 of
+    the fp64 oracle, and the riding form bit-identical when the run is repeated (the order of the sum does not depend on who arrives last)."""
+    r, theta, iters = 256, 0.5, 20
+    rng = np.random.default_rng(5 + m)
+    V = _F(rng.random((m, n)).astype(np.float32))
+    W = _F((1.0 - rng.random((m, r))).astype(np.float32))
+    H = _F((1.0 - rng.random((r, n))).astype(np.float32))
+    V64, W64, H64 = (_F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run("nsnmf", V64, W64, H64, iters, theta=theta)
+    got = {}
+    for ride in ("0", "h", "w", None, None):
+        if ride is None:
+            monkeypatch.delenv("NMFAMD_TRI_RIDE", raising=False)
+        else:
+            monkeypatch.setenv("NMFAMD_TRI_RIDE", ride)
+        eng = na.Engine(m, n, r, "nsnmf", theta=theta, precision="bf16")
+        eng.upload(V); eng.set_factors(W, H)
+        eng.iterate(10, first_iteration=1, error_every=10)
+        f10 = eng.frobenius
+        eng.iterate(10, first_iteration=11, error_every=10, last_iteration=iters)
+        Wg, Hg = eng.get_factors()
+        key = ride if ride is not None else ("both" if "both" not in got else "both again")
+        got[key] = (Wg, Hg, f10, eng.frobenius)
+        eng.close()
+        assert _rel(Wg, W64) < 2e-2 and _rel(Hg, H64) < 2e-2, key
+        assert got[key][3] == pytest.approx(ref["frobenius"], rel=2e-3)
+    # (the forms differ in the order of fp32 sums -- K slices of the Gram matrices, and 8 instead of 9 K slices of W^T V when W^T W rides -- and a last-bit difference
+    #  flips the bf16 rounding of an operand here and there: 2e-5 after 20 iterations, against the mode's 2e-2)
+    for key in ("h", "w", "both"):
+        assert _rel(got[key][0], got["0"][0]) < 2e-4 and _rel(got[key][1], got["0"][1]) < 2e-4, key
+        assert got[key][2] == pytest.approx(got["0"][2], rel=1e-5) and got[key][3] == pytest.approx(got["0"][3], rel=1e-5)
+    assert np.array_equal(got["both"][0], got["both again"][0]) and np.array_equal(got["both"][1], got["both again"][1]) and got["both"][3] == got["both again"][3]
+
+
 def test_rank256_bf16_path_factors_read_in_the_middle_of_a_run():
     """get_factors() folds the pending column scale into W (and drops the fragments and the Gram image made from the unscaled panel); the run
     continues from the normalised W.  Same trajectory as the uninterrupted run up to the bf16 mode's rounding (bf16 of W D instead of bf16 of W)."""

@@ -1383,8 +1383,8 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 		bool hht_done = false;
 		GramReduceArgs tri_ride = {nullptr, 0, nullptr, nullptr, 0};
 		if (tri_) {
-			// (error iterations: the trace below reads H H^T before the product is launched -- the Gram matrix by its own launches then)
-			if (Status s = tri_prepare_h(HHt_, true, (!compute_error && !constant_w) ? &tri_ride : nullptr)) return s;
+			// (riding in the product launch below; on error iterations the trace that reads H H^T then runs behind that launch)
+			if (Status s = tri_prepare_h(HHt_, true, !constant_w ? &tri_ride : nullptr)) return s;
 			hht_done = true;
 		} else if (alg_ == ALG_NSNMF) {
 			const T off = (T)prm_.theta / (T)(unsigned)r_;
@@ -1405,7 +1405,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			}
 		}
 		if (!hht_done && !hht_rides) HIPX(launch_gram<T>(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
-		if (compute_error && !hht_rides) {
+		if (compute_error && !hht_rides && tri_ride.tri_frags == nullptr) {
 			const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 				if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
@@ -1443,6 +1443,8 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				}
 			} else {
 				if (Status s = product_w(Fh, tri_ride.tri_frags != nullptr ? &tri_ride : nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;
+				// (rank 256, H H^T rode in that launch: the error term's trace of H H^T against the unsmoothed W^T W of this iteration's H step, AlgorithmNonSmoothNMF.h:201-202)
+				if (compute_error && tri_ride.tri_frags != nullptr) HIPX(launch_trace_small<T>(HHt_, reinterpret_cast<const T*>(Gw_raw_), RP_, r_, psR_, stream_, tri_trace_scale()));
 			}
 			if (!ls_family) {
 				const bool gd_err = alg_ == ALG_GDCLS && compute_error;

@@ -890,7 +890,10 @@ def main_c4(args):
             avg_s = kernel_ms / 1e3 / kernel_launches
             roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0], "kernel": "k_factor_product_bf16",
-                        "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch}
+                        "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch,
+                        **({} if os.environ.get("NMFAMD_TRI_RIDE", "")[:1] == "0" else {"launch_also_carries": "32 passenger workgroups: the 256 x 256 Gram matrix of the launch's factor operand, its diagonal and split image (tri_gram_tile.h; "
+                                               "NMFAMD_TRI_RIDE=0 puts them back on four launches of their own): a product launch is 10-15 us longer than alone, the iteration "
+                                               "14 us shorter; bytes_per_launch counts the product's stream of V only"})}
         iter_flops = 4.0 * m * n * r + 6.0 * r * r * (m + n)
         print(json.dumps({
             "metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256",

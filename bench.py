@@ -433,11 +433,12 @@ def main():
         bytes_per_launch = 4.0 * M * N_COLS                   # the fp32 image of V (or V^T) one product streams
         roofline = roofline_mfma = None
         if kernel_launches > 0:
-            # Event pairs over-report a launch by a few us (an EMPTY pair on the idle stream reports idle_event_pair_us; the
-            # rocprofv3 trace of the same run averages ~2 us less per launch than the events).  No correction is applied:
-            # `achieved` is the conservative figure.
+            # The split-operand product's launches carry their own start / stop events (hipExtLaunchKernel: the dispatch's timestamps, as rocprofv3 reads
+            # them); the other product kernels are bracketed by two recorded events, which over-report a launch by a few us (an EMPTY pair on the idle
+            # stream reports idle_event_pair_us).  No correction is applied either way.
             avg_s = kernel_ms / 1e3 / kernel_launches
             common = {"avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
+                      "timed_by": "start/stop events of the launch itself (hipExtLaunchKernel)" if product_kernel == 2 else "an event recorded before and one after the launch",
                       "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch}
             if product_kernel == 2:
                 # fp32 product on the bf16 matrix pipe (operands split exactly into 3 bf16 terms): six bf16 MFMAs replace

@@ -347,6 +347,10 @@ Status Engine<T>::allocate() {
 	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
 	pin_psR_ = pin_psN_ + ps_stride_;
+	{
+		void* dp = nullptr;       // the device's view of the pinned buffer (fetch_error_terms writes it from a kernel)
+		if (hipHostGetDevicePointer(&dp, pin_psN_, 0) == hipSuccess) pin_psN_dev_ = static_cast<T*>(dp); else { (void)hipGetLastError(); pin_psN_dev_ = nullptr; }
+	}
 	HIPX(hipEventCreateWithFlags(&err_event_, hipEventDisableTiming));
 	HIPX(hipStreamSynchronize(stream_));
 	return ST_OK;
@@ -531,6 +535,19 @@ void Engine<T>::record_begin(int kind) {
 }
 
 template <typename T>
+bool Engine<T>::timed_launch_events(int kind, hipEvent_t* start, hipEvent_t* stop) {
+	*start = *stop = nullptr;
+	if (!timing_ || !timing_now_) return false;
+	if (ev_used_ + 2 > ev_.size()) {
+		for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; ev_.push_back(e); }
+	}
+	if (ev_kind_.size() < ev_.size() / 2) ev_kind_.resize(ev_.size() / 2, 0);
+	ev_kind_[ev_used_ / 2] = (char)kind;
+	*start = ev_[ev_used_]; *stop = ev_[ev_used_ + 1];
+	return true;
+}
+
+template <typename T>
 void Engine<T>::record_end() {
 	if (!timing_ || !timing_now_ || ev_used_ + 2 > ev_.size()) return;
 	(void)hipEventRecord(ev_[ev_used_ + 1], stream_);
@@ -636,10 +653,11 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
 			if (rg && !passengers_ride(planHx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
-			record_begin();
-			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_));
-			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg));
-			record_end();
+			hipEvent_t e0, e1;
+			const bool timed = timed_launch_events(0, &e0, &e1);
+			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_, e0, e1));
+			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, false, 128, e0, e1));
+			if (timed) timed_launch_done();
 			return ST_OK;
 		}
 		if (tiled_) {
@@ -687,9 +705,10 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
 			if (rg && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
-			record_begin(1);
-			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_));
-			record_end();
+			hipEvent_t e0, e1;
+			const bool timed = timed_launch_events(1, &e0, &e1);
+			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_, e0, e1));
+			if (timed) timed_launch_done();
 			return ST_OK;
 		}
 		if (tiled_) {
@@ -764,7 +783,10 @@ template <typename T>
 Status Engine<T>::fetch_error_terms(int count_n) {
 	finalize_error(false);   // the pinned buffers are about to be reused; an older fetch is long complete
 	(void)count_n;
-	HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
+	// (a kernel that writes the pinned buffer, not hipMemcpyAsync: the runtime's copy idles the stream for ~18 us around its blit; NMFAMD_ERROR_MEMCPY=1 restores it)
+	static const bool use_memcpy = std::getenv("NMFAMD_ERROR_MEMCPY") != nullptr;
+	if (use_memcpy || pin_psN_dev_ == nullptr) HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
+	else HIPX(launch_copy_small<T>(pin_psN_dev_, psN_, ps_stride_ + r_, stream_));
 	HIPX(hipEventRecord(err_event_, stream_));
 	err_pending_ = true;
 	err_count_ = count_n;

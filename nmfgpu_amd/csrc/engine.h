@@ -161,6 +161,8 @@ private:
 	void finalize_error(bool resolve);
 	void record_begin(int kind = 0);
 	void record_end();
+	bool timed_launch_events(int kind, hipEvent_t* start, hipEvent_t* stop);      // a sampled launch that takes its own start / stop events (hipExtLaunchKernel); then timed_launch_done()
+	void timed_launch_done() { ev_used_ += 2; }
 
 	int m_, n_, r_, RP_, alg_;
 	int row_blocks_ = 1;
@@ -284,6 +286,7 @@ private:
 	unsigned long long* op_stamps_ = nullptr;          // diagnostic builds (NMFAMD_ONEPASS_STAMPS = file the last launch's stamps go to)
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
+	T* pin_psN_dev_ = nullptr;      // the device's address of pin_psN_ (hipHostGetDevicePointer): fetch_error_terms writes it from a kernel
 	hipEvent_t err_event_ = nullptr;
 	bool err_pending_ = false, err_unresolved_ = false;
 	int err_count_ = 0;

@@ -240,6 +240,9 @@ constexpr int ROW_DOT_GROUPS = 128;
 
 template <typename T>
 hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, hipStream_t stream);
+// dst (device-visible host memory or device memory) <- src, count elements, by a small kernel on `stream`
+template <typename T>
+hipError_t launch_copy_small(T* dst, const T* src, long count, hipStream_t stream);
 
 // Ainv = (A + regulariser)^-1, regulariser = offdiag everywhere, diag on the diagonal.  work: 2 * r * r doubles
 // (r > 64 only; that route also adds the regulariser to A in place).
@@ -330,7 +333,10 @@ int bf16_product_workgroups(const FactorProductPlan& p);
 hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int KS, hipStream_t stream);
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
-                                    unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128);
+                                    unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128,
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// (ev_start / ev_stop: the launch's own start and stop times go to these events -- hipExtLaunchKernel -- instead of the caller recording two events around it:
+//  a bracketed launch costs the stream ~12 us of barrier packets, rocprofv3 trace of bench.py's sampled iterations)
 int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve = 0);
 
 // ---- one pass over V per multiplicative-update iteration at padded rank 64 (kernels_onepass.hip) -----------------------

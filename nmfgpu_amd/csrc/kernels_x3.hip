@@ -13,6 +13,7 @@
 // no transposition, splitting is three conversions and two subtractions per element in registers.
 // The factor panel is split once per product into fragment order (k_pack_panel_x3).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -446,6 +447,9 @@ int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
 	return std::max(1, std::min(by_fill, by_depth));
 }
 
+// events handed from launch_factor_product_x3 to the instantiation it dispatches to (per thread: rank threads launch concurrently)
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+
 template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
@@ -461,6 +465,14 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	if (t_ev_start != nullptr && t_ev_stop != nullptr) {
+		// (the caller wants this launch timed: its own start / stop timestamps, no event records around it)
+		const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
+		t_ev_start = t_ev_stop = nullptr;
+		hipExtLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
+		                      A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
@@ -475,8 +487,10 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 // of 16; p.th must be 128.  Passengers (Gram reduction, or the 64 x 64 inverse) ride only at RP = 64.
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
-                                    bool y_tiled, int image_tile) {
+                                    bool y_tiled, int image_tile, hipEvent_t ev_start, hipEvent_t ev_stop) {
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
+	t_ev_start = ev_start; t_ev_stop = ev_stop;
+	struct Clear { ~Clear() { t_ev_start = t_ev_stop = nullptr; } } clear_on_exit;      // (a path that did not consume them -- an error return, grid.y > 1 -- leaves nothing behind)
 #ifdef NMFAMD_DIAG_BUILD
 	if (image_tile == 16 && y_tiled && RP == 64 && stamps != nullptr) {
 		// stamped diagnostic builds of the y-tiled form with row-per-lane loads (tools/stamp_x3.py, NMFAMD_X3_VARIANT = 30..33)

@@ -318,8 +318,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API from Python (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
-    ap.add_argument("--event-stride", type=int, default=0, help="time the factor-product launches of every k-th timed iteration (0 = every 8th, and every (steps / 10)-th from 80 steps "
-                                                                 "up: an event pair costs the launch it brackets ~4.5 us, so ten samples per form are what a long run pays for)")
+    ap.add_argument("--event-stride", type=int, default=0, help="time the factor-product launches of every k-th timed iteration (0 = every max(10, steps / 5)-th: a sampled iteration "
+                                                                 "costs the stream ~23 us of waits around its two timed launches -- rocprofv3 trace --, so a run pays for two to five samples per form)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
                          "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
@@ -337,7 +337,7 @@ def main():
     ap.add_argument("--team-worker", action="store_true", help=argparse.SUPPRESS)      # (internal: the child process that runs the N rank threads)
     args = ap.parse_args()
     if args.event_stride <= 0:
-        args.event_stride = max(8, args.steps // 10)
+        args.event_stride = max(10, args.steps // 5)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):

@@ -783,6 +783,11 @@ template <typename T>
 Status Engine<T>::fetch_error_terms(int count_n) {
 	finalize_error(false);   // the pinned buffers are about to be reused; an older fetch is long complete
 	(void)count_n;
+	if (error_terms_stay_) {
+		// a sharded run gathers the terms of all ranks on the device (error_terms_to_device) and resolves them itself: no host copy, no event here
+		err_count_ = count_n;
+		return ST_OK;
+	}
 	// (a kernel that writes the pinned buffer, not hipMemcpyAsync: the runtime's copy idles the stream for ~18 us around its blit; NMFAMD_ERROR_MEMCPY=1 restores it)
 	static const bool use_memcpy = std::getenv("NMFAMD_ERROR_MEMCPY") != nullptr;
 	if (use_memcpy || pin_psN_dev_ == nullptr) HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
@@ -797,8 +802,8 @@ template <typename T>
 long Engine<T>::error_terms_to_device(T* dst, long capacity) {
 	const long cnt = (long)err_count_ + r_;
 	if (err_count_ <= 0 || capacity < cnt) return -1;
-	if (hipMemcpyAsync(dst, psN_, sizeof(T) * (size_t)err_count_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return -1;
-	if (hipMemcpyAsync(dst + err_count_, psR_, sizeof(T) * (size_t)r_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return -1;
+	// ONE small launch for both pieces (two runtime copies were two blit kernels)
+	if (launch_copy_two<T>(dst, psN_, err_count_, psR_, r_, stream_) != hipSuccess) return -1;
 	return cnt;
 }
 

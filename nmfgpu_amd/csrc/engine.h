@@ -97,6 +97,8 @@ public:
 	const std::vector<T>& terms_hhtwtw() { finalize_error(false); return h_psR_; }
 	const std::vector<T>& terms_vtv_sorted() const { return h_vtv_; }
 	long error_terms_to_device(T* dst, long capacity);   // [psN (last count) | psR (r)], D2D on the stream
+	// sharded runs: the terms are fetched with error_terms_to_device() only -- the engine's own copy to the host (and its event) is skipped
+	void set_error_terms_stay_on_device(bool stay) { error_terms_stay_ = stay; }
 	void resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);
 
 	// Error of the most recent error iteration.  The n + r partial sums travel to the host
@@ -286,6 +288,7 @@ private:
 	unsigned long long* op_stamps_ = nullptr;          // diagnostic builds (NMFAMD_ONEPASS_STAMPS = file the last launch's stamps go to)
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
+	bool error_terms_stay_ = false;
 	T* pin_psN_dev_ = nullptr;      // the device's address of pin_psN_ (hipHostGetDevicePointer): fetch_error_terms writes it from a kernel
 	hipEvent_t err_event_ = nullptr;
 	bool err_pending_ = false, err_unresolved_ = false;

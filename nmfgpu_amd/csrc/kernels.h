@@ -243,6 +243,8 @@ hipError_t launch_fill_small(T* A, int RP, int r, int reuse, T offdiag, T diag, 
 // dst (device-visible host memory or device memory) <- src, count elements, by a small kernel on `stream`
 template <typename T>
 hipError_t launch_copy_small(T* dst, const T* src, long count, hipStream_t stream);
+template <typename T>
+hipError_t launch_copy_two(T* dst, const T* a, long na, const T* b, long nb, hipStream_t stream);      // dst = [a | b]
 
 // Ainv = (A + regulariser)^-1, regulariser = offdiag everywhere, diag on the diagonal.  work: 2 * r * r doubles
 // (r > 64 only; that route also adds the regulariser to A in place).

@@ -922,6 +922,20 @@ hipError_t launch_copy_small(T* dst, const T* src, long count, hipStream_t strea
 	hipLaunchKernelGGL((k_copy_small<T>), dim3((unsigned)std::min<long>(64, (count + 255) / 256)), dim3(256), 0, stream, dst, src, count);
 	return hipGetLastError();
 }
+// dst = [a (na elements) | b (nb elements)]
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_two(T* __restrict__ dst, const T* __restrict__ a, long na, const T* __restrict__ b, long nb) {
+	for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (long)gridDim.x * 256) dst[i] = i < na ? a[i] : b[i - na];
+}
+
+template <typename T>
+hipError_t launch_copy_two(T* dst, const T* a, long na, const T* b, long nb, hipStream_t stream) {
+	if (na + nb <= 0) return hipSuccess;
+	hipLaunchKernelGGL((k_copy_two<T>), dim3((unsigned)std::min<long>(64, (na + nb + 255) / 256)), dim3(256), 0, stream, dst, a, na, b, nb);
+	return hipGetLastError();
+}
+template hipError_t launch_copy_two<float>(float*, const float*, long, const float*, long, hipStream_t);
+template hipError_t launch_copy_two<double>(double*, const double*, long, const double*, long, hipStream_t);
 template hipError_t launch_copy_small<float>(float*, const float*, long, hipStream_t);
 template hipError_t launch_copy_small<double>(double*, const double*, long, hipStream_t);
 

@@ -64,6 +64,10 @@ Status ShardedRank<T>::prepare() {
 	const long L = slot_len();
 	if (!dalloc(&err_dev_, L * world)) return fail("hipMalloc(error terms)");
 	if (hipHostMalloc((void**)&err_pin_, sizeof(T) * (size_t)(L * world)) != hipSuccess) return fail("hipHostMalloc(error terms)");
+	{
+		void* dp = nullptr;
+		if (hipHostGetDevicePointer(&dp, err_pin_, 0) == hipSuccess) err_pin_dev_ = static_cast<T*>(dp); else (void)hipGetLastError();
+	}
 	if (hipEventCreateWithFlags(&err_event_, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
 
 	// the sorted tr(V^T V) terms of ALL columns, once (V does not change): gather the local vectors through the
@@ -100,6 +104,10 @@ Status ShardedRank<T>::iterate(bool compute_error) {
 	const int eb = (int)sizeof(T);
 	hipStream_t s = eng_->stream();
 	auto comm_fail = [&](Status st) { last_error_ = comm_->last_error(); return st; };
+	// this run gathers the error terms of all ranks on the device (launch_error_gather) and resolves them itself: the engine's own copy to the host and its
+	// event are skipped while an iteration of the run is being enqueued (KL: the terms travel in the exchange buffer and the engine keeps them)
+	struct StayGuard { Engine<T>* e; bool on; ~StayGuard() { if (on) e->set_error_terms_stay_on_device(false); } } stay{eng_, !eng_->is_kl()};
+	if (stay.on) eng_->set_error_terms_stay_on_device(true);
 	if (Status st = eng_->h_step(compute_error)) { last_error_ = eng_->last_error(); return st; }
 	if (direct_) {
 		T* mine = xslot_[iterations_++ & 1];
@@ -144,9 +152,18 @@ Status ShardedRank<T>::launch_error_gather() {
 	const int world = comm_->world(), rank = comm_->rank();
 	const long L = slot_len();
 	hipStream_t s = eng_->stream();
+	if (world == 1 && !rehearse_ && err_pin_dev_ != nullptr) {
+		// a team of one: nothing to gather -- the terms go straight to the pinned buffer
+		if (eng_->error_terms_to_device(err_pin_dev_, L) < 0) return fail("error_terms_to_device");
+		if (hipEventRecord(err_event_, s) != hipSuccess) return fail("hipEventRecord");
+		err_pending_ = true;
+		return ST_OK;
+	}
 	if (eng_->error_terms_to_device(err_dev_ + (long)rank * L, L) < 0) return fail("error_terms_to_device");
 	if (Status st = comm_->all_gather_inplace(err_dev_, L, (int)sizeof(T), s)) { last_error_ = comm_->last_error(); return st; }
-	if (hipMemcpyAsync(err_pin_, err_dev_, sizeof(T) * (size_t)(L * world), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync(error terms)");
+	// (a kernel that writes the pinned buffer: the runtime's device-to-host copy idles the stream ~18 us around its blit -- Engine::fetch_error_terms)
+	if (err_pin_dev_ != nullptr) { if (launch_copy_small<T>(err_pin_dev_, err_dev_, L * world, s) != hipSuccess) return fail("copy of the error terms"); }
+	else if (hipMemcpyAsync(err_pin_, err_dev_, sizeof(T) * (size_t)(L * world), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("hipMemcpyAsync(error terms)");
 	if (hipEventRecord(err_event_, s) != hipSuccess) return fail("hipEventRecord");
 	err_pending_ = true;
 	return ST_OK;

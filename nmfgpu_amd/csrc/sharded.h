@@ -68,6 +68,7 @@ private:
 	T* colsq_ = nullptr;                    // RP sums of squares
 	T* err_dev_ = nullptr;                  // world * (nloc_max + r) gathered error terms
 	T* err_pin_ = nullptr;
+	T* err_pin_dev_ = nullptr;      // the device's address of err_pin_
 	hipEvent_t err_event_ = nullptr;
 	bool err_pending_ = false;
 	std::vector<T> vtv_all_;

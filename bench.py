@@ -115,6 +115,14 @@ def engine_stream(torch) -> int:
 # Untimed set-up iterations before the W warm-up steps of a single-GPU line (config 2's shape; a third of it for config 4's 0.44 ms iteration, a tenth for config 3's 1.3 ms):
 # ~25 ms of the hot path, after which the factors go back to W0, H0.  The line reports it as config.setup_iterations.
 SETUP_ITERATIONS = 240
+# Untimed replay behind the timed steps of a single-GPU line: at least this many further iterations, REPLAY_SAMPLES of them with their product launches timed by the
+# launches' own start / stop events (roofline.avg_launch_us)
+REPLAY_ITERATIONS, REPLAY_SAMPLES = 60, 12
+TIMED_BY_REPLAY = "sampled in an untimed replay right behind the timed steps (same engine, same stream, iterations continue); the timed region carries no events"
+
+
+def replay_iterations(K: int, c4: bool) -> int:
+    return max(REPLAY_ITERATIONS // (3 if c4 else 1), min(K, 200))
 
 
 def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
@@ -318,8 +326,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API from Python (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
-    ap.add_argument("--event-stride", type=int, default=0, help="time the factor-product launches of every k-th timed iteration (0 = every max(10, steps / 5)-th: a sampled iteration "
-                                                                 "costs the stream ~23 us of waits around its two timed launches -- rocprofv3 trace --, so a run pays for two to five samples per form)")
+    ap.add_argument("--event-stride", type=int, default=0, help="(kept for old command lines; unused since round 5: the launch samples are taken in an untimed replay behind the timed steps)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
                          "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
@@ -390,15 +397,18 @@ def main():
         eng.set_factors(W, H)
         eng.iterate(Wm, first_iteration=1, error_every=10)
         eng.synchronize()
-        if not args.no_kernel_events:
-            eng.kernel_timing(args.event_stride)
         barrier()
         t0 = time.perf_counter()
         eng.iterate(K, first_iteration=Wm + 1, error_every=10)
-        eng.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         if not args.no_kernel_events:
+            # the launch samples of `roofline` come from an UNTIMED replay right behind the timed steps (iterations Wm + K + 1 ..., same stream, same engine, the device
+            # still warm): a sampled iteration costs the stream ~23 us of waits around its two timed launches, which round 4 paid inside the timed region
+            replay = replay_iterations(K, False)
+            eng.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+            eng.iterate(replay, first_iteration=Wm + K + 1, error_every=10)
+            eng.synchronize()
             kernel_ms, kernel_launches, pair_overhead_ms, form_ms, form_launches = eng.kernel_timing_read3()
             eng.kernel_timing(0)
         frob = eng.frobenius
@@ -414,15 +424,16 @@ def main():
         shard.engine.set_factors(W, H)
         drv.run(Wm, first_iteration=1, error_every=10)
         shard.synchronize()
-        if not args.no_kernel_events:
-            shard.engine.kernel_timing(args.event_stride)
         barrier()
         t0 = time.perf_counter()
         drv.run(K, first_iteration=Wm + 1, error_every=10)
-        shard.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         if not args.no_kernel_events:
+            replay = replay_iterations(K, False)
+            shard.engine.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+            drv.run(replay, first_iteration=Wm + K + 1, error_every=10)
+            shard.synchronize()
             kernel_ms, kernel_launches, pair_overhead_ms = shard.engine.kernel_timing_read2()
         frob = drv.frobenius
         product_kernel = shard.engine.geometry()["product_kernel"]
@@ -438,7 +449,7 @@ def main():
             # stream reports idle_event_pair_us).  No correction is applied either way.
             avg_s = kernel_ms / 1e3 / kernel_launches
             common = {"avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
-                      "timed_by": "start/stop events of the launch itself (hipExtLaunchKernel)" if product_kernel == 2 else "an event recorded before and one after the launch",
+                      "timed_by": ("start/stop events of the launch itself (hipExtLaunchKernel), " if product_kernel == 2 else "an event recorded before and one after the launch, ") + TIMED_BY_REPLAY,
                       "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch}
             if product_kernel == 2:
                 # fp32 product on the bf16 matrix pipe (operands split exactly into 3 bf16 terms): six bf16 MFMAs replace
@@ -616,8 +627,6 @@ def team_worker(args):
             phase(f"team: rank {g} warm-up")
             run.iterate(Wm, first_iteration=1, error_every=10)
             eng.synchronize()
-            if g == 0 and not args.no_kernel_events:
-                eng.kernel_timing(args.event_stride)
             torch.cuda.synchronize()
             gate.wait()
             phase(f"team: rank {g} timed iterations")
@@ -628,8 +637,17 @@ def team_worker(args):
             torch.cuda.synchronize()
             gate.wait()
             kernel = (0.0, 0, 0.0)
-            if g == 0 and not args.no_kernel_events:
-                kernel = eng.kernel_timing_read2()
+            if not args.no_kernel_events:
+                # untimed replay behind the timed steps (every rank runs it: the iteration holds a rendezvous); rank 0's product launches are sampled there
+                phase(f"team: rank {g} untimed replay (launch samples)")
+                replay = replay_iterations(K, pb["c4"])
+                if g == 0:
+                    eng.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+                run.iterate(replay, first_iteration=Wm + K + 1, error_every=10)
+                eng.synchronize()
+                if g == 0:
+                    kernel = eng.kernel_timing_read2()
+                gate.wait()
             res[g] = (dt, kernel, run.frobenius if g == 0 else 0.0)
         except BaseException as e:                          # noqa: BLE001 -- a failed rank releases its peers (collectives, the gate) and the process exits non-zero
             errors.append((g, e))
@@ -757,8 +775,6 @@ def rccl_ranks(args):
     phase("RCCL: warm-up")
     run.iterate(Wm, first_iteration=1, error_every=10)
     eng.synchronize()
-    if not args.no_kernel_events:
-        eng.kernel_timing(args.event_stride)
     barrier()
     phase("RCCL: timed iterations")
     t0 = time.perf_counter()
@@ -766,7 +782,16 @@ def rccl_ranks(args):
     eng.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    kernel = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
+    kernel = (0.0, 0, 0.0)
+    if not args.no_kernel_events:
+        # untimed replay behind the timed steps (a collective: every rank runs it); this rank's product launches are sampled there
+        phase("RCCL: untimed replay (launch samples)")
+        replay = replay_iterations(K, pb["c4"])
+        eng.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+        run.iterate(replay, first_iteration=Wm + K + 1, error_every=10)
+        eng.synchronize()
+        kernel = eng.kernel_timing_read2()
+        barrier()
     frob = run.frobenius
     t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -800,15 +825,19 @@ def main_c3(args):
     eng.set_factors(W, H)
     eng.iterate(Wm, first_iteration=1, error_every=10)
     eng.synchronize()
-    if not args.no_kernel_events:
-        eng.kernel_timing(args.event_stride)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.iterate(K, first_iteration=Wm + 1, error_every=10)
-    eng.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else eng.kernel_timing_read2()
+    kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
+    if not args.no_kernel_events:
+        replay = max(10, min(K, 30))       # untimed replay behind the timed steps: the launch samples of `roofline`
+        eng.kernel_timing(max(1, replay // 5))
+        eng.iterate(replay, first_iteration=Wm + K + 1, error_every=10)
+        eng.synchronize()
+        kernel_ms, kernel_launches, pair_overhead_ms = eng.kernel_timing_read2()
+        eng.kernel_timing(0)
     rp = eng.geometry()["padded_rank"]
     # per launch of the fused half-step kernel (two per iteration; SURVEY 8d's accounting): value + index of every stored entry
     # in, the row pointers, one pass over both factors, the numerator panel out (average of the H and the W half-step)
@@ -875,15 +904,19 @@ def main_c4(args):
 
     drv.run(Wm, first_iteration=1, error_every=10)
     shard.synchronize()
-    if not args.no_kernel_events:
-        shard.engine.kernel_timing(args.event_stride)
     barrier()
     t0 = time.perf_counter()
     drv.run(K, first_iteration=Wm + 1, error_every=10)
-    shard.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_launches, pair_overhead_ms = (0.0, 0, 0.0) if args.no_kernel_events else shard.engine.kernel_timing_read2()
+    kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
+    if not args.no_kernel_events:
+        replay = replay_iterations(K, True)       # untimed replay behind the timed steps: the launch samples of `roofline`
+        shard.engine.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+        drv.run(replay, first_iteration=Wm + K + 1, error_every=10)
+        shard.synchronize()
+        kernel_ms, kernel_launches, pair_overhead_ms = shard.engine.kernel_timing_read2()
+        shard.engine.kernel_timing(0)
     if rank == 0:
         bytes_per_launch = 2.0 * m * n                       # one pass over the bf16 image of the shard
         roofline = None

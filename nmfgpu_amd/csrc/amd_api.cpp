@@ -516,12 +516,14 @@ static int op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 	    hipMemset(dF.p, 0, sizeof(float) * RP * Yp) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(dA.p, Xp * sizeof(float), A, lda * sizeof(float), X * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(dF.p, RP * sizeof(float), F, ldf * sizeof(float), r * sizeof(float), Y, hipMemcpyHostToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
-	// x-tiled image of A, or (y_tiled) the image tiled along the reduction index = the x-tiled image of A^T
-	const long tstride = y_tiled ? 128 * Xp : 128 * Yp;
-	if (y_tiled) { if (launch_tile_transposed<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 128, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR; }
+	// x-tiled image of A (128-row tiles), or (y_tiled) the image tiled along the reduction index in 16-row tiles = the x-tiled image of A^T with tile height 16:
+	// the form W^T V runs in on the engine's ONE resident image of V
+	const int ith = y_tiled ? 16 : 128;
+	const long tstride = y_tiled ? 16 * Xp : 128 * Yp;
+	if (y_tiled) { if (launch_tile_transposed<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 16, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR; }
 	else if (launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 128, false, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_factor_product_x3(plan, (const float*)dT.p, tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_factor_product_x3(plan, (const float*)dT.p, tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled, ith) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (reps > 0 && avg_us) {
@@ -532,9 +534,9 @@ static int op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 		if (hipMemcpy(dT2.p, dT.p, sizeof(float) * Xp * Yp, hipMemcpyDeviceToDevice) != hipSuccess) return NMFAMD_HIP_ERROR;
 		hipEvent_t e0, e1;
 		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return NMFAMD_HIP_ERROR;
-		for (int i = 0; i < 4; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled);
+		for (int i = 0; i < 4; ++i) (void)launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled, ith);
 		(void)hipEventRecord(e0, nullptr);
-		for (int i = 0; i < reps; ++i) launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled);
+		for (int i = 0; i < reps; ++i) (void)launch_factor_product_x3(plan, (const float*)((i & 1) ? dT2.p : dT.p), tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled, ith);
 		(void)hipEventRecord(e1, nullptr);
 		if (hipEventSynchronize(e1) != hipSuccess) return NMFAMD_HIP_ERROR;
 		float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -553,36 +555,45 @@ int nmfamd_op_factor_product_x3_ytiled(const float* A, long lda, int X, int Y, c
 }
 
 int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves) {
+	// X x Y = rows x columns of V (config 2: 10 000 x 5 000).  ONE image in 16-row tiles, as the engine keeps it; the two production forms alternate on it as they do
+	// in an iteration (W^T V y-tiled, V H^T x-tiled), so the stamped launch finds the memory-side cache in the state the iteration leaves it in.
+	// NMFAMD_X3_VARIANT = 10..13: the x-tiled launch is stamped; 30..33: the y-tiled one (kernels_x3.hip).
 	if (X <= 0 || Y <= 0 || !stamps_out || !waves) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
 	const int RP = 64;
-	const long Xp = pad128(X), Yp = pad128(Y);
-	const int KS = (Y + 15) / 16;
-	FactorProductPlan plan; plan.th = 128; plan.xtiles = (int)(Xp / 128); plan.steps_total = KS; plan.nb = 2; plan.chunks = 1;
-	plan.splits = plan_splits_x3(plan.xtiles, KS, prop.multiProcessorCount);
-	const long nwaves = (long)plan.xtiles * plan.splits * 4;
-	if (stamps_capacity < 8 * nwaves) return NMFAMD_INVALID_ARGUMENT;
-	DevBuf dA, dA2, dF, dFb, dS, dT;
-	const long slab_stride = (long)RP * Xp;
-	if (dA.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dA2.alloc(sizeof(float) * Xp * Yp) != hipSuccess || dF.alloc(sizeof(float) * RP * Yp) != hipSuccess ||
-	    dFb.alloc(3 * 16 * (size_t)(KS + 1) * (RP / 32) * 64) != hipSuccess || dS.alloc(sizeof(float) * slab_stride * plan.splits) != hipSuccess ||
-	    dT.alloc(sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
-	if (launch_fill_uniform<float>((float*)dA.p, (int)Xp, (int)Xp, Yp, Yp, 1, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_fill_uniform<float>((float*)dA2.p, (int)Xp, (int)Xp, Yp, Yp, 3, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_fill_uniform<float>((float*)dF.p, RP, RP, Yp, Yp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (hipMemset(dT.p, 0, sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_HIP_ERROR;
-	// NMFAMD_X3_VARIANT >= 30: the y-tiled form on 16-row tiles (any buffer of the right size is an image of random data)
+	const long Mp = pad128(X), Np = pad128(Y);
+	const int ksW = (Y + 15) / 16, ksH = (X + 15) / 16;
+	FactorProductPlan planW, planH;                  // V H^T: x = rows of V; W^T V: x = columns of V
+	planW.th = planH.th = 128; planW.nb = planH.nb = 2; planW.chunks = planH.chunks = 1;
+	planW.xtiles = (int)(Mp / 128); planW.steps_total = ksW; planW.splits = plan_splits_x3(planW.xtiles, ksW, prop.multiProcessorCount);
+	planH.xtiles = (int)(Np / 128); planH.steps_total = ksH; planH.splits = plan_splits_x3(planH.xtiles, ksH, prop.multiProcessorCount);
 	const char* ve = tuning_env("NMFAMD_X3_VARIANT");
 	const bool ytiled = ve != nullptr && std::atoi(ve) >= 30;
-	unsigned long long* dummy = nullptr;
-	for (int i = 0; i < 6; ++i) {
-		unsigned long long* st = i == 5 ? (unsigned long long*)dT.p : (ytiled ? (unsigned long long*)dT.p : dummy);
-		hipError_t e = ytiled ? launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 16 * Xp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, st, true, 16)
-		                      : launch_factor_product_x3(plan, (const float*)((i & 1) ? dA2.p : dA.p), 128 * Yp, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, st);
-		if (e != hipSuccess) return NMFAMD_HIP_ERROR;
+	const FactorProductPlan& sp = ytiled ? planH : planW;
+	const long nwaves = (long)sp.xtiles * sp.splits * 4;
+	if (stamps_capacity < 8 * nwaves) return NMFAMD_INVALID_ARGUMENT;
+	DevBuf dA, dW, dH, dWx, dHx, dS, dT;
+	const long slab_stride = (long)RP * std::max(Mp, Np);
+	if (dA.alloc(sizeof(float) * Mp * Np) != hipSuccess || dW.alloc(sizeof(float) * RP * Mp) != hipSuccess || dH.alloc(sizeof(float) * RP * Np) != hipSuccess ||
+	    dWx.alloc(3 * 16 * (size_t)(ksH + 1) * (RP / 32) * 64) != hipSuccess || dHx.alloc(3 * 16 * (size_t)(ksW + 1) * (RP / 32) * 64) != hipSuccess ||
+	    dS.alloc(sizeof(float) * slab_stride * std::max(planW.splits, planH.splits)) != hipSuccess ||
+	    dT.alloc(sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
+	// (any buffer of the right size is an image of random data)
+	if (launch_fill_uniform<float>((float*)dA.p, (int)Mp, (int)Mp, Np, Np, 1, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_fill_uniform<float>((float*)dW.p, RP, RP, Mp, Mp, 2, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_fill_uniform<float>((float*)dH.p, RP, RP, Np, Np, 3, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_x3((const float*)dW.p, RP, X, dWx.p, ksH, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (launch_pack_panel_x3((const float*)dH.p, RP, Y, dHx.p, ksW, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
+	if (hipMemset(dT.p, 0, sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return NMFAMD_HIP_ERROR;
+	const long stride = 16 * Np;
+	for (int i = 0; i < 40; ++i) {
+		const bool last = i == 39;
+		unsigned long long* sy = last && ytiled ? (unsigned long long*)dT.p : nullptr;
+		unsigned long long* sx = last && !ytiled ? (unsigned long long*)dT.p : nullptr;
+		if (launch_factor_product_x3(planH, (const float*)dA.p, stride, dWx.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, sy, true, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
+		if (launch_factor_product_x3(planW, (const float*)dA.p, stride, dHx.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, sx, false, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
 	}
 	if (hipMemcpy(stamps_out, dT.p, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
 	*waves = nwaves;

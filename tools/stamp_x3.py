@@ -1,4 +1,6 @@
-"""Main-loop cycles per K-step of the split product (diagnostic builds, NMFAMD_X3_VARIANT=10..13)."""
+"""Main-loop cycles per K-step of the split product in its two production forms on ONE 16-row-tile image (diagnostic build:
+NMFAMD_LIBRARY=.../libnmfgpu64_diag.so, NMFAMD_X3_VARIANT = 10..13 x-tiled V H^T / 30..33 y-tiled W^T V; last digit 0 = no ring refill,
+1 = A only, 2 = F only, 3 = the production loop).  Arguments: rows columns of V (default 10000 5000)."""
 import ctypes as C
 import os
 import sys

@@ -18,7 +18,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 #include "kernels.h"
 #include "tuning.h"
@@ -434,277 +433,6 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 	}
 }
 
-// Written-out loads and counted waits of k_factor_product_x3s (see the comment at its loop).  A load's destination counts as written when the statement ends, for
-// hipcc; the data lands later: every consumer reads the OUTPUT of a wait statement that names the register.
-template <bool TR, int IMG>
-constexpr int x3s_a_off(int i) {       // byte offset of load i (0..7) of a group of four row blocks, from the group's address
-	return IMG == 16 ? (TR ? ((i >> 1) * 256 + 4 * (i & 1)) * 4 : i * 64) : i * 128 * 4;
-}
-constexpr int x3s_f_off(int cb, int pl) { return (pl * 64 + 16 * (cb & 1)) * 16; }     // fragment (column block cb, plane pl) from the address of its 32-column block
-template <int OFF> __device__ inline void x3s_load_v(f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%c2" : "=v"(dst) : "v"(p), "i"(OFF) : "memory"); }
-template <int OFF> __device__ inline void x3s_load_v_tied(f32x4& dst, const float* p, bf16x8& tie) {
-	asm volatile("global_load_dwordx4 %0, %2, off offset:%c3" : "=v"(dst), "+v"(tie) : "v"(p), "i"(OFF) : "memory");
-}
-template <int OFF> __device__ inline void x3s_load_a(u32x4& dst, const bf16x8* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:%c2" : "=a"(dst) : "v"(p), "i"(OFF) : "memory"); }
-template <int OFF> __device__ inline void x3s_load_a_tied(u32x4& dst, const bf16x8* p, bf16x8& tie) {
-	asm volatile("global_load_dwordx4 %0, %2, off offset:%c3" : "=a"(dst), "+v"(tie) : "v"(p), "i"(OFF) : "memory");
-}
-template <int N> __device__ inline void x3s_wait8(f32x4 (&g)[8]) {
-	asm volatile("s_waitcnt vmcnt(%c8)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]) : "i"(N) : "memory");
-}
-template <int N> __device__ inline void x3s_wait2(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(a), "+v"(b) : "i"(N) : "memory"); }
-template <int N, int NC> __device__ inline void x3s_wait_frags(u32x4 (&f)[NC][3]) {
-	if constexpr (NC == 4)
-		asm volatile("s_waitcnt vmcnt(%c12)" : "+a"(f[0][0]), "+a"(f[0][1]), "+a"(f[0][2]), "+a"(f[1][0]), "+a"(f[1][1]), "+a"(f[1][2]),
-		             "+a"(f[2][0]), "+a"(f[2][1]), "+a"(f[2][2]), "+a"(f[3][0]), "+a"(f[3][1]), "+a"(f[3][2]) : "i"(N) : "memory");
-	else
-		asm volatile("s_waitcnt vmcnt(%c6)" : "+a"(f[0][0]), "+a"(f[0][1]), "+a"(f[0][2]), "+a"(f[1][0]), "+a"(f[1][1]), "+a"(f[1][2]) : "i"(N) : "memory");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-// Round 5: the same product on v_mfma_f32_16x16x32_bf16.
-// The loop of k_factor_product_x3 above runs at 35-37 cycles per 32-cycle MFMA -- and at 1.2-1.35 GHz: the chip holds its clock down under this load (power),
-// so wall time per launch is set by energy per MFMA, not by the issue stream (tools/stamp_x3.py, profiles/r05_x3_shape.md).  The 16 x 16 x 32 shape does the
-// same FLOP per cycle and the chip holds a ~20 % higher clock on it with the same operand-split work beside it (tools/probe/x3_shape_probe.hip: 2.09-2.25 GHz
-// against 1.73-1.98).  Same six exact terms per product, smallest first; another summation order inside an instruction (32 k instead of 16), so other bits
-// than the 32 x 32 x 16 kernel -- every form of THIS kernel (x-tiled / y-tiled, 16- / 128-row image tiles, 64 / 32 panel columns per workgroup) gives the
-// same bits as every other.
-//
-// Wave tile: 128 rows x (32 NBW) panel columns = 8 row blocks x (2 NBW) column blocks of 16 x 16, reduction in DOUBLE steps of 32 k (two K-steps of the
-// split image).  The factor fragments are the MFMA's A operand (lane l: panel column 16 cb + l % 16, k = 8 (l / 16) .. + 7 -- the image's 16-byte unit,
-// whatever the shape), the split values of V its B operand (lane l: row l % 16 of the row block, the same k), so accumulator register e of lane l is
-// panel column 16 cb + 4 (l / 16) + e of that row: four CONSECUTIVE panel columns per lane = one 16-byte store into the slab.
-// Row of row block rb held by lane l (r = l % 16):
-//   x-tiled (either image): 64 (rb / 4) + 4 r + rb % 4 -- a lane's 16-byte load is four consecutive rows of one column, one for each row block of a group of four
-//   y-tiled (16-row tiles): 16 rb + r -- a lane's two 16-byte loads are the eight k of its row; consecutive lanes read consecutive 64-byte column chunks
-// Ring: one double step of V in flight per wave (two groups of 8 loads, each refilled in the phase that follows the last split of its values) and the
-// factor fragments of the next double step in a second register set (12 loads, issued with the first group's refill): at most 28 loads in flight, as above.
-template <int NBW, bool TR, int IMG, int DIAG = 0>
-__global__ __launch_bounds__(256, NBW == 1 ? 2 : 1) void k_factor_product_x3s(
-	const float* __restrict__ A, long tile_stride,
-	const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP,
-	int steps_total, int xtiles, int splits, GramReduceArgs rg, unsigned long long* stamps) {
-	static_assert(NBW == 1 || NBW == 2, "one or two 32-column blocks per wave tile");
-	static_assert(!TR || IMG == 16, "the y-tiled form reads 16-row tiles");
-	constexpr int TH = 128, NC = 2 * NBW;
-	unsigned long long t_loop0 = 0, t_loop1 = 0, r_loop0 = 0, r_loop1 = 0, r_entry = 0, r_tail = 0;
-	if (DIAG != 0) r_entry = __builtin_amdgcn_s_memrealtime();
-	extern __shared__ __attribute__((aligned(16))) float lds[];
-	constexpr bool FOLD = NBW == 1;
-	const int pblocks = xtiles * splits * (FOLD ? 2 : 1);
-	if (blockIdx.x >= (unsigned)pblocks) {
-		// passengers: as in k_factor_product_x3
-		if (blockIdx.y != 0) return;
-		if (rg.inv_a != nullptr) inverse_gj64_body<float, 4>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
-		else if (rg.image != nullptr) gram_image_block(rg, blockIdx.x - pblocks, lds);
-		else gram_reduce_block_x3<256>(rg, blockIdx.x - pblocks, lds);
-		return;
-	}
-	int vb = blockIdx.x;
-	if (XCD_REMAP) {
-		const int q8 = pblocks / 8, r8 = pblocks % 8, xcd = vb % 8, idx = vb / 8;
-		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-	}
-	const int chunk = FOLD ? (vb & 1) : (int)blockIdx.y;
-	if (FOLD) vb >>= 1;
-	const int xt = vb % xtiles, sp = vb / xtiles;
-	const int coff = 32 * NBW * chunk;
-	const long fstep = (long)NBT * 192;                 // factor fragments per K-step of 16
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	const int r16 = lane & 15, kq = lane >> 4;
-	const int nw = splits * 4;
-	const int widx = sp * 4 + wave;
-	// the reduction range in double steps, dealt to the nw waves of the x-tile; a double step past an odd range's end meets the all-zero K-step that closes the
-	// factor image (index steps_total) with a re-read of the last valid K-step of A
-	const int units = (steps_total + 1) / 2;
-	const int S0 = (int)(((long)units * widx) / nw), S1 = (int)(((long)units * (widx + 1)) / nw);
-	const int kend = steps_total - 1;
-
-	f32x4 acc[8][NC];
-#pragma unroll
-	for (int rb = 0; rb < 8; ++rb)
-#pragma unroll
-		for (int cb = 0; cb < NC; ++cb)
-#pragma unroll
-			for (int e = 0; e < 4; ++e) acc[rb][cb][e] = 0.f;
-
-	if (S1 > S0) {
-		// Every load of the loop is WRITTEN OUT (asm, x3s_* above), and so is every wait for one.  Why: the factor fragments must land in the accumulator half of
-		// the register file (an MFMA reads its A / B operands from there as well; two sets of 12 NBW registers beside the 64 NBW accumulators leave the 256
-		// architectural VGPRs to the ring of V and the operand split) and hipcc only loads into VGPRs and copies (78 v_accvgpr_write per double step); and a
-		// wait hipcc counts for ITS loads waits for every written-out load in flight as well.  So: loads as asm statements placed where they are to issue --
-		// each behind an MFMA, tied to the operand register the MFMAs on either side read, which is what keeps hipcc's scheduler from moving them --, counted
-		// s_waitcnt statements that name the registers they release (the consumers read the statement's outputs: nothing is read before its wait), and a
-		// drain at the loop's end that keeps the destination registers of the last (unused) requests live until they have landed.
-		constexpr bool RA = DIAG == 0 || DIAG == 2 || DIAG == 4, RF = DIAG == 0 || DIAG == 3 || DIAG == 4;       // refill V / the fragments (measurement forms switch them off)
-		// lane part of the streamed operand's address; + the lane's K-step (2 S + kq / 2, clamped) times its stride, + the group's offset; loads at constant offsets
-		const float* ap = IMG == 16 ? (TR ? A + ((long)xt * TH + r16) * 16 + 8 * (kq & 1)
-		                                  : A + ((long)xt * 8 + (r16 >> 2)) * tile_stride + (8 * (kq & 1)) * 16 + 4 * (r16 & 3))
-		                            : A + (long)xt * tile_stride + (8 * (kq & 1)) * TH + 4 * r16;
-		const long kstride = IMG == 16 ? (TR ? tile_stride : 256) : 16 * TH;            // floats per K-step of 16
-		const long gstride = IMG == 16 ? (TR ? 64 * 16 : 4 * tile_stride) : 64;           // floats between the two groups of four row blocks
-		auto a_step = [&](int S) -> const float* {
-			int so = 2 * S + (kq >> 1);
-			so = so < kend ? so : kend;
-			return ap + (long)so * kstride;
-		};
-		const bf16x8* fp = F + (long)(kq >> 1) * fstep + (kq & 1) * 32 + r16 + (long)chunk * (NBW * 192);      // + 2 S * fstep + (cb / 2) * 192 + plane * 64 + 16 (cb % 2)
-		f32x4 va[2][8];
-		u32x4 fb[2][NC][3];
-		bf16x8 op[2][3];
-#define X3S_IC(n) std::integral_constant<int, (n)>{}
-		{
-			const float* s_ = a_step(S0);
-			const float* s1_ = s_ + gstride;
-			const bf16x8* f_ = fp + (long)(2 * S0) * fstep;
-			const bf16x8* f1_ = f_ + 192;
-#define X3S_PRO(i) x3s_load_v<x3s_a_off<TR, IMG>(i)>(va[0][i], s_); x3s_load_v<x3s_a_off<TR, IMG>(i)>(va[1][i], s1_);
-			X3S_PRO(0) X3S_PRO(1) X3S_PRO(2) X3S_PRO(3) X3S_PRO(4) X3S_PRO(5) X3S_PRO(6) X3S_PRO(7)
-#undef X3S_PRO
-#define X3S_PRO(cb, pl) if constexpr (cb < NC) { x3s_load_a<x3s_f_off(cb, pl)>(fb[0][cb][pl], cb < 2 ? f_ : f1_); if (!RF) x3s_load_a<x3s_f_off(cb, pl)>(fb[1][cb][pl], cb < 2 ? f_ : f1_); }
-			X3S_PRO(0, 0) X3S_PRO(0, 1) X3S_PRO(0, 2) X3S_PRO(1, 0) X3S_PRO(1, 1) X3S_PRO(1, 2) X3S_PRO(2, 0) X3S_PRO(2, 1) X3S_PRO(2, 2) X3S_PRO(3, 0) X3S_PRO(3, 1) X3S_PRO(3, 2)
-#undef X3S_PRO
-			x3s_wait8<0>(va[0]); x3s_wait8<0>(va[1]);
-			x3s_wait_frags<0, NC>(fb[0]);
-			if (!RF) x3s_wait_frags<0, NC>(fb[1]);
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		if (DIAG != 0) { t_loop0 = __builtin_amdgcn_s_memtime(); r_loop0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
-		auto operand = [&](int rb, float (&v)[8]) {
-#pragma unroll
-			for (int j = 0; j < 8; ++j) v[j] = TR ? va[rb >> 2][2 * (rb & 3) + (j >> 2)][j & 3] : va[rb >> 2][j][rb & 3];
-		};
-		{ float v[8]; operand(0, v); split3(v, op[0][0], op[0][1], op[0][2]); }
-		// One double step = eight phases (row blocks).  Phase rb: the 6 NC MFMAs of its row block, interleaved with the split of row block rb + 1 (in phase 7: of the
-		// NEXT double step).  Requests, in issue order -- x-tiled: phase 3 group 0 of V of the next step (its last split ran in phase 2), phase 4 the next step's
-		// fragments into the other register set, phase 7 group 1; y-tiled: a row block's two loads in ITS phase (its split ran one phase ago: eight phases ahead of
-		// their next use), the fragments in phase 4 behind that phase's two.  Waits (requests younger than the awaited one that may stay in flight) -- x-tiled: group 1
-		// at phase 3: none; group 0 at phase 7: the fragments; the fragments at the step's head: group 1.  y-tiled: row block rb + 1 at phase rb: six phases' pairs
-		// and the fragments (at phase 4: the pairs only); the fragments at the step's head: three pairs.
-		constexpr int NFR = RF ? 3 * NC : 0;                  // fragment requests per double step
-		auto step = [&](auto U, int S) __attribute__((always_inline)) {
-			constexpr int u = decltype(U)::value;
-			int Sn = S + 1;
-			Sn = Sn < S1 ? Sn : S1 - 1;                                         // past this wave's piece: a harmless re-read
-			const float* sn0_ = a_step(Sn);
-			const float* sn1_ = sn0_ + gstride;
-			const bf16x8* fn_ = fp + (long)(2 * Sn) * fstep;
-			const bf16x8* fn1_ = fn_ + 192;
-			if (S != S0) x3s_wait_frags<(TR ? (RA ? 6 : 0) : (RA ? 8 : 0)), NC>(fb[u]);
-			__builtin_amdgcn_sched_barrier(0);
-			auto phase = [&](auto RB) __attribute__((always_inline)) {
-				constexpr int rb = decltype(RB)::value, cur = rb & 1, nxt = cur ^ 1, nrb = (rb + 1) & 7;
-				if constexpr (TR) x3s_wait2<(RA ? 12 : 0) + (rb == 4 ? 0 : NFR)>(va[nrb >> 2][2 * (nrb & 3)], va[nrb >> 2][2 * (nrb & 3) + 1]);
-				else if constexpr (rb == 3) x3s_wait8<0>(va[1]);
-				else if constexpr (rb == 7) x3s_wait8<NFR>(va[0]);
-				{ float v[8]; operand(nrb, v); split3(v, op[nxt][0], op[nxt][1], op[nxt][2]); }
-				// MFMA (t, cb), t = term (smallest first: planes (fragment, operand) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)), then the request slot behind it: slot = t NC + cb.
-				// x-tiled: the eight loads of a group in slots 1, 3, .. 15 (NC = 2: 0 .. 7) of phases 3 / 7; y-tiled: the row block's pair in slots 1 and 3 of every phase;
-				// the fragments in phase 4: NC = 4: slots 4 .. 15; NC = 2: slots 4, 6, .. 14
-				auto issue = [&](auto SLOT, bf16x8& tie) __attribute__((always_inline)) {
-					constexpr int slot = decltype(SLOT)::value;
-					if constexpr (RA && TR && (slot == 1 || slot == 3)) {
-						constexpr int i = 2 * (rb & 3) + (slot == 3 ? 1 : 0);
-						x3s_load_v_tied<x3s_a_off<TR, IMG>(i)>(va[rb >> 2][i], rb < 4 ? sn0_ : sn1_, tie);
-					}
-					if constexpr (RA && !TR && (rb == 3 || rb == 7) && NC == 4 && (slot & 1) == 1 && slot < 16)
-						x3s_load_v_tied<x3s_a_off<TR, IMG>(slot >> 1)>(va[rb >> 2][slot >> 1], rb == 3 ? sn0_ : sn1_, tie);
-					if constexpr (RA && !TR && (rb == 3 || rb == 7) && NC == 2 && slot < 8)
-						x3s_load_v_tied<x3s_a_off<TR, IMG>(slot)>(va[rb >> 2][slot], rb == 3 ? sn0_ : sn1_, tie);
-					if constexpr (RF && rb == 4 && NC == 4 && slot >= 4 && slot < 16) {
-						constexpr int fi = slot - 4, cb = fi / 3, pl = fi % 3;
-						x3s_load_a_tied<x3s_f_off(cb, pl)>(fb[u ^ 1][cb][pl], cb < 2 ? fn_ : fn1_, tie);
-					}
-					if constexpr (RF && rb == 4 && NC == 2 && slot >= 2 && slot < 8) {
-						constexpr int fi = slot - 2, cb = fi / 3, pl = fi % 3;
-						x3s_load_a_tied<x3s_f_off(cb, pl)>(fb[u ^ 1][cb][pl], fn_, tie);
-					}
-				};
-				auto term = [&](auto T, auto PF, auto PO) __attribute__((always_inline)) {
-					constexpr int t = decltype(T)::value, pf = decltype(PF)::value, po = decltype(PO)::value;
-					acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[u][0][pf]), op[cur][po], acc[rb][0], 0, 0, 0);
-					issue(X3S_IC(t * NC + 0), op[cur][po]);
-					acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[u][1][pf]), op[cur][po], acc[rb][1], 0, 0, 0);
-					issue(X3S_IC(t * NC + 1), op[cur][po]);
-					if constexpr (NC == 4) {
-						acc[rb][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[u][2][pf]), op[cur][po], acc[rb][2], 0, 0, 0);
-						issue(X3S_IC(t * NC + 2), op[cur][po]);
-						acc[rb][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[u][3][pf]), op[cur][po], acc[rb][3], 0, 0, 0);
-						issue(X3S_IC(t * NC + 3), op[cur][po]);
-					}
-				};
-				term(X3S_IC(0), X3S_IC(0), X3S_IC(2));
-				term(X3S_IC(1), X3S_IC(2), X3S_IC(0));
-				term(X3S_IC(2), X3S_IC(1), X3S_IC(1));
-				term(X3S_IC(3), X3S_IC(0), X3S_IC(1));
-				term(X3S_IC(4), X3S_IC(1), X3S_IC(0));
-				term(X3S_IC(5), X3S_IC(0), X3S_IC(0));
-				constexpr int NM = 6 * NC;                      // MFMAs of the phase; 44 VALU of the split (+ a few of addressing)
-				constexpr int VPM = (44 + NM - 1) / NM;
-#pragma unroll
-				for (int gi = 0; gi < NM; ++gi) {
-					__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-					__builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // VALU
-				}
-				__builtin_amdgcn_sched_barrier(0);
-			};
-			phase(X3S_IC(0)); phase(X3S_IC(1)); phase(X3S_IC(2)); phase(X3S_IC(3)); phase(X3S_IC(4)); phase(X3S_IC(5)); phase(X3S_IC(6)); phase(X3S_IC(7));
-		};
-		int S = S0;
-		for (; S + 2 <= S1; S += 2) {
-			step(std::integral_constant<int, 0>{}, S);
-			step(std::integral_constant<int, 1>{}, S + 1);
-		}
-		if (S < S1) step(std::integral_constant<int, 0>{}, S);
-		// the last step's requests (re-reads that nobody uses) are still in flight and hipcc does not know of them: wait, and keep their destination registers
-		// live until then
-		x3s_wait8<0>(va[0]); x3s_wait8<0>(va[1]);
-		x3s_wait_frags<0, NC>(fb[0]); x3s_wait_frags<0, NC>(fb[1]);
-		__builtin_amdgcn_sched_barrier(0);
-#undef X3S_IC
-		if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); t_loop1 = __builtin_amdgcn_s_memtime(); r_loop1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
-	}
-
-	if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); r_tail = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
-	// in-workgroup sum of the four waves' tiles through LDS in wave order, sixteen 16 x 16 tiles per round; a lane's accumulator IS a 16-byte piece of the
-	// slab (four consecutive panel columns of one row)
-	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
-	float* slab = slabs + (long)sp * slab_stride;
-	constexpr int ROUNDS = 8 * NC / 16;
-#pragma unroll
-	for (int rd = 0; rd < ROUNDS; ++rd) {
-		if (rd > 0) __syncthreads();
-#pragma unroll
-		for (int tl = 0; tl < 16; ++tl) {
-			const int t = 16 * rd + tl;
-			l4[(wave * 16 + tl) * 64 + lane] = acc[t / NC][t % NC];
-		}
-		__syncthreads();
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const int tl = wave * 4 + i;
-			const int t = 16 * rd + tl, rb = t / NC, cb = t % NC;
-			f32x4 s = l4[(0 * 16 + tl) * 64 + lane];
-#pragma unroll
-			for (int p = 1; p < 4; ++p) s += l4[(p * 16 + tl) * 64 + lane];
-			const int x = xt * TH + (TR ? 16 * rb + r16 : 64 * (rb >> 2) + 4 * r16 + (rb & 3));
-			*reinterpret_cast<f32x4*>(slab + (long)x * RP + coff + 16 * cb + 4 * kq) = s;
-		}
-	}
-	if (DIAG != 0 && stamps != nullptr) {
-		__builtin_amdgcn_s_waitcnt(0);
-		const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
-		if (lane == 0) {
-			// as k_factor_product_x3: shader cycles and 100 MHz ticks in the main loop, K-steps (of 16) run there; then 100 MHz stamps of the wave's life
-			unsigned long long* o = stamps + 8 * ((long)blockIdx.x * 4 + wave);
-			o[0] = t_loop1 - t_loop0; o[1] = r_loop1 - r_loop0; o[2] = (unsigned long long)(2 * (S1 - S0));
-			o[3] = r_entry; o[4] = r_loop0; o[5] = r_loop1; o[6] = r_tail; o[7] = r_end;
-		}
-	}
-}
-
 // Every wave piece (four per slice) gets at least two turns of the 3-deep ring; as many slices as fill the chip.
 // reserve: CUs kept free for passenger workgroups beyond the sixteen (K-split Gram passengers of a column shard's W^T V)
 int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
@@ -750,31 +478,6 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	return hipGetLastError();
 }
 
-template <int NBW, bool TR, int IMG, int DIAG = 0>
-static hipError_t launch_fp_x3s(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
-                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
-	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
-	const bool with_reduce = wanted && RP == 64;
-	if (wanted && !with_reduce) return hipErrorInvalidValue;
-	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
-	if (NBW == 1 && RP != 64) return hipErrorInvalidValue;
-	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(256);
-	const size_t lds_bytes = 4 * 16 * 64 * sizeof(f32x4);          // the epilogue's exchange image (the passengers need less)
-	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3s<NBW, TR, IMG, DIAG>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	if (t_ev_start != nullptr && t_ev_stop != nullptr) {
-		const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
-		t_ev_start = t_ev_stop = nullptr;
-		hipExtLaunchKernelGGL((k_factor_product_x3s<NBW, TR, IMG, DIAG>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
-		                      A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
-		return hipGetLastError();
-	}
-	hipLaunchKernelGGL((k_factor_product_x3s<NBW, TR, IMG, DIAG>), grid, block, lds_bytes, stream,
-	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
-	return hipGetLastError();
-}
-
 // y_tiled: A is the image tiled along the REDUCTION index (128-row tiles of y, tile_stride apart, each holding all x as
 // columns of 128 contiguous y) -- i.e. the x-tiled image of the transposed matrix; steps_total K-steps of 16 y, and the
 // image must cover 128 * xtiles columns.  image_tile: rows of the tiled index per tile of the image, 128 (tile_stride = 128 *
@@ -788,38 +491,6 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
 	t_ev_start = ev_start; t_ev_stop = ev_stop;
 	struct Clear { ~Clear() { t_ev_start = t_ev_stop = nullptr; } } clear_on_exit;      // (a path that did not consume them -- an error return, grid.y > 1 -- leaves nothing behind)
-	// Round 5: panels of 64 k columns (k odd) run on the 16 x 16 x 32 MFMA shape (k_factor_product_x3s); NMFAMD_X3_SHAPE32 (measurement builds) keeps the 32 x 32 x 16 kernel.
-	// Whole multiples of 128 columns stay on the 128-column form of the 32 x 32 x 16 kernel (half the passes over A).
-	static const bool shape32 = tuning_env("NMFAMD_X3_SHAPE32") != nullptr;
-	// (the 128 x 32 form, two workgroups per CU at 256 registers each, does not fit that budget with its ring in written-out loads yet: it stays on the 32 x 32 x 16 kernel)
-	if (!shape32 && RP % 128 != 0 && !(y_tiled && image_tile != 16) && !(RP == 64 && p.col_split == 2)) {
-		const bool fold = false;
-#ifdef NMFAMD_DIAG_BUILD
-		if (image_tile == 16 && RP == 64 && stamps != nullptr && !fold) {
-			// stamped forms (tools/stamp_x3.py): NMFAMD_X3_VARIANT = 10..13 the x-tiled form, 30..33 the y-tiled one; last digit 0 = no ring refill, 1 = A only, 2 = F only, 3 = the production loop
-			static const int yv = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();
-			if (!y_tiled) switch (yv % 10) {
-				case 0: return launch_fp_x3s<2, false, 16, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				case 1: return launch_fp_x3s<2, false, 16, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				case 2: return launch_fp_x3s<2, false, 16, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				default: return launch_fp_x3s<2, false, 16, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			}
-			switch (yv % 10) {
-				case 0: return launch_fp_x3s<2, true, 16, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				case 1: return launch_fp_x3s<2, true, 16, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				case 2: return launch_fp_x3s<2, true, 16, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-				default: return launch_fp_x3s<2, true, 16, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			}
-		}
-#endif
-		if (stamps != nullptr) return hipErrorNotSupported;
-		if (image_tile == 16) {
-			if (fold) return y_tiled ? launch_fp_x3s<1, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3s<1, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-			return y_tiled ? launch_fp_x3s<2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3s<2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		}
-		if (fold) return launch_fp_x3s<1, false, 128>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return launch_fp_x3s<2, false, 128>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-	}
 #ifdef NMFAMD_DIAG_BUILD
 	if (image_tile == 16 && RP == 64 && stamps != nullptr) {
 		// stamped diagnostic builds of the PRODUCTION forms on the one resident image (tools/stamp_x3.py): NMFAMD_X3_VARIANT = 10..13 the x-tiled form,

@@ -672,8 +672,10 @@ def team_worker(args):
             print(f"bench.py: team rank {g} failed in phase '{_PHASE['name']}': {e!r}", file=sys.stderr, flush=True)
         raise SystemExit(4)
     elapsed = max(r[0] for r in res)
+    selftest = group.selftest_report() or "peer-transport self-test: not run"
     out = multi_line(args, problems[0], N, elapsed, res[0][1], res[0][2],
-                     "in-library team (one process, one rank thread per GPU; in-process transport: the ranks' kernels read each other's buffers in place, peer access over xGMI)",
+                     "in-library team (one process, one rank thread per GPU; in-process transport: the ranks' kernels read each other's buffers in place, peer access over xGMI; "
+                     + selftest + ")",
                      shared_devices=devices if devices < N else 0)
     print(json.dumps(out), flush=True)
 

@@ -209,6 +209,13 @@ NMFAMD_API void nmfamd_local_group_abort(nmfamd_local_group* g);
 NMFAMD_API int nmfamd_comm_create_local(nmfamd_local_group* g, int rank, nmfamd_comm** out);
 /* why nmfamd_comm_create_local failed: names the pair of devices that cannot map each other's memory (valid until the calling thread's next call) */
 NMFAMD_API const char* nmfamd_local_group_last_error(nmfamd_local_group* g);
+/* Set-up self-test of the in-process transport (run by nmfamd_comm_create_local when world > 1; NMFAMD_SELFTEST=0 skips it): every rank publishes a pattern in
+ * both exchange slots and in a collective's buffer, every rank reads every peer's through the kernels the iteration uses (the W update's prologue, the r x r
+ * sum, the reduce / gather kernels) and checks every word; then a second pattern at the SAME addresses.  A mismatch fails nmfamd_comm_create_local on every
+ * rank and names the (reader, owner) pair in nmfamd_local_group_last_error.  One line about the test (empty before it ran; valid until the thread's next call).
+ * Lifetime rules of the transport: the exchange buffers belong to the GROUP and live until every rank has closed its communicator; closing a communicator
+ * (nmfamd_comm_destroy) first drains the rank's device, so that no kernel of this rank still reads a peer's buffer. */
+NMFAMD_API const char* nmfamd_local_group_selftest(nmfamd_local_group* g);
 /* "rccl" / "in-process (peer reads)" */
 NMFAMD_API const char* nmfamd_comm_transport(const nmfamd_comm* c);
 /* nmfamd_engine_create with the padded row count rounded up to a multiple of 128 * row_blocks (equal row blocks of W) */

@@ -221,6 +221,12 @@ const char* nmfamd_local_group_last_error(nmfamd_local_group* g) {
 	return text.c_str();
 }
 
+const char* nmfamd_local_group_selftest(nmfamd_local_group* g) {
+	static thread_local std::string text;
+	text = (g && g->g) ? local_group_selftest(*g->g) : std::string();
+	return text.c_str();
+}
+
 const char* nmfamd_comm_transport(const nmfamd_comm* c) { return (c && c->c) ? c->c->transport() : ""; }
 
 int nmfamd_sharded_create(nmfamd_engine* e, nmfamd_comm* c, int mode, long rows, long total_columns, nmfamd_sharded** out) {

@@ -79,5 +79,7 @@ void local_group_barrier(LocalGroup& g);
 void local_group_abort(LocalGroup& g);
 // why a set-up on this group failed (which pair of devices could not map each other's memory); empty when nothing failed
 std::string local_group_failure(LocalGroup& g);
+// one line about the set-up self-test of the peer transport (empty: not run -- all ranks on one device and NMFAMD_SELFTEST unset)
+std::string local_group_selftest(LocalGroup& g);
 
 } // namespace nmfamd

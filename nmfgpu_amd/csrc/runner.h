@@ -246,7 +246,12 @@ public:
 		return command(CMD_STORE);
 	}
 	void synchronize() override { (void)command(CMD_SYNC); }
-	const char* describe() const override { return local_ ? "column shards, in-process peer-read transport" : "column shards, RCCL"; }
+	const char* describe() const override {
+		if (!local_) return "column shards, RCCL";
+		describe_text_ = "column shards, in-process peer-read transport";
+		if (transport_group_) { const std::string t = nmfamd::local_group_selftest(*transport_group_); if (!t.empty()) describe_text_ += "; " + t; }
+		return describe_text_.c_str();
+	}
 	const char* last_error() const override { return error_.c_str(); }
 
 private:
@@ -389,6 +394,7 @@ private:
 	bool rccl_fallback_ = false, fallback_id_ok_ = false;
 	std::vector<std::unique_ptr<Rank>> ranks_;
 	std::string error_;
+	mutable std::string describe_text_;
 	std::vector<std::thread> workers_;
 	std::shared_ptr<nmfamd::LocalGroup> rendezvous_, transport_group_;
 	unsigned char unique_id_[nmfamd::COMM_UNIQUE_ID_BYTES] = {0};

@@ -300,6 +300,13 @@ class LocalGroup:
         if getattr(self, "_h", None):
             self._lib.nmfamd_local_group_abort(self._h)
 
+    def selftest_report(self) -> str:
+        """One line about the transport's set-up self-test (empty before the ranks have joined, or when NMFAMD_SELFTEST=0 skipped it)."""
+        if not getattr(self, "_h", None):
+            return ""
+        self._lib.nmfamd_local_group_selftest.restype = C.c_char_p
+        return (self._lib.nmfamd_local_group_selftest(self._h) or b"").decode()
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.nmfamd_local_group_destroy(self._h)

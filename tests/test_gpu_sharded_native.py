@@ -433,3 +433,90 @@ def test_team_of_rank_threads_through_the_c_abi_runs_twice_on_one_communicator()
     assert np.array_equal(results[("repl", 0)][0], results[("repl again", 0)][0])
     for g in range(world):
         assert np.array_equal(results[("repl", g)][1], results[("repl again", g)][1])
+
+
+def _join_group(world, env_report=None):
+    """`world` rank threads on device 0 join one in-process group; returns (errors, selftest report of the group)."""
+    import threading
+    import torch
+    group = na.LocalGroup(world)
+    errors, comms = [], [None] * world
+
+    def rank_thread(g):
+        try:
+            torch.cuda.set_device(0)
+            comms[g] = na.LocalComm(group, g)
+        except BaseException as e:          # noqa: BLE001
+            errors.append((g, e))
+
+    threads = [threading.Thread(target=rank_thread, args=(g,), daemon=True) for g in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    report = group.selftest_report()
+    for c in comms:
+        if c is not None:
+            c.close()
+    return errors, report
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_peer_transport_selftest_passes_on_a_shared_device(world):
+    """Set-up self-test of the in-process transport: pattern A then pattern B at the SAME addresses, both exchange slots and the collectives' buffers,
+    read through the iteration's own kernels (k_mu64_update32 with PeerSlabs, k_sum_peers, k_local_sum, k_local_gather), every word checked; a one-off of about a millisecond."""
+    import re
+    errors, report = _join_group(world)
+    assert not errors, errors[:1]
+    assert f"{world} ranks" in report and "passed" in report, report
+    # (the first group of a fresh process pays for loading the kernels' code objects -- ~100 ms once; the second group is the steady figure)
+    errors, report = _join_group(world)
+    assert not errors and "passed" in report
+    ms = float(re.search(r"\(([\d.]+) ms\)", report).group(1))
+    print(report)
+    assert ms < 5.0, report
+
+
+def test_peer_transport_selftest_names_the_pair_when_an_owner_skips_its_second_write(tmp_path):
+    """Fault injection (measurement build only: NMFAMD_SELFTEST_FAULT = rank): the owner skips its pattern-B writes, so every reader finds pattern A at the addresses it
+    read before -- what a stale line would look like.  The set-up fails on EVERY rank and the failure text names reader and owner; nmfgpu::compute with numGpus then
+    returns ErrorExternalLibrary instead of iterating on a transport that did not deliver."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "nmfgpu_amd", "lib", "libnmfgpu64_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("measurement build (python -m nmfgpu_amd.build --diag) not present")
+    code = r'''
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np, torch
+import nmfgpu_amd as na
+world = 3
+group = na.LocalGroup(world)
+errors = []
+def rank_thread(g):
+    try:
+        torch.cuda.set_device(0)
+        na.LocalComm(group, g)
+    except BaseException as e:
+        errors.append((g, str(e)))
+ts = [threading.Thread(target=rank_thread, args=(g,)) for g in range(world)]
+[t.start() for t in ts]; [t.join(120) for t in ts]
+print("ERRORS", len(errors)); print("TEXT", errors[0][1] if errors else ""); print("REPORT", group.selftest_report())
+na.initialize(); na.set_verbosity(na.Verbosity.Nothing)
+rng = np.random.default_rng(0)
+V = np.asfortranarray(rng.random((300, 200)).astype(np.float32))
+W = np.asfortranarray(rng.random((300, 64)).astype(np.float32)); H = np.asfortranarray(rng.random((64, 200)).astype(np.float32))
+res = na.compute(V, W, H, algorithm=na.NmfAlgorithm.Multiplicative, iterations=5, parameters={"numGpus": 2, "shardMode": 1})
+print("COMPUTE", res.name)
+''' % root
+    env = dict(os.environ, NMFAMD_LIBRARY=diag, NMFAMD_SELFTEST_FAULT="1", NMFAMD_COMM="p2p")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    assert "ERRORS 3" in text, text                                   # every rank's set-up failed
+    assert "owner rank 1" in text and "reader rank" in text and "pattern B" in text, text
+    assert "FAILED" in text
+    assert "COMPUTE ErrorExternalLibrary" in text, text

@@ -493,10 +493,11 @@ def main():
             "value": world * K / elapsed,
             "unit": "iterations/s" if world == 1 else "shard-iterations/s (one 10000x5000 column shard per GPU)",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: dense random V 10000x5000 (per GPU), r=64, MU Frobenius, fp32" if algorithm == "mu" else
+            # (N = 1 is the first point of north_star's 1/2/4/8 series of the ONE 10000 x 5000 problem, which `--gpus N` column-shards: strong scaling)
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: dense random V 10000x5000, r=64, MU Frobenius, fp32" if algorithm == "mu" else
                                    f"configs[4]: {names[algorithm]} at dense random V 10000x5000, r=64, fp32, parameters {alg_kw}",
-                       "rows": M, "columns_per_gpu": N_COLS, "features": R, "error_every": 10, "setup_iterations": 0 if args.sharded else SETUP_ITERATIONS, "parallelism": parallelism,
+                       "rows": M, "columns": N_COLS, "features": R, "error_every": 10, "setup_iterations": 0 if args.sharded else SETUP_ITERATIONS, "parallelism": parallelism,
                        "arithmetic": ("fp32 operands and fp32 accumulation; the two big products run on the bf16 matrix pipe with every operand "
                                       "split EXACTLY into three bf16 terms (six cross products kept, dropped terms <= 2^-23 relative): measured "
                                       "error against fp64 equals the native fp32 MFMA kernel's (tests/test_gpu_parity.py)") if product_kernel == 2
@@ -927,9 +928,8 @@ def main_c4(args):
             roofline = {"bound": "hbm", "achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": measured_traffic("factor_product_bf16", "nmfgpu_amd/csrc/kernels_bf16.hip")[0], "kernel": "k_factor_product_bf16",
                         "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches, "bytes_per_launch": bytes_per_launch,
-                        **({} if os.environ.get("NMFAMD_TRI_RIDE", "")[:1] == "0" else {"launch_also_carries": "32 passenger workgroups: the 256 x 256 Gram matrix of the launch's factor operand, its diagonal and split image (tri_gram_tile.h; "
-                                               "NMFAMD_TRI_RIDE=0 puts them back on four launches of their own): a product launch is 10-15 us longer than alone, the iteration "
-                                               "14 us shorter; bytes_per_launch counts the product's stream of V only"})}
+                        "launch_also_carries": "32 passenger workgroups: the 256 x 256 Gram matrix of the launch's factor operand, its diagonal and split image (tri_gram_tile.h): "
+                                               "a product launch is 10-15 us longer than alone, the iteration 14 us shorter; bytes_per_launch counts the product's stream of V only"}
         iter_flops = 4.0 * m * n * r + 6.0 * r * r * (m + n)
         print(json.dumps({
             "metric": "nsNMF iterations/sec, bf16 operands, dense 50000 x 6250 column shard per GPU, r=256",

@@ -54,3 +54,25 @@ def library() -> C.CDLL:
         _share_torch_hip_runtime()
         _lib = C.CDLL(_PATH, mode=C.RTLD_LOCAL)
     return _lib
+
+
+class use_library:
+    """Context manager for tests and measurements: another BUILD of the same library (the measurement build, nmfgpu_amd/lib/libnmfgpu64_diag.so) becomes what library()
+    returns inside the block.  Objects created inside keep the library they were created with.  Never a fallback: the file must exist."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise LibraryMissing(f"{path} not found (python -m nmfgpu_amd.build --diag)")
+        self._path = path
+
+    def __enter__(self):
+        global _lib
+        library()                          # (the default one first: it decides which HIP runtime the process shares)
+        self._saved = _lib
+        _lib = C.CDLL(self._path, mode=C.RTLD_LOCAL)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False

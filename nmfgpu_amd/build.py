@@ -21,6 +21,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
+# the measurement build (-DNMFAMD_DIAG_BUILD, csrc/tuning.h): the same library with its A/B switches and stamped kernel variants compiled in; the tests that compare
+# kernel FORMS with each other select them there (tests/conftest.py, fixture diag_build); never loaded by the product path
+DIAG_LIB = os.path.join(LIBDIR, "libnmfgpu64_diag.so")
 SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "kernels_onepass.hip", "kernels_tri.hip", "comm.hip", "engine.cpp", "sharded.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
 ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 # translation units without device code or HIP runtime calls: plain C++ (function multiversioning
@@ -83,24 +86,24 @@ def packed_scalar_sources(obj: str) -> list:
 
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     """diag: the measurement build (-DNMFAMD_DIAG_BUILD, csrc/tuning.h) -> lib/libnmfgpu64_diag.so; select it with NMFAMD_LIBRARY."""
-    global LIB, OBJDIR, USER_FLAGS
+    lib, objdir, user_flags = LIB, OBJDIR, USER_FLAGS
     if diag:
-        LIB = os.path.join(LIBDIR, "libnmfgpu64_diag.so")
-        OBJDIR = os.path.join(LIBDIR, "obj_diag")
-        USER_FLAGS = [*USER_FLAGS, "-DNMFAMD_DIAG_BUILD"]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps():
-        return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
+        lib = DIAG_LIB
+        objdir = os.path.join(LIBDIR, "obj_diag")
+        user_flags = [*USER_FLAGS, "-DNMFAMD_DIAG_BUILD"]
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _deps():
+        return lib
+    os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if src in HOST_ONLY:
             cmd = [cc, *[f for f in FLAGS if not f.startswith("--offload-arch")], "-x", "c++", "-pthread", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
-            cmd = [cc, *FLAGS, *DEVICE_FLAGS, *EXTRA_FLAGS.get(src, []), *USER_FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc, *FLAGS, *DEVICE_FLAGS, *EXTRA_FLAGS.get(src, []), *user_flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -124,10 +127,10 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     if bad:
         raise RuntimeError("packed fp32 instructions with a scalar-register source (csrc/split3.h, in_vgpr):\n" + "\n".join(bad[:40]))
     # -z defs: an undefined symbol fails the link here, not at the first call inside a running process
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB + ".tmp", *objs]
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib + ".tmp", *objs]
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":

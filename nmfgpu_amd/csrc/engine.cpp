@@ -139,7 +139,7 @@ Status Engine<T>::allocate() {
 		// workgroups (tri_gram_tile.h) -- its consumer is the update kernel behind the launch.  V (S H)^T leaves the CUs free as it is (config 4: 224 workgroups);
 		// W^T V is planned with one K slice fewer (9 -> 8: 252 -> 224 workgroups).  NMFAMD_TRI_RIDE = 0 / h / w: none / only (S H)(S H)^T / only W^T W.
 		if (RP_ == 256 && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && tri_kernels_available(RP_)) {
-			const char* e = std::getenv("NMFAMD_TRI_RIDE");
+			const char* e = tuning_env("NMFAMD_TRI_RIDE");
 			const bool want_w = e == nullptr || (e[0] != '0' && e[0] != 'h'), want_h = e == nullptr || (e[0] != '0' && e[0] != 'w');
 			if (want_w && num_cus_ > 2 * TRI_PASSENGERS) {
 				FactorProductPlan t = planH_;
@@ -180,7 +180,7 @@ Status Engine<T>::allocate() {
 			const double pairs = (ksH_ + 2) / 2;
 			while (gram_ksplit_ < GRAM_KSPLIT_MAX && 24.0 * (pairs / 317.0) / gram_ksplit_ > 0.55 * product_us) gram_ksplit_ *= 2;      // (24 us for config 2's 317 pairs in one slice: one CU's L2 rate, gram_image.h)
 			// (NMFAMD_GRAM_KSPLIT = 1 / 2 / 4 / 8 forces the slice count: the parity tests run every form at shapes the oracle covers)
-			if (const char* e = std::getenv("NMFAMD_GRAM_KSPLIT")) { const int k = std::atoi(e); if (k == 1 || k == 2 || k == 4 || k == 8) gram_ksplit_ = k; }
+			if (const char* e = tuning_env("NMFAMD_GRAM_KSPLIT")) { const int k = std::atoi(e); if (k == 1 || k == 2 || k == 4 || k == 8) gram_ksplit_ = k; }
 		}
 		planH_.splits = plan_splits_x3(planH_.xtiles, ksH_, num_cus_, gram_ksplit_ > 1 ? GRAM_IMAGE_TILES * gram_ksplit_ : 0);
 		planW_.splits = plan_splits_x3(planW_.xtiles, ksW_, num_cus_);
@@ -214,7 +214,7 @@ Status Engine<T>::allocate() {
 		w_col_split_ = false;
 		if (RP_ == 64 && fused_capable() && !one_image_ && 2 * planW_.xtiles + GRAM_REDUCE_BLOCKS <= 2 * num_cus_) {
 			w_col_split_ = ksW_ <= 80 && 4 * planW_.xtiles >= num_cus_;
-			if (const char* e = std::getenv("NMFAMD_X3_COLSPLIT")) { const int v = std::atoi(e); if (v == 0) w_col_split_ = false; else if (v == 1) w_col_split_ = true; }
+			if (const char* e = tuning_env("NMFAMD_X3_COLSPLIT")) { const int v = std::atoi(e); if (v == 0) w_col_split_ = false; else if (v == 1) w_col_split_ = true; }
 			if (w_col_split_) { planW_.splits = planWx_.splits = 1; planWx_.col_split = 2; }
 		}
 		// (measurement builds, NMFAMD_X3_COLSPLIT = 2: both products from 128 x 32 workgroups, two per CU, with the plan's K slices)
@@ -295,7 +295,7 @@ Status Engine<T>::allocate() {
 			HIPX(dalloc(&Gw_raw_, rr));
 			HIPX(dalloc(&Gh_raw_, rr));
 			HIPX(dalloc(&colsq_, (long)RP_ * colsq_stage_parts()));
-			tri_w_den_bf16_ = std::getenv("NMFAMD_TRI_FP32_DEN") == nullptr;
+			tri_w_den_bf16_ = tuning_env("NMFAMD_TRI_FP32_DEN") == nullptr;
 		}
 	}
 	if (alg_ == ALG_NSNMF) {
@@ -789,7 +789,7 @@ Status Engine<T>::fetch_error_terms(int count_n) {
 		return ST_OK;
 	}
 	// (a kernel that writes the pinned buffer, not hipMemcpyAsync: the runtime's copy idles the stream for ~18 us around its blit; NMFAMD_ERROR_MEMCPY=1 restores it)
-	static const bool use_memcpy = std::getenv("NMFAMD_ERROR_MEMCPY") != nullptr;
+	static const bool use_memcpy = tuning_env("NMFAMD_ERROR_MEMCPY") != nullptr;
 	if (use_memcpy || pin_psN_dev_ == nullptr) HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
 	else HIPX(launch_copy_small<T>(pin_psN_dev_, psN_, ps_stride_ + r_, stream_));
 	HIPX(hipEventRecord(err_event_, stream_));
@@ -1255,7 +1255,7 @@ template <typename T>
 Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (from_gram_partials) {
-			if (x3_ && Graw64_ != nullptr && std::getenv("NMFAMD_NORMALIZE_TWO_LAUNCHES") == nullptr) {
+			if (x3_ && Graw64_ != nullptr && tuning_env("NMFAMD_NORMALIZE_TWO_LAUNCHES") == nullptr) {
 				// ONE launch (round 4): column scales from the update's sums of squares, G = D (sum of the partial Gram matrices) D, W <- W D and its split image
 				HIPX(launch_gram64_reduce_scale_all(gramW_part_, (int)(mpad_ / 64), sumsq_part_, norm_parts, G_, scale_, Wt_, (int)mpad_, Wx3_, ksH_, stream_));
 			} else if (x3_ && Graw64_ != nullptr) {

@@ -1,5 +1,6 @@
 // sharded.cpp -- one rank of the column-sharded multiplicative update (see sharded.h).
 #include "sharded.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <cmath>
@@ -33,9 +34,9 @@ Status ShardedRank<T>::prepare() {
 	// buffers alternate, ONE rendezvous per iteration (Comm::exchange_publish).  NMFAMD_SHARD_REHEARSE=1 makes a team of ONE go through exactly that path
 	// (panel written, published, read back by pointer, r x r part summed by the small launch) instead of the fused single-GPU iteration it would otherwise
 	// equal: what a rank of an N-GPU team runs, minus link time and the cross-device event wait -- the basis of DESIGN section 6's projection.
-	const char* rehearse = std::getenv("NMFAMD_SHARD_REHEARSE");
+	const char* rehearse = tuning_env("NMFAMD_SHARD_REHEARSE");
 	rehearse_ = world == 1 && rehearse != nullptr && std::atoi(rehearse) != 0;
-	const char* no_direct = std::getenv("NMFAMD_SHARD_NO_DIRECT");
+	const char* no_direct = tuning_env("NMFAMD_SHARD_NO_DIRECT");
 	direct_ = mode_ == SHARD_REPLICATED && eng_->direct_w_finish() && comm_->direct_exchange() && !(no_direct != nullptr && std::atoi(no_direct) != 0);
 	eng_->set_sole_rank(world == 1 && mode_ == SHARD_REPLICATED && !rehearse_);
 	long first = 0, count = 0;

@@ -1,12 +1,16 @@
 // tuning.h -- where measurement switches live (internal header).
 //
 // Two kinds of environment variables reach this library:
-//   * behaviour the tests and callers rely on (cross-check paths, layout choices, thread counts): read with
-//     std::getenv where they are used -- NMFAMD_FORCE_VALU, NMFAMD_NO_FUSED_MU, NMFAMD_ONE_IMAGE, NMFAMD_FP_TILE,
-//     NMFAMD_GRAM_PARTIALS, NMFAMD_GRAM_KSPLIT, NMFAMD_X3_COLSPLIT, NMFAMD_TRI_RIDE, NMFAMD_ERROR_MEMCPY, NMFAMD_SHARD_REHEARSE, NMFAMD_SHARD_NO_DIRECT, NMFAMD_HOST_THREADS, NMFAMD_COMM, NMFAMD_MALL_MB, NMFAMD_ONE_PASS, NMFAMD_KL_BLOCK_KB, NMFAMD_TRI_FP32_DEN;
-//   * A/B switches and stamped kernel variants that exist for measurements only: those go through tuning_env() and are
-//     dead code in the shipped library -- they are compiled in by `python -m nmfgpu_amd.build --diag`
-//     (-DNMFAMD_DIAG_BUILD, output lib/libnmfgpu64_diag.so; select it with NMFAMD_LIBRARY).
+//   * behaviour callers may rely on, read with std::getenv where they are used -- the complete list (tests/test_abi.py checks the shipped .so's strings against it):
+//       NMFAMD_COMM (transport of a numGpus team: rccl / p2p), NMFAMD_SELFTEST (0: skip the peer transport's set-up self-test), NMFAMD_HOST_THREADS (host initialisers),
+//       NMFAMD_MALL_MB (size of the memory-side cache when the device does not report it), NMFAMD_KL_BLOCK_KB (L2 block of the KL gather), NMFAMD_ONE_IMAGE (0 / 1: two
+//       images of V or one), NMFAMD_ONE_PASS (1: the opt-in one-pass iteration), and the cross-check PATHS the parity tests compare with each other -- all of them
+//       complete, correct implementations: NMFAMD_FORCE_VALU, NMFAMD_NO_FUSED_MU, NMFAMD_GRAM_PARTIALS, NMFAMD_FP_TILE;
+//   * A/B switches, forced kernel forms, rehearsal modes and stamped kernel variants that exist for measurements and form-against-form tests only: those go through
+//     tuning_env() and are dead code in the shipped library -- they are compiled in by `python -m nmfgpu_amd.build --diag` (-DNMFAMD_DIAG_BUILD, output
+//     lib/libnmfgpu64_diag.so; tests/conftest.py `diag_build`, tools: NMFAMD_LIBRARY).  Round 5 moved here: NMFAMD_SHARD_REHEARSE (a value > 1 makes a rank update
+//     1 / N of W's rows: timing only, the factors mean nothing), NMFAMD_SHARD_NO_DIRECT, NMFAMD_ERROR_MEMCPY, NMFAMD_GRAM_KSPLIT, NMFAMD_X3_COLSPLIT, NMFAMD_TRI_RIDE,
+//     NMFAMD_TRI_FP32_DEN, NMFAMD_NORMALIZE_TWO_LAUNCHES.
 #pragma once
 
 #include <cstdlib>

@@ -166,3 +166,21 @@ def test_no_packed_fp32_instruction_reads_a_scalar_register():
     assert b._PACKED_SCALAR.search("v_pk_mul_f32 v[2:3], v[2:3], s4")
     assert not b._PACKED_SCALAR.search("v_pk_fma_f32 v[22:23], v[36:37], v[22:23], v[42:43] op_sel_hi:[0,1,0]")
     assert not b._PACKED_SCALAR.search("v_pk_mul_f32 v[2:3], v[2:3], v[36:37]")
+
+
+def test_shipped_library_reads_only_the_documented_environment_variables():
+    """Product-library hygiene: the A/B switches, forced kernel forms and rehearsal modes live behind tuning_env() and exist in the measurement build
+    only (csrc/tuning.h); the shipped libnmfgpu64.so may name nothing but the behavioural variables listed there.  NMFAMD_SHARD_REHEARSE in particular -- a value > 1
+    makes a rank update 1 / N of W's rows -- must not be readable from the product."""
+    import re
+    import subprocess
+    from nmfgpu_amd import _lib
+    allowed = {"NMFAMD_COMM", "NMFAMD_SELFTEST", "NMFAMD_HOST_THREADS", "NMFAMD_MALL_MB", "NMFAMD_KL_BLOCK_KB", "NMFAMD_ONE_IMAGE", "NMFAMD_ONE_PASS",
+               "NMFAMD_FORCE_VALU", "NMFAMD_NO_FUSED_MU", "NMFAMD_GRAM_PARTIALS", "NMFAMD_FP_TILE"}
+    path = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "lib", "libnmfgpu64.so")
+    text = subprocess.run(["strings", "-n", "8", path], check=True, capture_output=True, text=True).stdout
+    found = set(re.findall(r"NMFAMD_[A-Z0-9_]+", text))
+    assert found <= allowed, sorted(found - allowed)
+    header = open(os.path.join(ROOT, "nmfgpu_amd", "csrc", "tuning.h")).read()
+    for name in sorted(found):
+        assert name in header, f"{name} is read by the shipped library but not documented in csrc/tuning.h"

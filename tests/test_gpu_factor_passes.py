@@ -190,10 +190,10 @@ def test_rank256_bf16_path_tracks_fp32(m, n):
 
 
 @pytest.mark.parametrize("m,n", [(33000, 140), (700, 1900)])
-def test_rank256_gram_matrices_as_passengers_of_the_products(m, n, monkeypatch):
+def test_rank256_gram_matrices_as_passengers_of_the_products(m, n, monkeypatch, diag_build):
     """Round 4: at padded rank 256 the Gram matrix of the operand a product multiplies V with (W^T W from W's fragments, (S H)(S H)^T from the smoothed H's) rides in
     that product's launch as 32 passenger workgroups -- 16 K slices x 2 halves of the tiles; the last workgroup of a half to arrive adds the slices in slice order and
-    writes the matrix, its diagonal and its split image (tri_gram_tile.h).  NMFAMD_TRI_RIDE = 0 / h / w keeps both / one of them on their own launches
+    writes the matrix, its diagonal and its split image (tri_gram_tile.h).  NMFAMD_TRI_RIDE = 0 / h / w (measurement build: fixture diag_build) keeps both / one of them on their own launches
     (k_gram_tri_bf16 + k_gram_tri_reduce_image): same factors and reported errors up to the summation order of the K slices, every form within the bf16 mode's 2e-2 of
     the fp64 oracle, and the riding form bit-identical when the run is repeated (the order of the sum does not depend on who arrives last)."""
     r, theta, iters = 256, 0.5, 20

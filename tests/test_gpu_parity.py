@@ -1113,10 +1113,10 @@ def test_long_horizon_fused_mu_stays_on_the_oracle_trajectory():
 
 
 @pytest.mark.parametrize("m,n", [(4000, 200), (1500, 900)])
-def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m, n, monkeypatch):
+def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m, n, monkeypatch, diag_build):
     """Round 4 (column shards): W^T W rides in the W^T V launch cut into K slices -- 10 passenger workgroups per slice write UNSCALED partial matrices, the H update
     adds them in order and scales them by the pending column scale, which comes from the W update's per-workgroup sums of squares (gram_image.h, k_mu64_update32).
-    The engine picks the slice count from the shard's shape; here every count is forced (NMFAMD_GRAM_KSPLIT) at shapes the fp64 oracle covers: same factors and
+    The engine picks the slice count from the shard's shape; here every count is forced (NMFAMD_GRAM_KSPLIT, read by the measurement build only: fixture diag_build) at shapes the fp64 oracle covers: same factors and
     reported errors as the one-slice form up to summation order, all within the fp32 tolerance of the oracle.  4 000 x 200 also gives W^T V ten K slices: the H update's
     13-slab batches (k_mu64_update32<false, 13, QS>)."""
     r, iters = 64, 40
@@ -1140,7 +1140,7 @@ def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m
         assert rel(got[ks][0], got[1][0]) < 5e-6 and rel(got[ks][1], got[1][1]) < 5e-6
 
 
-def test_column_split_product_gives_the_bits_of_the_whole_panel_form(monkeypatch):
+def test_column_split_product_gives_the_bits_of_the_whole_panel_form(monkeypatch, diag_build):
     """Round 4 (narrow column shards): V H^T with a short reduction range runs as 128 x 32 workgroups, two per x-tile (FactorProductPlan::col_split, kernels_x3.hip NBW = 1),
     when the plan has one K slice.  Every output element sees the same MFMAs in the same order as in the 128 x 64 form: same bits, both against the fp64 oracle."""
     m, n, r, iters = 4000, 200, 64, 30

@@ -65,10 +65,10 @@ def test_compute_with_numgpus_matches_oracle_and_single_gpu(alg, r, params, dtyp
 
 
 @pytest.mark.parametrize("ranks", [2, 3, 5])
-def test_direct_exchange_gives_the_bits_of_the_reduced_exchange(ranks, monkeypatch):
+def test_direct_exchange_gives_the_bits_of_the_reduced_exchange(ranks, monkeypatch, diag_build):
     """Round 4's small-message form of the W step (replicated mode at padded rank 64: the W update reads the ranks' exchange panels in place and adds them
     in rank order in its prologue, two alternating buffers, one rendezvous per iteration) against round 3's form of the same step (the panels summed by the
-    transport's reduction kernel in rank order, the sum copied back, the W update on the one reduced panel; NMFAMD_SHARD_NO_DIRECT=1): the same values are
+    transport's reduction kernel in rank order, the sum copied back, the W update on the one reduced panel; NMFAMD_SHARD_NO_DIRECT=1 in the measurement build): the same values are
     added in the same order, so the factors and the reported error must agree BIT FOR BIT -- on ragged shards, across an odd rank count, error iterations included."""
     m, n, r, iters = 700, 530, 48, 31
     V, W0, H0 = problem(m, n, r, np.float32, seed=40 + ranks)

@@ -1,6 +1,9 @@
 """Config 4 as stated (8 shards on one device, 50 000 x 8 192, r = 256, nsNMF, bf16): the single-engine run once, each shard mode several times;
 prints every run's distance from the single-engine result -- a deterministic path prints the same number every time.
 usage: python tools/c4_modes_repeat.py   (needs a GPU; test infrastructure only)"""
+# (the switches this tool sets are read by the measurement build only: csrc/tuning.h)
+import os as _os
+_os.environ.setdefault("NMFAMD_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,8 @@
 """One config-4 shard (50 000 x 6 250, r = 256, nsNMF theta = 0.5, bf16 operands) through the fused loop and the native sharded loop of a team of one in both
 W-step modes (0 = row blocks, 1 = replicated): what the row-block form costs before a byte crosses a link.  usage: c4_shard_modes.py [ITERS]"""
+# (the rehearsal switch this tool sets is read by the measurement build only: csrc/tuning.h)
+import os as _os
+_os.environ.setdefault("NMFAMD_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,9 @@
 """One column shard of configs[1] (10 000 x NC, r = 64, MU) through the native sharded loop on a one-rank RCCL clique (or with the
 in-library exchange, NMFAMD_COMM=p2p), for rocprofv3 --kernel-trace --stats: itemises the shard iteration's fixed cost.
 usage: shard_trace.py NC MODE(0 row blocks | 1 replicated | fused) [ITERS]"""
+# (the switches this tool sets are read by the measurement build only: csrc/tuning.h)
+import os as _os
+_os.environ.setdefault("NMFAMD_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

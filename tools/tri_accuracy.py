@@ -1,5 +1,8 @@
 """Rank-256 bf16 mode against the fp64 oracle: relative error of W, H and the Frobenius value after `iters` iterations (nsNMF theta = 0.5).
 usage: [NMFAMD_TRI_FP32_DEN=1] python tools/tri_accuracy.py   (needs a GPU; test infrastructure only)"""
+# (the switches this tool sets are read by the measurement build only: csrc/tuning.h)
+import os as _os
+_os.environ.setdefault("NMFAMD_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

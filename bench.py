@@ -142,8 +142,8 @@ def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
     oracle.run(algorithm, V, Wc, Hc, iters, **kw)
     dt = max(time.perf_counter() - t0 - setup, 1e-9)
     return {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{iters} {algorithm.upper()} iterations of the full {V.shape[0]}x{V.shape[1]} r={W.shape[1]} fp32 problem (oracle/nmf_oracle.c, OpenMP; "
-                      f"products by oracle/sgemm_avx2.h; {setup * 1e3:.0f} ms of per-run setup timed apart and excluded)"}
+            "sample": f"{iters} {algorithm.upper()} iterations of the full {V.shape[0]}x{V.shape[1]} r={W.shape[1]} {'fp32' if V.dtype == np.float32 else 'fp64'} problem (oracle/nmf_oracle.c, OpenMP; "
+                      + ("products by oracle/sgemm_avx2.h; " if V.dtype == np.float32 else "") + f"{setup * 1e3:.0f} ms of per-run setup timed apart and excluded)"}
 
 
 def cpu_baseline_blas(V, W, H, threads: int, budget_s: float = 6.0):
@@ -327,9 +327,11 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API from Python (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=0, help="(kept for old command lines; unused since round 5: the launch samples are taken in an untimed replay behind the timed steps)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "c5-gdcls", "c2-f64", "example"], default="c2",
                     help="c2 (default) = BASELINE configs[1], the metric line; c3 = configs[2] (sparse CSR, KL-divergence MU, r=128); "
-                         "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape)")
+                         "c4 = one configs[3] column shard per GPU (nsNMF, r=256, bf16 operands); c5 / c5-gdcls = configs[4] (AHCLS / GDCLS at config 2's shape); "
+                         "c2-f64 = config 2's shape in DOUBLE precision (the instantiation the reference's own callers run); example = the reference's example program "
+                         "(example/main.cpp:31-33,119-126: 4096 x 165, r = 158, nsNMF theta 0.5, double)")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                     help="N > 1, c2: strong (what auto means there) = the ONE 10000x5000 problem of configs[1] column-sharded over the N GPUs -- BASELINE north_star's "
                          "1/2/4/8-GPU series, value in iterations/s of that problem; weak = one 10000x5000 column shard per GPU.  c4 is one shard per GPU (weak) by definition")
@@ -364,6 +366,8 @@ def main():
         return main_c3(args)
     if args.workload == "c4":
         return main_c4(args)
+    if args.workload in ("c2-f64", "example"):
+        return main_f64(args)
     algorithm, alg_kw = "mu", {}
     if args.workload.startswith("c5"):
         algorithm = "gdcls" if args.workload.endswith("gdcls") else "ahcls"
@@ -806,6 +810,83 @@ def rccl_ranks(args):
     dist.barrier()
     dist.destroy_process_group()
 
+
+
+PEAK_FP64_MFMA_TFLOPS = 78.6    # /opt/skills/guides (kernels_f64.hip header): the fp64 matrix peak of gfx950 equals its vector peak, 78.6 TFLOP/s
+EXAMPLE = {"rows": 4096, "columns": 165, "features": 158, "theta": 0.5}      # /root/reference example/main.cpp:31-33,119-126
+
+
+def main_f64(args):
+    """The double-precision instantiation -- what the reference's own callers run (example/main.cpp: NmfDescription<double>; the R binding is double by nature).
+    c2-f64: config 2's shape, MU, r = 64.  example: the reference's example program's problem (4096 x 165, r = 158, nsNMF theta = 0.5).  Products on
+    v_mfma_f64_16x16x4_f64 (kernels_f64.hip); roofline: the factor product against the fp64 MFMA peak.  Same timing contract as the default workload."""
+    import torch
+    import nmfgpu_amd as na
+    if not torch.cuda.is_available() or na.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(0)
+    ex = args.workload == "example"
+    if ex:
+        m, n, r, alg, kw = EXAMPLE["rows"], EXAMPLE["columns"], EXAMPLE["features"], "nsnmf", dict(theta=EXAMPLE["theta"])
+        rs = np.random.RandomState(1)
+        # the example's data: multiples of 1/255 in [0, 254/255] (rand() % 255 / 255.0); start values U(0, 1] as everywhere here (the example draws AllRandomValues)
+        V = np.asfortranarray(rs.randint(0, 255, size=(m, n)).astype(np.float64) / 255.0)
+        W = np.asfortranarray(1.0 - rs.random_sample((m, r)))
+        H = np.asfortranarray(1.0 - rs.random_sample((r, n)))
+        setup = 2000
+    else:
+        m, n, r, alg, kw = M, N_COLS, R, "mu", {}
+        V32, W32, H32 = make_problem(0)
+        V, W, H = (np.asfortranarray(x.astype(np.float64)) for x in (V32, W32, H32))
+        del V32
+        setup = SETUP_ITERATIONS // 2
+    K, Wm = args.steps, args.warmup
+    eng = na.Engine(m, n, r, alg, dtype=np.float64, stream=engine_stream(torch), **kw)
+    eng.upload(V)
+    eng.set_factors(W, H)
+    eng.iterate(setup, first_iteration=1, error_every=10)       # set-up (first launches, the device's ramp from idle: see main()), then back to W0, H0
+    eng.synchronize()
+    eng.set_factors(W, H)
+    eng.iterate(Wm, first_iteration=1, error_every=10)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.iterate(K, first_iteration=Wm + 1, error_every=10)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches, pair_overhead_ms = 0.0, 0, 0.0
+    if not args.no_kernel_events:
+        replay = replay_iterations(K, False)
+        eng.kernel_timing(max(1, replay // REPLAY_SAMPLES))
+        eng.iterate(replay, first_iteration=Wm + K + 1, error_every=10)
+        eng.synchronize()
+        kernel_ms, kernel_launches, pair_overhead_ms = eng.kernel_timing_read2()
+        eng.kernel_timing(0)
+    frob = eng.frobenius
+    flops_per_launch = 2.0 * m * n * r
+    bytes_per_launch = 8.0 * m * n
+    roofline = None
+    if kernel_launches > 0:
+        avg_s = kernel_ms / 1e3 / kernel_launches
+        ach = flops_per_launch / avg_s / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "kernel": "k_factor_product_f64", "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
+                    "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
+                    "timed_by": "an event recorded before and one after the launch (over-reports by about idle_event_pair_us), " + TIMED_BY_REPLAY,
+                    "hbm_side": {"achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS}}
+    iter_flops = 4.0 * m * n * r + (6.0 if ex else 4.0) * r * r * (m + n)
+    out = {"metric": ("nsNMF iterations/sec, double precision, the reference example's 4096x165 r=158" if ex else "NMF MU iterations/sec, double precision, dense 10kx5k r=64"),
+           "value": K / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": ("the reference's example program (example/main.cpp): dense V 4096x165 of multiples of 1/255, r=158, nsNMF theta=0.5, double" if ex else
+                                   "configs[1]'s shape in double precision: dense random V 10000x5000, r=64, MU Frobenius, fp64"),
+                      "rows": m, "columns": n, "features": r, "error_every": 10, "setup_iterations": setup, "parallelism": "single GPU",
+                      "arithmetic": "fp64 throughout; products on v_mfma_f64_16x16x4_f64"},
+           "frobenius_last": frob, "iter_flops": iter_flops, "achieved_tflops_whole_iteration": iter_flops * (K / elapsed) / 1e12,
+           "roofline": whole_iteration(roofline, elapsed / K, floor_flops=2.0 * flops_per_launch, basis="the two products against V at the fp64 MFMA peak")}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(V, W, H, budget_s=15.0, algorithm=alg, **kw)
+    print(json.dumps(out), flush=True)
 
 def main_c3(args):
     """BASELINE configs[2] on one GPU: CSR V 100000 x 20000 at 1 % (2e7 stored entries), r = 128, multiplicative update on

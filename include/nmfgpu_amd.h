@@ -233,7 +233,9 @@ NMFAMD_API const char* nmfamd_sharded_last_error(const nmfamd_sharded* s);
  * leading dimension ld, clusters m x k (ldc), membership n entries; *iterations receives the passes done.
  * host_init: method is the NmfInitializationMethod value (include/nmfgpu.h:87-96) for MeanColumns,
  * KMeans* and EInNMF (source/init/KMeansStrategy.cpp:31-65, EInNMF.cu:44-119); W is m x r (ld m), H r x n
- * (ld r) or NULL.  Return 0, or 1 (invalid argument) for arguments the reference rejects. */
+ * (ld r) or NULL.  method 100 / 101 / 102: the SVD-based start NNDSVD / NNDSVDa / NNDSVDar (Boutsidis & Gallopoulos 2008; not in the reference -- BASELINE's
+ * north star names it -- nmfgpu::compute selects it with Parameter{"nndsvd", 0 | 1 | 2}, which overrides initMethod): truncated SVD of V by block subspace
+ * iteration on the host, in double.  Return 0, or 1 (invalid argument) for arguments the reference rejects. */
 NMFAMD_API int nmfamd_host_kmeans_f32(const float* data, long ld, int m, int n, float* clusters, long ldc, int k,
                                       unsigned* membership, unsigned seed, unsigned maxiter, double threshold, unsigned* iterations);
 NMFAMD_API int nmfamd_host_kmeans_f64(const double* data, long ld, int m, int n, double* clusters, long ldc, int k,

@@ -124,7 +124,15 @@ int host_init(const T* V, long ldv, int m, int n, int r, int method, unsigned se
 	nmfgpu::NmfDescription<T> d{};
 	d.inputMatrix.rows = (unsigned)m; d.inputMatrix.columns = (unsigned)n; d.inputMatrix.format = nmfgpu::StorageFormat::Dense;
 	d.inputMatrix.dense.values = const_cast<T*>(V); d.inputMatrix.dense.leadingDimension = (unsigned)ldv;
-	d.features = (unsigned)r; d.seed = seed; d.initMethod = (nmfgpu::NmfInitializationMethod)method;
+	d.features = (unsigned)r; d.seed = seed;
+	// method 100 + v: the SVD-based start (NNDSVD, v = 0 plain / 1 "a" / 2 "ar"), which nmfgpu::compute selects with Parameter{"nndsvd", v}
+	nmfgpu::Parameter svd{"nndsvd", (double)(method - 100)};
+	if (method >= 100 && method <= 102) {
+		if (r > std::min(m, n)) return nmfamd::ST_INVALID;
+		d.initMethod = nmfgpu::NmfInitializationMethod::AllRandomValues; d.parameters = &svd; d.numParameters = 1;
+		return nmfgpu::hostinit::initialize<T>(d, W, H) ? nmfamd::ST_OK : nmfamd::ST_INVALID;
+	}
+	d.initMethod = (nmfgpu::NmfInitializationMethod)method;
 	if ((d.initMethod != nmfgpu::NmfInitializationMethod::MeanColumns) && r >= n) return nmfamd::ST_INVALID;
 	return nmfgpu::hostinit::initialize<T>(d, W, H) ? nmfamd::ST_OK : nmfamd::ST_INVALID;
 }

@@ -7,6 +7,9 @@
 //   KMeans* strategies                  source/init/KMeansStrategy.cpp:31-65
 //   EIn-NMF membership transform        source/init/EInNMF.cu:44-91
 //   MeanColumns                         source/init/MeanColumnStrategy.cpp:43-56, KernelMeanColumn.cu:30-50
+// and one strategy the reference does not have (BASELINE north star names it; include/nmfgpu.h:80-100 has no such member, so it is selected by a Parameter):
+//   NNDSVD / NNDSVDa / NNDSVDar         Boutsidis & Gallopoulos, "SVD based initialization: a head start for NMF", Pattern Recognition 41 (2008);
+//                                       Parameter{"nndsvd", 0 | 1 | 2} overrides initMethod; truncated SVD by block subspace iteration, in double
 // Summation orders kept from the reference so that memberships and centres agree bit for bit:
 //   * squared distances: 32 strided lane partials, fused multiply-add, then the xor-butterfly of
 //     sumWarpReduction (kMeans.cu:41-50, KernelHelper.cuh:31-43);
@@ -277,10 +280,237 @@ void fill_uniform(T* P, size_t r, size_t len, size_t ld, unsigned seed) {
 
 } // namespace
 
+
+// ---- NNDSVD ------------------------------------------------------------------------------------------------------------------------------------------
+// Truncated SVD of V (m x n, column-major T) by block subspace iteration in double: Q (m x b, orthonormal columns) <- orth(V orth(V^T Q)) until the Ritz values
+// stand still; then the SVD of the small B = Q^T V by one-sided Jacobi.  Blocks are ROW-major (a row = b contiguous doubles): both big products are
+// "row of the result += scalar x row of the block", vectorised over b, and every output element is summed in one fixed order whatever the thread count.
+namespace {
+
+// Y (m x b) = V Z, Z (n x b)
+template <typename T>
+void nnd_mul_v(const T* V, size_t m, size_t n, const double* Z, size_t b, double* Y) {
+	parallel_chunks(m, 64, 256, [&](size_t i0, size_t i1, size_t) {
+		for (size_t t0 = i0; t0 < i1; t0 += 64) {
+			const size_t t1 = std::min(i1, t0 + 64);
+			std::fill(Y + t0 * b, Y + t1 * b, 0.0);
+			for (size_t k = 0; k < n; ++k) {
+				const T* col = V + k * m;
+				const double* z = Z + k * b;
+				for (size_t i = t0; i < t1; ++i) {
+					const double v = (double)col[i];
+					if (v == 0.0) continue;
+					double* y = Y + i * b;
+					for (size_t j = 0; j < b; ++j) y[j] += v * z[j];
+				}
+			}
+		}
+	});
+}
+
+// Z (n x b) = V^T Q, Q (m x b)
+template <typename T>
+void nnd_mul_vt(const T* V, size_t m, size_t n, const double* Q, size_t b, double* Z) {
+	parallel_chunks(n, 8, 8, [&](size_t k0, size_t k1, size_t) {
+		for (size_t c0 = k0; c0 < k1; c0 += 8) {
+			const size_t c1 = std::min(k1, c0 + 8);
+			std::fill(Z + c0 * b, Z + c1 * b, 0.0);
+			for (size_t t0 = 0; t0 < m; t0 += 128) {
+				const size_t t1 = std::min(m, t0 + 128);
+				for (size_t k = c0; k < c1; ++k) {
+					const T* col = V + k * m;
+					double* z = Z + k * b;
+					for (size_t i = t0; i < t1; ++i) {
+						const double v = (double)col[i];
+						if (v == 0.0) continue;
+						const double* q = Q + i * b;
+						for (size_t j = 0; j < b; ++j) z[j] += v * q[j];
+					}
+				}
+			}
+		}
+	});
+}
+
+// Orthonormalises the columns of Y (rows x b, row-major) in place by Cholesky QR, twice; G = Y^T Y from fixed 512-row chunks added in chunk order.  A column that
+// depends on its predecessors (rank-deficient V) becomes zero.
+void nnd_orthonormalize(double* Y, size_t rows, size_t b) {
+	for (int pass = 0; pass < 2; ++pass) {
+		const size_t chunks = (rows + 511) / 512;
+		std::vector<double> part(chunks * b * b, 0.0), G(b * b, 0.0), R(b * b, 0.0);
+		parallel_chunks(chunks, 1, 1, [&](size_t c0, size_t c1, size_t) {
+			for (size_t c = c0; c < c1; ++c) {
+				double* g = part.data() + c * b * b;
+				for (size_t i = c * 512; i < std::min(rows, (c + 1) * 512); ++i) {
+					const double* y = Y + i * b;
+					for (size_t p = 0; p < b; ++p) { const double yp = y[p]; if (yp == 0.0) continue; double* gr = g + p * b; for (size_t q = p; q < b; ++q) gr[q] += yp * y[q]; }
+				}
+			}
+		});
+		for (size_t c = 0; c < chunks; ++c) for (size_t e = 0; e < b * b; ++e) G[e] += part[c * b * b + e];
+		// upper Cholesky factor R (G = R^T R), row by row
+		double gmax = 0.0;
+		for (size_t p = 0; p < b; ++p) gmax = std::max(gmax, G[p * b + p]);
+		std::vector<char> dead(b, 0);
+		for (size_t p = 0; p < b; ++p) {
+			double d = G[p * b + p];
+			for (size_t k = 0; k < p; ++k) d -= R[k * b + p] * R[k * b + p];
+			if (!(d > 1e-26 * gmax) || gmax == 0.0) { dead[p] = 1; R[p * b + p] = 1.0; continue; }
+			const double rpp = std::sqrt(d);
+			R[p * b + p] = rpp;
+			for (size_t q = p + 1; q < b; ++q) {
+				double v = G[p * b + q];
+				for (size_t k = 0; k < p; ++k) v -= R[k * b + p] * R[k * b + q];
+				R[p * b + q] = v / rpp;
+			}
+		}
+		// Y <- Y R^{-1}: row by row, forward over the columns
+		parallel_chunks(rows, 1, 256, [&](size_t i0, size_t i1, size_t) {
+			for (size_t i = i0; i < i1; ++i) {
+				double* y = Y + i * b;
+				for (size_t q = 0; q < b; ++q) {
+					if (dead[q]) { y[q] = 0.0; continue; }
+					double v = y[q];
+					for (size_t k = 0; k < q; ++k) v -= y[k] * R[k * b + q];
+					y[q] = v / R[q * b + q];
+				}
+			}
+		});
+	}
+}
+
+// One-sided Jacobi SVD of A (rows x b, row-major): on return the columns of A are mutually orthogonal (A <- A Rot), rot (b x b, row-major) = Rot, sigma[j] = the
+// norm of column j.  A_in = (A_out columns / sigma) diag(sigma) Rot^T.
+void nnd_jacobi(double* A, size_t rows, size_t b, double* rot, double* sigma) {
+	std::fill(rot, rot + b * b, 0.0);
+	for (size_t j = 0; j < b; ++j) rot[j * b + j] = 1.0;
+	for (int sweep = 0; sweep < 60; ++sweep) {
+		double off = 0.0;
+		for (size_t p = 0; p + 1 < b; ++p)
+			for (size_t q = p + 1; q < b; ++q) {
+				double app = 0, aqq = 0, apq = 0;
+				for (size_t i = 0; i < rows; ++i) { const double x = A[i * b + p], y = A[i * b + q]; app += x * x; aqq += y * y; apq += x * y; }
+				if (std::fabs(apq) <= 1e-15 * std::sqrt(app * aqq) || apq == 0.0) continue;
+				off = std::max(off, std::fabs(apq) / std::sqrt(app * aqq));
+				const double zeta = (aqq - app) / (2.0 * apq);
+				const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+				const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+				for (size_t i = 0; i < rows; ++i) { const double x = A[i * b + p], y = A[i * b + q]; A[i * b + p] = c * x - sn * y; A[i * b + q] = sn * x + c * y; }
+				for (size_t i = 0; i < b; ++i) { const double x = rot[i * b + p], y = rot[i * b + q]; rot[i * b + p] = c * x - sn * y; rot[i * b + q] = sn * x + c * y; }
+			}
+		if (off <= 1e-15) break;
+	}
+	for (size_t j = 0; j < b; ++j) { double s = 0; for (size_t i = 0; i < rows; ++i) s += A[i * b + j] * A[i * b + j]; sigma[j] = std::sqrt(s); }
+}
+
+// U (m x r, column-major), S (r), Vr (n x r, column-major): the r largest singular triplets of V
+template <typename T>
+void truncated_svd(const T* V, size_t m, size_t n, size_t r, std::vector<double>& U, std::vector<double>& S, std::vector<double>& Vr) {
+	const size_t full = std::min(m, n);
+	const size_t b = std::min(full, r + std::max<size_t>(8, r / 2));
+	std::vector<double> Q(m * b), Z(n * b), rot(b * b), sig(b), prev(b, 0.0);
+	// start: Z = a fixed pseudo-random block (the counter generator of the device fill: reproducible), Q = orth(V Z)
+	for (size_t e = 0; e < n * b; ++e) Z[e] = uniform01(0x4e4e4453ull, e, false) - 0.5;
+	nnd_orthonormalize(Z.data(), n, b);
+	nnd_mul_v(V, m, n, Z.data(), b, Q.data());
+	nnd_orthonormalize(Q.data(), m, b);
+	// (a work budget: ~2e11 multiply-adds for the iteration -- six seconds of the host's threads at config 2's size, where a random matrix's flat spectrum would
+	//  otherwise keep the block turning for minutes; a start value needs the leading directions, not their last digits)
+	const double per_it = 4.0 * (double)m * (double)n * (double)b;
+	const int max_it = b == full ? 2 : (int)std::max(8.0, std::min(300.0, 2e11 / per_it));
+	std::vector<double> Zs;
+	for (int it = 0; it < max_it; ++it) {
+		nnd_mul_vt(V, m, n, Q.data(), b, Z.data());                 // Z = V^T Q = B^T
+		Zs = Z;
+		nnd_jacobi(Zs.data(), n, b, rot.data(), sig.data());       // Ritz values of this step
+		std::vector<double> sorted(sig);
+		std::sort(sorted.begin(), sorted.end(), std::greater<double>());
+		double change = 0.0;
+		for (size_t j = 0; j < std::min(r, b); ++j) change = std::max(change, std::fabs(sorted[j] - prev[j]));
+		prev = sorted;
+		if (it + 1 >= max_it || (it >= 2 && change <= 1e-14 * sorted[0])) break;
+		nnd_orthonormalize(Z.data(), n, b);
+		nnd_mul_v(V, m, n, Z.data(), b, Q.data());
+		nnd_orthonormalize(Q.data(), m, b);
+	}
+	// B^T = Z = (Zs / sig) diag(sig) rot^T  =>  V ~ Q B = (Q rot) diag(sig) (Zs / sig)^T: left vectors Q rot, right vectors Zs / sig
+	std::vector<size_t> order(b);
+	std::iota(order.begin(), order.end(), size_t(0));
+	std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return sig[x] > sig[y]; });
+	U.assign(m * r, 0.0); S.assign(r, 0.0); Vr.assign(n * r, 0.0);
+	for (size_t j = 0; j < std::min(r, b); ++j) {
+		const size_t c = order[j];
+		S[j] = sig[c];
+		if (!(sig[c] > 0.0)) continue;
+		for (size_t i = 0; i < n; ++i) Vr[j * n + i] = Zs[i * b + c] / sig[c];
+		parallel_chunks(m, 1, 2048, [&](size_t i0, size_t i1, size_t) {
+			for (size_t i = i0; i < i1; ++i) { double s = 0; const double* q = Q.data() + i * b; for (size_t k = 0; k < b; ++k) s += q[k] * rot[k * b + c]; U[j * m + i] = s; }
+		});
+	}
+}
+
+} // namespace
+
+int nndsvd_variant(const Parameter* parameters, unsigned count) {
+	for (unsigned i = 0; i < count; ++i)
+		if (parameters != nullptr && parameters[i].name != nullptr && std::strcmp(parameters[i].name, "nndsvd") == 0) {
+			const double v = parameters[i].value;
+			return v == 1.0 ? 1 : (v == 2.0 ? 2 : 0);
+		}
+	return -1;
+}
+
+// W (m x r, ld m), H (r x n, ld r; may be null).  variant 0: NNDSVD (zeros stay), 1: NNDSVDa (zeros -> mean of V), 2: NNDSVDar (zeros -> mean / 100 x U(0, 1], seeded)
+template <typename T>
+void nndsvd(const T* V, size_t m, size_t n, size_t r, int variant, unsigned seed, T* W, T* H) {
+	std::vector<double> U, S, Vr;
+	truncated_svd(V, m, n, r, U, S, Vr);
+	std::vector<double> Wd(m * r, 0.0), Hd(r * n, 0.0);
+	for (size_t j = 0; j < r; ++j) {
+		const double* x = U.data() + j * m;
+		const double* y = Vr.data() + j * n;
+		if (j == 0) {
+			// the leading pair of a non-negative matrix has one sign (Perron-Frobenius): its absolute values
+			const double s = std::sqrt(S[0]);
+			for (size_t i = 0; i < m; ++i) Wd[i] = s * std::fabs(x[i]);
+			for (size_t i = 0; i < n; ++i) Hd[i * r] = s * std::fabs(y[i]);
+			continue;
+		}
+		double xp = 0, xn = 0, yp = 0, yn = 0;
+		for (size_t i = 0; i < m; ++i) { if (x[i] > 0) xp += x[i] * x[i]; else xn += x[i] * x[i]; }
+		for (size_t i = 0; i < n; ++i) { if (y[i] > 0) yp += y[i] * y[i]; else yn += y[i] * y[i]; }
+		xp = std::sqrt(xp); xn = std::sqrt(xn); yp = std::sqrt(yp); yn = std::sqrt(yn);
+		const double mp = xp * yp, mn = xn * yn;
+		const bool pos = mp > mn;
+		const double sigma = pos ? mp : mn, nx = pos ? xp : xn, ny = pos ? yp : yn;
+		if (!(sigma > 0.0) || !(S[j] > 0.0)) continue;
+		const double l = std::sqrt(S[j] * sigma);
+		for (size_t i = 0; i < m; ++i) { const double v = pos ? std::max(x[i], 0.0) : std::max(-x[i], 0.0); Wd[j * m + i] = l * v / nx; }
+		for (size_t i = 0; i < n; ++i) { const double v = pos ? std::max(y[i], 0.0) : std::max(-y[i], 0.0); Hd[i * r + j] = l * v / ny; }
+	}
+	// entries below machine precision count as zeros (as the reference implementations of the method do)
+	const double tiny = 1e-6 * (sizeof(T) == 4 ? 1.0 : 1e-4);
+	double mean = 0.0;
+	if (variant != 0) { for (size_t e = 0; e < m * n; ++e) mean += (double)V[e]; mean /= (double)(m * n); }
+	auto finish = [&](std::vector<double>& P, unsigned long long stream) {
+		for (size_t e = 0; e < P.size(); ++e) {
+			if (P[e] < tiny) P[e] = variant == 0 ? 0.0 : (variant == 1 ? mean : mean * 0.01 * uniform01((unsigned long long)seed + stream, e, false));
+		}
+	};
+	finish(Wd, 0); finish(Hd, 0x9e3779b9ull);
+	for (size_t e = 0; e < m * r; ++e) W[e] = (T)Wd[e];
+	if (H) for (size_t e = 0; e < r * n; ++e) H[e] = (T)Hd[e];
+}
+
 template <typename T>
 bool initialize(const NmfDescription<T>& d, T* W, T* H) {
 	const size_t m = d.inputMatrix.rows, n = d.inputMatrix.columns, r = d.features;
 	const std::vector<T> V = to_dense(d.inputMatrix);
+	// Parameter "nndsvd" present: the SVD-based start, whatever initMethod says (the enum of the reference has no member for it)
+	if (const int variant = nndsvd_variant(d.parameters, d.numParameters); variant >= 0) {
+		nndsvd<T>(V.data(), m, n, r, variant, d.seed, W, H);
+		return true;
+	}
 	switch (d.initMethod) {
 	case NmfInitializationMethod::MeanColumns: {
 		const unsigned meanCount = 5;

@@ -114,7 +114,8 @@ public:
 	// InitializationStrategy::create + initializeMatrixW/H (source/init/InitializationStrategy.cpp:36-47)
 	Status init_run(NmfDescription<T>& d, bool want_h) override {
 		const unsigned m = d.inputMatrix.rows, n = d.inputMatrix.columns, r = d.features;
-		switch (d.initMethod) {
+		// (Parameter "nndsvd": the SVD-based start overrides initMethod -- host_init.cpp)
+		switch (hostinit::nndsvd_variant(d.parameters, d.numParameters) >= 0 ? NmfInitializationMethod::MeanColumns : d.initMethod) {
 		case NmfInitializationMethod::CopyExisting:
 			return engine_->set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension,
 			                           want_h ? d.outputMatrixH.dense.values : nullptr, d.outputMatrixH.dense.leadingDimension);
@@ -201,10 +202,12 @@ public:
 		init_method_ = d.initMethod; seed_ = d.seed; want_h_ = want_h;
 		hostW_ = nullptr; hostH_ = nullptr; ldw_ = ldh_ = 0;
 		std::vector<T> W, H;
-		if (d.initMethod == NmfInitializationMethod::CopyExisting) {
+		const bool svd_start = hostinit::nndsvd_variant(d.parameters, d.numParameters) >= 0;      // (Parameter "nndsvd" overrides initMethod)
+		if (svd_start) init_method_ = NmfInitializationMethod::MeanColumns;                          // (any host-side method: the ranks take W and their columns of H)
+		if (!svd_start && d.initMethod == NmfInitializationMethod::CopyExisting) {
 			hostW_ = d.outputMatrixW.dense.values; ldw_ = d.outputMatrixW.dense.leadingDimension;
 			hostH_ = d.outputMatrixH.dense.values; ldh_ = d.outputMatrixH.dense.leadingDimension;
-		} else if (d.initMethod != NmfInitializationMethod::AllRandomValues) {
+		} else if (svd_start || d.initMethod != NmfInitializationMethod::AllRandomValues) {
 			// the host-side initialisers see the whole matrix, once; every rank takes W and its columns of H
 			W.resize((size_t)m_ * r_); H.resize(want_h ? (size_t)r_ * n_ : 0);
 			if (!hostinit::initialize<T>(d, W.data(), want_h ? H.data() : nullptr)) return nmfamd::ST_INVALID;

@@ -546,8 +546,11 @@ def host_kmeans(data: np.ndarray, k: int, *, seed: int = 0, iterations: int = 10
     return clusters, membership, int(it.value)
 
 
+NNDSVD, NNDSVD_A, NNDSVD_AR = 100, 101, 102      # `method` values of host_init for the SVD-based start (Parameter "nndsvd" = 0 / 1 / 2 of nmfgpu::compute)
+
+
 def host_init(V: np.ndarray, r: int, method: int, *, seed: int = 0, want_h: bool = True):
-    """W (m x r) and H (r x n) of the MeanColumns / KMeans* / EInNMF initialisers (nmfamd_host_init_*)."""
+    """W (m x r) and H (r x n) of the MeanColumns / KMeans* / EInNMF initialisers, or of NNDSVD / NNDSVDa / NNDSVDar (method 100 / 101 / 102) (nmfamd_host_init_*)."""
     lib = library()
     V = _f(V)
     m, n = V.shape

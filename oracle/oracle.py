@@ -314,3 +314,55 @@ def einnmf_h(V, W):
     getattr(kmeans_lib(), f"oracle_einnmf_h_{_sfx(V.dtype)}")(_ptr(V), C.c_long(_ld(V)), _ptr(W), C.c_long(_ld(W)), C.c_uint(m),
                                                               C.c_uint(r), C.c_uint(n), _ptr(H), C.c_long(r))
     return H
+
+
+# ---- NNDSVD (not in the reference: BASELINE north_star names it; Boutsidis & Gallopoulos, Pattern Recognition 41 (2008) 1350-1362) ----------------------------
+
+def _uniform01(seed: int, index: int) -> float:
+    """The counter-based (0, 1] generator of the engine (csrc/host_init.cpp uniform01 / kernels.hip k_fill_uniform), double form."""
+    M64 = (1 << 64) - 1
+    z = (seed * 0x9E3779B97F4A7C15 + index + 0x632BE59BD9B4E019) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    z = z ^ (z >> 31)
+    return ((z >> 11) + 1) * (1.0 / 9007199254740992.0)
+
+
+def nndsvd(V, r: int, variant: int = 0, seed: int = 0):
+    """W0 (m x r), H0 (r x n) of the SVD-based start, computed with numpy's full SVD in double: the leading pair by absolute values, pair j > 0 by the
+    larger of its positive and negative sections (section II of the paper); variant 1 (NNDSVDa) fills the zeros with mean(V), variant 2 (NNDSVDar) with
+    mean(V) / 100 x U(0, 1] from the engine's counter generator (stream seed for W, seed + 0x9e3779b9 for H, index = the entry's position column-major
+    in W (m x r) and in H (r x n))."""
+    V64 = np.asarray(V, dtype=np.float64)
+    m, n = V64.shape
+    U, S, Vt = np.linalg.svd(V64, full_matrices=False)
+    W = np.zeros((m, r)); H = np.zeros((r, n))
+    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0]); H[0, :] = np.sqrt(S[0]) * np.abs(Vt[0, :])
+    for j in range(1, min(r, len(S))):
+        x, y = U[:, j], Vt[j, :]
+        xp, xn, yp, yn = np.maximum(x, 0), np.maximum(-x, 0), np.maximum(y, 0), np.maximum(-y, 0)
+        nxp, nxn, nyp, nyn = (np.linalg.norm(a) for a in (xp, xn, yp, yn))
+        mp, mn = nxp * nyp, nxn * nyn
+        if mp > mn:
+            u, v, sigma = xp / nxp, yp / nyp, mp
+        else:
+            if mn == 0.0:
+                continue
+            u, v, sigma = xn / nxn, yn / nyn, mn
+        lbd = np.sqrt(S[j] * sigma)
+        W[:, j] = lbd * u; H[j, :] = lbd * v
+    tiny = 1e-6 * (1.0 if np.asarray(V).dtype == np.float32 else 1e-4)
+    mean = V64.mean()
+    if variant == 0:
+        W[W < tiny] = 0.0; H[H < tiny] = 0.0
+    elif variant == 1:
+        W[W < tiny] = mean; H[H < tiny] = mean
+    else:
+        Wf, Hf = W.reshape(-1, order="F"), H.reshape(-1, order="F")          # (copies: column-major positions)
+        for e in np.nonzero(Wf < tiny)[0]:
+            Wf[e] = mean * 0.01 * _uniform01(seed, int(e))
+        for e in np.nonzero(Hf < tiny)[0]:
+            Hf[e] = mean * 0.01 * _uniform01(seed + 0x9e3779b9, int(e))
+        W, H = Wf.reshape((m, r), order="F"), Hf.reshape((r, n), order="F")
+    dt = np.asarray(V).dtype
+    return np.asfortranarray(W.astype(dt)), np.asfortranarray(H.astype(dt))

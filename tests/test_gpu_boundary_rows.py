@@ -346,3 +346,50 @@ def test_kl_blocked_gather_equals_unblocked(monkeypatch):
     ref = oracle.run_kl_csr(m, n, val, ptr, idx, W64, H64, 10)
     assert rel(Wb, W64) < 1e-4 and rel(Hb, H64) < 1e-4
     assert klb == pytest.approx(ref["kl"], rel=1e-5)
+
+
+# ------------------------------------------------------------------ (n1) NNDSVD start through the boundary (Parameter "nndsvd"; not in the reference, named by BASELINE's north star)
+
+def _decaying(m, n, k, dtype, seed, noise=0.01):
+    rng = np.random.default_rng(seed)
+    A, B, s = rng.random((m, k)), rng.random((k, n)), 0.8 ** np.arange(k)
+    return F(((A * s) @ B + noise * rng.random((m, n))).astype(dtype))
+
+
+@pytest.mark.parametrize("m,n,r,dtype,tol", [(300, 200, 8, np.float64, 1e-9), (500, 260, 16, np.float32, 1e-5), (4096, 165, 158, np.float64, 1e-8)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_nndsvd_start_through_compute_matches_the_numpy_restatement(m, n, r, dtype, tol, variant):
+    """Parameter{"nndsvd", 0 | 1 | 2} overrides initMethod (host_init.cpp; truncated SVD on the host): with numIterations = 0 nmfgpu::compute hands back W0, H0 --
+    equal to oracle.nndsvd (numpy's full SVD; the method does not depend on the sign of a singular pair) at three shapes, the third being the reference example's;
+    the "ar" form's fill is seeded with the run's seed (first draw of mt19937(description.seed))."""
+    V = _decaying(m, n, min(r + 5, n), dtype, seed=m + r)
+    W = F(np.zeros((m, r), dtype=dtype)); H = F(np.zeros((r, n), dtype=dtype))
+    dout = []
+    assert na.compute(V, W, H, init=Init.AllRandomValues, iterations=0, seed=9, parameters={"nndsvd": float(variant)}, description_out=dout) == na.ResultType.Success
+    run_seed = int(oracle.seed_stream(9, 1)[0])
+    Wo, Ho = oracle.nndsvd(V, r, variant, seed=run_seed)
+    assert np.abs(W - Wo).max() <= tol * np.abs(Wo).max() and np.abs(H - Ho).max() <= tol * np.abs(Ho).max()
+    W2, H2 = na.host_init(V, r, 100 + variant, seed=run_seed)
+    assert np.array_equal(W, W2) and np.array_equal(H, H2)
+    # ... and on two ranks (the host-side start sees the whole matrix once; every rank takes W and its columns of H)
+    if variant == 1 and m == 500:
+        W3 = F(np.zeros((m, r), dtype=dtype)); H3 = F(np.zeros((r, n), dtype=dtype))
+        assert na.compute(V, W3, H3, init=Init.CopyExisting, iterations=0, seed=9, parameters={"nndsvd": 1.0, "numGpus": 2.0}) == na.ResultType.Success
+        assert np.array_equal(W3, W) and np.array_equal(H3, H)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_twenty_mu_iterations_from_nndsvd_beat_a_random_start(dtype):
+    """What the start is for (Boutsidis & Gallopoulos 2008, section 4): after the same 20 multiplicative iterations the Frobenius error from NNDSVDa is below the one from
+    AllRandomValues -- on a matrix with structure, and on a plain random one."""
+    for V in (_decaying(1500, 900, 40, dtype, seed=2, noise=0.05), F(np.random.default_rng(4).random((1200, 700)).astype(dtype))):
+        m, n = V.shape
+        r = 24
+        err = {}
+        for name, kw in (("random", dict(init=Init.AllRandomValues)), ("nndsvda", dict(init=Init.AllRandomValues, parameters={"nndsvd": 1.0}))):
+            W = F(np.zeros((m, r), dtype=dtype)); H = F(np.zeros((r, n), dtype=dtype))
+            s = na.Summary()
+            assert na.compute(V, W, H, iterations=20, seed=3, summary=s, **kw) == na.ResultType.Success
+            err[name] = s.record(0).frobenius
+            assert s.record(0).frobenius == pytest.approx(np.linalg.norm(V.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)), rel=1e-3)
+        assert err["nndsvda"] < err["random"], err

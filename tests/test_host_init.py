@@ -170,3 +170,62 @@ def test_host_initialisers_under_sanitizers(tmp_path, flags):
     assert run.returncode == 0, run.stdout + run.stderr
     assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr
     assert run.stdout.strip().endswith("ok")
+
+
+# ------------------------------------------------------------------ NNDSVD (not in the reference; BASELINE north_star names it)
+
+def _decaying(m, n, k, dtype, seed, noise=0.01):
+    """Non-negative matrix with a geometrically decaying spectrum (k directions) plus a little noise: separated singular values, so the truncated SVD's vectors are
+    well defined and the comparison with numpy's full SVD is meaningful."""
+    rng = np.random.default_rng(seed)
+    A, B, s = rng.random((m, k)), rng.random((k, n)), 0.8 ** np.arange(k)
+    return np.asfortranarray(((A * s) @ B + noise * rng.random((m, n))).astype(dtype))
+
+
+@pytest.mark.parametrize("m,n,r,dtype,tol", [(300, 200, 8, np.float64, 1e-9), (500, 200, 8, np.float32, 1e-5), (257, 131, 20, np.float64, 1e-6),
+                                             (96, 64, 64, np.float64, 1e-9), (700, 900, 30, np.float32, 2e-4)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_nndsvd_matches_the_numpy_restatement(m, n, r, dtype, tol, variant):
+    """NNDSVD / NNDSVDa / NNDSVDar on the host (block subspace iteration + one-sided Jacobi, in double) against oracle.nndsvd (numpy's full SVD): same W0, H0 -- the
+    method is invariant under the sign of a singular pair, so no sign convention is needed -- including the seeded fill of the "ar" form, entry by entry.
+    Tolerances: the subspace iteration stops when the Ritz VALUES stand still at 1e-14; the vectors of the last, closely spaced pairs are then good to the square
+    root of that (1e-8 measured at 257 x 131, r = 20) -- more than a start value needs; where the block spans the whole space (96 x 64, r = 64) the SVD is exact."""
+    V = _decaying(m, n, r + 5, dtype, seed=m + n)
+    W, H = eng.host_init(V, r, eng.NNDSVD + variant, seed=11)
+    Wo, Ho = oracle.nndsvd(V, r, variant, seed=11)
+    assert (W >= 0).all() and (H >= 0).all()
+    assert np.abs(W - Wo).max() <= tol * np.abs(Wo).max() and np.abs(H - Ho).max() <= tol * np.abs(Ho).max()
+    if variant == 0:
+        assert ((W == 0) == (Wo == 0)).mean() > 0.999           # the zero pattern of the plain form
+    else:
+        assert (W > 0).all() and (H > 0).all()                  # "a" / "ar": no zeros left (multiplicative updates cannot leave a zero)
+
+
+def test_nndsvd_is_a_head_start_and_reproducible():
+    """What the method is for: ||V - W0 H0|| is far below a random start's, on a matrix with structure; and two calls give the same bits (fixed start block, fixed
+    summation orders whatever the thread count)."""
+    V = _decaying(400, 300, 12, np.float64, seed=3)
+    W, H = eng.host_init(V, 10, eng.NNDSVD_A, seed=1)
+    W2, H2 = eng.host_init(V, 10, eng.NNDSVD_A, seed=1)
+    assert np.array_equal(W, W2) and np.array_equal(H, H2)
+    rng = np.random.default_rng(0)
+    Wr, Hr = rng.random(W.shape), rng.random(H.shape)
+    scale = (V * (Wr @ Hr)).sum() / ((Wr @ Hr) ** 2).sum()       # (the best scalar for the random pair)
+    W0, H0 = eng.host_init(V, 10, eng.NNDSVD, seed=1)             # (the plain form: the "a" form's fill with mean(V) is there for the updates, not for the fit)
+    assert np.linalg.norm(V - W0 @ H0) < 0.5 * np.linalg.norm(V - scale * (Wr @ Hr))
+    env = dict(os.environ, NMFAMD_HOST_THREADS="1")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from nmfgpu_amd import engine as eng; from tests.test_host_init import _decaying; "
+            "W, H = eng.host_init(_decaying(400, 300, 12, np.float64, seed=3), 10, eng.NNDSVD_A, seed=1); print(float(W.sum()).hex(), float(H.sum()).hex())" % ROOT)
+    one = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-1000:]
+    assert one.stdout.split() == [float(W.sum()).hex(), float(H.sum()).hex()]
+
+
+def test_nndsvd_rank_deficient_and_rejected_arguments():
+    rng = np.random.default_rng(5)
+    V = np.asfortranarray(rng.random((60, 4)) @ rng.random((4, 50)))            # rank 4, r = 6: the last two pairs have singular value ~ 0
+    W, H = eng.host_init(V, 6, eng.NNDSVD, seed=0)
+    assert np.isfinite(W).all() and np.isfinite(H).all() and (W >= 0).all() and (H >= 0).all()
+    assert np.linalg.norm(V - W[:, :4] @ H[:4, :]) < 0.6 * np.linalg.norm(V)
+    with pytest.raises(eng.EngineError):
+        eng.host_init(V, 51, eng.NNDSVD, seed=0)                                   # more features than min(m, n)

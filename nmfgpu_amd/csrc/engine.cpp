@@ -469,7 +469,7 @@ Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
 		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
-		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false;
+		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemsetAsync(Wt_, 0, sizeof(T) * (size_t)RP_ * mpad_, stream_));
@@ -514,7 +514,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; }
+	if (w) { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -1101,7 +1101,7 @@ Status Engine<T>::w_update_rows(const T* num_rows, const T* hht, long row0, long
 	// Gw_raw_ is the Gram matrix of the panel WITHOUT its pending column scale: the trace below needs that scale even when materialize_w() is about to
 	// fold it into the panel (a caller that used w_finish() before: ADVICE r3) -- the staged sums stay where they are
 	const T* trace_scale = tri_trace_scale();
-	if (Status s = materialize_w()) return s;           // (a pending column scale belongs to the old W; fold it in first)
+	if (Status s = materialize_w(false)) return s;      // (a pending column scale belongs to the old W; fold it in first.  This rank's rows are current: no gather)
 	if (compute_error) {
 		const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + its scale)
 		if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
@@ -1156,6 +1156,7 @@ Status Engine<T>::tri_prepare_w(GramReduceArgs* ride) {
 	if constexpr (std::is_same<T, float>::value) {
 		const bool wide = qx3_ != nullptr && panel_update_wide_available(RP_);
 		if (!wtb_valid_) {
+			if (Status s = ensure_w_rows()) return s;      // (the fp32 rows of the other ranks first: engine.h, w_fragment_exchange)
 			// plain re-rounding of the panel as it lies (no smoothing, no normalisation: W is as the caller / the gather left it)
 			HIPX(launch_finish_panel_bf16(Wt_, RP_, r_, 0, mpad_, nullptr, 0, 0.0f, 1.0f, Wtb_, ksH_, stream_));
 			wtb_valid_ = true;
@@ -1277,7 +1278,19 @@ Status Engine<T>::normalize_w(bool from_gram_partials, int norm_parts) {
 }
 
 template <typename T>
-Status Engine<T>::materialize_w() {
+Status Engine<T>::ensure_w_rows() {
+	// (row-block sharded run with the fragment exchange: whoever wants the WHOLE fp32 panel gets the other ranks' rows first -- a collective, engine.h)
+	if (w_rows_stale_) {
+		if (!w_gather_hook_) { last_error_ = "the fp32 rows of the other ranks' blocks were not gathered (the sharded run that owns the exchange is closed)"; return ST_INVALID; }
+		if (Status s = w_gather_hook_()) return s;
+		w_rows_stale_ = false;
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::materialize_w(bool whole_panel) {
+	if (whole_panel) { if (Status s = ensure_w_rows()) return s; }
 	if constexpr (std::is_same<T, float>::value) {
 		if (w_pending_) {
 			// column norms from the partial Grams of the unnormalised W, then W <- W diag(scale)

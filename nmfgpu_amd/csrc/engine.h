@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "kernels.h"
@@ -91,6 +92,21 @@ public:
 	Status w_normalize_rows(long row0, long rows, T* colsq);
 	void w_rows_replaced() { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
+	// Row-block form at padded rank 256 with bf16 operands (config 4): between two W updates the OTHER ranks read only the bf16 fragments of a rank's rows (the next
+	// W^T V's operand and the Gram matrix are made from them) -- so the all-gather carries the fragments w_normalize_rows() left for this rank's rows (RP / 2 four-byte
+	// words per row: 25.6 MB at config 4 instead of 51.2 MB of fp32 rows) and the fp32 rows of the other ranks stay STALE in w_panel() until somebody needs them
+	// (get_factors, a fresh set of fragments): then the hook -- the sharded run's all-gather of the fp32 row blocks, a COLLECTIVE -- runs first.
+	bool w_fragment_exchange() const { return tri_; }
+	void* w_fragments() { return Wtb_; }
+	long w_fragment_words_per_row() const { return RP_ / 2; }
+	// the fragments of every rank's rows have been gathered into w_fragments(); stale: the fp32 rows of the other ranks were not
+	void w_fragments_gathered(bool stale) {
+		kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
+		tri_scale_pending_ = false; tri_scale_from_gram_ = false; wtb_valid_ = true; w_rows_stale_ = stale;
+	}
+	void set_w_gather_hook(std::function<Status()> hook) { w_gather_hook_ = std::move(hook); }
+	void w_rows_gathered() { w_rows_stale_ = false; }
+	bool w_rows_stale() const { return w_rows_stale_; }
 	Status materialize() { return materialize_w(); }
 	// error terms of the last error iteration (host copies): n_local per-column terms and r terms
 	const std::vector<T>& terms_htwtv() { finalize_error(false); return h_psN_; }
@@ -149,7 +165,8 @@ private:
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
 	Status iterate_onepass(bool compute_error);      // the one-pass iteration of kernels_onepass.hip
 	Status onepass_check();                          // host sync: did a one-pass launch give up?
-	Status materialize_w();                          // fold the pending column scale into Wt_
+	Status materialize_w(bool whole_panel = true);
+	Status ensure_w_rows();                          // fold the pending column scale into Wt_
 	Status normalize_w(bool from_gram_partials, int norm_parts);   // column normalisation of W after its update
 	Status normal_inverse(T* A, T offdiag, T diag);  // Qinv_ <- (A + regulariser)^-1, A destroyed
 	Status normal_inverse_fork(T* A, T offdiag, T diag);   // the same on the side stream; normal_inverse_join() before Qinv_ is read
@@ -259,6 +276,8 @@ private:
 	const T* tri_trace_scale() const { return (tri_ && tri_scale_pending_) ? reinterpret_cast<const T*>(colsq_) : nullptr; }
 	bool tri_gw_ready_ = false;      // Gw_raw_ / G_ describe the current W
 	bool tri_rows_cover_ = false;    // the last w_normalize_rows() covered every row of W
+	bool w_rows_stale_ = false;      // row-block sharded run with the fragment exchange: the fp32 rows of the other ranks' blocks in Wt_ are those of an earlier iteration
+	std::function<Status()> w_gather_hook_;
 	int colsq_parts_ = 1;            // staged partial vectors in colsq_ (kernels_tri.hip: launch_colsq_stage)
 	float *gram_tri_part_ = nullptr, *Gw_raw_ = nullptr, *Gh_raw_ = nullptr, *colsq_ = nullptr;
 	bool qx3_holds_g_ = false, qx3_holds_hht_ = false;   // qx3_ holds the split image of G_ / of the smoothed H H^T (k_smooth_gram)

@@ -15,6 +15,7 @@ ShardedRank<T>::ShardedRank(Engine<T>* engine, Comm* comm, int mode, long rows, 
 
 template <typename T>
 ShardedRank<T>::~ShardedRank() {
+	if (eng_) eng_->set_w_gather_hook(nullptr);       // (an engine that outlives its run and still lacks the other ranks' rows says so instead of handing out stale ones)
 	if (exchange_) (void)hipFree(exchange_);
 	if (blk_) (void)hipFree(blk_);
 	if (colsq_) (void)hipFree(colsq_);
@@ -59,6 +60,8 @@ Status ShardedRank<T>::prepare() {
 		const int pretend = (world == 1 && rehearse != nullptr && std::atoi(rehearse) > 1) ? std::atoi(rehearse) : world;
 		if (mpad % (128l * pretend) != 0) { last_error_ = "engine was not created with set_row_blocks(world)"; return ST_INVALID; }
 		blk_rows_ = mpad / pretend;
+		rehearse_rows_ = pretend != world;
+		eng_->set_w_gather_hook([this]() { return gather_w_rows(); });
 		if (!dalloc(&blk_, RP * blk_rows_) || !dalloc(&colsq_, RP)) return fail("hipMalloc(row block)");
 	}
 	for (int p = 0; p < world; ++p) { long f, c; shard_columns(total_columns_, world, p, &f, &c); nloc_max_ = std::max(nloc_max_, c); }
@@ -140,10 +143,30 @@ Status ShardedRank<T>::iterate(bool compute_error) {
 		if (Status st = eng_->w_update_rows(blk_, hht, row0, blk_rows_, compute_error, colsq_)) { last_error_ = eng_->last_error(); return st; }
 		if (Status st = comm_->all_reduce(colsq_, RP, eb, s)) return comm_fail(st);
 		if (Status st = eng_->w_normalize_rows(row0, blk_rows_, colsq_)) { last_error_ = eng_->last_error(); return st; }
-		if (Status st = comm_->all_gather_inplace(eng_->w_panel(), RP * blk_rows_, eb, s)) return comm_fail(st);
-		eng_->w_rows_replaced();
+		if (eng_->w_fragment_exchange() && blk_rows_ % 16 == 0) {
+			// exchange what the consumers read (round 5): until the next W update the other ranks need this rank's rows only as the bf16 fragments that
+			// w_normalize_rows() just wrote -- half the bytes of the fp32 rows (config 4: 25.6 MB over the links instead of 51.2), and no rank re-rounds all rows
+			// (25 us); the fp32 rows are gathered when somebody asks for the factors (gather_w_rows, through the engine's hook)
+			if (Status st = comm_->all_gather_inplace(eng_->w_fragments(), eng_->w_fragment_words_per_row() * blk_rows_, 4, s)) return comm_fail(st);
+			eng_->w_fragments_gathered(world > 1 || rehearse_rows_);
+		} else {
+			if (Status st = comm_->all_gather_inplace(eng_->w_panel(), RP * blk_rows_, eb, s)) return comm_fail(st);
+			eng_->w_rows_replaced();
+		}
 	}
 	if (compute_error && !eng_->is_kl()) return launch_error_gather();      // (KL: the terms travelled in the exchange buffer, the engine keeps them)
+	return ST_OK;
+}
+
+// The fp32 rows of every rank's block into w_panel() (row-block mode with the fragment exchange: Engine::get_factors and friends call this through the hook).
+// A COLLECTIVE: every rank's engine must ask for its factors.
+template <typename T>
+Status ShardedRank<T>::gather_w_rows() {
+	if (mode_ != SHARD_ROW_BLOCKS || blk_rows_ <= 0) return ST_OK;
+	if (comm_->world() > 1) {
+		if (Status st = comm_->all_gather_inplace(eng_->w_panel(), eng_->rp() * blk_rows_, (int)sizeof(T), eng_->stream())) { last_error_ = comm_->last_error(); return st; }
+	}
+	eng_->w_rows_gathered();
 	return ST_OK;
 }
 

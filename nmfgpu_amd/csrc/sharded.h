@@ -50,6 +50,7 @@ public:
 private:
 	Status fail(const char* what) { last_error_ = what; (void)hipGetLastError(); return ST_HIP_ERROR; }
 	Status launch_error_gather();
+	Status gather_w_rows();
 	// elements per rank in the gathered error-term buffer: [n_local terms | r terms], padded to whole 16-byte units
 	long slot_len() const { return ((std::max<long>(nloc_max_, eng_->r()) + eng_->r() + 3) / 4) * 4; }
 	void finalize();
@@ -62,6 +63,7 @@ private:
 	long nloc_max_ = 0;
 	T* exchange_ = nullptr;                 // [panel RP x mpad | H H^T RP x RP]
 	bool direct_ = false, rehearse_ = false; // the W update reads the ranks' exchange buffers itself (sharded.cpp, prepare)
+	bool rehearse_rows_ = false;             // measurement build: a team of one updates 1 / N of the rows (timing only)
 	T* xslot_[2] = {nullptr, nullptr};      // ... this rank's two exchange buffers (the transport's), alternating by iteration
 	unsigned long iterations_ = 0;
 	T* blk_ = nullptr;                      // reduced (V H^T)^T rows of this rank

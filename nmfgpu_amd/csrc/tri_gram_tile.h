@@ -133,10 +133,14 @@ __device__ inline void tri_gram_passenger(const bf16x8* __restrict__ frags, int 
 #pragma unroll
 			for (int g = 0; g < 16; ++g) out[(long)t * 1024 + g * 64 + lane] = acc[q][g];
 		}
-	// release this workgroup's partial tiles, count it in; the last of the sixteen of this half finishes the half's tiles
+	// release this workgroup's partial tiles, count it in; the last of the sixteen of this half finishes the half's tiles.
+	// Round 5: ONE release per workgroup (every storing wave drains its stores, the barrier, then lane 0 writes the XCD's L2 back once and adds to the counter) and ONE
+	// acquire by the finishing workgroup's first wave -- round 4 had all 256 threads run __threadfence() (write-back + invalidate per wave: 128 L2 write-backs per launch
+	// beside the product's own stores) and every thread of the last arriver invalidate.  TRI_RIDE_FENCE_ALL=1 (A/B) restores that form.
+	__shared__ unsigned s_last;
+#if defined(TRI_RIDE_FENCE_ALL) && TRI_RIDE_FENCE_ALL
 	__threadfence();
 	__syncthreads();
-	__shared__ unsigned s_last;
 	if (tid == 0) {
 		const unsigned old = __hip_atomic_fetch_add(counters + half, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		s_last = old == (unsigned)(TRI_RIDE_SLICES - 1) ? 1u : 0u;
@@ -145,6 +149,23 @@ __device__ inline void tri_gram_passenger(const bf16x8* __restrict__ frags, int 
 	__syncthreads();
 	if (!s_last) return;
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (tid == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (hipcc may drop the wait behind the write-back when it knows the counter empty: written out)
+		const unsigned old = __hip_atomic_fetch_add(counters + half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_last = old == (unsigned)(TRI_RIDE_SLICES - 1) ? 1u : 0u;
+		if (s_last) {
+			__hip_atomic_store(counters + half, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch finds zero)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 holds nothing of the partials yet that another CU has since rewritten ...
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... once the invalidate has completed: the barrier below holds the other waves until then
+		}
+	}
+	__syncthreads();
+	if (!s_last) return;
+#endif
 	for (int k = 0; k < 18; ++k) {
 		const int t = 2 * k + half;
 		int i, j;

@@ -254,7 +254,7 @@ def run_child(cmd, env, what: str, timeout: float):
 
 def worker_argv(args, role: str):
     argv = [sys.executable, os.path.abspath(__file__), role, "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
-            "--scaling", args.scaling, "--shard-mode", str(args.shard_mode), "--event-stride", str(args.event_stride)]
+            "--scaling", args.scaling, "--shard-mode", str(args.shard_mode), "--event-stride", str(args.event_stride), "--setup-iterations", str(args.setup_iterations)]
     for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-kernel-events", args.no_kernel_events), ("--allow-shared-device", args.allow_shared_device)):
         if on:
             argv.append(flag)
@@ -324,6 +324,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--setup-iterations", type=int, default=-1,
+                    help="untimed iterations of the hot path BEFORE the --warmup steps (first launches of every kernel, the device's ramp from idle; the factors go back to W0, H0 "
+                         "afterwards).  -1 (default): 240 at config 2's shape (scaled for the slower workloads), as in round 4 -- the line reports what ran in config.setup_iterations; "
+                         "0: the timed steps follow the driver's warm-up directly")
     ap.add_argument("--sharded", action="store_true", help="N = 1 only: drive the three-phase sharded API from Python (no collective) instead of the fused loop")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket any factor-product launch with HIP events")
     ap.add_argument("--event-stride", type=int, default=0, help="(kept for old command lines; unused since round 5: the launch samples are taken in an untimed replay behind the timed steps)")
@@ -347,6 +351,9 @@ def main():
     args = ap.parse_args()
     if args.event_stride <= 0:
         args.event_stride = max(10, args.steps // 5)
+    global SETUP_ITERATIONS
+    if args.setup_iterations >= 0:
+        SETUP_ITERATIONS = args.setup_iterations
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):
@@ -396,7 +403,8 @@ def main():
         eng.set_factors(W, H)
         # set-up, not steps (as in the multi-GPU paths below): the first launches of every kernel and the device's ramp from idle -- measured, iterations 26-75 of a
         # process run at 101 us, 76-100 at 96, from ~125 on at 91-92 (profiles/r04_warmup_timeline.txt; the same ramp follows 2 s of idling) -- then back to W0, H0
-        eng.iterate(SETUP_ITERATIONS, first_iteration=1, error_every=10)
+        if SETUP_ITERATIONS > 0:
+            eng.iterate(SETUP_ITERATIONS, first_iteration=1, error_every=10)
         eng.synchronize()
         eng.set_factors(W, H)
         eng.iterate(Wm, first_iteration=1, error_every=10)

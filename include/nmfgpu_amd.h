@@ -133,10 +133,15 @@ typedef struct nmfamd_geometry {
 	int one_pass;          /* rank-64 multiplicative update: 1 = V is streamed ONCE per iteration (W^T V, the H update and V H^T in one
 	                          persistent launch, kernels_onepass.hip; opt-in: NMFAMD_ONE_PASS=1); 0 = two passes (the default); 2 = a one-pass launch
 	                          gave up (it could not keep its workgroups resident) and the engine reported the error */
+	/* round 5: the counts that fix the ORDER of partial sums (and so the bits of a result), so that a run can be reproduced: all of them functions of the
+	 * shape and of the device's properties only (never of what else occupies the device) */
+	int kl_blocks_w, kl_blocks_h;   /* KL update: L2-sized blocks the gathered factor is cut into (1 = unblocked; 0 = not the KL update) */
+	int gram_k_slices;              /* rank-64 multiplicative update: K slices of the W^T W passengers */
+	int w_col_split;                /* 1: V H^T runs as 128 x 32 workgroups (narrow column shards) */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 /* The same for a caller compiled against an older (shorter) or newer (longer) nmfamd_geometry: writes min(struct_size, sizeof(nmfamd_geometry)) bytes, never
- * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
+ * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`, round 5 the four counts behind it).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
 NMFAMD_API int nmfamd_engine_geometry_sized(const nmfamd_engine* e, void* out, unsigned long struct_size);
 
 /* ---- column-sharded multi-GPU form of the multiplicative update ------------------------------

@@ -1615,11 +1615,13 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 			// five blocks or more: a multiple of eight, so that every XCD gathers from its OWN blocks (k_kl_fused) and fetches 1 / 8 of the factor per launch
 			auto by_xcd = [](int b) { return b >= 5 ? ((b + 7) / 8) * 8 : b; };
 			kl_blocks_w_ = by_xcd(kl_blocks_w_); kl_blocks_h_ = by_xcd(kl_blocks_h_);
-			// every block writes its own partial numerator panel (and k_kl_update reads them all): keep that scratch within a quarter of the free memory
-			// (64 blocks of a 1M-row factor were 32 GB), halving the block count until it fits
+			// every block writes its own partial numerator panel (and k_kl_update reads them all): keep that scratch within an eighth of the DEVICE's memory
+			// (64 blocks of a 1M-row factor were 32 GB), halving the block count until it fits.  A function of the shape and of the device only
+			// (round 4 asked the FREE memory, so the block count -- and with it the order of the partial sums, i.e. the bits -- depended on what else
+			// occupied the device); if the allocation then fails, the unblocked gather runs (below).  geometry() reports the counts that ran.
 			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)1 << 62; }
-			auto fit = [&](int b, long panel_rows) { while (b > 1 && (double)b * RP_ * (double)panel_rows * sizeof(T) > 0.25 * (double)free_b) b = b > 8 ? ((b / 2 + 7) / 8) * 8 : b / 2; return b; };
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)1 << 62; }
+			auto fit = [&](int b, long panel_rows) { while (b > 1 && (double)b * RP_ * (double)panel_rows * sizeof(T) > 0.125 * (double)total_b) b = b > 8 ? ((b / 2 + 7) / 8) * 8 : b / 2; return b; };
 			kl_blocks_w_ = fit(kl_blocks_w_, mpad_); kl_blocks_h_ = fit(kl_blocks_h_, npad_);
 			auto boundaries = [&](const std::vector<int>& ptr, const std::vector<int>& idx, int rows, long range, int blocks, int** dev) -> hipError_t {
 				if (blocks <= 1) return hipSuccess;

@@ -92,6 +92,9 @@ public:
 	Status w_normalize_rows(long row0, long rows, T* colsq);
 	void w_rows_replaced() { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
+	int kl_blocks(bool w_step) const { return prm_.divergence != 0 ? (w_step ? kl_blocks_w_ : kl_blocks_h_) : 0; }
+	int gram_k_slices() const { return gram_ksplit_; }
+	bool w_col_split() const { return w_col_split_; }
 	// Row-block form at padded rank 256 with bf16 operands (config 4): between two W updates the OTHER ranks read only the bf16 fragments of a rank's rows (the next
 	// W^T V's operand and the Gram matrix are made from them) -- so the all-gather carries the fragments w_normalize_rows() left for this rank's rows (RP / 2 four-byte
 	// words per row: 25.6 MB at config 4 instead of 51.2 MB of fp32 rows) and the fp32 rows of the other ranks stay STALE in w_panel() until somebody needs them

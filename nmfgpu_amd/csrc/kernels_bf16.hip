@@ -609,324 +609,13 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	}
 }
 
-// ---- 256 panel columns per pass, round 4: the roles of the two operands swapped ------------------------------------------------------
-// Round 2's kernel (above) sends the HBM-streamed operand A through "global load -> register ring -> LDS park -> barrier -> LDS read" and keeps the
-// L2-hot factor fragments on a private register ring; with the MFMAs removed it takes the same 155 us, i.e. it is bound by that chain on the stream
-// that comes from HBM (profiles/r02_c4_kernel_experiments.md).  Here:
-//   * workgroup = 4 waves, one per SIMD, = 8 row blocks of 32 (256 rows) x 256 columns x one K slice; wave w OWNS row blocks 2 w, 2 w + 1 for all 256
-//     columns: 16 accumulator tiles = 256 AGPRs, 16 MFMAs per K-step;
-//   * A: a wave loads the fragments of ITS two row blocks (2 KiB contiguous per K-step: the image is in fragment order) straight into the registers the
-//     MFMAs read -- a D-deep ring, 2 D loads in flight per wave, no LDS, no barrier between HBM and the matrix pipe;
-//   * F: the 8 KiB of factor fragments of a K-step are the same for all four waves: every wave loads two of the eight blocks (DF-deep register ring),
-//     parks them in a three-slot LDS ring, and all waves read the eight blocks from there (8 ds_read_b128 per 16 MFMAs: 64 B / clk of the CU's 128);
-//   * one barrier per K-step (it now guards the L2-hot operand); branch-free loop, every memory instruction between two MFMAs, as in round 2;
-//   * no cross-wave sum: the waves own disjoint rows, every wave stores its own tiles.
-// 196 workgroups for config 4's 1 563 row blocks (round 2: 224 of 7): the same time per K-step decides either way -- a wave with two row blocks sets the pace.
-#ifndef BFD_R3_D
-#define BFD_R3_D 8                    // register-ring depth of the A operand (K-steps in flight per wave, two loads each)
-#endif
-#ifndef BFD_R3_DF
-#define BFD_R3_DF 4                   // ... of the factor fragments on their way to LDS (divides BFD_R3_D)
-#endif
-template <int D, int DF>
-__global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r3(
-	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
-	static_assert(D % 2 == 0 && D % DF == 0 && DF >= 2, "ring depths");
-	constexpr int AHEAD = 2, SLOTS = 3;
-	__shared__ __attribute__((aligned(16))) bf16x8 l8[SLOTS * 512];      // [slot][factor block 0..7][lane]
-	const int nblk = tiles * splits;
-	int vb = blockIdx.x;
-	{
-		const int q8 = nblk / 8, r8 = nblk % 8, xcd = vb % 8, idx = vb / 8;      // XCD-aware placement, as in kernels_x3.hip
-		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-	}
-	const int t = vb % tiles, sp = vb / tiles, grp = blockIdx.y;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	const int half = lane >> 5, l31 = lane & 31;
-	const int b0 = (int)(((long)steps_total * sp) / splits);
-	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
-	const int n = b1 - b0;
-	const int last = n > 0 ? n - 1 : 0;
-	const long fstep = (long)NBT * 64;
-
-	// this wave's two row blocks (beyond the image: a repeat of the last block -- its tiles are not stored); wave-uniform bases, scalar-base loads
-	const int gb0 = t * 8 + 2 * wave;
-	const bf16x8* abase[2];
-#pragma unroll
-	for (int j = 0; j < 2; ++j) {
-		int gb = gb0 + j;
-		gb = gb < total_blocks ? gb : total_blocks - 1;
-		abase[j] = A + (long)(gb >> 2) * tile_frags + (long)b0 * 256 + (gb & 3) * 64;
-	}
-	const bf16x8* fbase = F + ((long)b0 * NBT + grp * 8 + 2 * wave) * 64;
-	const bf16x8* zbase = g_bf_zero_block;
-	// K-steps past the end of the slice: A reads a block of zeros (nothing is selected per lane), F repeats the last step (times zero)
-	auto a_src = [&](int j, int k) -> const bf16x8* { return k < n ? abase[j] + (long)k * 256 : zbase; };
-	auto f_src = [&](int k) -> const bf16x8* { return fbase + (long)(k < last ? k : last) * fstep; };
-	const int pblk = 2 * wave * 64 + lane;                    // this wave's two factor blocks inside a slot (+ 64 for the second)
-
-	f32x16 acc[2][8];
-#pragma unroll
-	for (int b = 0; b < 2; ++b)
-#pragma unroll
-		for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
-
-	bf16x8 stA[D][2], stF[DF][2];
-#pragma unroll
-	for (int q = 0; q < D; ++q) { stA[q][0] = a_src(0, q)[lane]; stA[q][1] = a_src(1, q)[lane]; }
-#pragma unroll
-	for (int q = 0; q < DF; ++q) { stF[q][0] = f_src(q)[lane]; stF[q][1] = f_src(q)[64 + lane]; }
-	// factor steps 0 .. AHEAD - 1 parked, their ring slots reloaded with steps DF ...
-#pragma unroll
-	for (int q = 0; q < AHEAD; ++q) {
-		l8[q * 512 + pblk] = stF[q][0];
-		l8[q * 512 + pblk + 64] = stF[q][1];
-		stF[q][0] = f_src(DF + q)[lane]; stF[q][1] = f_src(DF + q)[64 + lane];
-	}
-	__syncthreads();
-	bf16x8 vf[2][8];
-#pragma unroll
-	for (int nb = 0; nb < 8; ++nb) vf[0][nb] = l8[nb * 64 + lane];
-	__builtin_amdgcn_sched_barrier(0);
-
-	const int n_pad = ((n + D - 1) / D) * D;
-	int rd = 1, wr = AHEAD;                              // LDS slots of factor step s + 1 (to read) and s + AHEAD (to park)
-	for (int t0 = 0; t0 < n_pad; t0 += D) {
-#pragma unroll
-		for (int u = 0; u < D; ++u) {
-			const int s = t0 + u;
-			__syncthreads();                             // factor step s + 1 visible; the slot of step s + AHEAD free
-			// ONE scheduling region: the sixteen MFMAs of step s and, between them, the park of factor step s + AHEAD, the factor loads of step
-			// s + AHEAD + DF, the operand reads of factor step s + 1, and the A loads of step s + D into the ring slot whose MFMAs have been issued
-			l8[wr * 512 + pblk] = stF[(u + AHEAD) % DF][0];
-			l8[wr * 512 + pblk + 64] = stF[(u + AHEAD) % DF][1];
-			stF[(u + AHEAD) % DF][0] = f_src(s + AHEAD + DF)[lane];
-			stF[(u + AHEAD) % DF][1] = f_src(s + AHEAD + DF)[64 + lane];
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) vf[(u + 1) & 1][nb] = l8[rd * 512 + nb * 64 + lane];
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][0], vf[u & 1][nb], acc[0][nb], 0, 0, 0);
-			stA[u][0] = a_src(0, s + D)[lane];
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][1], vf[u & 1][nb], acc[1][nb], 0, 0, 0);
-			stA[u][1] = a_src(1, s + D)[lane];
-			// MFMA, then one memory instruction: 2 LDS writes, 2 factor loads, 8 LDS reads (twelve of the sixteen gaps); the A loads follow the MFMAs that
-			// read their registers: the first after MFMA 8, the second after MFMA 16
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
-				if (i < 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        // DS write
-				else if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read (F)
-				else if (i == 7 || i == 15) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read (A)
-				else if (i < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // DS read (8 of them: i = 4..6, 8..12)
-			}
-			rd = rd == SLOTS - 1 ? 0 : rd + 1;
-			wr = wr == SLOTS - 1 ? 0 : wr + 1;
-			__builtin_amdgcn_sched_barrier(0);
-		}
-	}
-
-	// epilogue: C/D map of the 32 x 32 MFMA: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31
-	float* slab = slabs + (long)sp * slab_stride;
-#pragma unroll
-	for (int b = 0; b < 2; ++b) {
-		const int gb = gb0 + b;
-		if (gb < total_blocks) {
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) {
-				const int c = 256 * grp + 32 * nb + l31;
-#pragma unroll
-				for (int g = 0; g < 16; ++g) {
-					const int x = 32 * gb + (g & 3) + 8 * (g >> 2) + 4 * half;
-					slab[(long)x * RP + c] = acc[b][nb][g];
-				}
-			}
-		}
-	}
-}
-
-// ---- the same kernel with its global loads and their waits written by hand -------------------------------------------------------------
-// hipcc counts vmcnt exactly inside the unrolled body, but at every trip round the loop it assumes nothing about the loads of the previous trip and waits until
-// only the loads issued SINCE THE BACK EDGE are outstanding (vmcnt(7) at the first step of a trip, rising to 15 at the eighth: profiles/r04_c4_product_kernel.md)
-// -- the deep rings drain once per trip.  Here the loop's global loads are inline assembly (the compiler does not see them as memory operations and places no
-// wait), and every wait is a counted s_waitcnt written for the steady state.  Issue order inside a step, one load behind every fourth MFMA:
-//     F0 (factor block 2 w of step s + AHEAD + D) | A0 (row block 0 of step s + D) | F1 | A1
-// so that at the start of step s the ring slot about to be parked (loaded D steps ago, F1 the younger of its two) has 4 D - 3 younger loads behind it, and
-// the second row block's operand (A1 of step s - D) 4 D - 2 behind it when its MFMAs start.  The waits name the registers they guard ("+v"), which keeps the
-// compiler from moving a use above them.
-__device__ inline void bf_load_frag(bf16x8& dst, unsigned voff, const bf16x8* base) {
-	asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
-}
-__device__ inline void bf_load_frag_1k(bf16x8& dst, unsigned voff, const bf16x8* base) {
-	asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst) : "v"(voff), "s"(base));
-}
-template <int N>
-__device__ inline void bf_wait1(bf16x8& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }      // (one operand per register: naming one twice hands the compiler a second, never written, copy)
-template <int N>
-__device__ inline void bf_wait3(bf16x8& a, bf16x8& b, bf16x8& c) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
-
-template <int D>
-__global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r3a(
-	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles) {
-	static_assert(D % 2 == 0 && 4 * D - 2 <= 63, "ring depth even; the waits fit the 6-bit vmcnt field");
-	constexpr int AHEAD = 2, SLOTS = 3;
-	__shared__ __attribute__((aligned(16))) bf16x8 l8[SLOTS * 512];      // [slot][factor block 0..7][lane]
-	const int nblk = tiles * splits;
-	int vb = blockIdx.x;
-	{
-		const int q8 = nblk / 8, r8 = nblk % 8, xcd = vb % 8, idx = vb / 8;
-		vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-	}
-	const int t = vb % tiles, sp = vb / tiles, grp = blockIdx.y;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	const int half = lane >> 5, l31 = lane & 31;
-	const unsigned voff = (unsigned)lane * 16u;
-	const int b0 = (int)(((long)steps_total * sp) / splits);
-	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
-	const int n = b1 - b0;
-	const int last = n > 0 ? n - 1 : 0;
-	const long fstep = (long)NBT * 64;
-	const int gb0 = t * 8 + 2 * wave;
-	const bf16x8* abase[2];
-#pragma unroll
-	for (int j = 0; j < 2; ++j) {
-		int gb = gb0 + j;
-		gb = gb < total_blocks ? gb : total_blocks - 1;
-		abase[j] = A + (long)(gb >> 2) * tile_frags + (long)b0 * 256 + (gb & 3) * 64;
-	}
-	const bf16x8* fbase = F + ((long)b0 * NBT + grp * 8 + 2 * wave) * 64;
-	const bf16x8* zbase = g_bf_zero_block;
-	auto a_src = [&](int j, int k) -> const bf16x8* { return k < n ? abase[j] + (long)k * 256 : zbase; };
-	auto f_src = [&](int k) -> const bf16x8* { return fbase + (long)(k < last ? k : last) * fstep; };
-	const int pblk = 2 * wave * 64 + lane;
-
-	f32x16 acc[2][8];
-#pragma unroll
-	for (int b = 0; b < 2; ++b)
-#pragma unroll
-		for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-			for (int g = 0; g < 16; ++g) acc[b][nb][g] = 0.f;
-
-	// prologue with ordinary loads (the compiler waits for them where they are used): A steps 0 .. D - 1, factor steps 0 .. AHEAD - 1 parked at once and the
-	// ring filled with steps AHEAD .. AHEAD + D - 1
-	bf16x8 stA[D][2], stF[D][2];
-	{
-		bf16x8 f0[AHEAD][2];
-#pragma unroll
-		for (int q = 0; q < AHEAD; ++q) { f0[q][0] = f_src(q)[lane]; f0[q][1] = f_src(q)[64 + lane]; }
-#pragma unroll
-		for (int q = 0; q < AHEAD; ++q) { l8[q * 512 + pblk] = f0[q][0]; l8[q * 512 + pblk + 64] = f0[q][1]; }
-	}
-	__syncthreads();
-	bf16x8 vf[2][8];
-#pragma unroll
-	for (int nb = 0; nb < 8; ++nb) vf[0][nb] = l8[nb * 64 + lane];
-	// ... from here on every global load is hand-issued, in the loop's order (F0, A0, F1, A1 per step), so that the counts of the first trip are the loop's
-	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-	for (int q = 0; q < D; ++q) {
-		// ring slot (q + AHEAD) % D receives factor step q + AHEAD: the slot step q parks from (step q parks factor step q + AHEAD)
-		bf_load_frag(stF[(q + AHEAD) % D][0], voff, f_src(q + AHEAD));
-		bf_load_frag(stA[q][0], voff, a_src(0, q));
-		bf_load_frag_1k(stF[(q + AHEAD) % D][1], voff, f_src(q + AHEAD));
-		bf_load_frag(stA[q][1], voff, a_src(1, q));
-	}
-	__builtin_amdgcn_sched_barrier(0);
-
-	const int n_pad = ((n + D - 1) / D) * D;
-	int rd = 1, wr = AHEAD;
-	for (int t0 = 0; t0 < n_pad; t0 += D) {
-#pragma unroll
-		for (int u = 0; u < D; ++u) {
-			const int s = t0 + u;
-			constexpr int W0 = 4 * D - 3, W1 = 4 * D - 2;
-			const int fu = (u + AHEAD) % D;
-			__builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads of the previous step have landed
-			__builtin_amdgcn_s_barrier();                // factor step s + 1 visible; the slot of step s + AHEAD free
-			bf_wait3<W0>(stF[fu][0], stF[fu][1], stA[u][0]);
-			l8[wr * 512 + pblk] = stF[fu][0];
-			l8[wr * 512 + pblk + 64] = stF[fu][1];
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) vf[(u + 1) & 1][nb] = l8[rd * 512 + nb * 64 + lane];
-#pragma unroll
-			for (int nb = 0; nb < 4; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][0], vf[u & 1][nb], acc[0][nb], 0, 0, 0);
-			// MFMA, LDS instruction, four times: 2 writes + 2 reads here, 3 + 3 reads in the next two groups
-#pragma unroll
-			for (int i = 0; i < 2; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
-#pragma unroll
-			for (int i = 0; i < 2; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-			__builtin_amdgcn_sched_barrier(0);
-			bf_load_frag(stF[fu][0], voff, f_src(s + AHEAD + D));
-#pragma unroll
-			for (int nb = 4; nb < 8; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][0], vf[u & 1][nb], acc[0][nb], 0, 0, 0);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-			__builtin_amdgcn_sched_barrier(0);
-			bf_load_frag(stA[u][0], voff, a_src(0, s + D));
-			bf_wait1<W1>(stA[u][1]);
-#pragma unroll
-			for (int nb = 0; nb < 4; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][1], vf[u & 1][nb], acc[1][nb], 0, 0, 0);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-			__builtin_amdgcn_sched_barrier(0);
-			bf_load_frag_1k(stF[fu][1], voff, f_src(s + AHEAD + D));
-#pragma unroll
-			for (int nb = 4; nb < 8; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(stA[u][1], vf[u & 1][nb], acc[1][nb], 0, 0, 0);
-			__builtin_amdgcn_sched_barrier(0);
-			bf_load_frag(stA[u][1], voff, a_src(1, s + D));
-			rd = rd == SLOTS - 1 ? 0 : rd + 1;
-			wr = wr == SLOTS - 1 ? 0 : wr + 1;
-			__builtin_amdgcn_sched_barrier(0);
-		}
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the loads still in flight write registers: nothing below may be allocated over them before they land
-
-	float* slab = slabs + (long)sp * slab_stride;
-#pragma unroll
-	for (int b = 0; b < 2; ++b) {
-		const int gb = gb0 + b;
-		if (gb < total_blocks) {
-#pragma unroll
-			for (int nb = 0; nb < 8; ++nb) {
-				const int c = 256 * grp + 32 * nb + l31;
-#pragma unroll
-				for (int g = 0; g < 16; ++g) {
-					const int x = 32 * gb + (g & 3) + 8 * (g >> 2) + 4 * half;
-					slab[(long)x * RP + c] = acc[b][nb][g];
-				}
-			}
-		}
-	}
-}
-
-static hipError_t launch_fp_bf16_r3(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
-                                     float* slabs, long slab_stride, hipStream_t stream) {
-	const int tiles = (4 * p.xtiles + 7) / 8, splits = p.splits;
-	if (splits < 1 || KS < 1) return hipErrorInvalidValue;
-	dim3 grid(tiles * splits, RP / 256), block(256);
-	static const bool compiler_waits = tuning_env("NMFAMD_BF_R3_PLAIN") != nullptr;      // A/B switch: the same kernel with hipcc's own loads and waits
-	if (!compiler_waits) {
-		hipLaunchKernelGGL((k_factor_product_bf16_r3a<BFD_R3_D>), grid, block, 0, stream,
-		                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-		                   slabs, slab_stride, RP, KS, splits, tiles);
-		return hipGetLastError();
-	}
-	hipLaunchKernelGGL((k_factor_product_bf16_r3<BFD_R3_D, BFD_R3_DF>), grid, block, 0, stream,
-	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-	                   slabs, slab_stride, RP, KS, splits, tiles);
-	return hipGetLastError();
-}
+// (Round 4 built two more memory skeletons for this product -- the HBM stream straight into the MFMA operand registers with the factor fragments through LDS, and the
+//  same with hand-written loads and counted waits: 158.5 / 157.7 us per launch against this kernel's 159.6, profiles/r04_c4_product_kernel.md.  Removed in round 5:
+//  git history holds them -- k_factor_product_bf16_r3 / r3a.)
 
 // workgroups along x and K slices of the round-2 kernel for `xtiles` 128-row tiles and KS K-steps
 static void plan_bf16_dma(int xtiles, int KS, int num_cus, int* tiles, int* splits) {
-	const int nrb = tuning_env("NMFAMD_BF_R3") != nullptr ? 8 : BFD_NRB;      // row blocks per workgroup: 7 (round 2's kernel, what ships) or 8 (k_factor_product_bf16_r3, measurement builds)
+	const int nrb = BFD_NRB;      // row blocks per workgroup
 	*tiles = (4 * xtiles + nrb - 1) / nrb;
 	const int by_fill = std::max(1, num_cus / std::max(1, *tiles));
 	const int by_depth = std::max(1, KS / 48);               // at least 48 K-steps per slice: the rings are 8 deep
@@ -1005,14 +694,8 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 		if (rg != nullptr && rg->partials != nullptr) return hipErrorInvalidValue;
 		const bool tri_ride = rg != nullptr && rg->tri_frags != nullptr;
 		static const bool staged = tuning_env("NMFAMD_BF_STAGED") != nullptr;          // A/B switch: the round-1 kernel
-		if (tri_ride && (staged || tuning_env("NMFAMD_BF_R3") != nullptr)) return hipErrorInvalidValue;      // (only the shipped kernel carries passengers)
+		if (tri_ride && staged) return hipErrorInvalidValue;      // (only the shipped kernel carries passengers)
 		if (staged) return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
-		// Round 4 built the role swap VERDICT r3 asked for (k_factor_product_bf16_r3: the HBM stream straight into the MFMA operand registers, the factor fragments
-		// through LDS) and its form with hand-written loads and counted waits (r3a): 158.5 / 157.7 us per launch against this kernel's 159.6 on the same box
-		// (profiles/r04_c4_product_kernel.md) -- three different memory skeletons, one time.  The round-2 kernel stays the default; NMFAMD_BF_R3=1 (measurement
-		// builds) selects the new one, NMFAMD_BF_R3_PLAIN=1 its compiler-scheduled form.
-		static const bool r3 = tuning_env("NMFAMD_BF_R3") != nullptr;
-		if (r3) return launch_fp_bf16_r3(p, A, KS, F, RP, slabs, slab_stride, stream);
 		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	}
 	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);

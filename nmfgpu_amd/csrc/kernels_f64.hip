@@ -556,7 +556,9 @@ __global__ __launch_bounds__(256, 2) void k_gram_f64(const double* __restrict__ 
 hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* partial, double* G, hipStream_t stream) {
 	if (RP != 64 && RP % 128 != 0) return hipErrorInvalidValue;
 	const int nb = RP == 64 ? 1 : RP / 128, nsuper = nb * (nb + 1) / 2;
-	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
+	// at least 16 K-steps (64 panel rows) per slice -- except for short panels (the H side of the reference example: 165 columns at r = 158 were TWO slices, six
+	// workgroups with 21 dependent K-steps each: 19.8 us for 21 MFLOP): there 4 K-steps per slice, so that the launch is one short round (round 5)
+	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len >= 1024 ? len / 64 : len / 16)));
 	if (RP == 64) hipLaunchKernelGGL((k_gram_f64<2, 8>), dim3(parts, 1), dim3(256), 0, stream, P, RP, len, parts, partial);
 	else hipLaunchKernelGGL((k_gram_f64<4, 6>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();

@@ -272,8 +272,6 @@ NMFAMD_API int nmfamd_op_factor_product_x3(const float* A, long lda, int X, int 
  * output index): one resident image of V serves both products. */
 NMFAMD_API int nmfamd_op_factor_product_x3_ytiled(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo,
                                                   int reps, double* avg_us);
-/* ... from 256-row workgroups whose waves share the factor fragments through LDS (csrc/kernels_x3w.hip; r <= 64; y_tiled 0: x-tiled image in 128-row tiles, 1: the image tiled along the reduction index in 16-row tiles, 2: x-tiled image in 16-row tiles) */
-NMFAMD_API int nmfamd_op_factor_product_x3w(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int y_tiled);
 /* Diagnostic (NMFAMD_X3_VARIANT = 10..13 builds): per wave {shader cycles, 100 MHz ticks, K-steps of the main loop; 100 MHz
  * stamps at entry, loop start, loop end, tail end, exit} of one more launch; stamps_capacity in 8-byte words; *waves receives the number of waves stamped. */
 NMFAMD_API int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves);

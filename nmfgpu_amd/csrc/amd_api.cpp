@@ -512,8 +512,8 @@ int nmfamd_op_factor_product_bf16(const float* A, long lda, int X, int Y, const 
 	return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
 }
 
-// wide: the 256-row form; x16 (wide only): the x-tiled image in 16-row tiles (the engine's ONE resident image, read along its output index)
-static int op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us, bool y_tiled, bool wide = false, bool x16 = false) {
+// x16: the x-tiled image in 16-row tiles (the engine's ONE resident image, read along its output index)
+static int op_factor_product_x3(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int reps, double* avg_us, bool y_tiled, bool x16 = false) {
 	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
 	int dev = 0; hipDeviceProp_t prop;
@@ -539,18 +539,6 @@ static int op_factor_product_x3(const float* A, long lda, int X, int Y, const fl
 	if (y_tiled) { if (launch_tile_transposed<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, 16, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR; }
 	else if (launch_tile<float>((const float*)dA.p, Xp, X, Y, (float*)dT.p, tstride, ith, false, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_pack_panel_x3((const float*)dF.p, RP, Y, dFb.p, KS, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-	if (wide) {
-		// the 256-row form (kernels_x3w.hip): its own plan (one K slice per workgroup) and slab count
-		if (RP != 64) return NMFAMD_INVALID_ARGUMENT;
-		FactorProductPlan pw = plan;
-		plan_x3w(Xp, KS, prop.multiProcessorCount, 0, &pw.xtiles, &pw.splits);
-		DevBuf dSw;
-		if (dSw.alloc(sizeof(float) * slab_stride * pw.splits) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;
-		if (launch_factor_product_x3w(pw, (const float*)dT.p, tstride, dFb.p, RP, (float*)dSw.p, slab_stride, Xp, nullptr, nullptr, nullptr, y_tiled, ith) != hipSuccess) return NMFAMD_HIP_ERROR;
-		if (launch_reduce_slabs<float>((const float*)dSw.p, pw.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
-		if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
-		return hipDeviceSynchronize() == hipSuccess ? NMFAMD_OK : NMFAMD_HIP_ERROR;
-	}
 	if (launch_factor_product_x3(plan, (const float*)dT.p, tstride, dFb.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, nullptr, y_tiled, ith) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (launch_reduce_slabs<float>((const float*)dS.p, plan.splits, slab_stride, (float*)dO.p, slab_stride, nullptr) != hipSuccess) return NMFAMD_HIP_ERROR;
 	if (hipMemcpy2D(OUT, ldo * sizeof(float), dO.p, RP * sizeof(float), r * sizeof(float), X, hipMemcpyDeviceToHost) != hipSuccess) return NMFAMD_HIP_ERROR;
@@ -582,9 +570,6 @@ int nmfamd_op_factor_product_x3_ytiled(const float* A, long lda, int X, int Y, c
 	return op_factor_product_x3(A, lda, X, Y, F, ldf, r, OUT, ldo, reps, avg_us, true);
 }
 
-int nmfamd_op_factor_product_x3w(const float* A, long lda, int X, int Y, const float* F, long ldf, int r, float* OUT, long ldo, int y_tiled) {
-	return op_factor_product_x3(A, lda, X, Y, F, ldf, r, OUT, ldo, 0, nullptr, y_tiled == 1, true, y_tiled == 2);
-}
 
 int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, long stamps_capacity, long* waves) {
 	// X x Y = rows x columns of V (config 2: 10 000 x 5 000).  ONE image in 16-row tiles, as the engine keeps it; the two production forms alternate on it as they do
@@ -603,12 +588,6 @@ int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, 
 	planH.xtiles = (int)(Np / 128); planH.steps_total = ksH; planH.splits = plan_splits_x3(planH.xtiles, ksH, prop.multiProcessorCount);
 	const char* ve = tuning_env("NMFAMD_X3_VARIANT");
 	const bool ytiled = ve != nullptr && std::atoi(ve) >= 30;
-	// NMFAMD_X3W=1: the 256-row form (kernels_x3w.hip) in both roles
-	const bool wide = tuning_env("NMFAMD_X3W") != nullptr;
-	if (wide) {
-		plan_x3w(Mp, ksW, prop.multiProcessorCount, 0, &planW.xtiles, &planW.splits);
-		plan_x3w(Np, ksH, prop.multiProcessorCount, 0, &planH.xtiles, &planH.splits);
-	}
 	const FactorProductPlan& sp = ytiled ? planH : planW;
 	const long nwaves = (long)sp.xtiles * sp.splits * 4;
 	if (stamps_capacity < 8 * nwaves) return NMFAMD_INVALID_ARGUMENT;
@@ -630,11 +609,6 @@ int nmfamd_tune_factor_product_x3(int X, int Y, unsigned long long* stamps_out, 
 		const bool last = i == 39;
 		unsigned long long* sy = last && ytiled ? (unsigned long long*)dT.p : nullptr;
 		unsigned long long* sx = last && !ytiled ? (unsigned long long*)dT.p : nullptr;
-		if (wide) {
-			if (launch_factor_product_x3w(planH, (const float*)dA.p, stride, dWx.p, RP, (float*)dS.p, slab_stride, Np, nullptr, nullptr, sy, true, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
-			if (launch_factor_product_x3w(planW, (const float*)dA.p, stride, dHx.p, RP, (float*)dS.p, slab_stride, Mp, nullptr, nullptr, sx, false, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
-			continue;
-		}
 		if (launch_factor_product_x3(planH, (const float*)dA.p, stride, dWx.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, sy, true, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
 		if (launch_factor_product_x3(planW, (const float*)dA.p, stride, dHx.p, RP, (float*)dS.p, slab_stride, nullptr, nullptr, sx, false, 16) != hipSuccess) return NMFAMD_HIP_ERROR;
 	}

@@ -121,12 +121,6 @@ hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, l
 //  the pending column scale, GramReduceArgs::colsq_part)
 // out[i] = sum_k src.p[k][i] (rank order), count a multiple of 4: the r x r parts of the ranks' exchange buffers
 hipError_t launch_sum_peers(const PeerSlabs& src, float* out, int count, hipStream_t stream);
-// The same product from 256-row workgroups whose four waves split the ROWS and share the factor fragments through LDS (kernels_x3w.hip, round 5): padded rank 64;
-// p.xtiles / p.splits from plan_x3w (one K slice per workgroup); rows_total = rows of the output index the image and the slabs hold (a multiple of 128).
-void plan_x3w(long rows_total, int KS, int num_cus, int reserve, int* xtiles, int* splits);
-hipError_t launch_factor_product_x3w(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP, float* slabs, long slab_stride, long rows_total,
-                                     hipStream_t stream, const GramReduceArgs* rg = nullptr, unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128,
-                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // G (64 x 64) = P P^T from the split image of P (image_ks K-steps); normalize / scale as in GramReduceArgs.  Stand-alone form
 // of the passenger workgroups of the split-operand product launch.
 hipError_t launch_gram_from_image(const void* image, int image_ks, float* G, float* scale, int normalize, hipStream_t stream, const float* colsq_part = nullptr, int colsq_parts = 0);

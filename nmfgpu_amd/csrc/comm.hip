@@ -501,9 +501,16 @@ Status LocalComm::self_test(std::string* report) {
 	std::string why;
 	auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && why.empty()) { why = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); } return e == hipSuccess; };
 	bool good = ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "stream");
-	auto dalloc = [&](float** p, long n) { return good && (good = ok(hipMalloc((void**)p, sizeof(float) * (size_t)n), "hipMalloc")); };
-	dalloc(&P, SELFTEST_PANEL); dalloc(&P2, SELFTEST_PANEL); dalloc(&Q, 4096); dalloc(&scale, 64); dalloc(&ps, 4096); dalloc(&x3, x3_floats);
-	dalloc(&expect, (long)world * SELFTEST_COUNT); dalloc(&sums, 4096); dalloc(&coll, (long)world * coll_count); dalloc(&res, res_total);
+	// (one allocation for all of the test's scratch: ten hipMalloc / hipFree pairs per rank were a third of its time)
+	float* pool = nullptr;
+	{
+		long need = 0;
+		auto take = [&](long n) { const long at = need; need += (n + 63) / 64 * 64; return at; };
+		const long oP = take(SELFTEST_PANEL), oP2 = take(SELFTEST_PANEL), oQ = take(4096), oS = take(64), oPs = take(4096), oX = take(x3_floats),
+		           oE = take((long)world * SELFTEST_COUNT), oSu = take(4096), oC = take((long)world * coll_count), oR = take(res_total);
+		good = good && ok(hipMalloc((void**)&pool, sizeof(float) * (size_t)need), "hipMalloc");
+		if (good) { P = pool + oP; P2 = pool + oP2; Q = pool + oQ; scale = pool + oS; ps = pool + oPs; x3 = pool + oX; expect = pool + oE; sums = pool + oSu; coll = pool + oC; res = pool + oR; }
+	}
 	Status st = good ? ST_OK : ST_NO_DEVICE_MEMORY;
 	// the exchange buffers of the test ARE the transport's (exchange_alloc): the first sharded run that needs no larger ones reuses these very addresses
 	if (st != ST_OK) { g.fail("rank " + std::to_string(rank_) + ": self-test set-up: " + why); g.aborted.store(true, std::memory_order_release); }
@@ -621,7 +628,7 @@ Status LocalComm::self_test(std::string* report) {
 	if (s) (void)hipStreamSynchronize(s);
 	(void)barrier_hard(g);
 	const bool all_good = !g.aborted.load(std::memory_order_acquire);
-	for (float* p : {P, P2, Q, scale, ps, x3, expect, sums, coll, res}) if (p) (void)hipFree(p);
+	if (pool) (void)hipFree(pool);
 	if (s) (void)hipStreamDestroy(s);
 	(void)hipGetLastError();
 	const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -380,18 +380,21 @@ def test_nndsvd_start_through_compute_matches_the_numpy_restatement(m, n, r, dty
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_twenty_mu_iterations_from_nndsvd_beat_a_random_start(dtype):
-    """What the start is for (Boutsidis & Gallopoulos 2008, section 4): after the same 20 multiplicative iterations the Frobenius error from NNDSVDa is below the one from
-    AllRandomValues on a matrix with structure; on a plain random matrix (a flat spectrum: nothing for the SVD to find) it is no head start, and no harm either (measured:
-    167.4 against 165.9)."""
+    """What the start is for (Boutsidis & Gallopoulos 2008, section 4): after the same 20 multiplicative iterations the Frobenius error from NNDSVD and from NNDSVDar is far
+    below the one from AllRandomValues on a matrix with structure (fp64 oracle: 98.4 / 92.2 against 165.8; NNDSVDa, whose zeros are filled with mean(V), starts slower
+    -- 167.4 -- and is ahead by iteration 100: 74.2 against 91.1); on a plain random matrix (a flat spectrum: nothing for the SVD to find) every form is a little ahead."""
     for structured, V in ((True, _decaying(1500, 900, 40, dtype, seed=2, noise=0.05)), (False, F(np.random.default_rng(4).random((1200, 700)).astype(dtype)))):
         m, n = V.shape
         r = 24
         err = {}
-        for name, kw in (("random", dict(init=Init.AllRandomValues)), ("nndsvda", dict(init=Init.AllRandomValues, parameters={"nndsvd": 1.0}))):
+        for name, kw in (("random", dict()), ("nndsvd", dict(parameters={"nndsvd": 0.0})), ("nndsvda", dict(parameters={"nndsvd": 1.0})), ("nndsvdar", dict(parameters={"nndsvd": 2.0}))):
             W = F(np.zeros((m, r), dtype=dtype)); H = F(np.zeros((r, n), dtype=dtype))
             s = na.Summary()
-            assert na.compute(V, W, H, iterations=20, seed=3, summary=s, **kw) == na.ResultType.Success
+            assert na.compute(V, W, H, init=Init.AllRandomValues, iterations=20, seed=3, summary=s, **kw) == na.ResultType.Success
             err[name] = s.record(0).frobenius
             # (the reported value is ||V - W_19 H_20||, the reference's formula: close to, not equal to, the residual of the pair handed back)
             assert s.record(0).frobenius == pytest.approx(np.linalg.norm(V.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64)), rel=2e-2)
-        assert (err["nndsvda"] < err["random"]) if structured else (err["nndsvda"] < 1.03 * err["random"]), err
+        if structured:
+            assert err["nndsvd"] < 0.7 * err["random"] and err["nndsvdar"] < 0.7 * err["random"] and err["nndsvda"] < 1.05 * err["random"], err
+        else:
+            assert max(err["nndsvd"], err["nndsvda"], err["nndsvdar"]) < err["random"], err

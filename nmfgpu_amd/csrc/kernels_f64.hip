@@ -547,9 +547,39 @@ __global__ __launch_bounds__(256, 2) void k_gram_f64(const double* __restrict__ 
 			for (int g = 0; g < 4; ++g) {
 				const int r = ca + NT * (kq + 4 * g) + a;
 				const int c = cb + NT * l15 + b;
+				// (off-diagonal super-blocks: the mirrored half is written ONCE, by the reduction -- k_gram_reduce_sym_f64; round 4 wrote it here, per slice, as
+				//  8-byte stores 2 KB apart: a third of the kernel's time at the reference example's shape)
 				out[(long)r * RP + c] = acc[a][b][g];
-				if (I != J) out[(long)c * RP + r] = acc[a][b][g];
 			}
+}
+
+// G = sum of the slices' partial matrices in k_reduce_partials' order (four groups of consecutive slices, eight loads in flight, groups added 0..3).  The slices hold
+// the super-blocks (I, J), I <= J, of 128 x 128: an element of a block above the diagonal is also written to its mirrored place, an element below is left to its mirror.
+__global__ __launch_bounds__(256) void k_gram_reduce_sym_f64(const double* __restrict__ partial, int parts, int RP, double* __restrict__ G) {
+	__shared__ double red[4][64];
+	const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+	const long e = (long)blockIdx.x * 64 + tx;                 // (RP is a multiple of 64: a workgroup's 64 elements share a row and a super-block column)
+	const int r = (int)(e / RP), c = (int)(e % RP);
+	const int I = r >> 7, J = c >> 7;
+	if (I > J) return;                                          // (whole workgroups: uniform)
+	const long stride = (long)RP * RP;
+	const int p0 = (parts * g) / 4, p1 = (parts * (g + 1)) / 4;
+	double s = 0;
+	for (int p = p0; p < p1; p += 8) {
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = partial[(long)(p + u < p1 ? p + u : p0) * stride + e];
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			if (p + u < p1) s += v[u];
+	}
+	red[g][tx] = s;
+	__syncthreads();
+	if (g == 0) {
+		const double v = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+		G[e] = v;
+		if (I < J) G[(long)c * RP + r] = v;
+	}
 }
 
 // len: valid panel rows (rows behind them up to the padded length are zero); partial: parts * RP * RP elements of scratch
@@ -563,7 +593,9 @@ hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* 
 	else hipLaunchKernelGGL((k_gram_f64<4, 6>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	return launch_reduce_partials<double>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
+	if (RP == 64) return launch_reduce_partials<double>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);      // (one super-block: nothing to mirror)
+	hipLaunchKernelGGL(k_gram_reduce_sym_f64, dim3((unsigned)((long)RP * RP / 64)), dim3(256), 0, stream, partial, parts, RP, G);
+	return hipGetLastError();
 }
 
 } // namespace nmfamd

@@ -37,33 +37,21 @@ constexpr int GRAM_IMAGE_LDS_FLOATS = 3456 + 256;
 #ifndef GRAM_IMAGE_RING
 #define GRAM_IMAGE_RING 4
 #endif
-__device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float* lds) {
+// One tile (ti, tj), ti <= tj, over the pairs of K-steps [p0, p1) of the calling wave (the four waves' ranges make up the segment).  partial: the tile goes out
+// unscaled into rg.G + slice * 4096 (K-split and spread forms), else scaled into rg.G.  seg: how many segments this workgroup ran before (LDS reuse).
+__device__ inline void gram_image_segment(const GramReduceArgs& rg, const int ti, const int tj, const int slice, const bool partial, const int p0, const int p1, float* lds, const int seg) {
 	typedef float f32x4v __attribute__((ext_vector_type(4)));
-	const int ksplit = rg.ksplit > 1 ? rg.ksplit : 1;
-	int ti = blk >> 2, tj = blk & 3, slice = 0;
-	if (ksplit > 1) {
-		// tile t of the upper triangle, row by row: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-		const int t = blk % GRAM_IMAGE_TILES;
-		slice = blk / GRAM_IMAGE_TILES;
-		if (slice >= ksplit) return;
-		ti = t < 4 ? 0 : t < 7 ? 1 : t < 9 ? 2 : 3;
-		tj = t < 4 ? t : t < 7 ? t - 3 : t < 9 ? t - 5 : 3;
-	}
-	if (ti > tj) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
 	const bf16x8* F = reinterpret_cast<const bf16x8*>(rg.image);
 	const int KS = rg.image_ks;                       // K-steps of 16 panel rows; step KS is the all-zero step that closes the image
 	const bool diag_block = ti == tj;
 	const bool from_parts = rg.normalize != 0 && rg.colsq_part != nullptr && slice == 0;
-	const bool need_diag = rg.normalize != 0 && !diag_block && rg.colsq_part == nullptr && ksplit == 1;
+	const bool need_diag = rg.normalize != 0 && !diag_block && rg.colsq_part == nullptr && !partial;
 	// slot of (K-step ks, column c, plane, half h): ((ks * 2 + (c >> 5)) * 3 + plane) * 64 + h * 32 + (c & 31)
 	const int ci = 16 * ti + l15, cj = 16 * tj + l15;
 	const long offi = (long)(ci >> 5) * 192 + (q & 1) * 32 + (ci & 31);
 	const long offj = (long)(cj >> 5) * 192 + (q & 1) * 32 + (cj & 31);
-	const int pairs = (KS + 2) / 2;                    // 32 k per MFMA = two K-steps
-	const int piece = slice * 4 + wave, pieces = 4 * ksplit;
-	const int p0 = (int)(((long)pairs * piece) / pieces), p1 = (int)(((long)pairs * (piece + 1)) / pieces);
 	f32x4v aij = {0.f, 0.f, 0.f, 0.f}, aii = aij, ajj = aij;
 	// RD pairs of K-steps in flight per wave (6 sixteen-byte loads each).  Round 3 kept ONE pair ahead of the MFMAs.  What bounds the block is not that
 	// latency but what ONE CU can pull from L2: 1.9 MB of fragments for the 632 K-steps of config 2's W = 24 us at ~80 GB/s, the same with four or
@@ -91,6 +79,7 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 #pragma unroll
 	for (int d = 0; d < RD; ++d) fetch(p0 + d, a[d], b[d]);
 	float* s_sq = lds + 3456;                            // [8][32]: partial sums of squares of the tile's 16 row- and 16 column-indices, eight groups of parts
+	if (seg > 0) __syncthreads();                        // (the first wave is done with the LDS of the workgroup's previous segment)
 	if (from_parts) {
 		// thread (g = tid >> 5, c = tid & 31) adds the parts g, g + 8, ... of column c -- up to 40 of them requested together (ONE round trip for the 316 parts
 		// of config 2's W: five batches of eight took 5 us of a column shard's 12 us launch), further batches beyond; the groups are added in order below
@@ -172,7 +161,7 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 	}
 	__builtin_amdgcn_s_waitcnt(0xc07f);
 	__builtin_amdgcn_wave_barrier();
-	if (ksplit > 1) {
+	if (partial) {
 		// this slice's partial tile as it is; the consumer adds the slices and scales.  The scales: slice 0, off-diagonal blocks hold them too but only the
 		// diagonal ones publish (above)
 		float* Gk = rg.G + (long)slice * 4096;
@@ -191,6 +180,48 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 		rg.G[(long)(16 * ti + r) * 64 + 16 * tj + c] = v;
 		if (!diag_block) rg.G[(long)(16 * tj + c) * 64 + 16 * ti + r] = v;
 	}
+}
+
+// tile t of the upper triangle, row by row: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+__device__ inline void gram_image_tile(int t, int* ti, int* tj) {
+	*ti = t < 4 ? 0 : t < 7 ? 1 : t < 9 ? 2 : 3;
+	*tj = t < 4 ? t : t < 7 ? t - 3 : t < 9 ? t - 5 : 3;
+}
+
+__device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float* lds) {
+	const int wave = threadIdx.x >> 6;
+	const int pairs = (rg.image_ks + 2) / 2;           // 32 k per MFMA = two K-steps
+	if (rg.spread > 0) {
+		// Spread form (round 5, the sixteen passengers of a whole problem's W^T V): the one-slice form leaves six of the sixteen workgroups idle (the lower-triangle
+		// tiles) and makes the ten others the LAST workgroups of the launch (config 2: 37 - 40 us under the product's stream against 33 - 36 for the product blocks).
+		// Here the ten tiles' K ranges, end to end, are dealt evenly to all sixteen: a workgroup runs 5 / 8 of a tile's range -- the end of one tile and the
+		// start of the next -- and a tile arrives in up to GRAM_SPREAD_SLICES unscaled pieces (piece = how many workgroups before this one worked on the tile)
+		// that the consumer adds in order and scales, exactly as for the K-split form.
+		const long total = (long)GRAM_IMAGE_TILES * pairs;
+		const long w0 = total * blk / GRAM_REDUCE_BLOCKS, w1 = total * (blk + 1) / GRAM_REDUCE_BLOCKS;
+		int seg = 0;
+		for (int t = (int)(w0 / pairs); t < GRAM_IMAGE_TILES && (long)t * pairs < w1; ++t) {
+			const long a = w0 > (long)t * pairs ? w0 : (long)t * pairs, b = w1 < (long)(t + 1) * pairs ? w1 : (long)(t + 1) * pairs;
+			if (b <= a) continue;
+			int first = blk;                         // the first workgroup whose range reaches into tile t
+			while (first > 0 && total * first / GRAM_REDUCE_BLOCKS > (long)t * pairs) --first;
+			int ti, tj;
+			gram_image_tile(t, &ti, &tj);
+			const int sb = (int)(a - (long)t * pairs), len = (int)(b - a);
+			gram_image_segment(rg, ti, tj, blk - first, true, sb + (int)(((long)len * wave) / 4), sb + (int)(((long)len * (wave + 1)) / 4), lds, seg++);
+		}
+		return;
+	}
+	const int ksplit = rg.ksplit > 1 ? rg.ksplit : 1;
+	int ti = blk >> 2, tj = blk & 3, slice = 0;
+	if (ksplit > 1) {
+		slice = blk / GRAM_IMAGE_TILES;
+		if (slice >= ksplit) return;
+		gram_image_tile(blk % GRAM_IMAGE_TILES, &ti, &tj);
+	}
+	if (ti > tj) return;
+	const int piece = slice * 4 + wave, pieces = 4 * ksplit;
+	gram_image_segment(rg, ti, tj, slice, ksplit > 1, (int)(((long)pairs * piece) / pieces), (int)(((long)pairs * (piece + 1)) / pieces), lds, 0);
 }
 
 } // namespace nmfamd

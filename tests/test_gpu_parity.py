@@ -1124,19 +1124,22 @@ def test_gram_k_slices_and_long_slab_lists_agree_with_one_slice_and_the_oracle(m
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
     ref = oracle.run("mu", V64, W64, H64, iters)
     got = {}
-    for ks in (1, 2, 4, 8):
-        monkeypatch.setenv("NMFAMD_GRAM_KSPLIT", str(ks))
+    # (round 5: one slice comes in two forms -- ten workgroups with a tile each, key 1, or the tiles' K ranges dealt to all sixteen passengers, the default, key 16)
+    for ks in (1, 16, 2, 4, 8):
+        monkeypatch.setenv("NMFAMD_GRAM_KSPLIT", str(1 if ks == 16 else ks))
+        monkeypatch.setenv("NMFAMD_GRAM_SPREAD", "1" if ks == 16 else "0")
         eng = na.Engine(m, n, r, "mu")
         eng.upload(V); eng.set_factors(W0, H0)
         eng.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
         Wg, Hg = eng.get_factors()
         got[ks] = (Wg, Hg, eng.frobenius, eng.geometry()["slabs_h"])
+        assert eng.geometry()["gram_k_slices"] == ks
         eng.close()
         assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4, (ks, rel(Wg, W64), rel(Hg, H64))
         assert got[ks][2] == pytest.approx(ref["frobenius"], rel=1e-5)
     if (m, n) == (4000, 200):
         assert got[1][3] > 8                                  # more slabs than one batch of eight
-    for ks in (2, 4, 8):
+    for ks in (16, 2, 4, 8):
         assert rel(got[ks][0], got[1][0]) < 5e-6 and rel(got[ks][1], got[1][1]) < 5e-6
 
 

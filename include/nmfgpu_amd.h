@@ -139,12 +139,10 @@ typedef struct nmfamd_geometry {
 	int gram_k_slices;              /* rank-64 multiplicative update: K slices of the W^T W passengers (1, 2, 4, 8), or 16: the ten tiles' K ranges dealt evenly
 	                                   to the sixteen passengers of a whole problem's W^T V launch (up to three pieces per tile, added in order) */
 	int w_col_split;                /* 1: V H^T runs as 128 x 32 workgroups (narrow column shards) */
-	int fused_tail;                 /* the last iteration's launches: bit 0 = the W^T V launch carried the H update as its tail, bit 1 = the V H^T launch carried the W
-	                                   update (same bits as the stand-alone update launches; needs the device for this engine alone; NMFAMD_NO_FUSED_TAIL=1 switches it off) */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 /* The same for a caller compiled against an older (shorter) or newer (longer) nmfamd_geometry: writes min(struct_size, sizeof(nmfamd_geometry)) bytes, never
- * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`, round 5 the four counts behind it and `fused_tail`).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
+ * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`, round 5 the four counts behind it).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
 NMFAMD_API int nmfamd_engine_geometry_sized(const nmfamd_engine* e, void* out, unsigned long struct_size);
 
 /* ---- column-sharded multi-GPU form of the multiplicative update ------------------------------

@@ -342,7 +342,6 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
 		out->product_kernel = g.product_kernel(); out->resident_images = g.resident_images(); out->one_pass = g.one_pass_state();
 		out->kl_blocks_w = g.kl_blocks(true); out->kl_blocks_h = g.kl_blocks(false); out->gram_k_slices = g.gram_k_slices(); out->w_col_split = g.w_col_split() ? 1 : 0;
-		out->fused_tail = g.fused_tail();
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);
 	return NMFAMD_OK;

@@ -12,7 +12,6 @@
 #include "tuning.h"
 
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,21 +70,8 @@ Status Engine<T>::hip_fail(hipError_t e, const char* what) {
 	return e == hipErrorOutOfMemory ? ST_NO_DEVICE_MEMORY : ST_HIP_ERROR;
 }
 
-// engines alive per device in this process: an update tail (UpdateTail, kernels.h) has workgroups that wait for the rest of their launch, which is only
-// harmless while no second engine's waiting workgroups can crowd the device
-static std::atomic<int> g_engines_alive[64];
-static unsigned long long* g_dbg_stamps = nullptr;
-
 template <typename T>
 Engine<T>::~Engine() {
-	if (device_ >= 0 && device_ < 64) g_engines_alive[device_].fetch_sub(1);
-	if (g_dbg_stamps != nullptr && std::getenv("NMFAMD_TAIL_STAMPS")) {
-		std::vector<unsigned long long> h(2 * 4 * 512);
-		(void)hipDeviceSynchronize();
-		if (hipMemcpy(h.data(), g_dbg_stamps, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) { if (FILE* f = std::fopen(std::getenv("NMFAMD_TAIL_STAMPS"), "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); } }
-	}
-	if (tail_count_) (void)hipFree(tail_count_);
-	if (tail_fault_) (void)hipHostFree(tail_fault_);
 	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, stage_};   // (psR_ lives behind psN_)
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
@@ -122,7 +108,6 @@ Status Engine<T>::allocate() {
 	hipDeviceProp_t prop;
 	HIPX(hipGetDeviceProperties(&prop, dev));
 	num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	if (device_ < 0) { device_ = dev; if (dev >= 0 && dev < 64) g_engines_alive[dev].fetch_add(1); }
 
 	// both products run on the MFMA pipe: fp32 (kernels.hip) or fp64 (kernels_f64.hip), each with its own cut
 	const bool f64 = std::is_same<T, double>::value;
@@ -358,17 +343,12 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&scale_, sizeof(float) * 64));
 		HIPX(hipMalloc((void**)&Gpart_, sizeof(float) * 4096 * GRAM_KSPLIT_MAX));
 		HIPX(hipMemsetAsync(Gpart_, 0, sizeof(float) * 4096 * GRAM_KSPLIT_MAX, stream_));      // (spread form: a tile's absent pieces are never written)
+		// W^T W of a whole problem (one K slice): the ten tiles' K ranges dealt to all sixteen passengers (gram_image.h) -- with a tile each, ten of them were the
+		// last workgroups of config 2's W^T V launch (37 - 40 us against 33 - 36.5 for the product blocks, profiles/r05_update_tail.md).  NMFAMD_GRAM_SPREAD=0
+		// (measurement builds) restores that form.
 		gram_spread_ = gram_ksplit_ == 1 && !(tuning_env("NMFAMD_GRAM_SPREAD") != nullptr && std::atoi(tuning_env("NMFAMD_GRAM_SPREAD")) == 0);
 		HIPX(hipMalloc((void**)&wsq_part_, sizeof(float) * 64 * (size_t)(mpad_ / 32)));
 		HIPX(hipMemsetAsync(wsq_part_, 0, sizeof(float) * 64 * (size_t)(mpad_ / 32), stream_));
-	}
-	if (x3_ && gram_image_ && RP_ == 64 && fused_capable() && !one_pass_ && std::getenv("NMFAMD_NO_FUSED_TAIL") == nullptr) {
-		HIPX(hipMalloc((void**)&tail_count_, 64 * sizeof(unsigned long long)));
-		HIPX(hipMemsetAsync(tail_count_, 0, 64 * sizeof(unsigned long long), stream_));
-		HIPX(hipHostMalloc((void**)&tail_fault_, sizeof(int)));
-		*tail_fault_ = 0;
-		void* dp = nullptr;
-		if (hipHostGetDevicePointer(&dp, tail_fault_, 0) == hipSuccess) { tail_fault_dev_ = static_cast<int*>(dp); tail_enabled_ = true; } else (void)hipGetLastError();
 	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
 	pin_psR_ = pin_psN_ + ps_stride_;
@@ -533,7 +513,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 		HIPX(hipMemcpy2DAsync(H, ldh * sizeof(T), H_, RP_ * sizeof(T), r_ * sizeof(T), n_, hipMemcpyDeviceToHost, stream_));
 	}
 	HIPX(hipStreamSynchronize(stream_));
-	return tail_check();
+	return ST_OK;
 }
 
 template <typename T>
@@ -638,60 +618,6 @@ Status Engine<T>::standalone_gram(const GramReduceArgs& rg) {
 	return ST_OK;
 }
 
-template <typename T>
-bool Engine<T>::tail_for(bool is_w, const GramReduceArgs& rg, const T* Q, bool compute_error, UpdateTail* out) {
-	if constexpr (std::is_same<T, float>::value) {
-		tail_last_ &= is_w ? ~2 : ~1;
-		{ static const int dbg = [] { const char* e = std::getenv("NMFAMD_TAIL_DEBUG"); return e ? std::atoi(e) : 0; }(); if ((dbg & 8) && is_w) return false; if ((dbg & 16) && !is_w) return false; }
-		if (!tail_enabled_ || tail_faulted_ || !x3_ || !gram_image_ || device_ < 0 || device_ >= 64 || g_engines_alive[device_].load() != 1) return false;
-		const FactorProductPlan& plan = is_w ? planWx_ : planHx_;
-		const bool y_tiled = !is_w && one_image_;
-		const int image_tile = is_w ? img_th_ : (one_image_ ? img_th_ : 128);
-		if (!factor_product_x3_tail_supported(plan, RP_, y_tiled, image_tile, is_w ? 3 : 1) || !passengers_ride(plan)) return false;
-		const int workgroups = factor_product_x3_workgroups(plan, &rg);
-		if (workgroups > num_cus_) return false;      // every workgroup on a CU of its own, all at once: the finishers wait for workgroups that are running
-		UpdateTail t;
-		t.units = (int)((is_w ? mpad_ : npad_) / 32);
-		t.P = is_w ? Wt_ : H_;
-		t.Q = Q;
-		t.scale = scale_;
-		t.eps = std::numeric_limits<float>::epsilon();
-		t.ps = is_w ? psR_ : psN_;
-		t.len_valid = is_w ? m_ : n_;
-		t.Gprev = is_w ? G_ : nullptr;
-		t.compute_error = compute_error ? 1 : 0;
-		t.x3_out = is_w ? Wx3_ : Hx3_;
-		t.x3_ks = is_w ? ksH_ : ksW_;
-		t.colsq_part = is_w ? wsq_part_ : nullptr;
-		const bool slices = !is_w && (const void*)Q == (const void*)Gpart_;
-		t.qsplit = slices ? gram_q_slices() : 0;
-		t.q_out = slices ? G_ : nullptr;
-		t.arrivals = tail_count_;
-		tail_total_ += (unsigned long long)workgroups;
-		t.target = tail_total_;
-		t.fault = tail_fault_dev_;
-		{
-			static unsigned long long* dbg = [] { unsigned long long* p = nullptr; if (std::getenv("NMFAMD_TAIL_STAMPS")) { (void)hipMalloc((void**)&p, 2 * 4 * 512 * 8); (void)hipMemset(p, 0, 2 * 4 * 512 * 8); } return p; }();
-			if (dbg) t.dbg_stamps = dbg + (is_w ? 4 * 512 : 0);
-			g_dbg_stamps = dbg;
-		}
-		*out = t;
-		tail_last_ |= is_w ? 2 : 1;
-		return true;
-	}
-	return false;
-}
-
-template <typename T>
-Status Engine<T>::tail_check() {
-	if (tail_fault_ != nullptr && *tail_fault_ != 0) {
-		tail_faulted_ = true;
-		last_error_ = "an update tail gave up waiting for its launch's workgroups (another process's kernels held the device): factors are void; set NMFAMD_NO_FUSED_TAIL=1";
-		return ST_HIP_ERROR;
-	}
-	return ST_OK;
-}
-
 // U_H / U_W of the rank-64 fast path (kernels_mu64.hip)
 template <typename T>
 Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error, const PeerSlabs* peers) {
@@ -712,7 +638,7 @@ Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride
 }
 
 template <typename T>
-Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked, const UpdateTail* tail) {
+Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked) {
 	if (sparse_) {
 		// W^T V as a row-gather SpMM over the CSC image: out(:, j) = sum_i V(i, j) F(:, i)
 		if (rg) { if (Status st = standalone_gram(*rg)) return st; }
@@ -736,9 +662,8 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 			if (rg && !passengers_ride(planHx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			hipEvent_t e0, e1;
 			const bool timed = timed_launch_events(0, &e0, &e1);
-			if (tail != nullptr && rg == nullptr) return ST_INVALID;      // (tail_for() vouched for riding passengers)
-			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_, e0, e1, tail, 1));
-			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, false, 128, e0, e1, tail, 1));
+			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_, e0, e1));
+			else HIPX(launch_factor_product_x3(planHx_, Vt_, strideVt_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, false, 128, e0, e1));
 			if (timed) timed_launch_done();
 			return ST_OK;
 		}
@@ -765,7 +690,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 }
 
 template <typename T>
-Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out, bool prepacked, const UpdateTail* tail) {
+Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out, bool prepacked) {
 	T* dest = (single_slab_out != nullptr && planW_.splits == 1) ? single_slab_out : slabs_;
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
@@ -789,8 +714,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 			if (rg && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			hipEvent_t e0, e1;
 			const bool timed = timed_launch_events(1, &e0, &e1);
-			if (tail != nullptr && (rg == nullptr || dest != slabs_)) return ST_INVALID;
-			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_, e0, e1, tail, 3));
+			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_, e0, e1));
 			if (timed) timed_launch_done();
 			return ST_OK;
 		}
@@ -921,8 +845,6 @@ void Engine<T>::finalize_error(bool resolve) {
 		resolve_error(h_vtv_, h_psN_, h_psR_, (long)((unsigned)m_ * (unsigned)(err_total_columns_ > 0 ? err_total_columns_ : n_)));
 		err_unresolved_ = false;
 	}
-	// (an update tail that gave up left the factors void: no error value either; iterate() / get_factors() return the failure)
-	if (tail_check() != ST_OK) frob_ = frob2_ = rmsd_ = std::numeric_limits<double>::quiet_NaN();
 }
 
 template <typename T>
@@ -954,14 +876,8 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 				fused_ready_ = true;
 			}
 			GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
-			const T* Qh = (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_;
-			UpdateTail th;
-			if (Status s = tail_check()) return s;
-			if (tail_for(false, rgW, Qh, compute_error, &th)) { if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_, &th)) return s; }
-			else {
-				if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-				if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, Qh, compute_error)) return s;
-			}
+			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
+			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 			hx3_valid_ = x3_;
 			return ST_OK;
 		}
@@ -1413,7 +1329,7 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		if (!fused_ready_) { normalize_next_ = 0; fused_ready_ = true; }
 		if (!wx3_valid_) { HIPX(launch_pack_panel_x3(Wt_, RP_, m_, Wx3_, ksH_, stream_)); wx3_valid_ = true; }
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
-		rgW.ksplit = 0; rgW.G = G_;                       // (the persistent launch reads the finished matrix)
+		rgW.ksplit = 0; rgW.spread = 0; rgW.G = G_;       // (the persistent launch reads the finished matrix)
 		if (Status s = standalone_gram(rgW)) return s;
 		OnePassArgs a;
 		a.V = V_; a.tile_stride = strideV_;
@@ -1471,7 +1387,6 @@ template <typename T>
 Status Engine<T>::iterate_mu64(bool compute_error) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (one_pass_) return iterate_onepass(compute_error);
-		if (Status s = tail_check()) return s;
 		const float eps = std::numeric_limits<float>::epsilon();
 		if (!fused_ready_) {
 			if (!gram_image_) HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
@@ -1479,19 +1394,11 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 			fused_ready_ = true;
 		}
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
-		const T* Qh = (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_;
-		UpdateTail th, tw;
-		if (tail_for(false, rgW, Qh, compute_error, &th)) { if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_, &th)) return s; }
-		else {
-			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, Qh, compute_error)) return s;
-		}
+		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
+		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 		GramReduceArgs rgH = gram_args(false, HHt_, nullptr, 0);
-		if (x3_ && tail_for(true, rgH, HHt_, compute_error, &tw)) { if (Status s = product_w(H_, &rgH, nullptr, true, &tw)) return s; }
-		else {
-			if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
-			if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, HHt_, compute_error)) return s;
-		}
+		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
+		if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, HHt_, compute_error)) return s;
 		wx3_valid_ = x3_;
 		hx3_valid_ = false;
 		normalize_next_ = 1;

@@ -95,7 +95,6 @@ public:
 	int kl_blocks(bool w_step) const { return prm_.divergence != 0 ? (w_step ? kl_blocks_w_ : kl_blocks_h_) : 0; }
 	int gram_k_slices() const { return gram_spread_ ? GRAM_REDUCE_BLOCKS : gram_ksplit_; }      // (16: the spread form)
 	bool w_col_split() const { return w_col_split_; }
-	int fused_tail() const { return tail_last_; }      // bit 0 / 1: the last W^T V / V H^T launch carried its update as the tail
 	// Row-block form at padded rank 256 with bf16 operands (config 4): between two W updates the OTHER ranks read only the bf16 fragments of a rank's rows (the next
 	// W^T V's operand and the Gram matrix are made from them) -- so the all-gather carries the fragments w_normalize_rows() left for this rank's rows (RP / 2 four-byte
 	// words per row: 25.6 MB at config 4 instead of 51.2 MB of fp32 rows) and the fp32 rows of the other ranks stay STALE in w_panel() until somebody needs them
@@ -162,8 +161,8 @@ private:
 	Status hip_fail(hipError_t e, const char* what);
 	Status h_step_impl(bool compute_error);
 	// prepacked: the split (x3) image of F is already in Wx3_ / Hx3_ (emitted by the update kernel that wrote F)
-	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false, const UpdateTail* tail = nullptr);   // slabs_ <- partials of F V   (r x n)
-	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false, const UpdateTail* tail = nullptr);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
+	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false);   // slabs_ <- partials of F V   (r x n)
+	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
@@ -259,19 +258,6 @@ private:
 	GramReduceArgs gram_args(bool of_w, float* G, float* scale, int normalize) const;
 	Status standalone_gram(const GramReduceArgs& rg);
 	Status mu64_update(bool is_w, const T* slabs, int S, long slab_stride, const T* Q, bool compute_error, const PeerSlabs* peers = nullptr);
-	// The update as the TAIL of the product launch that feeds it (UpdateTail, kernels.h; fused iteration at padded rank 64 on the split-operand path): one launch
-	// floor (~5 us) less per factor.  Used when the whole grid of the launch is resident at once (one workgroup per CU) and this engine is the only one alive on
-	// its device in this process; NMFAMD_NO_FUSED_TAIL=1 switches it off (a device shared with another process's kernels).  tail_for(): the arguments
-	// mu64_update() would launch with, or false.
-	bool tail_for(bool is_w, const GramReduceArgs& rg, const T* Q, bool compute_error, UpdateTail* out);
-	Status tail_check();                    // a finisher gave up (TAIL_WAIT_TICKS): the factors are void -- at every synchronisation the engine does for its caller
-	bool tail_enabled_ = false, tail_faulted_ = false;
-	int tail_last_ = 0;
-	unsigned long long* tail_count_ = nullptr;      // device: workgroups counted in
-	unsigned long long tail_total_ = 0;             // host: what the counter reads after the launches enqueued so far
-	int* tail_fault_ = nullptr;                     // pinned, mapped
-	int* tail_fault_dev_ = nullptr;
-	int device_ = -1;                               // (the process-wide count of engines alive per device: engine.cpp)
 	// generic rank-64 fp32 path: the update kernel leaves partial Gram matrices of what it wrote (gram_from_update())
 	bool gram_w_ready_ = false;      // G_ holds W^T W of the current (normalised) W
 	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams

@@ -116,34 +116,6 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 // device or in a peer's memory) instead of S slabs slab_stride apart
 constexpr int PEER_SLABS_MAX = 16;
 struct PeerSlabs { const float* p[PEER_SLABS_MAX]; int count; };
-// Tail of a split-operand product launch at padded rank 64 (kernels_x3.hip): the update that consumes the launch's split-K slabs and its passengers' Gram matrix
-// runs INSIDE the launch instead of as the next one -- every workgroup (product blocks and passengers) counts itself in when its stores are out (one release per
-// workgroup); the first `min(units, product blocks)` workgroups then wait for the count and run the 32-column update tiles (mu64_update32.h: the stand-alone
-// launch's instructions, same bits).  Only those few wait, and only for workgroups that never wait themselves; the caller (Engine) uses the tail when the whole
-// grid is resident at once.  A finisher that waited TAIL_WAIT_TICKS (another kernel held the device's CUs for that long) sets *fault and leaves: the factors are
-// void and the engine says so at its next synchronisation.
-struct UpdateTail {
-	int units = 0;                       // 32-column tiles of the panel (0: no tail)
-	float* P = nullptr;                  // panel to update; the slabs, their count and stride are the product's own
-	const float* Q = nullptr;            // r x r operand (qsplit > 1: that many unscaled K slices 4096 apart, as for launch_mu64_update32)
-	const float* scale = nullptr;
-	float eps = 0.f;
-	float* ps = nullptr;
-	int len_valid = 0;
-	const float* Gprev = nullptr;
-	int compute_error = 0;
-	void* x3_out = nullptr;
-	int x3_ks = 0;
-	float* colsq_part = nullptr;
-	int qsplit = 0;
-	float* q_out = nullptr;
-	unsigned long long* arrivals = nullptr;   // workgroups counted in, over all launches that used this counter
-	unsigned long long target = 0;            // its value once every workgroup of THIS launch is in
-	int* fault = nullptr;                     // host-visible word
-	int debug = 0;
-	unsigned long long* dbg_stamps = nullptr;
-};
-constexpr unsigned long long TAIL_WAIT_TICKS = 50000000ull;      // 0.5 s of the 100 MHz counter
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
                                 void* x3_out, int x3_ks, const PeerSlabs* peers = nullptr, float* colsq_part = nullptr, int qsplit = 0, float* q_out = nullptr);
@@ -368,11 +340,7 @@ hipError_t launch_pack_panel_x3(const float* P, int RP, int len, void* dst, int 
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
                                     unsigned long long* stamps = nullptr, bool y_tiled = false, int image_tile = 128,
-                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const UpdateTail* tail = nullptr, int tail_kind = 0);
-// (tail: the update that consumes this launch's slabs runs inside it -- UpdateTail above; tail_kind 1 = H update, 3 = W update; tail->target = the counter's value
-//  before this launch + factor_product_x3_workgroups())
-bool factor_product_x3_tail_supported(const FactorProductPlan& p, int RP, bool y_tiled, int image_tile, int tail_kind);
-int factor_product_x3_workgroups(const FactorProductPlan& p, const GramReduceArgs* rg);      // grid size of the launch (product blocks + passengers), RP = 64
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // (ev_start / ev_stop: the launch's own start and stop times go to these events -- hipExtLaunchKernel -- instead of the caller recording two events around it:
 //  a bracketed launch costs the stream ~12 us of barrier packets, rocprofv3 trace of bench.py's sampled iterations)
 int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve = 0);

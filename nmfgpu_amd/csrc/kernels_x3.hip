@@ -24,7 +24,6 @@
 #include "split3.h"
 #include "inverse_gj64.h"
 #include "gram_image.h"
-#include "mu64_update32.h"
 
 namespace nmfamd {
 
@@ -134,42 +133,6 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 	if (blk == 0 && tid < 64 && rg.scale) rg.scale[tid] = s_scale[tid];
 }
 
-// ---- the update as the tail of the product launch (UpdateTail, kernels.h) ------------------------------------------------
-// Every workgroup of the launch: its stores are out (each wave waits for its own, the barrier collects the waves), ONE release for the workgroup, one count.
-__device__ __forceinline__ void tail_arrive(const UpdateTail& t, bool write_back) {
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		if (write_back && !(t.debug & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		if (t.debug & 32) {
-			// the last one in raises the flag the finishers watch (a word of its own, 256 bytes from the counter)
-			const unsigned long long old = __hip_atomic_fetch_add(t.arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (old + 1 == t.target) __hip_atomic_store(t.arrivals + 32, t.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		} else (void)__hip_atomic_fetch_add(t.arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-// A finisher: waits (bounded) until every workgroup of the launch is in, then one acquire for the workgroup.  False: gave up (*t.fault set).
-__device__ __forceinline__ bool tail_wait(const UpdateTail& t, int* s_flag) {
-	if (threadIdx.x == 0) {
-		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-		int ok = 1;
-		while (!(t.debug & 4) && __hip_atomic_load(t.arrivals + ((t.debug & 32) ? 32 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t.target) {
-			if (t.debug & 64) __builtin_amdgcn_s_sleep(48); else __builtin_amdgcn_s_sleep(8);
-			if (__builtin_amdgcn_s_memrealtime() - t0 > TAIL_WAIT_TICKS) { ok = 0; break; }
-		}
-		if (ok) {
-			if (!(t.debug & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		} else {
-			__hip_atomic_store(t.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		*s_flag = ok;
-	}
-	__syncthreads();
-	return *s_flag != 0;
-}
-
 // Workgroup = X3_WAVES waves (four: one per SIMD, 512 registers each) = one 128-row x-tile times one
 // slice of the reduction range times one 64-column chunk of the panel (grid.y), the slice cut into
 // wave pieces of K-steps (16 y each).  A wave keeps the 128 x 64 accumulator block (8 tiles of 32 x 32),
@@ -182,16 +145,13 @@ __device__ __forceinline__ bool tail_wait(const UpdateTail& t, int* s_flag) {
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
 // R32 (y-tiled form on 16-row tiles, loads straight to registers): MFMA row r of M-block b is tile row 32 b + r (as in the YLDS form) instead of 4 r + b: consecutive lanes read
 // consecutive 64-byte column chunks -- 16 cache lines per wave instruction instead of 32
-// TAIL (padded rank 64, NBW = 2 only): 0 none; 1 / 2: the H update (U = 7 / 13 slabs per batch) runs as the launch's tail; 3: the W update (UpdateTail above)
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false, int TAIL = 0>
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
 __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
 	float* __restrict__ slabs, long slab_stride, int RP,
-	int steps_total, int xtiles, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps, UpdateTail tail) {
+	int steps_total, int xtiles, int splits, GramReduceArgs rg, unsigned long long* __restrict__ stamps) {
 	constexpr int TH = 128;
-	unsigned long long dbg_entry = 0;
-	if (TAIL != 0) dbg_entry = __builtin_amdgcn_s_memrealtime();
 	unsigned long long t_loop0 = 0, t_loop1 = 0, r_loop0 = 0, r_loop1 = 0, r_entry = 0, r_tail = 0;
 	if (DIAG != 0) r_entry = __builtin_amdgcn_s_memrealtime();
 	extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -208,10 +168,6 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 		if (rg.inv_a != nullptr) inverse_gj64_body<float, X3_WAVES>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
 		else if (rg.image != nullptr) { if (X3_WAVES == 4) gram_image_block(rg, blockIdx.x - pblocks, lds); }
 		else gram_reduce_block_x3<64 * X3_WAVES>(rg, blockIdx.x - pblocks, lds);
-		if (TAIL != 0) {
-			tail_arrive(tail, true);
-			if (tail.dbg_stamps != nullptr && threadIdx.x == 0) { unsigned long long* o = tail.dbg_stamps + 4 * blockIdx.x; o[0] = dbg_entry; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = o[3] = 0; }
-		}
 		return;
 	}
 	// XCD-aware placement (speed only): blocks b and b + 8 share an XCD and its L2; each XCD takes a CONTIGUOUS range of
@@ -461,40 +417,8 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 			for (int gi = 0; gi < 4; ++gi) {
 				const int mi = gi + 8 * q + 4 * half;
 				const int x = xt * TH + ((YLDS || R32) ? 32 * b + mi : 4 * mi + b);
-				// (with a tail: stores that are visible to the whole device when they complete -- written through this XCD's L2 -- so that the workgroup needs no
-				//  write-back of the L2 before it counts itself in: 256 of those cost the launch 7 us, and reads of lines still dirty in another XCD's L2 another 10)
-				if (TAIL != 0) __hip_atomic_store(&slab[(long)x * RP + coff + 32 * nb + l31], s[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				else slab[(long)x * RP + coff + 32 * nb + l31] = s[gi];
+				slab[(long)x * RP + coff + 32 * nb + l31] = s[gi];
 			}
-		}
-	}
-	if (TAIL != 0) {
-		// the launch's slabs -> the panel (UpdateTail): this workgroup is in; the first `finishers` workgroups wait for the rest and run the update tiles
-		tail_arrive(tail, false);
-		unsigned long long dbg_arr = __builtin_amdgcn_s_memrealtime(), dbg_wait = 0;
-		const int finishers = tail.units < pblocks ? tail.units : pblocks;
-		if ((int)blockIdx.x < finishers) {
-			float (*s_num)[68] = reinterpret_cast<float (*)[68]>(lds);
-			float (*s_old)[68] = reinterpret_cast<float (*)[68]>(lds + 32 * 68);
-			float (*s_ps)[32] = reinterpret_cast<float (*)[32]>(lds + 2 * 32 * 68);
-			int* s_flag = reinterpret_cast<int*>(lds + 2 * 32 * 68 + 128);
-			if (tail_wait(tail, s_flag)) {
-				dbg_wait = __builtin_amdgcn_s_memrealtime();
-				PeerSlabs nopeers;
-				nopeers.count = 0;
-				for (int unit = (int)blockIdx.x; unit < tail.units; unit += finishers) {
-					if (unit != (int)blockIdx.x) __syncthreads();
-					if (TAIL == 3) mu64_update32_body<true, 7, 1>(unit, tail.units, s_num, s_old, s_ps, tail.P, slabs, splits, slab_stride, tail.Q, tail.scale, tail.eps, tail.ps, tail.len_valid,
-					                                              tail.Gprev, tail.compute_error, reinterpret_cast<bf16x8*>(tail.x3_out), tail.x3_ks, nopeers, tail.colsq_part, 0, nullptr);
-					else mu64_update32_body<false, TAIL == 2 ? 13 : 7, 0>(unit, tail.units, s_num, s_old, s_ps, tail.P, slabs, splits, slab_stride, tail.Q, tail.scale, tail.eps, tail.ps,
-					                                                      tail.len_valid, tail.Gprev, tail.compute_error, reinterpret_cast<bf16x8*>(tail.x3_out), tail.x3_ks, nopeers,
-					                                                      tail.colsq_part, tail.qsplit > 1 ? tail.qsplit : 1, tail.q_out);
-				}
-			}
-		}
-		if (tail.dbg_stamps != nullptr && threadIdx.x == 0) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			unsigned long long* o = tail.dbg_stamps + 4 * blockIdx.x; o[0] = dbg_entry; o[1] = dbg_arr; o[2] = dbg_wait; o[3] = __builtin_amdgcn_s_memrealtime();
 		}
 	}
 	if (DIAG != 0 && stamps != nullptr) {
@@ -526,18 +450,10 @@ int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
 // events handed from launch_factor_product_x3 to the instantiation it dispatches to (per thread: rank threads launch concurrently)
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
-static thread_local const UpdateTail* t_tail = nullptr;      // (handed to the instantiation like the events)
-
-template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false, int TAIL = 0>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	UpdateTail tail;
-	if (TAIL != 0) {
-		if (t_tail == nullptr || t_tail->units <= 0 || t_tail->arrivals == nullptr || t_tail->fault == nullptr || RP != 64) return hipErrorInvalidValue;
-		tail = *t_tail;
-		if (const char* e = std::getenv("NMFAMD_TAIL_DEBUG")) tail.debug = std::atoi(e);
-	}
 	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
 	// (the passengers sit behind the product blocks in the grid, whatever the number of x-tiles; the caller sees to it that they find a CU
 	//  while the product runs -- Engine::passengers_ride)
@@ -547,35 +463,19 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	if (NBW == 1 && RP != 64) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
-	static_assert(TAIL == 0 || (NBW == 2 && WAVES == 4), "the update tail: 256 threads, padded rank 64");      // (and its LDS, 2 x 32 x 68 + 160 floats, fits the epilogue's 64 KiB)
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, TAIL>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	if (t_ev_start != nullptr && t_ev_stop != nullptr) {
 		// (the caller wants this launch timed: its own start / stop timestamps, no event records around it)
 		const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
 		t_ev_start = t_ev_stop = nullptr;
-		hipExtLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, TAIL>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
-		                      A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps, tail);
+		hipExtLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
+		                      A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 		return hipGetLastError();
 	}
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, TAIL>), grid, block, lds_bytes, stream,
-	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps, tail);
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, lds_bytes, stream,
+	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
-}
-
-// Which launches can carry the update as their tail: padded rank 64, the 128 x 64 production forms (x-tiled on either image, y-tiled on the 16-row image),
-// kind 1 = the H update behind W^T V, 3 = the W update behind V H^T
-bool factor_product_x3_tail_supported(const FactorProductPlan& p, int RP, bool y_tiled, int image_tile, int tail_kind) {
-	if (RP != 64 || p.col_split == 2 || (tail_kind != 1 && tail_kind != 3)) return false;
-	if (image_tile == 16) return tail_kind == 3 ? !y_tiled : y_tiled;
-	return image_tile == 128 && !y_tiled;
-}
-
-// grid size of a padded-rank-64 launch of the 128 x 64 forms: what an UpdateTail's target counts
-int factor_product_x3_workgroups(const FactorProductPlan& p, const GramReduceArgs* rg) {
-	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
-	const int passengers = !wanted ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
-	return p.xtiles * p.splits + passengers;
 }
 
 // y_tiled: A is the image tiled along the REDUCTION index (128-row tiles of y, tile_stride apart, each holding all x as
@@ -587,24 +487,10 @@ int factor_product_x3_workgroups(const FactorProductPlan& p, const GramReduceArg
 // of 16; p.th must be 128.  Passengers (Gram reduction, or the 64 x 64 inverse) ride only at RP = 64.
 hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
-                                    bool y_tiled, int image_tile, hipEvent_t ev_start, hipEvent_t ev_stop, const UpdateTail* tail, int tail_kind) {
+                                    bool y_tiled, int image_tile, hipEvent_t ev_start, hipEvent_t ev_stop) {
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
 	t_ev_start = ev_start; t_ev_stop = ev_stop;
-	struct Clear { ~Clear() { t_ev_start = t_ev_stop = nullptr; t_tail = nullptr; } } clear_on_exit;      // (a path that did not consume them -- an error return, grid.y > 1 -- leaves nothing behind)
-	if (tail != nullptr && tail->units > 0) {
-		// the update as the launch's tail: the production forms at padded rank 64 (see factor_product_x3_tail_supported)
-		if (!factor_product_x3_tail_supported(p, RP, y_tiled, image_tile, tail_kind) || stamps != nullptr) return hipErrorInvalidValue;
-		t_tail = tail;
-		const bool many = p.splits > 8;
-		if (image_tile == 16) {
-			if (tail_kind == 3) return launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16, false, false, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-			return many ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
-			            : launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		}
-		if (tail_kind == 3) return launch_fp_x3<X3_RING_X, 4, 0, 2, false, 128, false, false, 3>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return many ? launch_fp_x3<X3_RING_X, 4, 0, 2, false, 128, false, false, 2>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg)
-		            : launch_fp_x3<X3_RING_X, 4, 0, 2, false, 128, false, false, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-	}
+	struct Clear { ~Clear() { t_ev_start = t_ev_stop = nullptr; } } clear_on_exit;      // (a path that did not consume them -- an error return, grid.y > 1 -- leaves nothing behind)
 #ifdef NMFAMD_DIAG_BUILD
 	if (image_tile == 16 && RP == 64 && stamps != nullptr) {
 		// stamped diagnostic builds of the PRODUCTION forms on the one resident image (tools/stamp_x3.py): NMFAMD_X3_VARIANT = 10..13 the x-tiled form,

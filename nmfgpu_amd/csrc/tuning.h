@@ -4,8 +4,7 @@
 //   * behaviour callers may rely on, read with std::getenv where they are used -- the complete list (tests/test_abi.py checks the shipped .so's strings against it):
 //       NMFAMD_COMM (transport of a numGpus team: rccl / p2p), NMFAMD_SELFTEST (0: skip the peer transport's set-up self-test), NMFAMD_HOST_THREADS (host initialisers),
 //       NMFAMD_MALL_MB (size of the memory-side cache when the device does not report it), NMFAMD_KL_BLOCK_KB (L2 block of the KL gather), NMFAMD_ONE_IMAGE (0 / 1: two
-//       images of V or one), NMFAMD_ONE_PASS (1: the opt-in one-pass iteration), NMFAMD_NO_FUSED_TAIL (1: the rank-64 updates run as launches of their own instead of as the tails
-//       of the product launches -- for a device whose CUs another PROCESS's kernels share; UpdateTail, kernels.h), and the cross-check PATHS the parity tests compare with each other -- all of them
+//       images of V or one), NMFAMD_ONE_PASS (1: the opt-in one-pass iteration), and the cross-check PATHS the parity tests compare with each other -- all of them
 //       complete, correct implementations: NMFAMD_FORCE_VALU, NMFAMD_NO_FUSED_MU, NMFAMD_GRAM_PARTIALS, NMFAMD_FP_TILE;
 //   * A/B switches, forced kernel forms, rehearsal modes and stamped kernel variants that exist for measurements and form-against-form tests only: those go through
 //     tuning_env() and are dead code in the shipped library -- they are compiled in by `python -m nmfgpu_amd.build --diag` (-DNMFAMD_DIAG_BUILD, output

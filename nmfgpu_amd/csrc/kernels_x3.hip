@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -38,6 +39,9 @@ constexpr bool XCD_REMAP = NMFAMD_XCD_REMAP != 0;
 // so all of them give the same bits.
 #ifndef X3_RING_X
 #define X3_RING_X 2                   // K-steps in flight per wave (8 + 6 loads each), x-tiled form
+#endif
+#ifndef X3_DEAL_TURNS
+#define X3_DEAL_TURNS 0               // (A/B switch, tools/build_variant.sh: 1 = always deal the K-steps in whole turns of the ring, as rounds 2-4 did)
 #endif
 #ifndef X3_RING_Y
 #define X3_RING_Y 2                   // ... y-tiled form (its landing ring; two more steps sit in the LDS slots)
@@ -145,7 +149,8 @@ __device__ inline void gram_reduce_block_x3(const GramReduceArgs& rg, int blk, f
 // (shader cycles, 100 MHz ticks, K-steps per wave).  The production instantiation has DIAG = 0.
 // R32 (y-tiled form on 16-row tiles, loads straight to registers): MFMA row r of M-block b is tile row 32 b + r (as in the YLDS form) instead of 4 r + b: consecutive lanes read
 // consecutive 64-byte column chunks -- 16 cache lines per wave instruction instead of 32
-template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
+// ODD (ring depth 2): every wave piece is an ODD number of K-steps -- see the dealing below
+template <int D, int X3_WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false, bool ODD = false>
 __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_product_x3(
 	const float* __restrict__ A, long tile_stride,
 	const bf16x8* __restrict__ F, int NBT,              // NBT = RP / 32 column blocks per K-step
@@ -193,10 +198,17 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 	// valid step of A against the all-zero K-step that closes the factor image (index steps_total).
 	// (the unit is 2 for ring depths 1 and 2, so that every instantiation with such a ring deals the K-steps out the same way and
 	//  the forms stay bit-identical to each other whatever their depth)
+	// ODD (round 5): whole turns made config 2's pieces 28 K-steps for the last wave of a launch's last K slice beside 26 for the others (313 steps over 12
+	// pieces, 625 over 24) and the workgroups of that slice ended every launch ~2 us after the rest (per-workgroup stamps, tools/stamp_x3.py).  Pieces of an
+	// odd count each -- one step out of ring slot 1 AHEAD of the loop, then whole turns -- can be 27 and 25 there: piece i = 2 a_i + 1 steps with the a_i dealt
+	// evenly.  Every wave of the launch takes the same path (a piece-dependent branch in front of the loop made hipcc wait for vmcnt(0) inside it), the host
+	// picks the form with the shorter longest piece (x3_odd_pieces), the same for every instantiation of a width: the forms stay bit-identical to each other.
+	static_assert(!ODD || (D == 2 && !YLDS), "odd pieces: ring depth 2, loads straight to registers");
 	constexpr int DU = D <= 2 ? 2 : D;
 	const int units = (steps_total + DU - 1) / DU;
-	const int s0 = DU * (int)(((long)units * widx) / nw);
-	const int s1 = DU * (int)(((long)units * (widx + 1)) / nw);
+	const int pairs = (steps_total - nw + 1) / 2;               // ODD: whole turns to deal out beside one step per piece (the host made sure steps_total >= nw)
+	const int s0 = ODD ? 2 * (int)(((long)pairs * widx) / nw) + widx : DU * (int)(((long)units * widx) / nw);
+	const int s1 = ODD ? 2 * (int)(((long)pairs * (widx + 1)) / nw) + widx + 1 : DU * (int)(((long)units * (widx + 1)) / nw);
 	const int steps = s1 - s0;
 
 	f32x16 acc[4][NBW];
@@ -247,7 +259,8 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 		bf16x8 fb[D][NBW][3];
 #pragma unroll
 		for (int d = 0; d < D; ++d) {
-			const int st = s0 + d;                                  // steps >= D here
+			int st = s0 + (ODD ? (d ^ 1) : d);                      // (ODD: step s0 waits in ring slot 1, step s0 + 1 in slot 0; a piece of one step re-reads it there)
+			st = st < last ? st : last;
 			const int sa = st < kend ? st : kend, sf = st <= kend ? st : steps_total;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) va[d][j] = *reinterpret_cast<const f32x4*>(YLDS ? g_addr(sa, j) : a_addr(sa, j));
@@ -289,13 +302,13 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 		} else {
 			float v[8];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) v[j] = TR ? va[0][j >> 2][j & 3] : va[0][j][0];
+			for (int j = 0; j < 8; ++j) v[j] = TR ? va[ODD ? D - 1 : 0][j >> 2][j & 3] : va[ODD ? D - 1 : 0][j][0];
 			split3(v, op[0][0], op[0][1], op[0][2]);
 		}
-		int t = 0;
-		for (; t < steps; t += D) {
-#pragma unroll
-			for (int d = 0; d < D; ++d) {
+		// one K-step out of ring slot d; t = the first step of the turn it belongs to
+		auto kstep = [&](auto dtag, const int t) {
+			constexpr int d = decltype(dtag)::value;
+			{
 #pragma unroll
 				for (int b = 0; b < 4; ++b) {
 					const int cur = (d * 4 + b) & 1, nxt = cur ^ 1;
@@ -380,7 +393,18 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
+		};
+#define X3_KSTEP(dd) kstep(std::integral_constant<int, dd>{}, t)
+		int t = 0;
+		if constexpr (ODD) { t = -1; X3_KSTEP(1); t = 1; }      // the piece's first step: "turn -1", slot 1 -- its refill is the step slot 1 holds in the loop's first turn
+		for (; t < steps; t += D) {
+			X3_KSTEP(0);
+			if constexpr (D > 1) X3_KSTEP(1);
+			if constexpr (D > 2) X3_KSTEP(2);
+			if constexpr (D > 3) X3_KSTEP(3);
+			static_assert(D <= 4, "ring depth");
 		}
+#undef X3_KSTEP
 		if (DIAG != 0) { __builtin_amdgcn_sched_barrier(0); t_loop1 = __builtin_amdgcn_s_memtime(); r_loop1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
 	}
 
@@ -450,7 +474,7 @@ int plan_splits_x3(int xtiles, int KS, int num_cus, int reserve) {
 // events handed from launch_factor_product_x3 to the instantiation it dispatches to (per thread: rank threads launch concurrently)
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
-template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false>
+template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG = 128, bool YLDS = false, bool R32 = false, bool ODD = false>
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
@@ -464,18 +488,25 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, ODD>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	if (t_ev_start != nullptr && t_ev_stop != nullptr) {
 		// (the caller wants this launch timed: its own start / stop timestamps, no event records around it)
 		const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
 		t_ev_start = t_ev_stop = nullptr;
-		hipExtLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
+		hipExtLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, ODD>), grid, block, (std::uint32_t)lds_bytes, stream, e0, e1, 0u,
 		                      A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 		return hipGetLastError();
 	}
-	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32>), grid, block, lds_bytes, stream,
+	hipLaunchKernelGGL((k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, ODD>), grid, block, lds_bytes, stream,
 	                   A, tile_stride, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, p.steps_total, p.xtiles, p.splits, with_reduce ? *rg : none, stamps);
 	return hipGetLastError();
+}
+
+// Pieces of an odd number of K-steps (k_factor_product_x3, ODD) when their longest is shorter than the longest piece of whole turns of the two-deep ring
+static bool x3_odd_pieces(int steps_total, int pieces) {
+	if (X3_DEAL_TURNS != 0 || X3_RING_X != 2 || pieces <= 0 || steps_total < 3 * pieces) return false;
+	const int units = (steps_total + 1) / 2, pairs = (steps_total - pieces + 1) / 2;
+	return 2 * ((pairs + pieces - 1) / pieces) + 1 < 2 * ((units + pieces - 1) / pieces);
 }
 
 // y_tiled: A is the image tiled along the REDUCTION index (128-row tiles of y, tile_stride apart, each holding all x as
@@ -489,6 +520,7 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps,
                                     bool y_tiled, int image_tile, hipEvent_t ev_start, hipEvent_t ev_stop) {
 	if (RP % 64 != 0 || p.th != 128 || (image_tile != 128 && image_tile != 16)) return hipErrorInvalidValue;
+	const bool odd = x3_odd_pieces(p.steps_total, 4 * p.splits);      // (the 64- and 32-column forms; the 128-column ones keep whole turns: no register left for the step ahead of the loop)
 	t_ev_start = ev_start; t_ev_stop = ev_stop;
 	struct Clear { ~Clear() { t_ev_start = t_ev_stop = nullptr; } } clear_on_exit;      // (a path that did not consume them -- an error return, grid.y > 1 -- leaves nothing behind)
 #ifdef NMFAMD_DIAG_BUILD
@@ -497,16 +529,16 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		// 30..33 the y-tiled form (rows 32 b + r per lane); last digit 0 = no ring refill, 1 = refill A only, 2 = refill F only, 3 = the production loop
 		static const int yv = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();
 		if (!y_tiled) switch (yv % 10) {
-			case 0: return launch_fp_x3<X3_RING_X, 4, 1, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			case 1: return launch_fp_x3<X3_RING_X, 4, 2, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			case 2: return launch_fp_x3<X3_RING_X, 4, 3, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			default: return launch_fp_x3<X3_RING_X, 4, 4, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+			case 0: return (odd ? launch_fp_x3<X3_RING_X, 4, 1, 2, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 1, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			case 1: return (odd ? launch_fp_x3<X3_RING_X, 4, 2, 2, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 2, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			case 2: return (odd ? launch_fp_x3<X3_RING_X, 4, 3, 2, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 3, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			default: return (odd ? launch_fp_x3<X3_RING_X, 4, 4, 2, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 4, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
 		}
 		switch (yv % 10) {
-			case 0: return launch_fp_x3<X3_RING_X, 4, 1, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			case 1: return launch_fp_x3<X3_RING_X, 4, 2, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			case 2: return launch_fp_x3<X3_RING_X, 4, 3, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
-			default: return launch_fp_x3<X3_RING_X, 4, 4, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps);
+			case 0: return (odd ? launch_fp_x3<X3_RING_X, 4, 1, 2, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 1, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			case 1: return (odd ? launch_fp_x3<X3_RING_X, 4, 2, 2, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 2, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			case 2: return (odd ? launch_fp_x3<X3_RING_X, 4, 3, 2, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 3, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
+			default: return (odd ? launch_fp_x3<X3_RING_X, 4, 4, 2, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps) : launch_fp_x3<X3_RING_X, 4, 4, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg, stamps));
 		}
 	}
 #else
@@ -525,25 +557,25 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 		}
 #ifdef NMFAMD_DIAG_BUILD
 		if (RP == 64 && p.col_split == 2) {       // (measured slower at config 2: 41.9 -> 51.0 and 40.8 -> 45.4 us per launch; Engine::init)
-			if (!y_tiled) return launch_fp_x3<X3_RING_X, 4, 0, 1, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-			return launch_fp_x3<X3_RING_X, 4, 0, 1, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+			if (!y_tiled) return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 1, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 1, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
+			return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 1, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 1, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 		}
 #endif
-		if (!y_tiled) return launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (!y_tiled) return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 2, false, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 		if (ylds) return launch_fp_x3<X3_RING_Y, 4, 0, 2, true, 16, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		if (ydirect) return launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
-		return launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (ydirect) return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
+		return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 2, true, 16, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 	}
 	if (y_tiled) {
 		if (RP % 128 == 0) return launch_fp_x3<2, 4, 0, 4, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 #ifdef NMFAMD_DIAG_BUILD
-		if (RP == 64 && p.col_split == 2) return launch_fp_x3<X3_RING_X, 4, 0, 1, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		if (RP == 64 && p.col_split == 2) return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 1, true, 128, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 1, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 #endif
-		return launch_fp_x3<X3_RING_X, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+		return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 2, true, 128, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 2, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 	}
 	static const int variant = [] { const char* e = tuning_env("NMFAMD_X3_VARIANT"); return e ? std::atoi(e) : 0; }();   // A/B switch for measurements
 	// short reduction ranges (a column shard's V H^T): 128 x 32 per workgroup, two workgroups per x-tile (FactorProductPlan::col_split)
-	if (RP == 64 && p.col_split == 2) return launch_fp_x3<X3_RING_X, 4, 0, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	if (RP == 64 && p.col_split == 2) return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 1, false, 128, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4, 0, 1>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 	// wide panels: 128 columns per pass over A (256 accumulator registers, ring depth 2) -- half the passes, MFMA-bound
 	if (RP % 128 == 0 && variant != 20) return launch_fp_x3<2, 4, 0, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
 #ifdef NMFAMD_DIAG_BUILD
@@ -553,7 +585,7 @@ hipError_t launch_factor_product_x3(const FactorProductPlan& p, const float* A, 
 	default: break;
 	}
 #endif
-	return launch_fp_x3<X3_RING_X, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg);
+	return (odd ? launch_fp_x3<X3_RING_X, 4, 0, 2, false, 128, false, false, true>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg) : launch_fp_x3<X3_RING_X, 4>(p, A, tile_stride, F, RP, slabs, slab_stride, stream, rg));
 }
 
 } // namespace nmfamd

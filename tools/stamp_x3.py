@@ -27,3 +27,28 @@ t0 = s[:, 3].min()
 for name, col in (("entry", 3), ("loop start", 4), ("loop end", 5), ("tail end", 6), ("exit", 7)):
     v = (s[:, col] - t0) / 100
     print(f"  {name:10s}: median {np.median(v):6.2f} us  min {v.min():6.2f}  max {v.max():6.2f}")
+# which workgroups end the launch: exit time by x-tile, by K slice and by XCD (the kernel's placement: block b runs on XCD b % 8; each XCD takes a contiguous
+# range of (slice, x-tile) pairs -- kernels_x3.hip, XCD_REMAP)
+full = buf[: 8 * waves.value].reshape(-1, 8).astype(np.float64)
+nblk = len(full) // 4
+variant = int(os.environ.get("NMFAMD_X3_VARIANT", "13"))
+y_tiled = variant >= 30
+xtiles = ((Y if y_tiled else X) + 127) // 128
+live = full[:, 2].reshape(nblk, 4).max(axis=1) > 0
+pblocks = int(live.sum())
+splits = pblocks // xtiles
+ex = (full[:, 7].reshape(nblk, 4).max(axis=1) - t0) / 100
+q8, r8 = divmod(pblocks, 8)
+rows = []
+for b in range(pblocks):
+    xcd, idx = b % 8, b // 8
+    vb = (xcd * (q8 + 1) if xcd < r8 else r8 * (q8 + 1) + (xcd - r8) * q8) + idx
+    rows.append((b, xcd, vb % xtiles, vb // xtiles, ex[b]))
+rows = np.array(rows)
+print(f"  workgroups {pblocks} = {xtiles} x-tiles x {splits} K slices; exit: median {np.median(rows[:, 4]):.2f} us, p90 {np.percentile(rows[:, 4], 90):.2f}, max {rows[:, 4].max():.2f}")
+late = rows[np.argsort(rows[:, 4])[-8:]]
+print("  last eight (block, XCD, x-tile, slice, exit us):", [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), round(float(r[4]), 1)) for r in late])
+print("  median exit by XCD:", [round(float(np.median(rows[rows[:, 1] == k, 4])), 1) for k in range(8)])
+print("  median exit by slice:", [round(float(np.median(rows[rows[:, 3] == k, 4])), 1) for k in range(splits)])
+bx = np.array([np.median(rows[rows[:, 2] == k, 4]) for k in range(xtiles)])
+print("  x-tiles with the latest median exit:", [(int(k), round(float(bx[k]), 1)) for k in np.argsort(bx)[-5:]])

@@ -86,6 +86,7 @@ Engine<T>::~Engine() {
 	if (rowdot_part_) (void)hipFree(rowdot_part_);
 	if (tri_ride_counters_) (void)hipFree(tri_ride_counters_);
 	if (Gpart_) (void)hipFree(Gpart_);
+	if (gram_spread_counter_) (void)hipFree(gram_spread_counter_);
 	if (Graw64_) (void)hipFree(Graw64_);
 	if (gramH_part_) (void)hipFree(gramH_part_);
 	if (scale_) (void)hipFree(scale_);
@@ -347,6 +348,8 @@ Status Engine<T>::allocate() {
 		// last workgroups of config 2's W^T V launch (37 - 40 us against 33 - 36.5 for the product blocks, profiles/r05_update_tail.md).  NMFAMD_GRAM_SPREAD=0
 		// (measurement builds) restores that form.
 		gram_spread_ = gram_ksplit_ == 1 && !(tuning_env("NMFAMD_GRAM_SPREAD") != nullptr && std::atoi(tuning_env("NMFAMD_GRAM_SPREAD")) == 0);
+		HIPX(hipMalloc((void**)&gram_spread_counter_, 64));
+		HIPX(hipMemsetAsync(gram_spread_counter_, 0, 64, stream_));
 		HIPX(hipMalloc((void**)&wsq_part_, sizeof(float) * 64 * (size_t)(mpad_ / 32)));
 		HIPX(hipMemsetAsync(wsq_part_, 0, sizeof(float) * 64 * (size_t)(mpad_ / 32), stream_));
 	}
@@ -606,7 +609,7 @@ GramReduceArgs Engine<T>::gram_args(bool of_w, float* G, float* scale, int norma
 		// W^T W beside the W^T V launch of a column shard: K slices into Gpart_, added and scaled by the H update (mu64_update)
 		if (of_w && (const void*)G == (const void*)G_ && gram_ksplit_ > 1 && Gpart_ != nullptr && (normalize == 0 || rg.colsq_part != nullptr)) { rg.ksplit = gram_ksplit_; rg.G = Gpart_; }
 		// ... of a whole problem: the sixteen passengers share the ten tiles' K ranges evenly (gram_image.h, spread form), pieces into Gpart_ for the same consumer
-		else if (of_w && (const void*)G == (const void*)G_ && gram_spread_ && Gpart_ != nullptr && (normalize == 0 || rg.colsq_part != nullptr)) { rg.spread = 1; rg.G = Gpart_; }
+		else if (of_w && (const void*)G == (const void*)G_ && gram_spread_ && Gpart_ != nullptr && (normalize == 0 || rg.colsq_part != nullptr)) { rg.spread = 1; rg.G = Gpart_; rg.spread_out = G; rg.spread_counter = gram_spread_counter_; }
 	}
 	return rg;
 }
@@ -630,7 +633,7 @@ Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride
 		const int xks = is_w ? ksH_ : ksW_;
 		if (peers != nullptr && !gram_image_) return ST_INVALID;
 		if (gram_image_) HIPX(launch_mu64_update32(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? G_ : nullptr, compute_error ? 1 : 0, stream_, xo, xks, peers,
-		                                           is_w ? wsq_part_ : nullptr, (!is_w && (const void*)Q == (const void*)Gpart_) ? gram_q_slices() : 0, (!is_w && (const void*)Q == (const void*)Gpart_) ? G_ : nullptr));
+		                                           is_w ? wsq_part_ : nullptr, (!is_w && (const void*)Q == (const void*)Gpart_) ? gram_ksplit_ : 0, (!is_w && (const void*)Q == (const void*)Gpart_) ? G_ : nullptr));
 		else HIPX(launch_mu64_update(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? gramW_part_ : gramH_part_, is_w ? G_ : nullptr,
 		                             compute_error ? 1 : 0, stream_, xo, xks));
 	}
@@ -877,7 +880,7 @@ Status Engine<T>::h_step_impl(bool compute_error) {
 			}
 			GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 			if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
+			if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, rgW.ksplit > 1 ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 			hx3_valid_ = x3_;
 			return ST_OK;
 		}
@@ -1395,7 +1398,7 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 		}
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
 		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
-		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, (rgW.ksplit > 1 || rgW.spread > 0) ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
+		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, rgW.ksplit > 1 ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 		GramReduceArgs rgH = gram_args(false, HHt_, nullptr, 0);
 		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
 		if (Status s = mu64_update(true, slabs_, planW_.splits, slab_stride_, HHt_, compute_error)) return s;

@@ -247,8 +247,8 @@ private:
 	// rank-64 MU fast path: W is kept unnormalised with a pending column scale (kernels_mu64.hip)
 	float *gramW_part_ = nullptr, *gramH_part_ = nullptr, *scale_ = nullptr, *Graw64_ = nullptr;
 	bool w_col_split_ = false;       // V H^T from 128 x 32 workgroups and one slab (narrow column shards, Engine::init)
-	bool gram_spread_ = false;       // ... or, one slice: the sixteen passengers share the ten tiles' K ranges (gram_image.h, spread form); GRAM_SPREAD_SLICES pieces
-	int gram_q_slices() const { return gram_spread_ ? GRAM_SPREAD_SLICES : gram_ksplit_; }
+	bool gram_spread_ = false;       // ... or, one slice: the sixteen passengers share the ten tiles' K ranges (gram_image.h, spread form) and the last one finishes G_
+	unsigned* gram_spread_counter_ = nullptr;
 	int gram_ksplit_ = 1;            // K slices of the W^T W passengers (gram_image.h): > 1 for column shards narrower than config 2
 	float* Gpart_ = nullptr;         // [GRAM_KSPLIT_MAX][4096] unscaled slices of W^T W (the H update adds and scales them, and stores G_)
 	float* wsq_part_ = nullptr;      // [mpad / 32][64] partial sums of squares of the rows the last W update wrote (k_mu64_update32<true>): the pending column scale's source

@@ -195,8 +195,8 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 		// Spread form (round 5, the sixteen passengers of a whole problem's W^T V): the one-slice form leaves six of the sixteen workgroups idle (the lower-triangle
 		// tiles) and makes the ten others the LAST workgroups of the launch (config 2: 37 - 40 us under the product's stream against 33 - 36 for the product blocks).
 		// Here the ten tiles' K ranges, end to end, are dealt evenly to all sixteen: a workgroup runs 5 / 8 of a tile's range -- the end of one tile and the
-		// start of the next -- and a tile arrives in up to GRAM_SPREAD_SLICES unscaled pieces (piece = how many workgroups before this one worked on the tile)
-		// that the consumer adds in order and scales, exactly as for the K-split form.
+		// start of the next -- and a tile arrives in up to GRAM_SPREAD_SLICES unscaled pieces (piece = how many workgroups before this one worked on the tile);
+		// the last workgroup to finish adds them in order and scales the sum (below): long before the product's own workgroups are done.
 		const long total = (long)GRAM_IMAGE_TILES * pairs;
 		const long w0 = total * blk / GRAM_REDUCE_BLOCKS, w1 = total * (blk + 1) / GRAM_REDUCE_BLOCKS;
 		int seg = 0;
@@ -209,6 +209,33 @@ __device__ inline void gram_image_block(const GramReduceArgs& rg, int blk, float
 			gram_image_tile(t, &ti, &tj);
 			const int sb = (int)(a - (long)t * pairs), len = (int)(b - a);
 			gram_image_segment(rg, ti, tj, blk - first, true, sb + (int)(((long)len * wave) / 4), sb + (int)(((long)len * (wave + 1)) / 4), lds, seg++);
+		}
+		if (rg.spread_out == nullptr || rg.spread_counter == nullptr) return;
+		// hand-over (the scheme of tri_gram_tile.h): this workgroup's pieces are out -- each wave waits for its own stores, ONE release for the workgroup, one count;
+		// the last of the sixteen finishes the matrix (nobody waits for anybody)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		int* s_last = reinterpret_cast<int*>(lds);
+		if (threadIdx.x == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const unsigned old = __hip_atomic_fetch_add(rg.spread_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int last = old == (unsigned)(GRAM_REDUCE_BLOCKS - 1);
+			if (last) {
+				__hip_atomic_store(rg.spread_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch finds zero)
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			*s_last = last;
+		}
+		__syncthreads();
+		if (*s_last == 0) return;
+		for (int e = threadIdx.x; e < 4096; e += 256) {
+			const int r = e >> 6, c = e & 63;
+			float v = rg.G[e];
+#pragma unroll
+			for (int k = 1; k < GRAM_SPREAD_SLICES; ++k) v += rg.G[(long)k * 4096 + e];
+			rg.spread_out[e] = rg.scale != nullptr ? (v * rg.scale[c]) * rg.scale[r] : v;
 		}
 		return;
 	}

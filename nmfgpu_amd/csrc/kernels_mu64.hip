@@ -423,7 +423,7 @@ static void launch_update32_inst(dim3 grid, hipStream_t stream, float* P, const 
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
                                 void* x3_out, int x3_ks, const PeerSlabs* peers, float* colsq_part, int qsplit, float* q_out) {
-	if (x3_out == nullptr || len_pad % 32 != 0 || (qsplit > 1 && is_w) || (qsplit > 1 && qsplit != 2 && qsplit != 3 && qsplit != 4 && qsplit != 8)) return hipErrorInvalidValue;
+	if (x3_out == nullptr || len_pad % 32 != 0 || (qsplit > 1 && is_w) || (qsplit > 1 && qsplit != 2 && qsplit != 4 && qsplit != 8)) return hipErrorInvalidValue;
 	PeerSlabs pa = {};
 	if (peers != nullptr) {
 		if (peers->count < 1 || peers->count > PEER_SLABS_MAX) return hipErrorInvalidValue;
@@ -434,7 +434,6 @@ hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, l
 	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
 #define NMFAMD_U32(ISW, UU, QQ) launch_update32_inst<ISW, UU, QQ>(grid, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, pa, colsq_part, q_out)
 	if (is_w) { if (S > 8) NMFAMD_U32(true, 13, 1); else NMFAMD_U32(true, 7, 1); }
-	else if (qsplit == 3) { if (S > 8) NMFAMD_U32(false, 13, 3); else NMFAMD_U32(false, 7, 3); }
 	else if (S > 8) { if (qsplit == 2) NMFAMD_U32(false, 13, 2); else if (qsplit == 4) NMFAMD_U32(false, 13, 4); else if (qsplit == 8) NMFAMD_U32(false, 13, 8); else NMFAMD_U32(false, 13, 1); }
 	else { if (qsplit == 2) NMFAMD_U32(false, 7, 2); else if (qsplit == 4) NMFAMD_U32(false, 7, 4); else if (qsplit == 8) NMFAMD_U32(false, 7, 8); else NMFAMD_U32(false, 7, 1); }
 #undef NMFAMD_U32

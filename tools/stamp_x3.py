@@ -52,3 +52,8 @@ print("  median exit by XCD:", [round(float(np.median(rows[rows[:, 1] == k, 4]))
 print("  median exit by slice:", [round(float(np.median(rows[rows[:, 3] == k, 4])), 1) for k in range(splits)])
 bx = np.array([np.median(rows[rows[:, 2] == k, 4]) for k in range(xtiles)])
 print("  x-tiles with the latest median exit:", [(int(k), round(float(bx[k]), 1)) for k in np.argsort(bx)[-5:]])
+# the epilogue as the launch sees it: from the moment a workgroup's LAST wave leaves the loop to the workgroup's exit
+tl = (full[:, 6].reshape(nblk, 4).max(axis=1) - t0) / 100
+fl = (full[:, 6].reshape(nblk, 4).min(axis=1) - t0) / 100
+ep = (ex - tl)[:pblocks]
+print(f"  epilogue (last wave out of the loop -> exit): median {np.median(ep):.2f} us, p90 {np.percentile(ep, 90):.2f}; first to last wave out of the loop: median {np.median((tl - fl)[:pblocks]):.2f} us")

@@ -217,7 +217,7 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 	// exchange panel, as bench.py chooses -- 8 MB or more (config 4's 51 MB): row blocks; less (config 2's 2.6 MB): the replicated update, which at padded
 	// rank 64 reads the ranks' panels in place and needs one rendezvous per iteration (sharded.cpp)
 	int num_gpus = 1;
-	int shard_mode = (double)sizeof(T) * (double)d.inputMatrix.rows * (double)nmfamd::padded_rank((int)d.features) >= 8e6 ? nmfamd::SHARD_ROW_BLOCKS : nmfamd::SHARD_REPLICATED;
+	int shard_mode = (double)sizeof(T) * (double)d.inputMatrix.rows * (double)nmfamd::padded_rank((int)d.features, sizeof(T)) >= 8e6 ? nmfamd::SHARD_ROW_BLOCKS : nmfamd::SHARD_REPLICATED;
 	{
 		int idx = parameter_index(d.parameters, d.numParameters, "numGpus");
 		if (idx >= 0) num_gpus = (int)d.parameters[idx].value;

@@ -56,7 +56,7 @@ template <typename T>
 int op_factor_product(const T* A, long lda, int X, int Y, const T* F, long ldf, int r, T* OUT, long ldo, bool use_valu, int* out_slabs) {
 	if (!A || !F || !OUT || X <= 0 || Y <= 0 || r <= 0 || lda < X || ldf < r || ldo < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
-	const int RP = padded_rank(r);
+	const int RP = padded_rank(r, sizeof(T));
 	int dev = 0; hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMFAMD_HIP_ERROR;
 	FactorProductPlan plan = std::is_same<T, double>::value ? plan_factor_product_f64(X, Y, RP, prop.multiProcessorCount)
@@ -638,7 +638,7 @@ int nmfamd_op_gram_f32(const float* P, long ldp, int r, int len, float* G, long 
 int nmfamd_op_gram_f64(const double* P, long ldp, int r, int len, double* G, long ldg) {
 	if (!P || !G || r <= 0 || len <= 0 || ldp < r || ldg < r) return NMFAMD_INVALID_ARGUMENT;
 	if (nmfamd_device_count() <= 0) return NMFAMD_NO_DEVICE;
-	const int RP = padded_rank(r), parts = 128;
+	const int RP = padded_rank(r, sizeof(double)), parts = 128;
 	const long lp = pad128(len);
 	DevBuf dP, dPart, dG;
 	if (dP.alloc(sizeof(double) * RP * lp) != hipSuccess || dPart.alloc(sizeof(double) * (size_t)RP * RP * parts) != hipSuccess || dG.alloc(sizeof(double) * RP * RP) != hipSuccess) return NMFAMD_NO_DEVICE_MEMORY;

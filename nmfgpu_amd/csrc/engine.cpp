@@ -61,7 +61,7 @@ static size_t memory_side_cache_bytes(const hipDeviceProp_t& prop) {
 
 template <typename T>
 Engine<T>::Engine(int m, int n, int r, int algorithm, const AlgorithmParams& params)
-	: m_(m), n_(n), r_(r), RP_(padded_rank(r)), alg_(algorithm), prm_(params), mpad_(pad128(m)), npad_(pad128(n)) {}
+	: m_(m), n_(n), r_(r), RP_(padded_rank(r, (params.sparse_compute != 0 || params.divergence != 0) ? 4 : sizeof(T))), alg_(algorithm), prm_(params), mpad_(pad128(m)), npad_(pad128(n)) {}
 
 template <typename T>
 Status Engine<T>::hip_fail(hipError_t e, const char* what) {
@@ -119,7 +119,7 @@ Status Engine<T>::allocate() {
 	if (RP_ == 64 && r_ <= 32 && tuning_env("NMFAMD_FP_FULL_WIDTH") == nullptr) { planH_.nb = f64 ? 2 : 1; planW_.nb = planH_.nb; }      // (fp64 counts 16-column tiles)
 	if (!mfma) { planH_.splits = 1; planW_.splits = 1; planH_.th = planW_.th = 128; planH_.xtiles = (int)(pad128(n_) / 128); planW_.xtiles = (int)(pad128(m_) / 128); }
 	tiled_ = mfma;
-	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;
+	sparse_ = prm_.sparse_compute != 0 || prm_.divergence != 0;      // (the SpMM / KL kernels gather RP / 64 = 1, 2 or 4 values per lane: sparse runs keep the 128-column padding in either precision, see the constructor)
 	if (sparse_) {
 		if (alg_ != ALG_MU || RP_ > 256) return ST_INVALID;   // sparse compute: multiplicative update, padded rank 64 / 128 / 256
 		tiled_ = false;

@@ -30,7 +30,10 @@ struct AlgorithmParams {
 // the caller recreates the engine with precision = -1 (native fp32 MFMA instructions) -- nmfgpu::compute does that by itself
 enum Status { ST_OK = 0, ST_INVALID = 1, ST_NO_DEVICE_MEMORY = 2, ST_NO_HOST_MEMORY = 3, ST_HIP_ERROR = 4, ST_NO_DEVICE = 5, ST_VALUE_RANGE = 6 };
 
-inline int padded_rank(int r) { return r <= 64 ? 64 : ((r + 127) / 128) * 128; }
+// Padded rank of the factor panels: 64, or above that a multiple of 128 in fp32 (the 128-column forms of the split-operand product, the wide fp32 update and Gram
+// kernels) and of 64 in fp64 (round 5: every fp64 kernel works in 64-column units -- the reference example's r = 158 ran as 256, now 192: 0.56 of the r x r work
+// and 0.75 of the product's)
+inline int padded_rank(int r, size_t elem_bytes = 4) { return r <= 64 ? 64 : (elem_bytes == 8 ? ((r + 63) / 64) * 64 : ((r + 127) / 128) * 128); }
 inline long pad128(long v) { return ((v + 127) / 128) * 128; }
 
 template <typename T>

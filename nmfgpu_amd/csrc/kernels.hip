@@ -591,7 +591,7 @@ hipError_t launch_gram(const T* P, int RP, int len, int parts, T* partial, T* G,
 		if (gram_wide_available(RP) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return launch_gram_wide_f32(P, RP, len, parts, partial, G, stream);
 	}
 	if constexpr (std::is_same<T, double>::value) {
-		if ((RP == 64 || RP % 128 == 0) && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return launch_gram_f64(P, RP, len, parts, partial, G, stream);
+		if (RP % 64 == 0 && std::getenv("NMFAMD_FORCE_VALU") == nullptr) return launch_gram_f64(P, RP, len, parts, partial, G, stream);
 	}
 	int blocks = RP / 64; // RP is a multiple of 64
 	parts = std::max(1, std::min(parts, std::max(1, len / 64)));      // short panels: fewer, longer slices (less partial traffic)

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 #pragma unroll
 		for (int g = 0; g < 4; ++g) acc[i][g] = 0.0;
 	const double* qp = Q + (long)kq * RP + 16 * wave + l15;      // + 4 t RP per K-step, + 64 i per tile
-	const int steps = RP / 4;                                     // multiple of 32
+	const int steps = RP / 4;                                     // multiple of 16 (RP of 64): whole turns of the ring of eight
 	constexpr int D = 8;
 	double a[D][NCT], b[D];
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 	}
 }
 
-bool panel_update_wide_f64_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= 512; }
+bool panel_update_wide_f64_available(int RP) { return RP >= 128 && RP % 64 == 0 && RP <= 512; }
 
 template <int MODE, int NCT>
 static hipError_t launch_wide_f64(double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
@@ -447,10 +447,13 @@ hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs
 #define NMFAMD_WIDE64(NCT)                                                                                                                       \
 	return mode == PANEL_MU ? launch_wide_f64<PANEL_MU, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream) \
 	                        : launch_wide_f64<PANEL_LS, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream)
-	switch (RP / 128) {
-	case 1: NMFAMD_WIDE64(2);
-	case 2: NMFAMD_WIDE64(4);
-	case 3: NMFAMD_WIDE64(6);
+	switch (RP / 64) {      // 16-column tiles per wave
+	case 2: NMFAMD_WIDE64(2);
+	case 3: NMFAMD_WIDE64(3);
+	case 4: NMFAMD_WIDE64(4);
+	case 5: NMFAMD_WIDE64(5);
+	case 6: NMFAMD_WIDE64(6);
+	case 7: NMFAMD_WIDE64(7);
 	default: NMFAMD_WIDE64(8);
 	}
 #undef NMFAMD_WIDE64
@@ -555,12 +558,13 @@ __global__ __launch_bounds__(256, 2) void k_gram_f64(const double* __restrict__ 
 
 // G = sum of the slices' partial matrices in k_reduce_partials' order (four groups of consecutive slices, eight loads in flight, groups added 0..3).  The slices hold
 // the super-blocks (I, J), I <= J, of 128 x 128: an element of a block above the diagonal is also written to its mirrored place, an element below is left to its mirror.
-__global__ __launch_bounds__(256) void k_gram_reduce_sym_f64(const double* __restrict__ partial, int parts, int RP, double* __restrict__ G) {
+// shift: log2 of the super-block edge the Gram kernel ran with (7: 128 x 128, padded ranks of 128; 6: 64 x 64, the other multiples of 64)
+__global__ __launch_bounds__(256) void k_gram_reduce_sym_f64(const double* __restrict__ partial, int parts, int RP, double* __restrict__ G, int shift) {
 	__shared__ double red[4][64];
 	const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const long e = (long)blockIdx.x * 64 + tx;                 // (RP is a multiple of 64: a workgroup's 64 elements share a row and a super-block column)
 	const int r = (int)(e / RP), c = (int)(e % RP);
-	const int I = r >> 7, J = c >> 7;
+	const int I = r >> shift, J = c >> shift;
 	if (I > J) return;                                          // (whole workgroups: uniform)
 	const long stride = (long)RP * RP;
 	const int p0 = (parts * g) / 4, p1 = (parts * (g + 1)) / 4;
@@ -584,17 +588,19 @@ __global__ __launch_bounds__(256) void k_gram_reduce_sym_f64(const double* __res
 
 // len: valid panel rows (rows behind them up to the padded length are zero); partial: parts * RP * RP elements of scratch
 hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* partial, double* G, hipStream_t stream) {
-	if (RP != 64 && RP % 128 != 0) return hipErrorInvalidValue;
-	const int nb = RP == 64 ? 1 : RP / 128, nsuper = nb * (nb + 1) / 2;
+	if (RP % 64 != 0) return hipErrorInvalidValue;
+	// super-blocks of 128 x 128 where the padded rank is a multiple of 128, of 64 x 64 elsewhere (64, 192, 320 ...: round 5, fp64 panels are padded to 64)
+	const bool wide = RP % 128 == 0;
+	const int nb = wide ? RP / 128 : RP / 64, nsuper = nb * (nb + 1) / 2;
 	// at least 16 K-steps (64 panel rows) per slice -- except for short panels (the H side of the reference example: 165 columns at r = 158 were TWO slices, six
 	// workgroups with 21 dependent K-steps each: 19.8 us for 21 MFLOP): there 4 K-steps per slice, so that the launch is one short round (round 5)
 	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len >= 1024 ? len / 64 : len / 16)));
-	if (RP == 64) hipLaunchKernelGGL((k_gram_f64<2, 8>), dim3(parts, 1), dim3(256), 0, stream, P, RP, len, parts, partial);
+	if (!wide) hipLaunchKernelGGL((k_gram_f64<2, 8>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	else hipLaunchKernelGGL((k_gram_f64<4, 6>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	if (RP == 64) return launch_reduce_partials<double>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);      // (one super-block: nothing to mirror)
-	hipLaunchKernelGGL(k_gram_reduce_sym_f64, dim3((unsigned)((long)RP * RP / 64)), dim3(256), 0, stream, partial, parts, RP, G);
+	hipLaunchKernelGGL(k_gram_reduce_sym_f64, dim3((unsigned)((long)RP * RP / 64)), dim3(256), 0, stream, partial, parts, RP, G, wide ? 7 : 6);
 	return hipGetLastError();
 }
 

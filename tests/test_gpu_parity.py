@@ -263,6 +263,27 @@ def test_fp64_engine_matches_fp64_oracle():
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-9)
 
 
+@pytest.mark.parametrize("alg,r,kw,tol", [("mu", 158, {}, 1e-9), ("nsnmf", 158, dict(theta=0.5), 1e-9), ("mu", 129, {}, 1e-9), ("nsnmf", 300, dict(theta=0.3), 1e-9),
+                                          ("als", 190, {}, 1e-6), ("gdcls", 158, dict(lam=0.01), 1e-6), ("mu", 200, {}, 1e-9)])
+def test_fp64_panels_padded_to_64_columns(alg, r, kw, tol):
+    """Round 5: fp64 panels are padded to a multiple of 64 columns above 64 (fp32: 128) -- the reference example's r = 158 runs at 192 instead of 256.  Padded
+    ranks 192 and 320 take the 64 x 64 super-blocks of the fp64 Gram kernel and three / five 16-column tiles per wave of the wide update; every algorithm family
+    against the fp64 oracle (the least-squares ones amplify rounding by the condition of the normal matrix)."""
+    m, n, iters = 700, 330, 12
+    V, W, H = problem(m, n, r, np.float64, seed=31 + r)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    ref = oracle.run(alg, V, Wo, Ho, iters, **kw)
+    eng = na.Engine(m, n, r, alg, dtype=np.float64, **kw)
+    assert eng.geometry()["padded_rank"] == 64 * ((r + 63) // 64)
+    eng.upload(V); eng.set_factors(W, H)
+    eng.iterate(iters, first_iteration=1, error_every=4, last_iteration=iters)
+    Wg, Hg = eng.get_factors()
+    assert rel(Wg, Wo) < tol and rel(Hg, Ho) < tol, (rel(Wg, Wo), rel(Hg, Ho))
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=max(tol, 1e-9))
+    # fp32 keeps its 128-column padding (the 128-column forms of the split-operand product)
+    assert na.Engine(m, n, r, alg, **kw).geometry()["padded_rank"] == 128 * ((r + 127) // 128)
+
+
 @pytest.mark.parametrize("fmt,base", [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)])
 def test_sparse_upload_equals_dense_path_bit_exact(fmt, base):
     """Integer-valued V: the densified matrix must be identical, hence identical factors."""
@@ -695,7 +716,8 @@ def test_factor_product_bf16_is_exact_product_of_rounded_operands(X, Y, r):
 # ------------------------------------------------------------------ fp32 product by exact 3 x bf16 operand splitting
 
 @pytest.mark.parametrize("X,Y,r", [(128, 64, 64), (500, 200, 8), (1000, 777, 64), (130, 2049, 33), (2600, 4100, 64), (10000, 1203, 64),
-                                   (300, 500, 100), (257, 1111, 256), (129, 1, 64), (5, 7, 3), (300, 20, 256), (64, 33, 128), (640, 4100, 300)])
+                                   (300, 500, 100), (257, 1111, 256), (129, 1, 64), (5, 7, 3), (300, 20, 256), (64, 33, 128), (640, 4100, 300),
+                                   (128, 192, 64), (100, 208, 64)])       # (12 K-steps on four wave pieces: the shortest reduction range that takes odd pieces; 13: whole turns)
 def test_factor_product_split_operands_has_fp32_accuracy(X, Y, r):
     """The default fp32 product (kernels_x3.hip): six bf16 MFMAs per block on exactly split operands.  Same bound as the
     native fp32 MFMA kernel above -- |gpu - fp64| <= 4e-7 * sum|a*b| per element -- and an rms error within 2x of it."""
@@ -774,7 +796,7 @@ def test_one_resident_image_gives_identical_factors(alg, r, kw, monkeypatch):
     assert out[False][2] == out[True][2]
 
 
-@pytest.mark.parametrize("X,Y,r", [(300, 500, 64), (1000, 777, 40), (130, 2049, 33), (257, 1111, 256), (129, 1, 64), (5, 7, 3)])
+@pytest.mark.parametrize("X,Y,r", [(300, 500, 64), (1000, 777, 40), (130, 2049, 33), (257, 1111, 256), (129, 1, 64), (5, 7, 3), (128, 192, 64), (100, 208, 64)])
 def test_factor_product_split_y_tiled_is_bit_identical(X, Y, r):
     import ctypes as C
     from nmfgpu_amd._lib import library

@@ -40,6 +40,9 @@ constexpr bool XCD_REMAP = NMFAMD_XCD_REMAP != 0;
 #ifndef X3_RING_X
 #define X3_RING_X 2                   // K-steps in flight per wave (8 + 6 loads each), x-tiled form
 #endif
+#ifndef X3_EPILOGUE_ONE_ROUND
+#define X3_EPILOGUE_ONE_ROUND 1       // (A/B switch: 0 = the in-workgroup sum in two rounds of four accumulator tiles, 64 KiB of LDS, as rounds 2-4 had it)
+#endif
 #ifndef X3_DEAL_TURNS
 #define X3_DEAL_TURNS 0               // (A/B switch, tools/build_variant.sh: 1 = always deal the K-steps in whole turns of the ring, as rounds 2-4 did)
 #endif
@@ -414,29 +417,33 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 	if (YLDS) __syncthreads();            // the epilogue image overlays the staging slots of every wave
 	f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 	float* slab = slabs + (long)sp * slab_stride;
+	// TPR accumulator tiles per round: four (64 KiB of LDS for four waves), or -- X3_EPILOGUE_ONE_ROUND, the 64-column forms -- all eight at once (128 KiB: one
+	// workgroup per CU has them), one barrier instead of three
+	constexpr int TPR = (X3_EPILOGUE_ONE_ROUND && NBW == 2 && !YLDS) ? 8 : 4;
+	constexpr int ROUNDS = 4 * NBW / TPR;
 #pragma unroll
-	for (int rd = 0; rd < NBW; ++rd) {        // four accumulator tiles per round
+	for (int rd = 0; rd < ROUNDS; ++rd) {
 		if (rd > 0) __syncthreads();
 #pragma unroll
-		for (int tl = 0; tl < 4; ++tl) {
-			const int b = (4 * rd + tl) / NBW, nb = (4 * rd + tl) % NBW;
+		for (int tl = 0; tl < TPR; ++tl) {
+			const int b = (TPR * rd + tl) / NBW, nb = (TPR * rd + tl) % NBW;
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
 				f32x4 v;
 				v[0] = acc[b][nb][4 * q + 0]; v[1] = acc[b][nb][4 * q + 1];
 				v[2] = acc[b][nb][4 * q + 2]; v[3] = acc[b][nb][4 * q + 3];
-				l4[((wave * 4 + tl) * 4 + q) * 64 + lane] = v;
+				l4[((wave * TPR + tl) * 4 + q) * 64 + lane] = v;
 			}
 		}
 		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < 16 / X3_WAVES; ++i) {
-			const int sl = wave * (16 / X3_WAVES) + i;  // slice = (tile, q)
+		for (int i = 0; i < 4 * TPR / X3_WAVES; ++i) {
+			const int sl = wave * (4 * TPR / X3_WAVES) + i;  // slice = (tile, q)
 			const int q = sl & 3, tl = sl >> 2;
-			const int b = (4 * rd + tl) / NBW, nb = (4 * rd + tl) % NBW;
-			f32x4 s = l4[((0 * 4 + tl) * 4 + q) * 64 + lane];
+			const int b = (TPR * rd + tl) / NBW, nb = (TPR * rd + tl) % NBW;
+			f32x4 s = l4[((0 * TPR + tl) * 4 + q) * 64 + lane];
 #pragma unroll
-			for (int p = 1; p < X3_WAVES; ++p) s += l4[((p * 4 + tl) * 4 + q) * 64 + lane];
+			for (int p = 1; p < X3_WAVES; ++p) s += l4[((p * TPR + tl) * 4 + q) * 64 + lane];
 #pragma unroll
 			for (int gi = 0; gi < 4; ++gi) {
 				const int mi = gi + 8 * q + 4 * half;
@@ -486,7 +493,8 @@ static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long 
 	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
 	if (NBW == 1 && RP != 64) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(64 * WAVES);
-	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * 4 * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)), YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
+	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * ((X3_EPILOGUE_ONE_ROUND && NBW == 2 && !YLDS) ? 8 : 4) * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)),
+	                                          YLDS ? WAVES * 2 * 128 * 20 * sizeof(float) : 0);
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_x3<D, WAVES, DIAG, NBW, TR, IMG, YLDS, R32, ODD>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
 	if (t_ev_start != nullptr && t_ev_stop != nullptr) {

@@ -70,8 +70,35 @@ Status Engine<T>::hip_fail(hipError_t e, const char* what) {
 	return e == hipErrorOutOfMemory ? ST_NO_DEVICE_MEMORY : ST_HIP_ERROR;
 }
 
+#ifdef NMFAMD_DIAG_BUILD
+// measurement build, NMFAMD_BF_STAMPS=<file>: the waves' life stamps of the last W^T V (kind 0) and V H^T (kind 1) launch of the rank-256 bf16 product, written
+// to the file when an engine is destroyed (tools/stamp_bf16.py): [kind][512 workgroups][4 waves][entry, loop start, loop end, exit] in 100 MHz ticks
+static unsigned long long* g_bf_stamps = nullptr;
+static unsigned long long* bf_stamps(int kind) {
+	static const char* path = std::getenv("NMFAMD_BF_STAMPS");
+	if (path == nullptr) return nullptr;
+	if (g_bf_stamps == nullptr) {
+		if (hipMalloc((void**)&g_bf_stamps, 2 * 512 * 16 * sizeof(unsigned long long)) != hipSuccess) { g_bf_stamps = nullptr; return nullptr; }
+		(void)hipMemset(g_bf_stamps, 0, 2 * 512 * 16 * sizeof(unsigned long long));
+	}
+	return g_bf_stamps + (long)kind * 512 * 16;
+}
+static void bf_stamps_dump() {
+	const char* path = std::getenv("NMFAMD_BF_STAMPS");
+	if (g_bf_stamps == nullptr || path == nullptr) return;
+	std::vector<unsigned long long> h(2 * 512 * 16);
+	(void)hipDeviceSynchronize();
+	if (hipMemcpy(h.data(), g_bf_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+		if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
+	}
+}
+#endif
+
 template <typename T>
 Engine<T>::~Engine() {
+#ifdef NMFAMD_DIAG_BUILD
+	if (bf16_) bf_stamps_dump();
+#endif
 	T* bufs[] = {V_, Vt_, Wt_, H_, Ws_, Hs_, slabs_, numW_, Wold_, G_, G2_, HHt_, Qinv_, gram_part_, sumsq_part_, psN_, stage_};   // (psR_ lives behind psN_)
 	for (T* b : bufs) if (b) (void)hipFree(b);
 	if (inv_work_) (void)hipFree(inv_work_);
@@ -656,6 +683,9 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, m_, Wtb_, ksH_, stream_));
 			if (rg && rg->tri_frags == nullptr && planHb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin();
+#ifdef NMFAMD_DIAG_BUILD
+			if (unsigned long long* st = bf_stamps(0)) set_factor_product_bf16_stamps(st);
+#endif
 			HIPX(launch_factor_product_bf16(planHb_, Vtb_, ksH_, Wtb_, RP_, slabs_, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
@@ -708,6 +738,9 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 			if (!prepacked) HIPX(launch_pack_panel_bf16(F, RP_, n_, Hb_, ksW_, stream_));
 			if (rg && rg->tri_frags == nullptr && planWb_.xtiles < GRAM_REDUCE_BLOCKS) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			record_begin(1);
+#ifdef NMFAMD_DIAG_BUILD
+			if (unsigned long long* st = bf_stamps(1)) set_factor_product_bf16_stamps(st);
+#endif
 			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;

@@ -337,6 +337,9 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
 // workgroups the bf16 product launches for a plan at padded rank 256 (what is left of the chip can carry TRI_PASSENGERS)
 int bf16_product_workgroups(const FactorProductPlan& p);
+#ifdef NMFAMD_DIAG_BUILD
+void set_factor_product_bf16_stamps(unsigned long long* stamps);      // measurement build: the calling thread's next rank-256 product launch stamps its waves' lives (tools/stamp_bf16.py)
+#endif
 
 // ---- fp32 product by exact 3 x bf16 operand splitting (kernels_x3.hip), padded rank 64 ------------
 // The streamed matrix is the x-tiled fp32 image (tile height 128); the factor panel is split into

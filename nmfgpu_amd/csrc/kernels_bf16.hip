@@ -461,10 +461,20 @@ constexpr int BFD_NRB = 7;            // row blocks per workgroup
 #define BFD_R2_DF 8                   // ... of the factor fragments (divides BFD_R2_D): 4 -> 166 us, 3 -> 184, 2 -> 274 (their slice of the image streams through L2 once)
 #endif
 __device__ bf16x8 g_bf_zero_block[64];      // one all-zero fragment block: the A operand of K-steps past the end of a slice
+#ifdef NMFAMD_DIAG_BUILD
+// measurement build: per-wave life stamps of the NEXT launch of the round-2 kernel (100 MHz ticks: entry, loop start, loop end, exit; [block][wave][4]) -- tools/stamp_bf16.py
+static thread_local unsigned long long* t_bf_stamps = nullptr;
+void set_factor_product_bf16_stamps(unsigned long long* stamps) { t_bf_stamps = stamps; }
+#define BF_STAMP_ARG , unsigned long long* __restrict__ stamps
+#define BF_STAMP(i) do { if (stamps != nullptr && lane == 0) stamps[4 * ((long)blockIdx.x * 4 + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BF_STAMP_ARG
+#define BF_STAMP(i) do { } while (0)
+#endif
 template <int NRB, int D, int DF>
 __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg) {
+	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg BF_STAMP_ARG) {
 	static_assert(D % 2 == 0 && D % DF == 0 && DF >= 2 && NRB <= 8, "ring depth even (two operand sets) and a multiple of the factor ring's, at most eight row blocks");
 #ifndef BFD_PAIR
 #define BFD_PAIR 0
@@ -482,9 +492,15 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	if (blockIdx.x >= (unsigned)nblk) {
 		// passengers behind the product's workgroups: the Gram matrix of a factor panel, one tile per workgroup (tri_gram_tile.h)
 		static_assert(sizeof(l8) >= TRI_RIDE_LDS_BYTES, "the passengers' LDS overlays the product's ring");
+#ifdef NMFAMD_DIAG_BUILD
+		{ const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63; BF_STAMP(0); }
+#endif
 		if (blockIdx.y == 0 && rg.tri_frags != nullptr)
 			tri_gram_passenger(reinterpret_cast<const bf16x8*>(rg.tri_frags), rg.tri_ks, (int)blockIdx.x - nblk, rg.tri_partial, rg.tri_counters, rg.G,
 			                   reinterpret_cast<bf16x8*>(rg.tri_x3), rg.tri_diag, l8);
+#ifdef NMFAMD_DIAG_BUILD
+		{ const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BF_STAMP(3); }
+#endif
 		return;
 	}
 	int vb = blockIdx.x;
@@ -496,6 +512,7 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	const int half = lane >> 5, l31 = lane & 31;
+	BF_STAMP(0);
 	const int gb0 = t * NRB;
 	const int b0 = (int)(((long)steps_total * sp) / splits);
 	const int b1 = (int)(((long)steps_total * (sp + 1)) / splits);
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	__builtin_amdgcn_sched_barrier(0);
 
 	const int n_pad = ((n + D - 1) / D) * D;
+	BF_STAMP(1);
 	int rd = 1, wr = AHEAD;                              // LDS slots of step s + 1 (to read) and s + AHEAD (to park)
 	for (int t0 = 0; t0 < n_pad; t0 += D) {
 #pragma unroll
@@ -591,6 +609,7 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	}
 
 	// epilogue: C/D map of the 32 x 32 MFMA: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31
+	BF_STAMP(2);
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
 	for (int b = 0; b < NRB; ++b) {
@@ -607,6 +626,10 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 			}
 		}
 	}
+#ifdef NMFAMD_DIAG_BUILD
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	BF_STAMP(3);
+#endif
 }
 
 // (Round 4 built two more memory skeletons for this product -- the HBM stream straight into the MFMA operand registers with the factor fragments through LDS, and the
@@ -634,7 +657,14 @@ static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, i
 	dim3 grid(tiles * splits + (ride ? TRI_PASSENGERS : 0), RP / 256), block(256);
 	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none);
+	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none
+#ifdef NMFAMD_DIAG_BUILD
+	                   , t_bf_stamps
+#endif
+	                   );
+#ifdef NMFAMD_DIAG_BUILD
+	t_bf_stamps = nullptr;
+#endif
 	return hipGetLastError();
 }
 

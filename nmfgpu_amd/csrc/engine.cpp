@@ -112,8 +112,6 @@ Engine<T>::~Engine() {
 	if (wsq_part_) (void)hipFree(wsq_part_);
 	if (rowdot_part_) (void)hipFree(rowdot_part_);
 	if (tri_ride_counters_) (void)hipFree(tri_ride_counters_);
-	if (tri_fw_dev_) (void)hipFree(tri_fw_dev_);
-	if (tri_fw_fault_) (void)hipHostFree(tri_fw_fault_);
 	if (Gpart_) (void)hipFree(Gpart_);
 	if (gram_spread_counter_) (void)hipFree(gram_spread_counter_);
 	if (Graw64_) (void)hipFree(Graw64_);
@@ -326,16 +324,6 @@ Status Engine<T>::allocate() {
 			HIPX(dalloc(&Gh_raw_, rr));
 			HIPX(dalloc(&colsq_, (long)RP_ * colsq_stage_parts()));
 			tri_w_den_bf16_ = tuning_env("NMFAMD_TRI_FP32_DEN") == nullptr;
-			// the W update as the epilogue of the V (S H)^T launch (TriFusedW, kernels.h): one K slice, the passengers of that launch deliver H H^T as a split image
-			// (NMFAMD_TRI_FUSE_W=0, measurement builds: the stand-alone update, bit for bit the same result)
-			if (RP_ == 256 && planWb_.splits == 1 && tri_ride_h_ && tri_w_den_bf16_ && qx3_ != nullptr && row_blocks_ == 1 &&
-			    !(tuning_env("NMFAMD_TRI_FUSE_W") != nullptr && std::atoi(tuning_env("NMFAMD_TRI_FUSE_W")) == 0)) {
-				HIPX(hipMalloc((void**)&tri_fw_dev_, sizeof(TriFusedW)));
-				HIPX(hipHostMalloc((void**)&tri_fw_fault_, sizeof(int)));
-				*tri_fw_fault_ = 0;
-				void* dp = nullptr;
-				if (hipHostGetDevicePointer(&dp, tri_fw_fault_, 0) == hipSuccess) { tri_fw_fault_dev_ = static_cast<int*>(dp); tri_fuse_w_ = true; } else (void)hipGetLastError();
-			}
 		}
 	}
 	if (alg_ == ALG_NSNMF) {
@@ -735,7 +723,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 }
 
 template <typename T>
-Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out, bool prepacked, const TriFusedW* fused_w, int fused_w_control, int fused_w_parts) {
+Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab_out, bool prepacked) {
 	T* dest = (single_slab_out != nullptr && planW_.splits == 1) ? single_slab_out : slabs_;
 	if (sparse_) {
 		// (V H^T)^T over the CSR image: out(:, i) = sum_j V(i, j) F(:, j)
@@ -753,7 +741,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 #ifdef NMFAMD_DIAG_BUILD
 			if (unsigned long long* st = bf_stamps(1)) set_factor_product_bf16_stamps(st);
 #endif
-			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg, fused_w, fused_w_control, fused_w_parts));
+			HIPX(launch_factor_product_bf16(planWb_, Vb_, ksW_, Hb_, RP_, dest, slab_stride_, stream_, rg));
 			record_end();
 			return ST_OK;
 		}
@@ -1510,7 +1498,6 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 		}
 		if (!constant_w) {
 			const int S = planW_.splits;
-			bool w_fused_done = false;
 			T offW = 0, diagW = 0;
 			if (ls_family) {
 				if (alg_ == ALG_ACLS) diagW = (T)prm_.lambdaW;
@@ -1537,29 +1524,6 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 					// (the error term's trace reads the finished H H^T: behind the launch that made it)
 					if (compute_error) HIPX(launch_trace_small<T>(HHt_, G2_, RP_, r_, psR_, stream_, tri_trace_scale()));
 				}
-			} else if (tri_ && tri_fuse_w_ && tri_ride.tri_frags != nullptr && qx3_holds_hht_ && numW_ != nullptr) {
-				// rank 256: the W update runs as the epilogue of this launch (TriFusedW, kernels.h) -- the new rows land in the other of the two panels
-				if constexpr (std::is_same<T, float>::value) {
-					if (tri_fw_fault_ != nullptr && *tri_fw_fault_ != 0) { last_error_ = "the fused W update gave up waiting for the Gram passengers of its launch: factors are void"; return ST_HIP_ERROR; }
-					if (tri_fw_gen_ == 0) {
-						tri_fw_panel_[0] = Wt_; tri_fw_panel_[1] = numW_;
-						tri_fw_host_.panel[0] = Wt_; tri_fw_host_.panel[1] = numW_;
-						tri_fw_host_.Qx3 = qx3_;
-						tri_fw_host_.q_done = reinterpret_cast<const unsigned long long*>(tri_ride_counters_ + 4);
-						tri_fw_host_.old_colsq = colsq_;
-						tri_fw_host_.frag_out = Wtb_; tri_fw_host_.frag_KS = ksH_;
-						tri_fw_host_.eps = std::numeric_limits<float>::epsilon();
-						tri_fw_host_.fault = tri_fw_fault_dev_;
-						HIPX(hipMemcpyAsync(tri_fw_dev_, &tri_fw_host_, sizeof(TriFusedW), hipMemcpyHostToDevice, stream_));
-					}
-					tri_ride.tri_done = reinterpret_cast<unsigned long long*>(tri_ride_counters_ + 4);
-					const int dir = Wt_ == tri_fw_panel_[0] ? 0 : 1;
-					const int ctrl = tri_fused_w_control(dir, tri_scale_pending_, ++tri_fw_gen_);
-					if (Status s = product_w(Fh, &tri_ride, nullptr, true, tri_fw_dev_, ctrl, colsq_parts_)) return s;
-					if (compute_error) HIPX(launch_trace_small<T>(HHt_, reinterpret_cast<const T*>(Gw_raw_), RP_, r_, psR_, stream_, tri_trace_scale()));
-					std::swap(Wt_, numW_);
-					w_fused_done = true;
-				}
 			} else {
 				if (Status s = product_w(Fh, tri_ride.tri_frags != nullptr ? &tri_ride : nullptr, nullptr, tri_ || (x3_ && hx3_valid_ && Fh == H_))) return s;
 				// (rank 256, H H^T rode in that launch: the error term's trace of H H^T against the unsmoothed W^T W of this iteration's H step, AlgorithmNonSmoothNMF.h:201-202)
@@ -1570,12 +1534,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 				T* wpart = nullptr;
 				if constexpr (std::is_same<T, float>::value) { if (gram_from_update()) wpart = gramW_part_; }
 				wx3_valid_ = false;
-				if (tri_ && w_fused_done) {
-					// (what tri_update_w() leaves behind)
-					qx3_holds_g_ = qx3_holds_hht_ = false;
-					tri_scale_pending_ = true; tri_scale_from_gram_ = true;
-					wtb_valid_ = true; tri_rows_cover_ = true; tri_gw_ready_ = false;
-				} else if (tri_) {
+				if (tri_) {
 					if (Status s = tri_update_w(slabs_, S, slab_stride_, qx3_holds_hht_ ? nullptr : HHt_)) return s;
 				} else {
 					HIPX(launch_panel_update<T>(PANEL_MU, Wt_, slabs_, S, slab_stride_, HHt_, RP_, (int)mpad_, eps,

@@ -165,7 +165,7 @@ private:
 	Status h_step_impl(bool compute_error);
 	// prepacked: the split (x3) image of F is already in Wx3_ / Hx3_ (emitted by the update kernel that wrote F)
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false);   // slabs_ <- partials of F V   (r x n)
-	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false, const TriFusedW* fused_w = nullptr, int fused_w_control = 0, int fused_w_parts = 0);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
+	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
 	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
 	Status iterate_mu64(bool compute_error);         // the four-launch iteration of kernels_mu64.hip
@@ -266,15 +266,7 @@ private:
 	// padded rank 256 with bf16 product operands (kernels_tri.hip): one pass per factor between its update and the product that streams
 	// it (normalise + smooth + bf16 fragments), Gram matrices of the smoothed panels from the unsmoothed ones (S G S)
 	bool tri_ = false;
-	unsigned* tri_ride_counters_ = nullptr;          // arrival counters of the Gram passengers (tri_gram_tile.h): zero between launches (+ 16 bytes: the 64-bit "H H^T is written" count, TriFusedW)
-	// the W update as the epilogue of the V (S H)^T launch (TriFusedW, kernels.h): single engine, one K slice, rank 256, bf16 denominator operand
-	bool tri_fuse_w_ = false;
-	TriFusedW* tri_fw_dev_ = nullptr;                // the arguments that do not change from launch to launch, in device memory
-	TriFusedW tri_fw_host_;
-	float* tri_fw_panel_[2] = {nullptr, nullptr};    // the two W panels the fused update alternates between (Wt_ is always one of them, numW_ the other)
-	int tri_fw_gen_ = 0;
-	int* tri_fw_fault_ = nullptr;                    // pinned, mapped
-	int* tri_fw_fault_dev_ = nullptr;
+	unsigned* tri_ride_counters_ = nullptr;          // arrival counters of the Gram passengers (tri_gram_tile.h): zero between launches
 	bool tri_ride_w_ = false, tri_ride_h_ = false;   // the Gram matrix of W / of S H rides in the W^T V / V (S H)^T launch (Engine::init leaves TRI_PASSENGERS CUs free)
 	bool wtb_valid_ = false;         // Wtb_ holds the bf16 fragments of the current W as it lies in Wt_ (unsmoothed; without the pending column scale)
 	bool tri_scale_pending_ = false; // W = Wt_ diag(d), d(c) = 1 / sqrt(staged sums in colsq_): the column normalisation of the last W update has not been folded into the panel

@@ -78,27 +78,7 @@ struct GramReduceArgs {
 	float* tri_diag = nullptr;
 	float* tri_partial = nullptr;       // [TRI_PASSENGERS / 2][36][1024] partial tiles
 	unsigned* tri_counters = nullptr;   // two counters, zero between launches
-	unsigned long long* tri_done = nullptr;   // (or nullptr) each of the two finishing workgroups adds one when G and tri_x3 are written: TriFusedW::q_done
 };
-// The rank-256 multiplicative W update as the EPILOGUE of the V (S H)^T product launch (kernels_bf16.hip, round 5): with one K slice a row tile's numerator is
-// complete in its workgroup's accumulators, so the tile's rows are updated there -- no slab written or read back (2 x 51 MB at config 4), no second launch, and a
-// tile starts its update when ITS product is done, not when the launch's slowest workgroup is (profiles/r05_c4_product_timeline.txt).  Same MFMAs in the same
-// order as k_panel_update_rows_mu<8, false, true> (PanelTriExtras::old_as_bf16): same bits.  The new rows go to ANOTHER panel (the waves of a workgroup split the
-// columns and all read the tile's old rows as the operand of the r x r product), the caller swaps the two.
-struct TriFusedW {
-	// (in DEVICE memory: the kernel takes a pointer to it and two words that change from launch to launch -- a struct passed by value cost the product loop its
-	//  scalar registers: 178 -> 248 VGPRs and 372 bytes of scratch per lane)
-	float* panel[2] = {nullptr, nullptr};   // the two W panels [row][256]; control bit 0: 0 = read panel[0], write panel[1]; 1 = the other way round
-	const void* Qx3 = nullptr;         // split image of H H^T: written by THIS launch's Gram passengers (GramReduceArgs::tri_x3) ...
-	const unsigned long long* q_done = nullptr;   // ... whose two finishing workgroups each add one to this word (GramReduceArgs::tri_done): 2 * generation when both are through
-	const float* old_colsq = nullptr;  // pending column scale of the old panel (PanelTriExtras::old_colsq); control bit 1: in force
-	void* frag_out = nullptr;          // bf16 fragments of the new rows (PanelTriExtras::frag_out)
-	long frag_KS = 0;
-	float eps = 0.f;
-	int* fault = nullptr;              // host-visible: a workgroup gave up waiting for the passengers (never seen: they finish a hundred microseconds earlier)
-};
-// control word of a launch: bit 0 = direction (above), bit 1 = pending scale in force, bits 2.. = generation (launches with a fused W update so far, this one included)
-inline int tri_fused_w_control(int direction, bool scaled, int generation) { return (direction & 1) | (scaled ? 2 : 0) | (generation << 2); }
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 constexpr int TRI_PASSENGERS = 32;                 // tri_gram_tile.h: 16 K slices x 2 halves of the 36 upper-triangle tiles
 constexpr int GRAM_IMAGE_TILES = 10;               // gram_image.h: upper triangle of the 4 x 4 grid of 16 x 16 tiles
@@ -352,8 +332,7 @@ hipError_t launch_smooth_gram(const float* G, float* Gs, int RP, int r, float of
 hipError_t launch_finish_and_gram(const float* P_in, float* P_out, int RP, int r, long rows, int len, const float* colsq, int colsq_parts, float offdiag, float diag,
                                   void* dst, long KS, int max_parts, float* partial, float* G, int num_cus, hipStream_t stream);
 hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
-                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr,
-                                      const TriFusedW* fused_w_dev = nullptr, int fused_w_control = 0, int fused_w_colsq_parts = 0);
+                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr);
 // K-split of the bf16 product for `xtiles` x-tiles and KS K-steps at padded rank RP
 int plan_splits_bf16(int xtiles, int KS, int RP, int num_cus);
 // workgroups the bf16 product launches for a plan at padded rank 256 (what is left of the chip can carry TRI_PASSENGERS)

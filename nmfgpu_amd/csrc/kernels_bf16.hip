@@ -16,7 +16,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -472,11 +471,10 @@ void set_factor_product_bf16_stamps(unsigned long long* stamps) { t_bf_stamps = 
 #define BF_STAMP_ARG
 #define BF_STAMP(i) do { } while (0)
 #endif
-// FUSE_W: the workgroup updates its row tile of W instead of storing the slab (TriFusedW, kernels.h; one K slice, padded rank 256)
-template <int NRB, int D, int DF, bool FUSE_W = false>
+template <int NRB, int D, int DF>
 __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
-	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg, const TriFusedW* __restrict__ fwp, int fw_control, int fw_parts BF_STAMP_ARG) {
+	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg BF_STAMP_ARG) {
 	static_assert(D % 2 == 0 && D % DF == 0 && DF >= 2 && NRB <= 8, "ring depth even (two operand sets) and a multiple of the factor ring's, at most eight row blocks");
 #ifndef BFD_PAIR
 #define BFD_PAIR 0
@@ -499,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 #endif
 		if (blockIdx.y == 0 && rg.tri_frags != nullptr)
 			tri_gram_passenger(reinterpret_cast<const bf16x8*>(rg.tri_frags), rg.tri_ks, (int)blockIdx.x - nblk, rg.tri_partial, rg.tri_counters, rg.G,
-			                   reinterpret_cast<bf16x8*>(rg.tri_x3), rg.tri_diag, l8, rg.tri_done);
+			                   reinterpret_cast<bf16x8*>(rg.tri_x3), rg.tri_diag, l8);
 #ifdef NMFAMD_DIAG_BUILD
 		{ const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BF_STAMP(3); }
 #endif
@@ -612,131 +610,6 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 
 	// epilogue: C/D map of the 32 x 32 MFMA: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31
 	BF_STAMP(2);
-	if constexpr (FUSE_W) {
-		// ---- the W update of this row tile (TriFusedW): acc[b][nb] is the numerator of rows 32 (gb0 + b) .., columns 64 wave + 32 nb .. -----------------------
-		constexpr int WRP = 256, WNC = 8, FR = WNC * 192, KSTEPS = WRP / 16;
-		float* s_d = reinterpret_cast<float*>(l8);                 // [256] pending column scale of the old rows (the ring is done with)
-		int* s_ok = reinterpret_cast<int*>(l8) + 512;
-		__syncthreads();                                           // (every wave has read its last operands from the ring)
-		const TriFusedW fw = *fwp;                                 // (scalar loads, here and not in front of the product loop)
-		const bool scaled = (fw_control & 2) != 0;
-		const float* Pold = fw.panel[fw_control & 1];
-		float* Pnew = fw.panel[(fw_control & 1) ^ 1];
-		const unsigned long long q_target = 2ull * (unsigned long long)(fw_control >> 2);
-		if (scaled) s_d[threadIdx.x] = tri_pending_scale(fw.old_colsq, fw_parts, WRP, threadIdx.x);
-		if (threadIdx.x == 0) {
-			// H H^T and its split image come from this launch's passengers, long done (52 us of 160 at config 4): a bounded wait, for form's sake
-			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-			int ok = 1;
-			while (__hip_atomic_load(fw.q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_target) {
-				__builtin_amdgcn_s_sleep(32);
-				if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { ok = 0; break; }
-			}
-			if (ok) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-			else __hip_atomic_store(fw.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			*s_ok = ok;
-		}
-		__syncthreads();
-		if (*s_ok == 0) return;
-		const bf16x8* Qx3 = reinterpret_cast<const bf16x8*>(fw.Qx3);
-		bf16x8* frag_out = reinterpret_cast<bf16x8*>(fw.frag_out);
-		// four passes: column block nb of the wave's two, row blocks [B0, B0 + NB) of the tile's seven -- 64 accumulator registers of the denominator beside the 224
-		// of the numerator (all seven row blocks of a column block at once: 80 bytes of scratch per lane)
-		auto pass = [&](auto nbtag, auto b0tag, auto nbktag) {
-			constexpr int nb = decltype(nbtag)::value, B0 = decltype(b0tag)::value, NB = decltype(nbktag)::value;
-			__builtin_amdgcn_sched_barrier(0);
-			const int cb = 2 * wave + nb;                          // this pass's column block of 32
-			// den(y, c) = sum_k (old(y, k) d(k))_bf16 Q(k, c): A = the tile's rows (all four waves read them), B = three planes of Q; per (row block, K-step) the
-			// MFMAs of k_panel_update_rows_mu<8, false, true> in its order: (hi, q2), (hi, q1), (hi, q0)
-			f32x16 den[NB];
-#pragma unroll
-			for (int b = 0; b < NB; ++b)
-#pragma unroll
-				for (int g = 0; g < 16; ++g) den[b][g] = 0.f;
-			const bf16x8* qp = Qx3 + cb * 192 + lane;
-			bf16x8 qn[3] = {qp[0], qp[64], qp[128]};
-#pragma unroll 1
-			for (int ks = 0; ks < KSTEPS; ++ks) {
-				const bf16x8 q0 = qn[0], q1 = qn[1], q2 = qn[2];
-				const int kn = ks + 1 < KSTEPS ? ks + 1 : ks;
-				qn[0] = qp[(long)kn * FR]; qn[1] = qp[(long)kn * FR + 64]; qn[2] = qp[(long)kn * FR + 128];
-				f32x4 d0 = {1.f, 1.f, 1.f, 1.f}, d1 = d0;
-				if (scaled) { d0 = *reinterpret_cast<const f32x4*>(&s_d[16 * ks + 8 * half]); d1 = *reinterpret_cast<const f32x4*>(&s_d[16 * ks + 8 * half + 4]); }
-				auto rows_of = [&](int b, f32x4 (&r)[2]) {
-					int gb = gb0 + B0 + b;
-					gb = gb < total_blocks ? gb : total_blocks - 1;
-					const float* prow = Pold + ((long)32 * gb + l31) * WRP + 16 * ks + 8 * half;
-					r[0] = *reinterpret_cast<const f32x4*>(prow); r[1] = *reinterpret_cast<const f32x4*>(prow + 4);
-				};
-				f32x4 ra[2][2];
-				rows_of(0, ra[0]);
-#pragma unroll
-				for (int b = 0; b < NB; ++b) {
-					if (b + 1 < NB) rows_of(b + 1, ra[(b + 1) & 1]);
-					bf16x8 hi;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						float v0 = ra[b & 1][0][j], v1 = ra[b & 1][1][j];
-						if (scaled) { v0 *= d0[j]; v1 *= d1[j]; }
-						hi[j] = (__bf16)v0; hi[4 + j] = (__bf16)v1;
-					}
-					den[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q2, den[b], 0, 0, 0);
-					den[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q1, den[b], 0, 0, 0);
-					den[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, q0, den[b], 0, 0, 0);
-				}
-			}
-			// element-wise step and the bf16 fragments of the new rows (the code of k_panel_update_rows_mu for one column block)
-			const float dcol = scaled ? s_d[32 * cb + l31] : 1.0f;
-#pragma unroll
-			for (int b = 0; b < NB; ++b) {
-				__builtin_amdgcn_sched_barrier(0);            // (one row block at a time)
-				const int gb = gb0 + B0 + b;
-				if (gb < total_blocks) {
-					const long row0 = 32l * gb;
-					const float* pw = Pold + row0 * WRP + 32 * cb + 4 * half * WRP + l31;
-					float* ow = Pnew + row0 * WRP + 32 * cb + 4 * half * WRP + l31;
-					float oldv[16];
-#pragma unroll
-					for (int g = 0; g < 16; ++g) oldv[g] = pw[((g & 3) + 8 * (g >> 2)) * WRP];
-					float nw16[16];
-#pragma unroll
-					for (int g = 0; g < 16; ++g) {
-						const float num = acc[B0 + b][nb][g];
-						const float o = (oldv[g] * dcol) * num / (den[b][g] + fw.eps);
-						ow[((g & 3) + 8 * (g >> 2)) * WRP] = o;
-						nw16[g] = o;
-					}
-					if (frag_out != nullptr) {
-#pragma unroll
-						for (int kk = 0; kk < 2; ++kk) {
-							bf16x8 f;
-#pragma unroll
-							for (int g4 = 0; g4 < 4; ++g4) {
-								const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(nw16[8 * kk + g4]), __float_as_uint(nw16[8 * kk + 4 + g4]), false, false);
-								f[g4] = (__bf16)__uint_as_float(sw[0]);
-								f[4 + g4] = (__bf16)__uint_as_float(sw[1]);
-							}
-							const long ks = (row0 >> 4) + kk;
-							if (ks < fw.frag_KS) frag_out[(ks * WNC + cb) * 64 + lane] = f;
-						}
-					}
-				}
-			}
-		};
-		using IC0 = std::integral_constant<int, 0>;
-		using IC1 = std::integral_constant<int, 1>;
-		using IC4 = std::integral_constant<int, 4>;
-		static_assert(NRB > 4 && NRB <= 8, "two groups of row blocks");
-		pass(IC0{}, IC0{}, IC4{});
-		pass(IC0{}, IC4{}, std::integral_constant<int, NRB - 4>{});
-		pass(IC1{}, IC0{}, IC4{});
-		pass(IC1{}, IC4{}, std::integral_constant<int, NRB - 4>{});
-#ifdef NMFAMD_DIAG_BUILD
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		BF_STAMP(3);
-#endif
-		return;
-	}
 	float* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
 	for (int b = 0; b < NRB; ++b) {
@@ -773,7 +646,7 @@ static void plan_bf16_dma(int xtiles, int KS, int num_cus, int* tiles, int* spli
 }
 
 static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
-                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr, const TriFusedW* fw = nullptr, int fw_control = 0, int fw_parts = 0) {
+                                     float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg = nullptr) {
 	// (the K slices are the caller's plan -- plan_splits_bf16 from the engine's CU count, which also sized the slabs; the workgroups
 	//  along x follow from the tile count alone: no device query per launch)
 	const int tiles = (4 * p.xtiles + BFD_NRB - 1) / BFD_NRB, splits = p.splits;
@@ -782,25 +655,9 @@ static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, i
 	const bool ride = rg != nullptr && rg->tri_frags != nullptr;
 	if (ride && (RP != 256 || rg->G == nullptr || rg->tri_ks < 1 || rg->tri_partial == nullptr || rg->tri_counters == nullptr)) return hipErrorInvalidValue;
 	dim3 grid(tiles * splits + (ride ? TRI_PASSENGERS : 0), RP / 256), block(256);
-	if (fw != nullptr) {
-		// the W update in the epilogue: one K slice, rank 256, the Gram passengers of THIS launch deliver the split image of H H^T
-		// (fw points to DEVICE memory: the caller wrote it with the pointers this launch's rg names)
-		if (splits != 1 || RP != 256 || !ride || rg->tri_x3 == nullptr || rg->tri_done == nullptr || (fw_control >> 2) < 1) return hipErrorInvalidValue;
-		hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF, true>), grid, block, 0, stream,
-		                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-		                   slabs, slab_stride, RP, KS, splits, tiles, *rg, fw, fw_control, fw_parts
-#ifdef NMFAMD_DIAG_BUILD
-		                   , t_bf_stamps
-#endif
-		                   );
-#ifdef NMFAMD_DIAG_BUILD
-		t_bf_stamps = nullptr;
-#endif
-		return hipGetLastError();
-	}
 	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
-	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none, static_cast<const TriFusedW*>(nullptr), 0, 0
+	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none
 #ifdef NMFAMD_DIAG_BUILD
 	                   , t_bf_stamps
 #endif
@@ -858,10 +715,8 @@ int bf16_product_workgroups(const FactorProductPlan& p) { return ((4 * p.xtiles 
 // RP: padded rank of the panel (64, or a multiple of 128).  256 columns per pass over A when RP is a
 // multiple of 256, else 128 (64 for RP = 64); wider panels take RP / 256 (RP / 128) passes (grid.z).
 hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A, int KS, const void* F, int RP,
-                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg,
-                                      const TriFusedW* fused_w, int fused_w_control, int fused_w_colsq_parts) {
+                                      float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg) {
 	constexpr int D = 4;
-	if (fused_w != nullptr && (RP != 256 || tuning_env("NMFAMD_BF_UNSTAGED") != nullptr || tuning_env("NMFAMD_BF_STAGED") != nullptr)) return hipErrorInvalidValue;
 	if (RP == 64) return launch_fp_bf16<D, 1>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	if (RP % 256 == 0) {
 		static const bool unstaged = tuning_env("NMFAMD_BF_UNSTAGED") != nullptr;      // A/B switch for measurements
@@ -871,7 +726,7 @@ hipError_t launch_factor_product_bf16(const FactorProductPlan& p, const void* A,
 		static const bool staged = tuning_env("NMFAMD_BF_STAGED") != nullptr;          // A/B switch: the round-1 kernel
 		if (tri_ride && staged) return hipErrorInvalidValue;      // (only the shipped kernel carries passengers)
 		if (staged) return launch_fp_bf16_staged<6>(p, A, KS, F, RP, slabs, slab_stride, stream);
-		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream, rg, fused_w, fused_w_control, fused_w_colsq_parts);
+		return launch_fp_bf16_r2(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	}
 	if (RP % 128 == 0) return launch_fp_bf16<D, 2>(p, A, KS, F, RP, slabs, slab_stride, stream, rg);
 	return hipErrorInvalidValue;

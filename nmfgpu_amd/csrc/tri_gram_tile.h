@@ -78,10 +78,10 @@ __device__ inline void tri_ride_emit(const float* s_tile, int i, int j, float* _
 
 // passenger p of TRI_PASSENGERS (256 threads): half = p & 1 takes tiles t = 2 k + half, slice = p >> 1 the K-steps [slice, slice + 1) * steps_total / 16.
 // frags: [(ks * 8 + nb) * 64 + lane]; partial: [slice][36][1024] floats; counters: two unsigned, zero between launches; lds: TRI_RIDE_LDS_BYTES, 16-byte aligned
-// (always inlined: with two instantiations of the product kernel in one translation unit hipcc stopped inlining it -- a real call in a kernel that holds 224
-//  accumulator registers: 178 -> 248 VGPRs and 372 bytes of scratch per lane)
+// (always inlined: a second instantiation of the product kernel in the translation unit once made hipcc emit a real call here -- in a kernel that holds 224
+//  accumulator registers that was 178 -> 248 VGPRs and 372 bytes of scratch per lane; profiles/r05_c4_product_timeline.txt)
 __device__ __forceinline__ void tri_gram_passenger(const bf16x8* __restrict__ frags, int steps_total, int p, float* __restrict__ partial, unsigned* __restrict__ counters,
-                                          float* __restrict__ G, bf16x8* __restrict__ x3, float* __restrict__ diag, void* lds, unsigned long long* __restrict__ done = nullptr) {
+                                          float* __restrict__ G, bf16x8* __restrict__ x3, float* __restrict__ diag, void* lds) {
 	constexpr int GB = TRI_RIDE_RING, TPW = 5;
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -190,16 +190,6 @@ __device__ __forceinline__ void tri_gram_passenger(const bf16x8* __restrict__ fr
 		}
 		__syncthreads();
 		tri_ride_emit(s_tile, i, j, G, x3, diag);
-	}
-	if (done != nullptr) {
-		// this half of G and of its split image is written: tell the product workgroups of the launch that read them in their epilogue (TriFusedW, kernels.h)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();
-		if (tid == 0) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			(void)__hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
 	}
 }
 

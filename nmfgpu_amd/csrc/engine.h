@@ -121,7 +121,7 @@ public:
 	long error_terms_to_device(T* dst, long capacity);   // [psN (last count) | psR (r)], D2D on the stream
 	// sharded runs: the terms are fetched with error_terms_to_device() only -- the engine's own copy to the host (and its event) is skipped
 	void set_error_terms_stay_on_device(bool stay) { error_terms_stay_ = stay; }
-	void resolve_error(std::vector<T> vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);
+	void resolve_error(const std::vector<T>& vtv_sorted, std::vector<T> htwtv, std::vector<T> hhtwtw, long total_elements);      // (sorts copies: terms_htwtv() keeps the column order)
 
 	// Error of the most recent error iteration.  The n + r partial sums travel to the host
 	// asynchronously; the first reader waits for them and does the sorted summation, so a caller

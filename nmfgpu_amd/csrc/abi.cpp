@@ -306,6 +306,9 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 				return from_status(st);
 			}
 			if (computeError) {
+				// (the device would idle while the host waits for this iteration's error terms, sums them and decides: the first launch of the next
+				//  iteration -- it writes scratch only -- goes out first; wasted when the threshold ends the run here)
+				if (iteration < numIterations && !constW) (void)engine.begin_next_iteration();
 				elapsed_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - started).count();
 				const double current = thresholdType == NmfThresholdType::Frobenius ? engine.frobenius() : engine.rmsd();
 				delta = current - lastError;

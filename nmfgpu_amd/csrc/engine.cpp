@@ -435,6 +435,7 @@ Status Engine<T>::allocate() {
 template <typename T>
 Status Engine<T>::finish_upload(T* Vcol) {
 	int odd_values = 0;
+	h_product_ahead_ = false;
 	HIPX(hipMemsetAsync(range_flag_, 0, sizeof(int), stream_));
 	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_, x3_ ? range_flag_ : nullptr));
 	h_vtv_.resize(n_);
@@ -539,7 +540,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
+		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
@@ -585,7 +586,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
+	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -939,6 +940,7 @@ Status Engine<T>::h_step(bool compute_error) {
 template <typename T>
 Status Engine<T>::h_step_impl(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
+	h_product_ahead_ = false;                           // (the three-phase API enqueues its own W^T V)
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
 			// sharded form of the four-launch iteration (kernels_mu64.hip): K_H + U_H here
@@ -1378,6 +1380,7 @@ Status Engine<T>::materialize_w(bool whole_panel) {
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
 			w_pending_ = false;
 			fused_ready_ = false;
+			h_product_ahead_ = false;
 			wx3_valid_ = false;
 		}
 		if (tri_scale_pending_) {
@@ -1466,7 +1469,8 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 			fused_ready_ = true;
 		}
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
-		if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
+		if (h_product_ahead_) h_product_ahead_ = false;      // (begin_next_iteration() enqueued exactly this launch)
+		else if (Status s = product_h(Wt_, &rgW, x3_ && wx3_valid_)) return s;
 		if (Status s = mu64_update(false, slabs_, planH_.splits, slab_stride_, rgW.ksplit > 1 ? reinterpret_cast<const T*>(Gpart_) : G_, compute_error)) return s;
 		GramReduceArgs rgH = gram_args(false, HHt_, nullptr, 0);
 		if (Status s = product_w(H_, &rgH, nullptr, x3_)) return s;
@@ -1478,6 +1482,17 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 		if (compute_error) {
 			if (Status s = fetch_error_terms(n_)) return s;
 		}
+	}
+	return ST_OK;
+}
+
+template <typename T>
+Status Engine<T>::begin_next_iteration() {
+	if constexpr (std::is_same<T, float>::value) {
+		if (!fused_capable() || one_pass_ || !fused_ready_ || h_product_ahead_ || prm_.divergence != 0 || !x3_ || !wx3_valid_) return ST_OK;
+		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
+		if (Status s = product_h(Wt_, &rgW, true)) return s;
+		h_product_ahead_ = true;
 	}
 	return ST_OK;
 }

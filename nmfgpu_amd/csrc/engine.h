@@ -66,6 +66,11 @@ public:
 	// h_first_column: global index of this engine's first column (column shards draw their part of ONE stream)
 	Status randomize_factors(unsigned seed, bool w, bool h, long h_first_column = 0);
 
+	// The W^T V launch (and its Gram passengers) of the NEXT iteration, enqueued ahead of it: it writes the split-K slabs, G and the column scale -- scratch the
+	// next iterate() would overwrite anyway -- so a caller that is about to block on this iteration's error value (nmfgpu::compute: the threshold test decides
+	// whether there is a next iteration) keeps the device busy meanwhile.  Rank-64 fused path only; a no-op elsewhere.  The next iterate() skips the launch;
+	// set_factors / randomize / upload in between make it void.
+	Status begin_next_iteration();
 	// One iteration.  With compute_error the frobenius()/rmsd() values are refreshed (host sync).
 	Status iterate(bool compute_error, bool constant_w);
 
@@ -256,6 +261,7 @@ private:
 	float* Gpart_ = nullptr;         // [GRAM_KSPLIT_MAX][4096] unscaled slices of W^T W (the H update adds and scales them, and stores G_)
 	float* wsq_part_ = nullptr;      // [mpad / 32][64] partial sums of squares of the rows the last W update wrote (k_mu64_update32<true>): the pending column scale's source
 	bool fused_ready_ = false, w_pending_ = false;
+	bool h_product_ahead_ = false;   // begin_next_iteration() has enqueued the W^T V launch of the next iteration_mu64 (cleared by whatever changes W, H or V)
 	// split-operand path: Gram matrices from the split images (gram_image.h), 32-column update kernel -- no partial Gram matrices
 	bool gram_image_ = false;
 	GramReduceArgs gram_args(bool of_w, float* G, float* scale, int normalize) const;

@@ -38,6 +38,9 @@ public:
 	virtual Status init_run(NmfDescription<T>& d, bool want_h) = 0;
 	virtual Status set_constant_w(NmfDescription<T>& d) = 0;
 	virtual Status iterate(bool compute_error, bool constant_w) = 0;
+	// The caller is about to wait for the error value of the iteration it has just enqueued and will, unless that value ends the run, enqueue another one:
+	// whatever part of that next iteration changes nothing the caller could observe may be enqueued now (Engine::begin_next_iteration).  Optional.
+	virtual Status begin_next_iteration() { return nmfamd::ST_OK; }
 	virtual double frobenius() = 0;
 	virtual double rmsd() = 0;
 	virtual Status store(NmfDescription<T>& d) = 0;      // the factors into the caller's buffers
@@ -133,6 +136,7 @@ public:
 		return engine_->set_factors(d.outputMatrixW.dense.values, d.outputMatrixW.dense.leadingDimension, nullptr, 0);
 	}
 	Status iterate(bool compute_error, bool constant_w) override { return engine_->iterate(compute_error, constant_w); }
+	Status begin_next_iteration() override { return engine_->begin_next_iteration(); }
 	double frobenius() override { return engine_->frobenius(); }
 	double rmsd() override { return engine_->rmsd(); }
 	Status store(NmfDescription<T>& d) override {

@@ -386,6 +386,27 @@ def test_compute_threshold_stop_matches_oracle_iteration_count():
     assert s.record(0).numIterations % 10 == 0
 
 
+@pytest.mark.parametrize("m,n,r,thr", [(900, 700, 64, 1.0), (900, 700, 64, 0.0), (640, 500, 40, 2.0)])
+def test_compute_with_a_launch_enqueued_ahead_leaves_the_resident_engine_s_bits(m, n, r, thr):
+    """Round 5: on error iterations nmfgpu::compute enqueues the W^T V launch of the NEXT iteration before it waits for the error value (Engine::begin_next_iteration;
+    the launch writes scratch only, and is wasted when the threshold ends the run there).  The factors it returns must be the bits of a resident engine stepped
+    the same number of iterations one by one -- whether the run ends on the threshold, mid-way, or on its last iteration."""
+    V, W0, H0 = problem(m, n, r, np.float32, seed=19)
+    W, H = W0.copy(order="F"), H0.copy(order="F")
+    s = na.Summary()
+    total = 300 if thr > 0.0 else 60
+    assert na.compute(V, W, H, iterations=total, threshold=thr, summary=s) == na.ResultType.Success
+    done = int(s.record(0).numIterations)
+    assert (done < total) == (thr > 0.0), (done, thr)
+    eng = na.Engine(m, n, r, "mu")
+    eng.upload(V); eng.set_factors(W0, H0)
+    for k in range(1, done + 1):
+        eng.iterate(1, first_iteration=k, error_every=10, last_iteration=done)
+    We, He = eng.get_factors()
+    assert np.array_equal(W, We) and np.array_equal(H, He)
+    assert s.record(0).frobenius == eng.frobenius
+
+
 def test_compute_error_behaviour():
     V, W, H = problem(60, 40, 5, np.float32)
     assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.nsNMF, iterations=5) == na.ResultType.ErrorInvalidArgument  # theta missing

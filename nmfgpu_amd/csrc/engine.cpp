@@ -1650,8 +1650,13 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 		for (long p = 0; p < nnz; ++p) order[fill[rows[p]]++] = (int)p;       // stable by row
 	}
 	// inside a row: ascending column (stable), so that CSR / CSC / COO inputs of one matrix agree bit for bit
-	for (int i = 0; i < m_; ++i)
-		std::stable_sort(order.begin() + csr_ptr[i], order.begin() + csr_ptr[i + 1], [&](int x, int y) { return cols[x] < cols[y]; });
+	// (a row whose columns already ascend -- what a CSR input usually is -- needs no sort: the check is one pass, the sort allocates and merges per row:
+	//  ~0.2 s of config 3's 0.58 s set-up)
+	for (int i = 0; i < m_; ++i) {
+		const auto lo = order.begin() + csr_ptr[i], hi = order.begin() + csr_ptr[i + 1];
+		auto by_col = [&](int x, int y) { return cols[x] < cols[y]; };
+		if (!std::is_sorted(lo, hi, by_col)) std::stable_sort(lo, hi, by_col);
+	}
 	for (long q = 0; q < nnz; ++q) { csr_idx[q] = cols[order[q]]; csr_val[q] = vals[order[q]]; }
 	for (long q = 0; q < nnz; ++q) ++csc_ptr[csr_idx[q] + 1];
 	for (int j = 0; j < n_; ++j) csc_ptr[j + 1] += csc_ptr[j];

@@ -691,7 +691,8 @@ Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride
 	if constexpr (std::is_same<T, float>::value) {
 		const float eps = std::numeric_limits<float>::epsilon();
 		float* P = is_w ? Wt_ : H_;
-		float* ps = is_w ? psR_ : psN_;
+		// (ps_direct_: the update kernels write their error terms straight into the pinned host buffer -- no copy launch behind them, iterate_mu64)
+		float* ps = ps_direct_ ? (is_w ? pin_psN_dev_ + ps_stride_ : pin_psN_dev_) : (is_w ? psR_ : psN_);
 		const int len = is_w ? m_ : n_, len_pad = (int)(is_w ? mpad_ : npad_);
 		void* xo = x3_ ? (is_w ? Wx3_ : Hx3_) : nullptr;
 		const int xks = is_w ? ksH_ : ksW_;
@@ -870,7 +871,8 @@ Status Engine<T>::fetch_error_terms(int count_n) {
 	}
 	// (a kernel that writes the pinned buffer, not hipMemcpyAsync: the runtime's copy idles the stream for ~18 us around its blit; NMFAMD_ERROR_MEMCPY=1 restores it)
 	static const bool use_memcpy = tuning_env("NMFAMD_ERROR_MEMCPY") != nullptr;
-	if (use_memcpy || pin_psN_dev_ == nullptr) HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
+	if (ps_direct_) { /* the update kernels of this iteration wrote the pinned buffer themselves */ }
+	else if (use_memcpy || pin_psN_dev_ == nullptr) HIPX(hipMemcpyAsync(pin_psN_, psN_, sizeof(T) * (size_t)(ps_stride_ + r_), hipMemcpyDeviceToHost, stream_));
 	else HIPX(launch_copy_small<T>(pin_psN_dev_, psN_, ps_stride_ + r_, stream_));
 	HIPX(hipEventRecord(err_event_, stream_));
 	err_pending_ = true;
@@ -1463,6 +1465,12 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 	if constexpr (std::is_same<T, float>::value) {
 		if (one_pass_) return iterate_onepass(compute_error);
 		const float eps = std::numeric_limits<float>::epsilon();
+		// Error iterations of a single engine: the two update kernels write their n + r terms into the pinned host buffer themselves (its device address): the
+		// copy launch behind them (k_copy_small: 4.1 us, every tenth iteration) goes.  The previous error iteration's values leave the buffer first.
+		static const bool no_direct = tuning_env("NMFAMD_ERROR_MEMCPY") != nullptr || tuning_env("NMFAMD_ERROR_COPY_KERNEL") != nullptr;
+		ps_direct_ = compute_error && gram_image_ && !error_terms_stay_ && pin_psN_dev_ != nullptr && !no_direct;
+		if (ps_direct_) finalize_error(false);
+		struct DirectGuard { bool& f; ~DirectGuard() { f = false; } } direct_guard{ps_direct_};
 		if (!fused_ready_) {
 			if (!gram_image_) HIPX(launch_mu64_gram_partials(Wt_, (int)mpad_, gramW_part_, stream_));
 			normalize_next_ = 0;

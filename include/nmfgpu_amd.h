@@ -230,6 +230,13 @@ NMFAMD_API int nmfamd_engine_create_blocks(int m, int n, int r, int algorithm, c
 NMFAMD_API int nmfamd_sharded_create(nmfamd_engine* e, nmfamd_comm* c, int mode, long rows, long total_columns, nmfamd_sharded** out);
 NMFAMD_API void nmfamd_sharded_destroy(nmfamd_sharded* s);
 NMFAMD_API int nmfamd_sharded_iterate(nmfamd_sharded* s, int count, int first_iteration, int error_every, int last_iteration);
+/* Row-block mode at padded rank 256 with bf16 operands (config 4): between two W updates the ranks exchange the bf16 fragments of their row blocks only, so
+ * the fp32 rows of the OTHER ranks' blocks in nmfamd_engine_w_panel() are those of an earlier iteration until they are gathered.  They are gathered
+ *   (a) by nmfamd_sharded_iterate itself when a batch ends on its last_iteration (> 0), and
+ *   (b) by this call -- a COLLECTIVE: every rank of the communicator must make it, at the same point of its stream.
+ * nmfamd_engine_get_factors on an engine whose rows are still stale gathers them through the live sharded run (then it, too, is a collective that every rank must
+ * make); after nmfamd_sharded_destroy it fails with NMFAMD_INVALID_ARGUMENT rather than hand out stale rows.  A no-op in every other mode. */
+NMFAMD_API int nmfamd_sharded_gather_w(nmfamd_sharded* s);
 NMFAMD_API double nmfamd_sharded_frobenius(nmfamd_sharded* s);
 NMFAMD_API double nmfamd_sharded_rmsd(nmfamd_sharded* s);
 NMFAMD_API const char* nmfamd_sharded_last_error(const nmfamd_sharded* s);

@@ -191,6 +191,21 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 	// extension switches ride on Parameter names the reference ignores (lookup is by name only,
 	// Interface.cpp:41-49): absent => reference behaviour
 	{
+		// "nndsvd" (host_init.cpp): 0 / 1 / 2 only (3, -1 and NaN used to select the plain variant silently), and no more features than singular pairs exist
+		int sidx = parameter_index(d.parameters, d.numParameters, "nndsvd");
+		if (sidx >= 0) {
+			const double v = d.parameters[sidx].value;
+			if (!(v == 0.0 || v == 1.0 || v == 2.0)) {
+				log_error("[ERROR] Parameter 'nndsvd' has to be 0 (NNDSVD), 1 (NNDSVDa) or 2 (NNDSVDar)!");
+				return ResultType::ErrorInvalidArgument;
+			}
+			if (d.features > std::min(d.inputMatrix.rows, d.inputMatrix.columns)) {
+				log_error("[ERROR] The NNDSVD start needs a feature count of at most min(rows, columns)!");
+				return ResultType::ErrorInvalidArgument;
+			}
+		}
+	}
+	{
 		int idx = parameter_index(d.parameters, d.numParameters, "divergence");
 		if (idx >= 0) prm.divergence = d.parameters[idx].value;
 		idx = parameter_index(d.parameters, d.numParameters, "sparseCompute");
@@ -308,7 +323,14 @@ ResultType compute_impl(NmfDescription<T>& d, ISummary* summary_iface) {
 			if (computeError) {
 				// (the device would idle while the host waits for this iteration's error terms, sums them and decides: the first launch of the next
 				//  iteration -- it writes scratch only -- goes out first; wasted when the threshold ends the run here)
-				if (iteration < numIterations && !constW) (void)engine.begin_next_iteration();
+				if (iteration < numIterations && !constW) {
+					const nmfamd::Status ahead = engine.begin_next_iteration();
+					if (ahead != nmfamd::ST_OK) {
+						log_error("[ERROR] A HIP call failed while the next iteration's first launch was enqueued ahead!");
+						if (*engine.last_error()) log_error(engine.last_error());
+						return from_status(ahead);
+					}
+				}
 				elapsed_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - started).count();
 				const double current = thresholdType == NmfThresholdType::Frobenius ? engine.frobenius() : engine.rmsd();
 				delta = current - lastError;

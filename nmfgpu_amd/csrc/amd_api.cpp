@@ -258,6 +258,11 @@ int nmfamd_sharded_iterate(nmfamd_sharded* s, int count, int first_iteration, in
 	return (int)(s->elem_bytes == 4 ? s->f->run(count, first_iteration, error_every, last_iteration) : s->d->run(count, first_iteration, error_every, last_iteration));
 }
 
+int nmfamd_sharded_gather_w(nmfamd_sharded* s) {
+	if (!s) return NMFAMD_INVALID_ARGUMENT;
+	return (int)(s->elem_bytes == 4 ? s->f->gather_w_rows() : s->d->gather_w_rows());
+}
+
 double nmfamd_sharded_frobenius(nmfamd_sharded* s) { return !s ? 0.0 : (s->elem_bytes == 4 ? s->f->frobenius() : s->d->frobenius()); }
 double nmfamd_sharded_rmsd(nmfamd_sharded* s) { return !s ? 0.0 : (s->elem_bytes == 4 ? s->f->rmsd() : s->d->rmsd()); }
 const char* nmfamd_sharded_last_error(const nmfamd_sharded* s) { return !s ? "" : (s->elem_bytes == 4 ? s->f->last_error() : s->d->last_error()); }

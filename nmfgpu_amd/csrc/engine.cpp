@@ -305,7 +305,13 @@ Status Engine<T>::allocate() {
 	if (bf16_) {
 		HIPX(hipMalloc(&Vb_, 16 * (size_t)planW_.xtiles * ksW_ * 256));
 		HIPX(hipMalloc(&Vtb_, 16 * (size_t)planH_.xtiles * ksH_ * 256));
-		HIPX(hipMalloc(&Wtb_, 16 * (size_t)ksH_ * (RP_ / 32) * 64));
+		{
+			// (row-block sharded runs all-gather the fragments in place, world x blk_rows / 16 K-steps = mpad_ / 16 of them -- more than ksH_ whenever m is not a
+			//  multiple of 128 x world (config 4's 50 000 rows on 8 ranks are padded to 50 176); the K-steps behind ksH_ are never read by a product and stay zero)
+			const size_t ks_alloc = (size_t)std::max<long>(ksH_, mpad_ / 16);
+			HIPX(hipMalloc(&Wtb_, 16 * ks_alloc * (RP_ / 32) * 64));
+			if (ks_alloc > (size_t)ksH_) HIPX(hipMemsetAsync((char*)Wtb_ + 16 * (size_t)ksH_ * (RP_ / 32) * 64, 0, 16 * (ks_alloc - (size_t)ksH_) * (RP_ / 32) * 64, stream_));
+		}
 		HIPX(hipMalloc(&Hb_, 16 * (size_t)ksW_ * (RP_ / 32) * 64));
 	} else if (!sparse_) {
 		if (x3_) {
@@ -863,7 +869,7 @@ Status Engine<T>::normal_inverse_join() {
 template <typename T>
 Status Engine<T>::fetch_error_terms(int count_n) {
 	finalize_error(false);   // the pinned buffers are about to be reused; an older fetch is long complete
-	(void)count_n;
+	ps_last_direct_ = ps_direct_;
 	if (error_terms_stay_) {
 		// a sharded run gathers the terms of all ranks on the device (error_terms_to_device) and resolves them itself: no host copy, no event here
 		err_count_ = count_n;
@@ -884,6 +890,8 @@ template <typename T>
 long Engine<T>::error_terms_to_device(T* dst, long capacity) {
 	const long cnt = (long)err_count_ + r_;
 	if (err_count_ <= 0 || capacity < cnt) return -1;
+	// (the last error iteration's update kernels wrote the pinned host buffer themselves, iterate_mu64: psN_ / psR_ on the device are an older iteration's -- ADVICE r5)
+	if (ps_last_direct_) return launch_copy_two<T>(dst, pin_psN_dev_, err_count_, pin_psN_dev_ + ps_stride_, r_, stream_) == hipSuccess ? cnt : -1;
 	// ONE small launch for both pieces (two runtime copies were two blit kernels)
 	if (launch_copy_two<T>(dst, psN_, err_count_, psR_, r_, stream_) != hipSuccess) return -1;
 	return cnt;
@@ -1499,7 +1507,12 @@ Status Engine<T>::begin_next_iteration() {
 	if constexpr (std::is_same<T, float>::value) {
 		if (!fused_capable() || one_pass_ || !fused_ready_ || h_product_ahead_ || prm_.divergence != 0 || !x3_ || !wx3_valid_) return ST_OK;
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);
-		if (Status s = product_h(Wt_, &rgW, true)) return s;
+		// (not sampled: the launch belongs to the NEXT iteration -- or to none, when the threshold ends the run here)
+		const bool sampled = timing_now_;
+		timing_now_ = false;
+		const Status s = product_h(Wt_, &rgW, true);
+		timing_now_ = sampled;
+		if (s != ST_OK) return s;
 		h_product_ahead_ = true;
 	}
 	return ST_OK;

@@ -322,6 +322,7 @@ private:
 
 	T *pin_psN_ = nullptr, *pin_psR_ = nullptr;
 	bool error_terms_stay_ = false;
+	bool ps_last_direct_ = false;   // ... and the most recent error iteration did (error_terms_to_device reads the pinned buffer then)
 	bool ps_direct_ = false;        // this (error) iteration's update kernels write the pinned buffer directly (iterate_mu64)
 	T* pin_psN_dev_ = nullptr;      // the device's address of pin_psN_ (hipHostGetDevicePointer): fetch_error_terms writes it from a kernel
 	hipEvent_t err_event_ = nullptr;

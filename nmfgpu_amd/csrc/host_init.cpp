@@ -544,7 +544,7 @@ int nndsvd_variant(const Parameter* parameters, unsigned count) {
 	for (unsigned i = 0; i < count; ++i)
 		if (parameters != nullptr && parameters[i].name != nullptr && std::strcmp(parameters[i].name, "nndsvd") == 0) {
 			const double v = parameters[i].value;
-			return v == 1.0 ? 1 : (v == 2.0 ? 2 : 0);
+			return v == 1.0 ? 1 : (v == 2.0 ? 2 : 0);      // (nmfgpu::compute rejects anything but 0 / 1 / 2 before it gets here, abi.cpp)
 		}
 	return -1;
 }

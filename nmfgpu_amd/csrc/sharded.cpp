@@ -223,6 +223,10 @@ Status ShardedRank<T>::run(int count, int first_iteration, int error_every, int 
 		const bool err = (error_every > 0 && it % error_every == 0) || (last_iteration > 0 && it == last_iteration);
 		if (Status st = iterate(err)) return st;
 	}
+	// the batch that ends the run (every rank is told the same last_iteration): the fp32 rows of the other ranks' blocks are gathered HERE, inside the collective
+	// call, so that a single rank asking for its factors afterwards (nmfamd_engine_get_factors) neither starts a collective alone nor finds the hook gone
+	// after nmfamd_sharded_destroy
+	if (last_iteration > 0 && count > 0 && first_iteration + count - 1 == last_iteration && eng_->w_rows_stale()) return gather_w_rows();
 	return ST_OK;
 }
 

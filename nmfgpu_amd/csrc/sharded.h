@@ -40,6 +40,8 @@ public:
 	Status prepare();                       // buffers + the gathered, sorted tr(V^T V) terms (after the upload)
 	Status iterate(bool compute_error);
 	Status run(int count, int first_iteration, int error_every, int last_iteration);
+	// row-block mode with the fragment exchange: the fp32 rows of every rank's block into the engine's W panel -- a COLLECTIVE (nmfamd_sharded_gather_w)
+	Status gather_w_rows();
 	// (KL update: the engine resolves its own, reduced, error terms -- per row of W, not per column)
 	double frobenius() { if (eng_->is_kl()) return eng_->frobenius(); finalize(); return frob_; }
 	double rmsd() { if (eng_->is_kl()) return eng_->rmsd(); finalize(); return rmsd_; }
@@ -50,7 +52,6 @@ public:
 private:
 	Status fail(const char* what) { last_error_ = what; (void)hipGetLastError(); return ST_HIP_ERROR; }
 	Status launch_error_gather();
-	Status gather_w_rows();
 	// elements per rank in the gathered error-term buffer: [n_local terms | r terms], padded to whole 16-byte units
 	long slot_len() const { return ((std::max<long>(nloc_max_, eng_->r()) + eng_->r() + 3) / 4) * 4; }
 	void finalize();

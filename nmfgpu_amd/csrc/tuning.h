@@ -10,7 +10,8 @@
 //     tuning_env() and are dead code in the shipped library -- they are compiled in by `python -m nmfgpu_amd.build --diag` (-DNMFAMD_DIAG_BUILD, output
 //     lib/libnmfgpu64_diag.so; tests/conftest.py `diag_build`, tools: NMFAMD_LIBRARY).  Round 5 moved here: NMFAMD_SHARD_REHEARSE (a value > 1 makes a rank update
 //     1 / N of W's rows: timing only, the factors mean nothing), NMFAMD_SHARD_NO_DIRECT, NMFAMD_ERROR_MEMCPY, NMFAMD_GRAM_KSPLIT, NMFAMD_X3_COLSPLIT, NMFAMD_TRI_RIDE,
-//     NMFAMD_TRI_FP32_DEN, NMFAMD_NORMALIZE_TWO_LAUNCHES.
+//     NMFAMD_TRI_FP32_DEN, NMFAMD_NORMALIZE_TWO_LAUNCHES; also NMFAMD_ERROR_COPY_KERNEL (error terms through k_copy_small instead of written by the update kernels) and
+//     NMFAMD_GRAM_SPREAD (0: a tile per Gram passenger instead of the spread form).
 #pragma once
 
 #include <cstdlib>

@@ -372,6 +372,12 @@ class ShardedRun:
         if st != 0:
             raise EngineError(st, "nmfamd_sharded_iterate", (self._lib.nmfamd_sharded_last_error(self._h) or b"").decode())
 
+    def gather_w(self):
+        """Row-block mode with the bf16 fragment exchange: gathers the fp32 rows of every rank's block (a collective: every rank calls it)."""
+        st = self._lib.nmfamd_sharded_gather_w(self._h)
+        if st != 0:
+            raise EngineError(st, "nmfamd_sharded_gather_w", (self._lib.nmfamd_sharded_last_error(self._h) or b"").decode())
+
     @property
     def frobenius(self) -> float:
         return float(self._lib.nmfamd_sharded_frobenius(self._h))

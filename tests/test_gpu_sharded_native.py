@@ -320,10 +320,12 @@ def test_compute_with_numgpus_least_squares_family(name, ranks, r, dtype, tol):
     assert sn.record(0).frobenius == pytest.approx(s1.record(0).frobenius, rel=max(1e-5, tol / 10))
 
 
-def test_eight_ranks_rank256_against_the_oracle():
+@pytest.mark.parametrize("m", [2048, 2000])
+def test_eight_ranks_rank256_against_the_oracle(m):
     """BASELINE configs[3]'s cut (8 column shards, nsNMF theta = 0.5, r = 256) at a size the fp64 oracle covers, fp32 and bf16 operands,
-    both shard modes; the ranks share the box's one device (in-process transport)."""
-    m, n, r, iters = 2048, 8 * 160, 256, 6
+    both shard modes; the ranks share the box's one device (in-process transport).  m = 2000: the row-block form pads the rows to 8 x 256 = 2 048, i.e. 128
+    K-steps of bf16 fragments travel in the all-gather where the product reads 125 (the fragment buffer is allocated for what travels)."""
+    n, r, iters = 8 * 160, 256, 6
     V, W0, H0 = problem(m, n, r, np.float32, seed=8)
     V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W0, H0))
     ref = oracle.run("nsnmf", V64, W64, H64, iters, theta=0.5)

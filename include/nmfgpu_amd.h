@@ -139,10 +139,14 @@ typedef struct nmfamd_geometry {
 	int gram_k_slices;              /* rank-64 multiplicative update: K slices of the W^T W passengers (1, 2, 4, 8), or 16: the ten tiles' K ranges dealt evenly
 	                                   to the sixteen passengers of a whole problem's W^T V launch (up to three pieces per tile, added in order) */
 	int w_col_split;                /* 1: V H^T runs as 128 x 32 workgroups (narrow column shards) */
+	/* round 6 */
+	int fused_launches;             /* 4: an iteration is product (+ Gram passengers) / update / product (+ Gram passengers) / update -- fp32 at padded rank 64 and,
+	                                   round 6, double precision (multiplicative update and nsNMF, padded ranks up to 512); 0: the generic launch sequence */
+	int gram_ride_slices_h, gram_ride_slices_w;   /* double precision: K slices per 64 x 64 super-block of the Gram passengers riding in W^T V / V H^T (they fix the order of the partial sums) */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 /* The same for a caller compiled against an older (shorter) or newer (longer) nmfamd_geometry: writes min(struct_size, sizeof(nmfamd_geometry)) bytes, never
- * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`, round 5 the four counts behind it).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
+ * past the caller's struct (the struct only ever grows at its end; round 3 added `one_pass`, round 5 the four counts behind it, round 6 three more).  Returns NMFAMD_INVALID_ARGUMENT for struct_size < 8. */
 NMFAMD_API int nmfamd_engine_geometry_sized(const nmfamd_engine* e, void* out, unsigned long struct_size);
 
 /* ---- column-sharded multi-GPU form of the multiplicative update ------------------------------

@@ -144,6 +144,7 @@ Engine<T>::~Engine() {
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
+	{ void* fb[] = {f64_scale_, f64_partial_, f64_counters_}; for (void* b : fb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
 	if (rowdot_part_) (void)hipFree(rowdot_part_);
@@ -422,6 +423,22 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&wsq_part_, sizeof(float) * 64 * (size_t)(mpad_ / 32)));
 		HIPX(hipMemsetAsync(wsq_part_, 0, sizeof(float) * 64 * (size_t)(mpad_ / 32), stream_));
 	}
+	if (fused64_capable()) {
+		// Gram passengers of the two product launches (kernels_f64.hip, gram_ride_f64): as many K slices per 64 x 64 super-block as the product's grid leaves CUs for,
+		// at most 16 (the level-1 finisher adds them one after the other), at least 4 (a grid that fills the chip: the passengers queue behind the product blocks)
+		const int nbk = RP_ / 64, nsuper = nbk * (nbk + 1) / 2;
+		auto slices = [&](const FactorProductPlan& p, long len) {
+			const int room = (num_cus_ - p.xtiles * p.splits * p.chunks - nbk) / nsuper;
+			const int by_len = (int)std::max<long>(1, (len + 3) / 4 / 16);       // (at least 8 K-steps of four rows per wave half)
+			return std::max(1, std::min(std::min(16, by_len), std::max(4, room)));
+		};
+		f64_slices_h_ = slices(planH_, m_);      // W^T W beside W^T V
+		f64_slices_w_ = slices(planW_, n_);      // H H^T beside V H^T
+		HIPX(hipMalloc((void**)&f64_scale_, sizeof(double) * (size_t)RP_));
+		HIPX(hipMalloc((void**)&f64_partial_, sizeof(double) * 4096 * (size_t)nsuper * (size_t)std::max(f64_slices_h_, f64_slices_w_)));
+		HIPX(hipMalloc((void**)&f64_counters_, sizeof(unsigned) * (size_t)(nsuper + 1)));
+		HIPX(hipMemsetAsync(f64_counters_, 0, sizeof(unsigned) * (size_t)(nsuper + 1), stream_));
+	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
 	pin_psR_ = pin_psN_ + ps_stride_;
 	{
@@ -546,7 +563,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
+		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
@@ -592,7 +609,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
+	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -755,7 +772,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 	if constexpr (std::is_same<T, double>::value) {
 		if (tiled_) {
 			record_begin();
-			HIPX(launch_factor_product_f64(planH_, Vt_, strideVt_, F, RP_, slabs_, slab_stride_, stream_));
+			HIPX(launch_factor_product_f64(planH_, Vt_, strideVt_, F, RP_, slabs_, slab_stride_, stream_, ride64_));
 			record_end();
 			return ST_OK;
 		}
@@ -809,7 +826,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 	if constexpr (std::is_same<T, double>::value) {
 		if (tiled_) {
 			record_begin(1);
-			HIPX(launch_factor_product_f64(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_));
+			HIPX(launch_factor_product_f64(planW_, V_, strideV_, F, RP_, dest, slab_stride_, stream_, ride64_));
 			record_end();
 			return ST_OK;
 		}
@@ -1331,6 +1348,70 @@ bool Engine<T>::fused_capable() const {
 	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;   // (evaluated before allocate(): no tiled_ here)
 }
 
+// Double precision, multiplicative update and nsNMF on the MFMA kernels of kernels_f64.hip at any padded rank they cover: what the reference's own callers run
+// (example/main.cpp: NmfDescription<double>, nsNMF, r = 158; the R binding).  NMFAMD_NO_FUSED_MU=1 keeps the generic launch sequence (the cross-check path).
+template <typename T>
+bool Engine<T>::fused64_capable() const {
+	return std::is_same<T, double>::value && tiled_ && !sparse_ && !bf16_ && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && RP_ % 64 == 0 && RP_ <= 512 &&
+	       (RP_ == 64 || panel_update_wide_f64_available(RP_)) && std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
+}
+
+// One iteration in FOUR launches (the generic sequence: 10 at padded rank 64, 12 for nsNMF -- smoothing x 2, Gram + reduction x 2, product x 2, update x 2,
+// normalise + compaction of its partial sums):
+//   1. W^T V from the panel as it lies (Wt: unnormalised, unsmoothed) + passengers: Wt^T Wt, and the column scale d from the last W update's sums of squares
+//   2. H update: numerator S D (sum of the slabs) -- (Wt D S)^T V = S D (Wt^T V) --, denominator S D (Wt^T Wt) D S h with D and S applied around the MFMA
+//      product; writes H and, nsNMF, the smoothed panel S H
+//   3. V (S H)^T + passengers: (S H)(S H)^T
+//   4. W update: old rows read as W d, result left unnormalised + per-workgroup sums of squares (the first half of kernel::normalizeColumns)
+// References: AlgorithmMultiplicativeFrobenius.h:165-248, AlgorithmNonSmoothNMF.h:174-218 (same operation order per element; the column scale is a factor
+// 1 / sqrt(sum) where the reference divides by sqrt(sum): 1 ulp, inside the 1e-9 the fp64 tests ask).
+template <typename T>
+Status Engine<T>::iterate_fused64(bool compute_error) {
+	if constexpr (std::is_same<T, double>::value) {
+		const double eps = std::numeric_limits<double>::epsilon();
+		const bool ns = alg_ == ALG_NSNMF;
+		const double off = ns ? prm_.theta / (double)(unsigned)r_ : 0.0;
+		const double diag = ns ? (1.0 - prm_.theta) + off : 1.0;
+		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
+		struct RideGuard { const GramRideF64*& p; ~RideGuard() { p = nullptr; } } guard{ride64_};
+		// 1
+		GramRideF64 gw = {};
+		gw.P = Wt_; gw.len = m_; gw.slices = f64_slices_h_; gw.partial = f64_partial_; gw.counters = f64_counters_; gw.G = G_;
+		gw.sumsq_part = f64_pending_ ? sumsq_part_ : nullptr; gw.sumsq_parts = norm_parts; gw.scale_out = f64_scale_;
+		ride64_ = &gw;
+		if (Status s = product_h(Wt_)) return s;
+		ride64_ = nullptr;
+		// 2
+		PanelFusedF64 fh = {};
+		const double* dscale = f64_pending_ ? f64_scale_ : nullptr;
+		fh.h_side = (dscale != nullptr || ns) ? 1 : 0;      // (a normalised W and no smoothing: G_ is W^T W as the update needs it)
+		fh.scale = dscale; fh.r = r_;
+		if (ns) { fh.smooth = 1; fh.off = off; fh.diag = diag; fh.smooth_out = Hs_; }
+		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
+		else HIPX(launch_panel_update_wide_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
+		// 3
+		const double* Fh = ns ? Hs_ : H_;
+		GramRideF64 gh = {};
+		gh.P = Fh; gh.len = n_; gh.slices = f64_slices_w_; gh.partial = f64_partial_; gh.counters = f64_counters_; gh.G = HHt_;
+		ride64_ = &gh;
+		if (Status s = product_w(Fh)) return s;
+		ride64_ = nullptr;
+		// tr((S H)(S H)^T W^T W) with the W^T W of this iteration's H step, unsmoothed (AlgorithmNonSmoothNMF.h:201-202; AlgorithmMultiplicativeFrobenius.h:212)
+		// (G_ is the Gram matrix of the panel as it lies: the pending scale is applied on the way, D G D = W^T W of the normalised W)
+		if (compute_error) HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_, nullptr, dscale));
+		// 4
+		PanelFusedF64 fw = {};
+		fw.old_scale = dscale;
+		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));
+		else HIPX(launch_panel_update_wide_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));
+		f64_pending_ = true;
+		gram_w_ready_ = false;
+		hx3_valid_ = false; wx3_valid_ = false;
+		if (compute_error) { if (Status s = fetch_error_terms(n_)) return s; }
+	}
+	return ST_OK;
+}
+
 // GDCLS and the ALS family never smooth their factors, so the Gram matrix the next half-step needs is the Gram matrix of
 // exactly what the update kernel has just written: at fp32 / padded rank 64 that kernel emits it as partial matrices
 // (64 panel rows each) and the 16-block reduction of the fused MU path replaces a pass over the panel.
@@ -1382,6 +1463,12 @@ Status Engine<T>::ensure_w_rows() {
 template <typename T>
 Status Engine<T>::materialize_w(bool whole_panel) {
 	if (whole_panel) { if (Status s = ensure_w_rows()) return s; }
+	if (f64_pending_) {
+		// the fused double-precision iteration left W unnormalised: the second half of kernel::normalizeColumns, as the generic iteration runs it after every W update
+		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
+		f64_pending_ = false;
+		gram_w_ready_ = false;
+	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (w_pending_) {
 			// column norms from the partial Grams of the unnormalised W, then W <- W diag(scale)
@@ -1524,6 +1611,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	timing_now_ = timing_ && (timing_iter_++ % timing_stride_ == 0);
 	if (prm_.divergence != 0) return constant_w ? ST_INVALID : iterate_kl(compute_error);
 	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
+	if (fused64_capable() && !constant_w) return iterate_fused64(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 	h_partials_unneeded_ = !constant_w;              // (the fused iteration: H H^T rides the product where it can)
 	const Status hs = h_step_impl(compute_error);

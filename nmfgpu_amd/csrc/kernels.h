@@ -241,7 +241,7 @@ template <typename T>
 hipError_t launch_smooth_panel(const T* P, T* out, int RP, int r, long len_pad, T offdiag, T diag, hipStream_t stream);
 
 template <typename T>
-hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq = nullptr);
+hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq = nullptr, const T* b_scale = nullptr);
 
 template <typename T>
 hipError_t launch_row_dot(const T* A, const T* B, int RP, int r, long len, T* ps, hipStream_t stream, T* part = nullptr);      // part: ROW_DOT_GROUPS * RP scratch -> coalesced form
@@ -281,19 +281,44 @@ hipError_t launch_fill_uniform(T* P, int RP, int r, long len, long len_pad, uint
 
 // ---- fp64 MFMA factor product (kernels_f64.hip): same x-tiled image of A (tile height 128), K-steps of four y ----
 FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus);
+// Passengers of the fp64 product launch (kernels_f64.hip, gram_ride_f64): the Gram matrix of a factor panel as it lies, K-sliced, reduced by the last arriver of every
+// 64 x 64 super-block; and (W side) the pending column scale from the W update's sums of squares
+struct GramRideF64 {
+	const double* P;            // the panel (RP columns); nullptr: no passengers
+	int len;                    // its valid rows (rows behind them up to the padded length are zero)
+	int slices;                 // K slices per super-block
+	double* partial;            // [slices][super-blocks][4096] scratch
+	unsigned* counters;         // [super-blocks], zero between launches
+	double* G;                  // the reduced matrix, both triangles
+	const double* sumsq_part;   // the pending column scale's source: sumsq_parts vectors of RP partial sums of squares (nullptr: no scale passengers)
+	int sumsq_parts;
+	double* scale_out;          // [RP] d(c) = sum > 0 ? 1 / sqrt(sum) : 1
+};
+int gram_ride_f64_workgroups(int RP, int slices, bool with_scale);
 hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
-                                     double* slabs, long slab_stride, hipStream_t stream);
+                                     double* slabs, long slab_stride, hipStream_t stream, const GramRideF64* ride = nullptr);
 
+// Extras of the fused double-precision iteration (Engine::iterate_fused64): W stays unnormalised in its panel with a pending column scale d (a vector the scale
+// passengers of the W^T V launch leave), and nsNMF's smoothing S = (diag - off) I + off 1 1^T (first r entries) is applied where a row of the panel sits in LDS anyway
+struct PanelFusedF64 {
+	const double* old_scale;    // W update: every old value is read as old(y, c) * old_scale[c]
+	int h_side;                 // H update with W = Wt D (S): Q is the RAW Gram matrix of the panel Wt, and
+	const double* scale;        //   d (nullptr: ones):  num <- S D num  ((Wt D S)^T V = S D (Wt^T V)),  den = S D Q D S old  (D and S applied around the MFMA product)
+	int smooth;                 //   0: S = I
+	double off, diag;
+	int r;
+	double* smooth_out;         // H update: a second panel that receives S new(y, :) (the operand of V (S H)^T and of its Gram matrix)
+};
 // fp64 / padded rank 64 panel update on the fp64 MFMA pipe (32 panel rows per workgroup: len_pad / 32 norm partials)
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
-                                     double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream);
+                                     double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64* fused = nullptr);
 
 // fp64 Gram matrix on the MFMA pipe (padded rank 64 or k * 128)
 hipError_t launch_gram_f64(const double* P, int RP, int len, int parts, double* partial, double* G, hipStream_t stream);
 // fp64 / padded rank 128 ... 512: 16 panel rows per workgroup
 bool panel_update_wide_f64_available(int RP);
 hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
-                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream);
+                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64* fused = nullptr);
 
 // ---- bf16-operand factor product (kernels_bf16.hip) ------------------------------------------
 // Fragment-ordered bf16 images: streamed matrix (x-tiled by 128, KS = ceil(Y / 16) K-steps) and the factor

@@ -798,14 +798,19 @@ template hipError_t launch_smooth_panel<double>(const double*, double*, int, int
 // (kernel::traceMultiplication<false>, KernelTraceMultiplication.cu:43-80 at AlgorithmMultiplicativeFrobenius.h:212)
 // b_colsq (optional, r sums of squares): B stands for diag(f) B diag(f), f(c) = b_colsq[c] > 0 ? 1 / sqrt(b_colsq[c]) : 1 -- the Gram matrix of a panel whose
 // column normalisation is still pending (rank-256 bf16 path, PanelTriExtras)
+// b_scale (optional, r factors): the same with the factors given directly, f(c) = b_scale[c] (the fused double-precision iteration's pending column scale)
 template <typename T>
-__global__ __launch_bounds__(256) void k_trace_small(const T* __restrict__ A, const T* __restrict__ B, int RP, int r, T* __restrict__ ps, const T* __restrict__ b_colsq) {
+__global__ __launch_bounds__(256) void k_trace_small(const T* __restrict__ A, const T* __restrict__ B, int RP, int r, T* __restrict__ ps, const T* __restrict__ b_colsq,
+                                                     const T* __restrict__ b_scale) {
 	// one wave per diagonal element, lanes stride the inner index, butterfly sum (fixed order)
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int d = blockIdx.x * 4 + wave;
 	if (d >= r) return;
 	T s = 0;
-	if (b_colsq != nullptr) {
+	if (b_scale != nullptr) {
+		const T fd = b_scale[d];
+		for (int i = lane; i < r; i += 64) s += A[(long)i * RP + d] * (B[(long)d * RP + i] * (fd * b_scale[i]));
+	} else if (b_colsq != nullptr) {
 		const T fd = b_colsq[d] > T(0) ? T(1) / (T)sqrt(b_colsq[d]) : T(1);
 		for (int i = lane; i < r; i += 64) {
 			const T fi = b_colsq[i] > T(0) ? T(1) / (T)sqrt(b_colsq[i]) : T(1);
@@ -818,12 +823,12 @@ __global__ __launch_bounds__(256) void k_trace_small(const T* __restrict__ A, co
 }
 
 template <typename T>
-hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq) {
-	hipLaunchKernelGGL((k_trace_small<T>), dim3((r + 3) / 4), dim3(256), 0, stream, A, B, RP, r, ps, b_colsq);
+hipError_t launch_trace_small(const T* A, const T* B, int RP, int r, T* ps, hipStream_t stream, const T* b_colsq, const T* b_scale) {
+	hipLaunchKernelGGL((k_trace_small<T>), dim3((r + 3) / 4), dim3(256), 0, stream, A, B, RP, r, ps, b_colsq, b_scale);
 	return hipGetLastError();
 }
-template hipError_t launch_trace_small<float>(const float*, const float*, int, int, float*, hipStream_t, const float*);
-template hipError_t launch_trace_small<double>(const double*, const double*, int, int, double*, hipStream_t, const double*);
+template hipError_t launch_trace_small<float>(const float*, const float*, int, int, float*, hipStream_t, const float*, const float*);
+template hipError_t launch_trace_small<double>(const double*, const double*, int, int, double*, hipStream_t, const double*, const double*);
 
 // ps(d) = sum_y A(d, y) B(d, y) over two panels: the r terms of tr(W_old^T (V H^T)) used by the
 // least-squares family (AlgorithmAlternatingLeastSquares.h:199-205) and GDCLS (:259-264).

@@ -27,13 +27,205 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F64_TH = 128;
 
+// ------------------------------------------------------------------------------------------
+// Gram matrix of a factor panel as PASSENGER workgroups of the fp64 product launch (round 6)
+// ------------------------------------------------------------------------------------------
+// The generic iteration spent two launches per factor on its Gram matrix (k_gram_f64 + k_gram_reduce_sym_f64: 7.4 + 5.0 us at the reference example's shape, both at
+// the launch floor) in FRONT of the product against V, which does not need the result -- its consumer is the update kernel behind that launch.  So the matrix rides
+// in the product launch, as it does at padded rank 64 in fp32 (gram_image.h) and at rank 256 in bf16 (tri_gram_tile.h):
+//   * one passenger workgroup (8 waves) per 64 x 64 super-block (I <= J) and K slice: the two wave halves take the halves of the slice, a wave a 32 x 32 quarter as
+//     2 x 2 MFMA tiles (k_gram_f64<2, .>'s loop); the upper half adds its accumulators to the lower one's through LDS; one partial block per workgroup;
+//   * level 1: the workgroup releases its partial block and counts itself in on the super-block's counter; the LAST of the slices adds the partial blocks in slice
+//     order (whoever is last, the order is fixed) and writes the block and its mirror image;
+//   * W side: RP / 64 more passengers turn the W update's per-workgroup sums of squares into the pending column scale d(c) = 1 / sqrt(sum)
+//     (kernel::normalizeColumns, KernelNormalizeColumns.cu:37-58, as a factor).  The matrix stays RAW (W as it lies in its panel: unnormalised, unsmoothed): the
+//     H update applies D and nsNMF's S around its r x r product, S D G D S h (PanelFusedF64).  A first version formed S D G D S here, by the last finisher of all
+//     super-blocks: one workgroup walking the 192 x 192 matrix twice made the launch 76 us at the reference example's shape (the product alone: 17).
+// Nobody waits for anybody: no co-residency assumption.  The counters are left at zero.
+__device__ __forceinline__ bool ride64_arrive(unsigned* counter, unsigned target) {
+	__shared__ unsigned s_last;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_last = old == target - 1u ? 1u : 0u;
+		if (s_last) {
+			__hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch finds zero)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the barrier below holds the other waves until the invalidate has completed)
+		}
+	}
+	__syncthreads();
+	return s_last != 0u;
+}
+
+// passenger `pid` of a launch of 512-thread workgroups; lds: at least 32 KiB (and 2 * RP + 8 doubles)
+__device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int pid, double* lds) {
+	typedef double f64x2l __attribute__((ext_vector_type(2)));
+	typedef double f64x4l __attribute__((ext_vector_type(4)));
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int nb = RP / 64, nsuper = nb * (nb + 1) / 2;
+	const int nscale = g.sumsq_part != nullptr ? nb : 0;
+	if (pid >= nsuper * g.slices) {
+		// ---- scale passenger: 64 columns of the pending column scale from the update kernel's partial sums of squares (8 groups of parts, added in group order)
+		const int cb = pid - nsuper * g.slices;
+		if (cb >= nscale) return;
+		const int c = 64 * cb + lane;
+		const int p0 = (int)(((long)g.sumsq_parts * wave) / 8), p1 = (int)(((long)g.sumsq_parts * (wave + 1)) / 8);
+		double s = 0.0;
+		for (int p = p0; p < p1; p += 8) {
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = g.sumsq_part[(long)(p + u < p1 ? p + u : p0) * RP + c];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (p + u < p1) s += v[u];
+		}
+		lds[wave * 64 + lane] = s;
+		__syncthreads();
+		if (wave == 0) {
+			double t = lds[lane];
+#pragma unroll
+			for (int w = 1; w < 8; ++w) t += lds[w * 64 + lane];
+			g.scale_out[c] = t > 0.0 ? 1.0 / sqrt(t) : 1.0;
+		}
+		return;
+	}
+	const int sb = pid / g.slices, slice = pid - sb * g.slices;
+	int I = 0, rem = sb;
+	while (rem >= nb - I) { rem -= nb - I; ++I; }
+	const int J = I + rem;
+	const int l15 = lane & 15, kq = lane >> 4;
+	const int q = wave & 3, kh = wave >> 2;
+	const int ca = 64 * I + 32 * (q >> 1), cb = 64 * J + 32 * (q & 1);
+	const int steps_total = (g.len + 3) / 4;
+	const int pieces = 2 * g.slices, piece = 2 * slice + kh;
+	const int s0 = (int)(((long)steps_total * piece) / pieces), s1 = (int)(((long)steps_total * (piece + 1)) / pieces);
+	const int steps = s1 - s0;
+	f64x4l acc[2][2];
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int b = 0; b < 2; ++b)
+#pragma unroll
+			for (int gg = 0; gg < 4; ++gg) acc[a][b][gg] = 0.0;
+	if (steps > 0) {
+		constexpr int DG = 8;
+		const double* pa = g.P + ((long)4 * s0 + kq) * RP + ca + 2 * l15;
+		const double* pb = g.P + ((long)4 * s0 + kq) * RP + cb + 2 * l15;
+		const long step = 4 * (long)RP;
+		const int last = steps - 1;
+		f64x2l va[DG], vb[DG];
+#pragma unroll
+		for (int d = 0; d < DG; ++d) {
+			const int t = d < last ? d : last;
+			va[d] = *reinterpret_cast<const f64x2l*>(pa + t * step);
+			vb[d] = *reinterpret_cast<const f64x2l*>(pb + t * step);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		int t = 0;
+		for (; t + DG <= steps; t += DG) {
+#pragma unroll
+			for (int d = 0; d < DG; ++d) {
+#pragma unroll
+				for (int a = 0; a < 2; ++a)
+#pragma unroll
+					for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+				int tn = t + DG + d;
+				tn = tn < last ? tn : last;
+				va[d] = *reinterpret_cast<const f64x2l*>(pa + tn * step);
+				vb[d] = *reinterpret_cast<const f64x2l*>(pb + tn * step);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		const int remn = steps - t;
+#pragma unroll
+		for (int d = 0; d < DG; ++d) {
+			if (d < remn) {
+#pragma unroll
+				for (int a = 0; a < 2; ++a)
+#pragma unroll
+					for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[d][a], vb[d][b], acc[a][b], 0, 0, 0);
+			}
+		}
+	}
+	// the upper K half adds to the lower one through LDS ([quarter][16][64] doubles), which stores the workgroup's partial block:
+	// element ((a * 2 + b) * 4 + g) * 64 + lane of quarter q  (C/D map: register g of lane (l15, kq) is tile row kq + 4 g, tile column l15)
+	if (kh == 1) {
+#pragma unroll
+		for (int a = 0; a < 2; ++a)
+#pragma unroll
+			for (int b = 0; b < 2; ++b)
+#pragma unroll
+				for (int gg = 0; gg < 4; ++gg) lds[(q * 16 + (a * 2 + b) * 4 + gg) * 64 + lane] = acc[a][b][gg];
+	}
+	__syncthreads();
+	double* out = g.partial + ((long)slice * nsuper + sb) * 4096;
+	if (kh == 0) {
+#pragma unroll
+		for (int a = 0; a < 2; ++a)
+#pragma unroll
+			for (int b = 0; b < 2; ++b)
+#pragma unroll
+				for (int gg = 0; gg < 4; ++gg) {
+					const int e = (q * 16 + (a * 2 + b) * 4 + gg) * 64 + lane;
+					out[e] = acc[a][b][gg] + lds[e];
+				}
+	}
+	if (!ride64_arrive(g.counters + sb, (unsigned)g.slices)) return;
+	// ---- level 1: this workgroup was the last of the block's slices -- add the partial blocks in slice order
+	{
+		const long pstride = (long)nsuper * 4096;
+		const double* pp = g.partial + (long)sb * 4096 + 2 * tid;      // elements 2 tid, 2 tid + 1 of each 1 024-element quarter-half: pairs (e, e + 1) are lanes (l, l + 1)
+		f64x2l sum[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) sum[k] = f64x2l{0.0, 0.0};
+		for (int u0 = 0; u0 < g.slices; u0 += 8) {
+			f64x2l v[8][4];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+#pragma unroll
+				for (int k = 0; k < 4; ++k) v[u][k] = *reinterpret_cast<const f64x2l*>(pp + (long)(u0 + u < g.slices ? u0 + u : 0) * pstride + 1024 * k);
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (u0 + u < g.slices) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) sum[k] += v[u][k];
+				}
+		}
+		double* G = g.G;
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int e = 1024 * k + 2 * tid + h;
+				const int el = e & 63, eg = (e >> 6) & 3, eab = (e >> 8) & 3, eq = e >> 10;
+				const int rr = 64 * I + 32 * (eq >> 1) + 2 * ((el >> 4) + 4 * eg) + (eab >> 1);
+				const int cc = 64 * J + 32 * (eq & 1) + 2 * (el & 15) + (eab & 1);
+				G[(long)rr * RP + cc] = sum[k][h];
+				if (I < J) G[(long)cc * RP + rr] = sum[k][h];
+			}
+	}
+}
+
 template <int D, int NC>      // NC = 16-column tiles per wave: 4 (64 panel columns) or 2 (ranks <= 32: the first 32 columns only)
 __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const double* __restrict__ A, long tile_stride,
 	const double* __restrict__ F, int RP,
 	double* __restrict__ slabs, long slab_stride,
-	int steps_total, int splits) {
+	int steps_total, int splits, int xtiles, GramRideF64 ride) {
 	extern __shared__ __attribute__((aligned(16))) double lds64[];
+	if ((int)blockIdx.x >= xtiles) {
+		// passenger workgroups behind the x-tiles of every (slice, chunk) row of the grid
+		const int extra = (int)gridDim.x - xtiles;
+		const int pid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * extra + ((int)blockIdx.x - xtiles);
+		const int nbk = RP / 64;
+		if (ride.P != nullptr && pid < (nbk * (nbk + 1) / 2) * ride.slices + (ride.sumsq_part != nullptr ? nbk : 0)) gram_ride_f64(ride, RP, pid, lds64);
+		return;
+	}
 	const int xt = blockIdx.x, sp = blockIdx.y;
 	const int coff = 64 * blockIdx.z;             // 64-column chunk of the panel (grid.z = RP / 64)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,22 +361,35 @@ FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus) {
 
 // A: x-tiled image (launch_tile<double>, tile height 128, the reduction length padded to a multiple of 4 with zeros);
 // F: panel [y][RP]; slabs: plan.splits partial results, panel layout [x][RP].
+int gram_ride_f64_workgroups(int RP, int slices, bool with_scale) {
+	const int nb = RP / 64;
+	return (nb * (nb + 1) / 2) * slices + (with_scale ? nb : 0);
+}
+
 hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
-                                     double* slabs, long slab_stride, hipStream_t stream) {
+                                     double* slabs, long slab_stride, hipStream_t stream, const GramRideF64* ride_in) {
 	constexpr int D = 6;
 	if (p.th != F64_TH || RP % 64 != 0) return hipErrorInvalidValue;
 	const size_t lds_bytes = 8 * 8 * 2 * 64 * sizeof(f64x2);
-	dim3 grid(p.xtiles, p.splits, p.chunks), block(512);
+	GramRideF64 ride = {};
+	int extra = 0;
+	if (ride_in != nullptr && ride_in->P != nullptr) {
+		if (ride_in->slices < 1 || RP > 512) return hipErrorInvalidValue;
+		ride = *ride_in;
+		const int pass = gram_ride_f64_workgroups(RP, ride.slices, ride.sumsq_part != nullptr), rows = p.splits * p.chunks;
+		extra = (pass + rows - 1) / rows;
+	}
+	dim3 grid(p.xtiles + extra, p.splits, p.chunks), block(512);
 	if (p.nb == 2 && RP == 64) {
 		// ranks <= 32: the first 32 panel columns only (the rest of every slab stays at its initial zeros)
 		static std::atomic<unsigned long long> lds_done2{0ull};
 		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 2>), (int)lds_bytes, lds_done2); e != hipSuccess) return e;
-		hipLaunchKernelGGL((k_factor_product_f64<D, 2>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
+		hipLaunchKernelGGL((k_factor_product_f64<D, 2>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, p.xtiles, ride);
 		return hipGetLastError();
 	}
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 4>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_f64<D, 4>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits);
+	hipLaunchKernelGGL((k_factor_product_f64<D, 4>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, p.xtiles, ride);
 	return hipGetLastError();
 }
 
@@ -199,15 +404,62 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 //   A operand: lane (i = l & 15, kq = l >> 4) holds Q(4 t + kq, 16 w + i)  -- 128 contiguous bytes per kq, from L2;
 //   B operand: lane (j = l & 15, kq) holds vec(16 yt + j, 4 t + kq)        -- LDS;
 //   C/D: register g of lane (j, kq) is column c = 16 w + kq + 4 g of row y = 16 yt + j.
-template <int MODE>
+// Extras of the fused double-precision iteration (round 6; PanelFusedF64, kernels.h; template flag HS = the H update with W = Wt D S), applied to the [YB][LD]
+// LDS images of a workgroup's panel rows by all 256 threads (TPR = 256 / YB threads per row, columns sub, sub + TPR, ...):
+//   fused64_h_prepare:  s_dv(c) = d(c) on the first r_eff entries, zero behind them; s_rs(y) = sum of the old row's first r entries (smoothing only);
+//                       num(y, c) <- d(c) num(y, c), then nsNMF's S on the first r entries of the row (k_smooth_panel's formula) -- (Wt D S)^T V = S D (Wt^T V)
+//   the r x r product:  B operand u = D S old, formed as the value leaves LDS: u(k) = s_dv(k) ((diag - off) old(k) + off s_rs);  t = Q u on the MFMA pipe;
+//                       den = S D t: v(c) = s_dv(c) t(c), den(c) = off (sigma - v(c)) + diag v(c), sigma = the row's sum of v over all column tiles (through LDS)
+//                       -- S D (Wt^T Wt) D S old = (W S)^T (W S) old, AlgorithmNonSmoothNMF.h:175-177, without a pass over the r x r matrix
+//   fused64_smooth_out: out(y, c) = S new(y, :) -- the smoothed panel the next product and its Gram passengers read (AlgorithmNonSmoothNMF.h:194)
+template <int YB>
+__device__ __forceinline__ void fused64_h_prepare(double* s_num, const double* s_old, double* s_dv, double* s_rs, int LD, int RP, const PanelFusedF64& fx) {
+	constexpr int TPR = 256 / YB;
+	const int r_eff = fx.smooth ? fx.r : RP;
+	for (int c = threadIdx.x; c < RP; c += 256) s_dv[c] = c < r_eff ? (fx.scale != nullptr ? fx.scale[c] : 1.0) : 0.0;
+	const int y = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+	double* row = s_num + y * LD;
+	double sum = 0.0, osum = 0.0;
+	for (int c = sub; c < RP; c += TPR) {
+		double x = row[c];
+		if (fx.scale != nullptr) x *= fx.scale[c];
+		if (c >= r_eff) x = 0.0;
+		row[c] = x;
+		sum += x;
+		if (c < r_eff) osum += s_old[y * LD + c];
+	}
+	if (fx.smooth) {
+#pragma unroll
+		for (int w = 1; w < TPR; w <<= 1) { sum += __shfl_xor(sum, w); osum += __shfl_xor(osum, w); }
+		for (int c = sub; c < fx.r; c += TPR) { const double x = row[c]; row[c] = fx.off * (sum - x) + fx.diag * x; }
+		if (sub == 0) s_rs[y] = osum;
+	} else if (sub == 0) s_rs[y] = 0.0;
+}
+template <int YB>
+__device__ __forceinline__ void fused64_smooth_out(const double* s_new, int LD, int RP, long base, const PanelFusedF64& fx) {
+	constexpr int TPR = 256 / YB;
+	const int y = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+	const double* row = s_new + y * LD;
+	double sum = 0.0;
+	for (int c = sub; c < fx.r; c += TPR) sum += row[c];
+#pragma unroll
+	for (int w = 1; w < TPR; w <<= 1) sum += __shfl_xor(sum, w);
+	double* o = fx.smooth_out + base + (long)y * RP;
+	for (int c = sub; c < RP; c += TPR) { const double x = row[c]; o[c] = c < fx.r ? fx.off * (sum - x) + fx.diag * x : 0.0; }
+}
+
+template <int MODE, bool HS>
 __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 	double* __restrict__ P, const double* __restrict__ slabs, int S, long slab_stride,
 	const double* __restrict__ Q, double eps, double* __restrict__ ps, int len_valid,
-	double* __restrict__ sumsq_part, double* __restrict__ num_out) {
+	double* __restrict__ sumsq_part, double* __restrict__ num_out, PanelFusedF64 fx) {
 	constexpr int YB = 32, LD = 68;
 	__shared__ __attribute__((aligned(16))) double s_num[YB * LD];
 	__shared__ __attribute__((aligned(16))) double s_old[YB * LD];      // old values, then the new ones
 	__shared__ double s_ps[4][YB];
+	__shared__ double s_sig[HS ? 4 : 1][YB];
+	__shared__ double s_dv[HS ? 64 : 1];
+	__shared__ double s_rs[HS ? YB : 1];
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int l15 = lane & 15, kq = lane >> 4;
@@ -227,15 +479,25 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
 				const int e = tid + 256 * i, y = e >> 5, c2 = e & 31;
-				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+				f64x2 o = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+				if (fx.old_scale != nullptr) o *= *reinterpret_cast<const f64x2*>(fx.old_scale + 2 * c2);      // (the panel's own pending column scale)
+				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = o;
 			}
 		}
-		for (int k = 1; k < S; ++k) {
-			f64x2 t[4];
+		// (four slabs requested at a time, added in slab order: one slab per round trip made the H update of a short, wide problem -- 16 slabs at the reference
+		//  example's shape -- a chain of 15 dependent loads)
+		for (int k = 1; k < S; k += 4) {
+			f64x2 t[4][4];
 #pragma unroll
-			for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f64x2*>(slabs + (long)k * slab_stride + base + 2l * (tid + 256 * i));
+			for (int u = 0; u < 4; ++u)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) num[i] += t[i];
+				for (int i = 0; i < 4; ++i) t[u][i] = *reinterpret_cast<const f64x2*>(slabs + (long)(k + u < S ? k + u : 0) * slab_stride + base + 2l * (tid + 256 * i));
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				if (k + u < S) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) num[i] += t[u][i];
+				}
 		}
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
@@ -245,6 +507,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 		}
 	}
 	__syncthreads();
+	if (HS) {
+		fused64_h_prepare<YB>(s_num, s_old, s_dv, s_rs, LD, 64, fx);
+		__syncthreads();
+	}
 
 	const double* vec = (MODE == PANEL_MU ? s_old : s_num) + l15 * LD + kq;
 	f64x4 acc[2];
@@ -252,10 +518,38 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 	for (int yt = 0; yt < 2; ++yt)
 #pragma unroll
 		for (int g = 0; g < 4; ++g) acc[yt][g] = 0.0;
+	const double h_a = HS ? fx.diag - fx.off : 1.0, h_b0 = HS ? fx.off * s_rs[l15] : 0.0, h_b1 = HS ? fx.off * s_rs[16 + l15] : 0.0;
 #pragma unroll
 	for (int t = 0; t < 16; ++t) {
-		acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], vec[4 * t], acc[0], 0, 0, 0);
-		acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], vec[16 * LD + 4 * t], acc[1], 0, 0, 0);
+		double b0 = vec[4 * t], b1 = vec[16 * LD + 4 * t];
+		if (HS) { const double dk = s_dv[4 * t + kq]; b0 = dk * (h_a * b0 + h_b0); b1 = dk * (h_a * b1 + h_b1); }
+		acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], b0, acc[0], 0, 0, 0);
+		acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], b1, acc[1], 0, 0, 0);
+	}
+	if (HS) {
+		// den = S D t
+		double sig[2] = {0.0, 0.0};
+#pragma unroll
+		for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) { acc[yt][g] *= s_dv[16 * wave + kq + 4 * g]; sig[yt] += acc[yt][g]; }
+		if (fx.smooth) {
+#pragma unroll
+			for (int yt = 0; yt < 2; ++yt) {
+				double v = sig[yt];
+				v += __shfl_xor(v, 16);
+				v += __shfl_xor(v, 32);
+				if (kq == 0) s_sig[wave][16 * yt + l15] = v;
+			}
+			__syncthreads();
+#pragma unroll
+			for (int yt = 0; yt < 2; ++yt) {
+				const int y = 16 * yt + l15;
+				const double sigma = ((s_sig[0][y] + s_sig[1][y]) + s_sig[2][y]) + s_sig[3][y];
+#pragma unroll
+				for (int g = 0; g < 4; ++g) acc[yt][g] = fx.off * (sigma - acc[yt][g]) + fx.diag * acc[yt][g];
+			}
+		}
 	}
 
 	double nv[2][4];
@@ -291,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 		const int e = tid + 256 * i, y = e >> 5, c2 = e & 31;
 		*reinterpret_cast<f64x2*>(P + base + 2l * e) = *reinterpret_cast<const f64x2*>(s_old + y * LD + 2 * c2);
 	}
+	if (HS && fx.smooth_out != nullptr) fused64_smooth_out<YB>(s_old, LD, 64, base, fx);
 	if (ps != nullptr && tid < YB) {
 		const int y = blockIdx.x * YB + tid;
 		if (y < len_valid) ps[y] = ((s_ps[0][tid] + s_ps[1][tid]) + s_ps[2][tid]) + s_ps[3][tid];
@@ -307,17 +602,20 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 // workgroup as [16][RP + 4] LDS images, wave w owns the 16-column tiles ct = w, w + 4, ... (NCT of them); the A operand
 // (Q, RP x RP, L2-resident) comes through a register ring, the B operand is one LDS read per K-step shared by the
 // wave's NCT tiles.
-template <int MODE, int NCT>
+template <int MODE, int NCT, bool HS>
 __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 	double* __restrict__ P, const double* __restrict__ slabs, int S, long slab_stride,
 	const double* __restrict__ Q, int RP, double eps, double* __restrict__ ps, int len_valid,
-	double* __restrict__ sumsq_part, double* __restrict__ num_out) {
+	double* __restrict__ sumsq_part, double* __restrict__ num_out, PanelFusedF64 fx) {
 	extern __shared__ __attribute__((aligned(16))) double ldsw[];
 	constexpr int YB = 16;
 	const int LD = RP + 4;
 	double* s_num = ldsw;                  // [16][LD]
 	double* s_old = ldsw + YB * LD;        // [16][LD]
 	double* s_ps = s_old + YB * LD;        // [4][16]
+	double* s_sig = s_ps + 64;             // HS: [4][16]
+	double* s_rs = s_sig + 64;             // HS: [16]
+	double* s_dv = s_rs + 16;              // HS: [RP]
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int l15 = lane & 15, kq = lane >> 4;
@@ -333,15 +631,25 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 #pragma unroll
 			for (int i = 0; i < NE; ++i) {
 				const int e = tid + 256 * i, y = e / h2, c2 = e - y * h2;
-				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+				f64x2 o = *reinterpret_cast<const f64x2*>(P + base + 2l * e);
+				if (fx.old_scale != nullptr) o *= *reinterpret_cast<const f64x2*>(fx.old_scale + 2 * c2);      // (the panel's own pending column scale)
+				*reinterpret_cast<f64x2*>(s_old + y * LD + 2 * c2) = o;
 			}
 		}
-		for (int k = 1; k < S; ++k) {
-			f64x2 t[NE];
+		// (SB slabs requested at a time, added in slab order -- see k_panel_update64_f64)
+		constexpr int SB = NE <= 8 ? 4 : 2;
+		for (int k = 1; k < S; k += SB) {
+			f64x2 t[SB][NE];
 #pragma unroll
-			for (int i = 0; i < NE; ++i) t[i] = *reinterpret_cast<const f64x2*>(slabs + (long)k * slab_stride + base + 2l * (tid + 256 * i));
+			for (int u = 0; u < SB; ++u)
 #pragma unroll
-			for (int i = 0; i < NE; ++i) num[i] += t[i];
+				for (int i = 0; i < NE; ++i) t[u][i] = *reinterpret_cast<const f64x2*>(slabs + (long)(k + u < S ? k + u : 0) * slab_stride + base + 2l * (tid + 256 * i));
+#pragma unroll
+			for (int u = 0; u < SB; ++u)
+				if (k + u < S) {
+#pragma unroll
+					for (int i = 0; i < NE; ++i) num[i] += t[u][i];
+				}
 		}
 #pragma unroll
 		for (int i = 0; i < NE; ++i) {
@@ -351,6 +659,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		}
 	}
 	__syncthreads();
+	if (HS) {
+		fused64_h_prepare<YB>(s_num, s_old, s_dv, s_rs, LD, RP, fx);
+		__syncthreads();
+	}
 
 	const double* vec = (MODE == PANEL_MU ? s_old : s_num) + l15 * LD + kq;
 	f64x4 acc[NCT];
@@ -360,11 +672,14 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		for (int g = 0; g < 4; ++g) acc[i][g] = 0.0;
 	const double* qp = Q + (long)kq * RP + 16 * wave + l15;      // + 4 t RP per K-step, + 64 i per tile
 	const int steps = RP / 4;                                     // multiple of 16 (RP of 64): whole turns of the ring of eight
-	constexpr int D = 8;
+	constexpr int D = (HS && NCT >= 7) ? 4 : 8;                   // (the H-side form at 448 / 512 columns: a shorter ring instead of spills)
+	const double h_a = HS ? fx.diag - fx.off : 1.0, h_b = HS ? fx.off * s_rs[l15] : 0.0;
+	const double* dvp = s_dv + kq;
+	auto bval = [&](int t) { double h = vec[4 * t]; if (HS) h = dvp[4 * t] * (h_a * h + h_b); return h; };
 	double a[D][NCT], b[D];
 #pragma unroll
 	for (int d = 0; d < D; ++d) {
-		b[d] = vec[4 * d];
+		b[d] = bval(d);
 #pragma unroll
 		for (int i = 0; i < NCT; ++i) a[d][i] = qp[(long)(4 * d) * RP + 64 * i];
 	}
@@ -376,10 +691,29 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 			for (int i = 0; i < NCT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][i], b[d], acc[i], 0, 0, 0);
 			int tn = t + D + d;
 			tn = tn < steps ? tn : steps - 1;
-			b[d] = vec[4 * tn];
+			b[d] = bval(tn);
 #pragma unroll
 			for (int i = 0; i < NCT; ++i) a[d][i] = qp[(long)(4 * tn) * RP + 64 * i];
 			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	if (HS) {
+		// den = S D t
+		double sig = 0.0;
+#pragma unroll
+		for (int i = 0; i < NCT; ++i)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) { acc[i][g] *= s_dv[16 * (wave + 4 * i) + kq + 4 * g]; sig += acc[i][g]; }
+		if (fx.smooth) {
+			sig += __shfl_xor(sig, 16);
+			sig += __shfl_xor(sig, 32);
+			if (kq == 0) s_sig[wave * YB + l15] = sig;
+			__syncthreads();
+			const double sigma = ((s_sig[l15] + s_sig[YB + l15]) + s_sig[2 * YB + l15]) + s_sig[3 * YB + l15];
+#pragma unroll
+			for (int i = 0; i < NCT; ++i)
+#pragma unroll
+				for (int g = 0; g < 4; ++g) acc[i][g] = fx.off * (sigma - acc[i][g]) + fx.diag * acc[i][g];
 		}
 	}
 
@@ -412,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		const int e = tid + 256 * i, y = e / h2, c2 = e - y * h2;
 		*reinterpret_cast<f64x2*>(P + base + 2l * e) = *reinterpret_cast<const f64x2*>(s_old + y * LD + 2 * c2);
 	}
+	if (HS && fx.smooth_out != nullptr) fused64_smooth_out<YB>(s_old, LD, RP, base, fx);
 	if (ps != nullptr && tid < YB) {
 		const int y = blockIdx.x * YB + tid;
 		if (y < len_valid) ps[y] = ((s_ps[tid] + s_ps[YB + tid]) + s_ps[2 * YB + tid]) + s_ps[3 * YB + tid];
@@ -428,25 +763,30 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 
 bool panel_update_wide_f64_available(int RP) { return RP >= 128 && RP % 64 == 0 && RP <= 512; }
 
-template <int MODE, int NCT>
+template <int MODE, int NCT, bool HS>
 static hipError_t launch_wide_f64(double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
-                                  double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
-	const size_t lds_bytes = sizeof(double) * (2 * 16 * (size_t)(RP + 4) + 64);
-	const size_t max_bytes = sizeof(double) * (2 * 16 * (size_t)(64 * NCT + 4) + 64);
+                                  double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64& fx) {
+	const size_t lds_bytes = sizeof(double) * (2 * 16 * (size_t)(RP + 4) + 64 + (HS ? 64 + 16 + (size_t)RP : 0));
+	const size_t max_bytes = sizeof(double) * (2 * 16 * (size_t)(64 * NCT + 4) + 64 + (HS ? 64 + 16 + 64 * (size_t)NCT : 0));
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f64<MODE, NCT>), (int)max_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT>), dim3(len_pad / 16), dim3(256), lds_bytes, stream,
-	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out);
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f64<MODE, NCT, HS>), (int)max_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT, HS>), dim3(len_pad / 16), dim3(256), lds_bytes, stream,
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, fx);
 	return hipGetLastError();
 }
 
 // 16 panel rows per workgroup: len_pad / 16 norm partials (panel_update_parts, kernels.hip, knows)
 hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int RP, int len_pad,
-                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
+                                        double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64* fused) {
 	if (!panel_update_wide_f64_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % 16 != 0) return hipErrorInvalidValue;
+	PanelFusedF64 fx = {};
+	if (fused != nullptr) fx = *fused;
+	if (fx.h_side && mode != PANEL_MU) return hipErrorInvalidValue;
+	if (!fx.smooth) { fx.off = 0.0; fx.diag = 1.0; }
 #define NMFAMD_WIDE64(NCT)                                                                                                                       \
-	return mode == PANEL_MU ? launch_wide_f64<PANEL_MU, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream) \
-	                        : launch_wide_f64<PANEL_LS, NCT>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream)
+	return fx.h_side ? launch_wide_f64<PANEL_MU, NCT, true>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, fx) \
+	     : mode == PANEL_MU ? launch_wide_f64<PANEL_MU, NCT, false>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, fx) \
+	                        : launch_wide_f64<PANEL_LS, NCT, false>(P, slabs, S, slab_stride, Q, RP, len_pad, eps, ps, len_valid, sumsq_part, num_out, stream, fx)
 	switch (RP / 64) {      // 16-column tiles per wave
 	case 2: NMFAMD_WIDE64(2);
 	case 3: NMFAMD_WIDE64(3);
@@ -460,11 +800,16 @@ hipError_t launch_panel_update_wide_f64(int mode, double* P, const double* slabs
 }
 
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
-                                     double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream) {
+                                     double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64* fused) {
 	if ((mode != PANEL_MU && mode != PANEL_LS) || len_pad % 32 != 0) return hipErrorInvalidValue;
+	PanelFusedF64 fx = {};
+	if (fused != nullptr) fx = *fused;
+	if (fx.h_side && mode != PANEL_MU) return hipErrorInvalidValue;
+	if (!fx.smooth) { fx.off = 0.0; fx.diag = 1.0; }
 	dim3 grid(len_pad / 32), block(256);
-	if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
-	else hipLaunchKernelGGL((k_panel_update64_f64<PANEL_LS>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out);
+	if (fx.h_side) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU, true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);
+	else if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU, false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);
+	else hipLaunchKernelGGL((k_panel_update64_f64<PANEL_LS, false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);
 	return hipGetLastError();
 }
 

@@ -125,6 +125,47 @@ def replay_iterations(K: int, c4: bool) -> int:
     return max(REPLAY_ITERATIONS // (3 if c4 else 1), min(K, 200))
 
 
+def host_cpu_info() -> dict:
+    """What the CPU legs run on, probed ("the GPU box is probed, never assumed"): the cores this process may use -- its affinity mask, cut to the
+    cgroup's CPU quota where one is set (more threads than the quota only queue behind each other) -- and the CPU model."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max" and float(per) > 0:
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:      # cgroup v1
+                q, per = float(f.read()), float(g.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    available = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"cores_available": available, "affinity_cores": affinity, "cgroup_quota_cores": quota, "cpu_model": model}
+
+
+def set_cpu_threads(requested: int) -> None:
+    """Before the oracle is loaded: its OpenMP team takes every available core (host_cpu_info) unless --cpu-threads caps it."""
+    n = host_cpu_info()["cores_available"] if requested <= 0 else requested
+    os.environ["NMF_ORACLE_MAX_THREADS"] = str(n)
+    os.environ["OMP_NUM_THREADS"] = str(n)
+
+
 def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
     """The oracle (our CPU port of the reference's iteration) timed on this box's host cores.  A run's one-off work (the sorted
     tr(V^T V) vector of allocateMemory, workspace allocation) is timed by a zero-iteration run and taken out: the metric counts
@@ -141,7 +182,7 @@ def cpu_baseline(V, W, H, budget_s: float = 20.0, algorithm: str = "mu", **kw):
     t0 = time.perf_counter()
     oracle.run(algorithm, V, Wc, Hc, iters, **kw)
     dt = max(time.perf_counter() - t0 - setup, 1e-9)
-    return {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
+    return {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), **host_cpu_info(), "kind": "port",
             "sample": f"{iters} {algorithm.upper()} iterations of the full {V.shape[0]}x{V.shape[1]} r={W.shape[1]} {'fp32' if V.dtype == np.float32 else 'fp64'} problem (oracle/nmf_oracle.c, OpenMP; "
                       + ("products by oracle/sgemm_avx2.h; " if V.dtype == np.float32 else "") + f"{setup * 1e3:.0f} ms of per-run setup timed apart and excluded)"}
 
@@ -324,6 +365,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline legs; 0 (default) = every core available to this process (affinity mask, cgroup quota)")
     ap.add_argument("--setup-iterations", type=int, default=-1,
                     help="untimed iterations of the hot path BEFORE the --warmup steps (first launches of every kernel, the device's ramp from idle; the factors go back to W0, H0 "
                          "afterwards).  -1 (default): 240 at config 2's shape (scaled for the slower workloads), as in round 4 -- the line reports what ran in config.setup_iterations; "
@@ -354,6 +396,7 @@ def main():
     global SETUP_ITERATIONS
     if args.setup_iterations >= 0:
         SETUP_ITERATIONS = args.setup_iterations
+    set_cpu_threads(args.cpu_threads)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if os.environ.get("NMFAMD_BENCH_DUMP_AFTER"):
@@ -401,6 +444,18 @@ def main():
         eng = na.Engine(M, N_COLS, R, algorithm, dtype=np.float32, stream=engine_stream(torch), **alg_kw)
         eng.upload(V)
         eng.set_factors(W, H)
+        # First leg (round 6): the K steps right behind the driver's W warm-up steps and NOTHING else -- what `--warmup W` means taken literally; reported as
+        # value_driver_warmup_only / ms_per_step_driver_warmup_only beside the line's value, so that rounds stay comparable whatever the set-up phase below does.
+        cold_elapsed = None
+        if SETUP_ITERATIONS > 0:
+            eng.iterate(Wm, first_iteration=1, error_every=10)
+            eng.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            eng.iterate(K, first_iteration=Wm + 1, error_every=10)
+            barrier()
+            cold_elapsed = time.perf_counter() - t0
+            eng.set_factors(W, H)
         # set-up, not steps (as in the multi-GPU paths below): the first launches of every kernel and the device's ramp from idle -- measured, iterations 26-75 of a
         # process run at 101 us, 76-100 at 96, from ~125 on at 91-92 (profiles/r04_warmup_timeline.txt; the same ramp follows 2 s of idling) -- then back to W0, H0
         if SETUP_ITERATIONS > 0:
@@ -428,6 +483,7 @@ def main():
         resident_images = eng.geometry()["resident_images"]
         parallelism = "single GPU"
     else:
+        cold_elapsed = None
         from nmfgpu_amd.distributed import EngineShard, ShardedMU
         shard = EngineShard(V, W, H)
         drv = ShardedMU(shard, total_columns=N_COLS, rows=M)
@@ -488,12 +544,12 @@ def main():
                         forms[key] = {"form": what, "avg_launch_us": a * 1e6, "launches": cnt, "achieved": bytes_per_launch / a / 1e9, "frac": bytes_per_launch / a / 1e9 / PEAK_HBM_GBS}
                     roofline["forms"] = forms
                 # the same launches against the matrix pipe: six bf16 MFMAs per fp32 product term are what the kernel issues (12 mnr flops per launch); the share of
-                # the pipe's cycles they occupy, measured with SQ counters: profiles/r03_pmc_sq.md (43 - 48 % busy)
+                # the pipe's cycles they occupy, measured with SQ counters: profiles/r05_pmc_sq.md (55 - 57 % busy; round 3's kernel: 43 - 48 %)
                 mfma_tflops = 6.0 * flops_per_launch / avg_s / 1e12
                 roofline_mfma = {"bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": mfma_tflops / PEAK_BF16_MFMA_TFLOPS,
                                  "kernel": "k_factor_product_x3", "flops_per_launch": 6.0 * flops_per_launch,
                                  "achieved_is": "bf16 MFMA work issued (six exact cross terms per fp32 product) / launch time, against the dense bf16 peak",
-                                 "pipe_busy_measured": "43-48 % of cycles (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_pmc_sq.md)"}
+                                 "pipe_busy_measured": "55-57 % of cycles (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r05_pmc_sq.md)"}
             else:
                 achieved = flops_per_launch / avg_s / 1e12
                 traffic, traffic_source = measured_traffic("factor_product", "nmfgpu_amd/csrc/kernels.hip")
@@ -505,6 +561,10 @@ def main():
             "value": world * K / elapsed,
             "unit": "iterations/s" if world == 1 else "shard-iterations/s (one 10000x5000 column shard per GPU)",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            # the same K steps timed right behind the driver's W warm-up steps, before the set-up phase ran (same process, same engine; null when --setup-iterations 0
+            # makes `value` itself that figure)
+            "value_driver_warmup_only": (world * K / cold_elapsed) if cold_elapsed else None,
+            "ms_per_step_driver_warmup_only": (cold_elapsed / K * 1e3) if cold_elapsed else None,
             # (N = 1 is the first point of north_star's 1/2/4/8 series of the ONE 10000 x 5000 problem, which `--gpus N` column-shards: strong scaling)
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: dense random V 10000x5000, r=64, MU Frobenius, fp32" if algorithm == "mu" else
@@ -967,7 +1027,7 @@ def main_c3(args):
         t0 = time.perf_counter()
         oracle.run_kl_csr(m, n, val, ptr, idx, Wc, Hc, iters)
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
+        out["cpu_baseline"] = {"value": iters / dt, "unit": "iterations/s", "cores": oracle.num_threads(), **host_cpu_info(), "kind": "port",
                                "sample": f"{iters} KL-MU iterations of the full problem over the stored entries (oracle_kl_run_csr, C + OpenMP, fp32)"}
     print(json.dumps(out), flush=True)
 

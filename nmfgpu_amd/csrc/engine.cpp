@@ -144,6 +144,13 @@ Engine<T>::~Engine() {
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
+	if (f64_stamps_ != nullptr) {
+		std::vector<unsigned long long> h((size_t)4 * 4096 * 8);
+		if (hipMemcpy(h.data(), f64_stamps_, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+			if (FILE* f = std::fopen(tuning_env("NMFAMD_F64_STAMPS"), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
+		}
+		(void)hipFree(f64_stamps_);
+	}
 	{ void* fb[] = {f64_scale_, f64_partial_, f64_counters_}; for (void* b : fb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
@@ -428,7 +435,7 @@ Status Engine<T>::allocate() {
 		// at most 16 (the level-1 finisher adds them one after the other), at least 4 (a grid that fills the chip: the passengers queue behind the product blocks)
 		const int nbk = RP_ / 64, nsuper = nbk * (nbk + 1) / 2;
 		auto slices = [&](const FactorProductPlan& p, long len) {
-			const int room = (num_cus_ - p.xtiles * p.splits * p.chunks - nbk) / nsuper;
+			const int room = (num_cus_ - (p.half_tiles ? 2 : 1) * p.xtiles * p.splits * p.chunks - nbk) / nsuper;
 			const int by_len = (int)std::max<long>(1, (len + 3) / 4 / 16);       // (at least 8 K-steps of four rows per wave half)
 			return std::max(1, std::min(std::min(16, by_len), std::max(4, room)));
 		};
@@ -438,6 +445,10 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&f64_partial_, sizeof(double) * 4096 * (size_t)nsuper * (size_t)std::max(f64_slices_h_, f64_slices_w_)));
 		HIPX(hipMalloc((void**)&f64_counters_, sizeof(unsigned) * (size_t)(nsuper + 1)));
 		HIPX(hipMemsetAsync(f64_counters_, 0, sizeof(unsigned) * (size_t)(nsuper + 1), stream_));
+		if (tuning_env("NMFAMD_F64_STAMPS") != nullptr) {
+			HIPX(hipMalloc((void**)&f64_stamps_, sizeof(unsigned long long) * 4 * 4096 * 8));
+			HIPX(hipMemsetAsync(f64_stamps_, 0, sizeof(unsigned long long) * 4 * 4096 * 8, stream_));
+		}
 	}
 	HIPX(hipHostMalloc((void**)&pin_psN_, sizeof(T) * (size_t)(ps_stride_ + RP_)));
 	pin_psR_ = pin_psN_ + ps_stride_;
@@ -1378,6 +1389,8 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		GramRideF64 gw = {};
 		gw.P = Wt_; gw.len = m_; gw.slices = f64_slices_h_; gw.partial = f64_partial_; gw.counters = f64_counters_; gw.G = G_;
 		gw.sumsq_part = f64_pending_ ? sumsq_part_ : nullptr; gw.sumsq_parts = norm_parts; gw.scale_out = f64_scale_;
+		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gw.stop = std::atoi(e);
+		gw.stamps = f64_stamps_;
 		ride64_ = &gw;
 		if (Status s = product_h(Wt_)) return s;
 		ride64_ = nullptr;
@@ -1387,12 +1400,15 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		fh.h_side = (dscale != nullptr || ns) ? 1 : 0;      // (a normalised W and no smoothing: G_ is W^T W as the update needs it)
 		fh.scale = dscale; fh.r = r_;
 		if (ns) { fh.smooth = 1; fh.off = off; fh.diag = diag; fh.smooth_out = Hs_; }
+		fh.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 1l * 4096 * 8 : nullptr;
 		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
 		else HIPX(launch_panel_update_wide_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
 		// 3
 		const double* Fh = ns ? Hs_ : H_;
 		GramRideF64 gh = {};
 		gh.P = Fh; gh.len = n_; gh.slices = f64_slices_w_; gh.partial = f64_partial_; gh.counters = f64_counters_; gh.G = HHt_;
+		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gh.stop = std::atoi(e);
+		gh.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 2l * 4096 * 8 : nullptr;
 		ride64_ = &gh;
 		if (Status s = product_w(Fh)) return s;
 		ride64_ = nullptr;
@@ -1402,6 +1418,7 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		// 4
 		PanelFusedF64 fw = {};
 		fw.old_scale = dscale;
+		fw.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 3l * 4096 * 8 : nullptr;
 		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));
 		else HIPX(launch_panel_update_wide_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));
 		f64_pending_ = true;

@@ -310,6 +310,7 @@ private:
 	unsigned* f64_counters_ = nullptr;
 	int f64_slices_h_ = 0, f64_slices_w_ = 0;        // K slices of the Gram passengers riding in the W^T V / V H^T launch
 	const GramRideF64* ride64_ = nullptr;            // set around a product_h / product_w call
+	unsigned long long* f64_stamps_ = nullptr;       // measurement builds (NMFAMD_F64_STAMPS = file): [4 launches][4096][8] stamps of the LAST fused iteration, written out by the destructor
 	bool gram_h_partials_ = false;   // gramH_part_ describes the current H
 	bool h_partials_unneeded_ = false; // set by iterate() around its H step: GDCLS takes H H^T from the split image beside the product against V
 	int normalize_next_ = 0;

@@ -17,6 +17,7 @@ struct FactorProductPlan {
 	int splits;       // workgroup slices of the reduction range = number of output slabs
 	int nb;           // 32-wide N-blocks per wave tile: 2, or 1 when only the first 32 panel columns are needed (rank <= 32)
 	int chunks;       // launches needed to cover RP = chunks * 64 factor rows
+	int half_tiles = 0; // fp64 product: 1 = a workgroup takes one 64-row half of an x-tile and eight pieces of its K slice (kernels_f64.hip, RH = 1): small grids
 	int col_split = 0; // split-operand product, RP = 64 only: 2 = a workgroup takes 32 of the 64 panel columns (twice the workgroups, half the MFMAs per K-step and
 	                   // wave; the operand is split twice) -- for small reduction ranges, where the 128 x 64 form leaves most of the chip idle; same bits
 };
@@ -293,6 +294,8 @@ struct GramRideF64 {
 	const double* sumsq_part;   // the pending column scale's source: sumsq_parts vectors of RP partial sums of squares (nullptr: no scale passengers)
 	int sumsq_parts;
 	double* scale_out;          // [RP] d(c) = sum > 0 ? 1 / sqrt(sum) : 1
+	int stop;                   // measurement builds (NMFAMD_RIDE64_STOP): 1 = passengers return at once, 2 = after their partial block, 3 = after counting in (results void)
+	unsigned long long* stamps; // measurement builds: [4096][8] wall-clock stamps (product workgroups from 0, passengers from 2048), tools/stamp_f64.py
 };
 int gram_ride_f64_workgroups(int RP, int slices, bool with_scale);
 hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
@@ -308,6 +311,7 @@ struct PanelFusedF64 {
 	double off, diag;
 	int r;
 	double* smooth_out;         // H update: a second panel that receives S new(y, :) (the operand of V (S H)^T and of its Gram matrix)
+	unsigned long long* stamps; // measurement builds: [workgroups][8] wall-clock stamps (wide kernel)
 };
 // fp64 / padded rank 64 panel update on the fp64 MFMA pipe (32 panel rows per workgroup: len_pad / 32 norm partials)
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "tuning.h"
 
 namespace nmfamd {
 
@@ -42,6 +43,16 @@ constexpr int F64_TH = 128;
 //     H update applies D and nsNMF's S around its r x r product, S D G D S h (PanelFusedF64).  A first version formed S D G D S here, by the last finisher of all
 //     super-blocks: one workgroup walking the 192 x 192 matrix twice made the launch 76 us at the reference example's shape (the product alone: 17).
 // Nobody waits for anybody: no co-residency assumption.  The counters are left at zero.
+// LDS-only barrier: this wave's LDS traffic has completed (lgkmcnt(0)) before it arrives; global stores stay in flight -- __syncthreads() also waits for them
+// (vmcnt(0)), which made every round of the product's in-workgroup reduction wait for the previous round's slab stores (2.5 us per round: 10 us of a 19 us launch
+// at the reference example's shape, tools/stamp_f64.py)
+__device__ __forceinline__ void lds_barrier64() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// measurement builds: stamp k of workgroup `wg` (100 MHz wall clock), first lane of the workgroup only
+__device__ __forceinline__ void stamp64(unsigned long long* stamps, int wg, int k) {
+	if (stamps != nullptr && threadIdx.x == 0 && wg < 4096) stamps[(long)wg * 8 + k] = wall_clock64();
+}
+
 __device__ __forceinline__ bool ride64_arrive(unsigned* counter, unsigned target) {
 	__shared__ unsigned s_last;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -69,6 +80,9 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int nb = RP / 64, nsuper = nb * (nb + 1) / 2;
 	const int nscale = g.sumsq_part != nullptr ? nb : 0;
+	if (g.stop == 1) return;
+	const int swg = 2048 + pid;
+	stamp64(g.stamps, swg, 0);
 	if (pid >= nsuper * g.slices) {
 		// ---- scale passenger: 64 columns of the pending column scale from the update kernel's partial sums of squares (8 groups of parts, added in group order)
 		const int cb = pid - nsuper * g.slices;
@@ -113,7 +127,10 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 #pragma unroll
 			for (int gg = 0; gg < 4; ++gg) acc[a][b][gg] = 0.0;
 	if (steps > 0) {
-		constexpr int DG = 8;
+#ifndef RIDE64_RING
+#define RIDE64_RING 8
+#endif
+		constexpr int DG = RIDE64_RING;      // (K-steps in flight; sixteen measured +1 us per launch at the reference example's shape)
 		const double* pa = g.P + ((long)4 * s0 + kq) * RP + ca + 2 * l15;
 		const double* pb = g.P + ((long)4 * s0 + kq) * RP + cb + 2 * l15;
 		const long step = 4 * (long)RP;
@@ -175,7 +192,11 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 					out[e] = acc[a][b][gg] + lds[e];
 				}
 	}
-	if (!ride64_arrive(g.counters + sb, (unsigned)g.slices)) return;
+	stamp64(g.stamps, swg, 1);
+	if (g.stop == 2) return;
+	if (!ride64_arrive(g.counters + sb, (unsigned)g.slices)) { stamp64(g.stamps, swg, 2); return; }
+	stamp64(g.stamps, swg, 2);
+	if (g.stop == 3) return;
 	// ---- level 1: this workgroup was the last of the block's slices -- add the partial blocks in slice order
 	{
 		const long pstride = (long)nsuper * 4096;
@@ -183,6 +204,7 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 		f64x2l sum[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) sum[k] = f64x2l{0.0, 0.0};
+		// (eight slices = 32 loads of 16 bytes per thread requested at once: 128 registers, what the product's own path leaves without spilling)
 		for (int u0 = 0; u0 < g.slices; u0 += 8) {
 			f64x2l v[8][4];
 #pragma unroll
@@ -209,9 +231,13 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 				if (I < J) G[(long)cc * RP + rr] = sum[k][h];
 			}
 	}
+	stamp64(g.stamps, swg, 3);
 }
 
-template <int D, int NC>      // NC = 16-column tiles per wave: 4 (64 panel columns) or 2 (ranks <= 32: the first 32 columns only)
+// RH = row halves per workgroup: 2 (the 128-row x-tile: two halves x four pieces of the slice) or -- round 6 -- 1: a workgroup takes ONE 64-row half of an x-tile
+// and its eight waves eight pieces of the slice.  Twice the workgroups with half the MFMAs each: for grids that leave more than half of the chip idle (the
+// reference example's shape: 96 workgroups of 8 waves = two waves on every SIMD of 96 CUs, 15.6 us of matrix-pipe time per launch for 0.4 GFLOP, tools/stamp_f64.py).
+template <int D, int NC, int RH>      // NC = 16-column tiles per wave: 4 (64 panel columns) or 2 (ranks <= 32: the first 32 columns only)
 __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const double* __restrict__ A, long tile_stride,
 	const double* __restrict__ F, int RP,
@@ -226,14 +252,18 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 		if (ride.P != nullptr && pid < (nbk * (nbk + 1) / 2) * ride.slices + (ride.sumsq_part != nullptr ? nbk : 0)) gram_ride_f64(ride, RP, pid, lds64);
 		return;
 	}
-	const int xt = blockIdx.x, sp = blockIdx.y;
+	const int xt = RH == 2 ? (int)blockIdx.x : (int)blockIdx.x >> 1, sp = blockIdx.y;      // (xtiles counts the product workgroups along x: half tiles when RH = 1)
+	const int pwg = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * xtiles + (int)blockIdx.x;
+	stamp64(ride.stamps, pwg, 0);
 	const int coff = 64 * blockIdx.z;             // 64-column chunk of the panel (grid.z = RP / 64)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	const int l15 = lane & 15, kq = lane >> 4;
-	const int rh = wave & 1, kp = wave >> 1;      // row half, piece of the slice
+	const int rh = RH == 2 ? wave & 1 : (int)blockIdx.x & 1;      // row half,
+	const int kp = RH == 2 ? wave >> 1 : wave;                    // piece of the slice
+	constexpr int KP = 8 / RH;
 
-	const int np = splits * 4, pidx = sp * 4 + kp;
+	const int np = splits * KP, pidx = sp * KP + kp;
 	const int s0 = (int)(((long)steps_total * pidx) / np);
 	const int s1 = (int)(((long)steps_total * (pidx + 1)) / np);
 	const int steps = s1 - s0;
@@ -291,6 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 		}
 	}
 
+	stamp64(ride.stamps, pwg, 1);
 	// ---- sum the four pieces of each row half through LDS, eight tiles per round ------------------------------
 	// A round carries BPR = 8 / NC row blocks x NC column tiles of every wave.
 	// LDS image of a round: [wave 8][tile 8][pair 2][lane 64] f64x2   (128 KiB)
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	double* slab = slabs + (long)sp * slab_stride;
 #pragma unroll
 	for (int rd = 0; rd < ROUNDS; ++rd) {
-		if (rd > 0) __syncthreads();
+		if (rd > 0) lds_barrier64();
 #pragma unroll
 		for (int t8 = 0; t8 < 8; ++t8)
 #pragma unroll
@@ -311,8 +342,33 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 				v[0] = acc[b][nb][2 * pr]; v[1] = acc[b][nb][2 * pr + 1];
 				l2[(((wave * 8) + t8) * 2 + pr) * 64 + lane] = v;
 			}
-		__syncthreads();
-		{
+		lds_barrier64();
+		stamp64(ride.stamps, pwg, 3 + rd);
+		if (RH == 1) {
+			// 16 (tile, register pair) slices per round, eight pieces each; a wave takes two neighbouring column tiles of one (row block, pair):
+			//   NC = 4: row block w >> 2 of the round, pair (w >> 1) & 1, tiles 2 (w & 1) and 2 (w & 1) + 1;   NC = 2: row block w >> 1, pair w & 1, both tiles
+			const int obl = NC == 4 ? wave >> 2 : wave >> 1;
+			const int opr = NC == 4 ? (wave >> 1) & 1 : wave & 1;
+			const int nb0 = NC == 4 ? 2 * (wave & 1) : 0;
+			f64x2 sum[2];
+#pragma unroll
+			for (int q = 0; q < 2; ++q) {
+				const int t8 = obl * NC + nb0 + q;
+				f64x2 s = l2[((0 * 8 + t8) * 2 + opr) * 64 + lane];
+#pragma unroll
+				for (int p = 1; p < 8; ++p) s += l2[((p * 8 + t8) * 2 + opr) * 64 + lane];
+				sum[q] = s;
+			}
+			const int b = BPR * rd + obl;
+#pragma unroll
+			for (int gg = 0; gg < 2; ++gg) {
+				const int i = kq + 4 * (2 * opr + gg);
+				const int x = xt * F64_TH + 64 * rh + 4 * i + b;
+				f64x2 o;
+				o[0] = sum[0][gg]; o[1] = sum[1][gg];
+				*reinterpret_cast<f64x2*>(slab + (long)x * RP + coff + NC * l15 + nb0) = o;
+			}
+		} else {
 			// 32 (row half, tile, register pair) slices per round, four per wave: all NC column tiles of
 			//   NC = 4: (row half w & 1, row block (w >> 1) & 1 of the round, pair w >> 2)
 			//   NC = 2: (row half w & 1, pair (w >> 1) & 1, row blocks 2 (w >> 2) and 2 (w >> 2) + 1 of the round)
@@ -343,6 +399,7 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 			}
 		}
 	}
+	stamp64(ride.stamps, pwg, 2);
 }
 
 // Reduction length in K-steps of four y; as many slices as fill the CUs, at least 16 K-steps per wave piece.
@@ -351,11 +408,24 @@ FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus) {
 	p.th = F64_TH;
 	p.xtiles = (X + F64_TH - 1) / F64_TH;
 	p.steps_total = (Y + 3) / 4;
-	int max_splits = p.steps_total / (16 * 4);
+	int min_steps = 16;
+	if (const char* e = tuning_env("NMFAMD_F64_MIN_STEPS")) { if (std::atoi(e) > 0) min_steps = std::atoi(e); }
+	int max_splits = p.steps_total / (min_steps * 4);
 	if (max_splits < 1) max_splits = 1;
 	p.splits = std::max(1, std::min(num_cus / std::max(1, p.xtiles), max_splits));
 	p.nb = 4;
 	p.chunks = RP / 64;
+	// Half-tile workgroups (RH = 1: a 64-row half of an x-tile, eight pieces of the K slice per workgroup) where whole tiles would leave more than 60 % of the chip idle:
+	// twice the workgroups along x and, with eight pieces instead of four, HALF the K slices for the same K-steps per wave -- half the slabs the update kernel
+	// behind the launch adds.  Reference example (H side: 2 x-tiles x 3 chunks, 1 024 K-steps): 16 slices x 6 = 96 workgroups of 16 K-steps per wave (two waves
+	// per SIMD: 15.6 us of matrix pipe) -> 8 slices x 12 = 96 workgroups, the same pipe time, 8 slabs; W side (32 x-tiles, 42 K-steps): 96 -> 192 workgroups
+	// of 5 K-steps per wave.  76.0 -> 70.2 us per iteration (profiles/r06_f64_example.md).  The Gram passengers of the fused iteration take the CUs left over.
+	p.half_tiles = (10 * p.xtiles * p.splits * p.chunks <= 4 * num_cus && p.steps_total / 8 >= 4) ? 1 : 0;
+	if (const char* e = tuning_env("NMFAMD_F64_HALF_TILES")) p.half_tiles = std::atoi(e) != 0 ? 1 : 0;
+	if (p.half_tiles) {
+		max_splits = std::max(1, p.steps_total / (min_steps * 8));
+		p.splits = std::max(1, std::min(num_cus / std::max(1, 2 * p.xtiles * p.chunks), max_splits));
+	}
 	return p;
 }
 
@@ -379,18 +449,20 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 		const int pass = gram_ride_f64_workgroups(RP, ride.slices, ride.sumsq_part != nullptr), rows = p.splits * p.chunks;
 		extra = (pass + rows - 1) / rows;
 	}
-	dim3 grid(p.xtiles + extra, p.splits, p.chunks), block(512);
-	if (p.nb == 2 && RP == 64) {
-		// ranks <= 32: the first 32 panel columns only (the rest of every slab stays at its initial zeros)
-		static std::atomic<unsigned long long> lds_done2{0ull};
-		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 2>), (int)lds_bytes, lds_done2); e != hipSuccess) return e;
-		hipLaunchKernelGGL((k_factor_product_f64<D, 2>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, p.xtiles, ride);
-		return hipGetLastError();
-	}
-	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, 4>), (int)lds_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_factor_product_f64<D, 4>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, p.xtiles, ride);
-	return hipGetLastError();
+	const int xblocks = p.half_tiles ? 2 * p.xtiles : p.xtiles;
+	dim3 grid(xblocks + extra, p.splits, p.chunks), block(512);
+#define NMFAMD_F64_PRODUCT(NCV, RHV)                                                                                                                       \
+	do {                                                                                                                                                  \
+		static std::atomic<unsigned long long> done{0ull};                                                                                                \
+		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, NCV, RHV>), (int)lds_bytes, done); e != hipSuccess) return e; \
+		hipLaunchKernelGGL((k_factor_product_f64<D, NCV, RHV>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, xblocks, ride); \
+		return hipGetLastError();                                                                                                                         \
+	} while (0)
+	// ranks <= 32 (nb == 2): the first 32 panel columns only (the rest of every slab stays at its initial zeros)
+	if (p.nb == 2 && RP == 64) { if (p.half_tiles) NMFAMD_F64_PRODUCT(2, 1); else NMFAMD_F64_PRODUCT(2, 2); }
+	if (p.half_tiles) NMFAMD_F64_PRODUCT(4, 1);
+	NMFAMD_F64_PRODUCT(4, 2);
+#undef NMFAMD_F64_PRODUCT
 }
 
 
@@ -412,18 +484,21 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 //                       den = S D t: v(c) = s_dv(c) t(c), den(c) = off (sigma - v(c)) + diag v(c), sigma = the row's sum of v over all column tiles (through LDS)
 //                       -- S D (Wt^T Wt) D S old = (W S)^T (W S) old, AlgorithmNonSmoothNMF.h:175-177, without a pass over the r x r matrix
 //   fused64_smooth_out: out(y, c) = S new(y, :) -- the smoothed panel the next product and its Gram passengers read (AlgorithmNonSmoothNMF.h:194)
+// s_dv, filled at the kernel's start next to the slab loads (a first version read the scale from global memory inside fused64_h_prepare's loop: RP / TPR dependent
+// loads per thread, 3 us of the H update at the reference example's shape)
+__device__ __forceinline__ void fused64_fill_scale(double* s_dv, int RP, const PanelFusedF64& fx) {
+	const int r_eff = fx.smooth ? fx.r : RP;
+	for (int c = threadIdx.x; c < RP; c += 256) s_dv[c] = c < r_eff ? (fx.scale != nullptr ? fx.scale[c] : 1.0) : 0.0;
+}
 template <int YB>
 __device__ __forceinline__ void fused64_h_prepare(double* s_num, const double* s_old, double* s_dv, double* s_rs, int LD, int RP, const PanelFusedF64& fx) {
 	constexpr int TPR = 256 / YB;
 	const int r_eff = fx.smooth ? fx.r : RP;
-	for (int c = threadIdx.x; c < RP; c += 256) s_dv[c] = c < r_eff ? (fx.scale != nullptr ? fx.scale[c] : 1.0) : 0.0;
 	const int y = threadIdx.x / TPR, sub = threadIdx.x % TPR;
 	double* row = s_num + y * LD;
 	double sum = 0.0, osum = 0.0;
 	for (int c = sub; c < RP; c += TPR) {
-		double x = row[c];
-		if (fx.scale != nullptr) x *= fx.scale[c];
-		if (c >= r_eff) x = 0.0;
+		const double x = row[c] * s_dv[c];      // (zero from r_eff on)
 		row[c] = x;
 		sum += x;
 		if (c < r_eff) osum += s_old[y * LD + c];
@@ -470,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 #pragma unroll
 	for (int t = 0; t < 16; ++t) qa[t] = Q[(long)(4 * t + kq) * 64 + 16 * wave + l15];
 
+	if (HS) fused64_fill_scale(s_dv, 64, fx);
 	// numerator = sum of the split-K slabs (slab order), old panel values: four 16-byte pieces per thread and array
 	{
 		f64x2 num[4];
@@ -622,7 +698,9 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 	const long base = (long)blockIdx.x * YB * RP;
 	const int h2 = RP / 2;                 // 16-byte pieces per panel row
 	constexpr int NE = YB * 32 * NCT / 256;   // pieces per thread: 16 rows * (64 NCT / 2) / 256 threads = 2 NCT
+	stamp64(fx.stamps, blockIdx.x, 0);
 
+	if (HS) fused64_fill_scale(s_dv, RP, fx);
 	{
 		f64x2 num[NE];
 #pragma unroll
@@ -637,7 +715,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 			}
 		}
 		// (SB slabs requested at a time, added in slab order -- see k_panel_update64_f64)
-		constexpr int SB = NE <= 8 ? 4 : 2;
+#ifndef WIDE64_SB
+#define WIDE64_SB (NE <= 6 ? 8 : (NE <= 12 ? 4 : 2))
+#endif
+		constexpr int SB = WIDE64_SB;
 		for (int k = 1; k < S; k += SB) {
 			f64x2 t[SB][NE];
 #pragma unroll
@@ -659,10 +740,12 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		}
 	}
 	__syncthreads();
+	stamp64(fx.stamps, blockIdx.x, 1);
 	if (HS) {
 		fused64_h_prepare<YB>(s_num, s_old, s_dv, s_rs, LD, RP, fx);
 		__syncthreads();
 	}
+	stamp64(fx.stamps, blockIdx.x, 2);
 
 	const double* vec = (MODE == PANEL_MU ? s_old : s_num) + l15 * LD + kq;
 	f64x4 acc[NCT];
@@ -672,7 +755,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		for (int g = 0; g < 4; ++g) acc[i][g] = 0.0;
 	const double* qp = Q + (long)kq * RP + 16 * wave + l15;      // + 4 t RP per K-step, + 64 i per tile
 	const int steps = RP / 4;                                     // multiple of 16 (RP of 64): whole turns of the ring of eight
-	constexpr int D = (HS && NCT >= 7) ? 4 : 8;                   // (the H-side form at 448 / 512 columns: a shorter ring instead of spills)
+#ifndef WIDE64_RING
+#define WIDE64_RING ((HS && NCT >= 7) ? 4 : 8)
+#endif
+	constexpr int D = WIDE64_RING;                                // (the H-side form at 448 / 512 columns: a shorter ring instead of spills; sixteen K-steps in flight at narrow panels measured +1 us)
 	const double h_a = HS ? fx.diag - fx.off : 1.0, h_b = HS ? fx.off * s_rs[l15] : 0.0;
 	const double* dvp = s_dv + kq;
 	auto bval = [&](int t) { double h = vec[4 * t]; if (HS) h = dvp[4 * t] * (h_a * h + h_b); return h; };
@@ -697,6 +783,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
+	stamp64(fx.stamps, blockIdx.x, 3);
 	if (HS) {
 		// den = S D t
 		double sig = 0.0;
@@ -740,6 +827,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 	psum += __shfl_xor(psum, 32);
 	if (kq == 0) s_ps[wave * YB + l15] = psum;
 	__syncthreads();
+	stamp64(fx.stamps, blockIdx.x, 4);
 
 #pragma unroll
 	for (int i = 0; i < NE; ++i) {
@@ -759,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 			sumsq_part[(long)blockIdx.x * RP + c] = s;
 		}
 	}
+	stamp64(fx.stamps, blockIdx.x, 5);
 }
 
 bool panel_update_wide_f64_available(int RP) { return RP >= 128 && RP % 64 == 0 && RP <= 512; }

@@ -42,6 +42,14 @@ def test_default_bench_line_has_the_contract_fields():
         assert m2["achieved"] == pytest.approx(6.0 * r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12, rel=1e-6) and 0.1 < m2["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+    # round 6: the line says what the CPU legs ran on (probed: affinity mask, cgroup quota, /proc/cpuinfo) and uses every available core unless --cpu-threads caps it
+    assert c["affinity_cores"] >= c["cores_available"] >= 1 and c["cores"] == c["cores_available"] and isinstance(c["cpu_model"], str) and c["cpu_model"]
+    assert c["cgroup_quota_cores"] is None or c["cgroup_quota_cores"] > 0
+    # ... and carries BOTH warm states: `value` behind the harness's set-up phase (config.setup_iterations), value_driver_warmup_only = the same K steps right
+    # behind the driver's --warmup steps and nothing else (a cold device runs slower: the ramp from idle takes ~125 iterations, profiles/r04_warmup_timeline.txt)
+    assert d["config"]["setup_iterations"] > 0
+    assert d["value_driver_warmup_only"] == pytest.approx(1e3 / d["ms_per_step_driver_warmup_only"], rel=1e-6)
+    assert 0.5 * d["value"] < d["value_driver_warmup_only"] < 1.1 * d["value"]
     # the iteration converged to the same error as every other path on this input (oracle: 2022.63 after 220 iterations;
     # here after 50)
     assert 2000 < d["frobenius_last"] < 2100

@@ -151,7 +151,7 @@ Engine<T>::~Engine() {
 		}
 		(void)hipFree(f64_stamps_);
 	}
-	{ void* fb[] = {f64_scale_, f64_partial_, f64_counters_}; for (void* b : fb) if (b) (void)hipFree(b); }
+	{ void* fb[] = {f64_scale_, f64_partial_, f64_counters_, f64_items_h_, f64_items_w_}; for (void* b : fb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
 	if (rowdot_part_) (void)hipFree(rowdot_part_);
@@ -445,6 +445,15 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&f64_partial_, sizeof(double) * 4096 * (size_t)nsuper * (size_t)std::max(f64_slices_h_, f64_slices_w_)));
 		HIPX(hipMalloc((void**)&f64_counters_, sizeof(unsigned) * (size_t)(nsuper + 1)));
 		HIPX(hipMemsetAsync(f64_counters_, 0, sizeof(unsigned) * (size_t)(nsuper + 1), stream_));
+		if (tuning_env("NMFAMD_RIDE64_PID_ORDER") == nullptr) {
+			std::vector<int> items;
+			gram_ride_f64_items(planH_, RP_, f64_slices_h_, items);
+			HIPX(hipMalloc((void**)&f64_items_h_, sizeof(int) * items.size()));
+			HIPX(hipMemcpy(f64_items_h_, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+			gram_ride_f64_items(planW_, RP_, f64_slices_w_, items);
+			HIPX(hipMalloc((void**)&f64_items_w_, sizeof(int) * items.size()));
+			HIPX(hipMemcpy(f64_items_w_, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+		}
 		if (tuning_env("NMFAMD_F64_STAMPS") != nullptr) {
 			HIPX(hipMalloc((void**)&f64_stamps_, sizeof(unsigned long long) * 4 * 4096 * 8));
 			HIPX(hipMemsetAsync(f64_stamps_, 0, sizeof(unsigned long long) * 4 * 4096 * 8, stream_));
@@ -1391,6 +1400,7 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		gw.sumsq_part = f64_pending_ ? sumsq_part_ : nullptr; gw.sumsq_parts = norm_parts; gw.scale_out = f64_scale_;
 		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gw.stop = std::atoi(e);
 		gw.stamps = f64_stamps_;
+		gw.items = f64_items_h_;
 		ride64_ = &gw;
 		if (Status s = product_h(Wt_)) return s;
 		ride64_ = nullptr;
@@ -1409,6 +1419,7 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		gh.P = Fh; gh.len = n_; gh.slices = f64_slices_w_; gh.partial = f64_partial_; gh.counters = f64_counters_; gh.G = HHt_;
 		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gh.stop = std::atoi(e);
 		gh.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 2l * 4096 * 8 : nullptr;
+		gh.items = f64_items_w_;
 		ride64_ = &gh;
 		if (Status s = product_w(Fh)) return s;
 		ride64_ = nullptr;

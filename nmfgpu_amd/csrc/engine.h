@@ -308,6 +308,7 @@ private:
 	bool f64_pending_ = false;
 	double *f64_scale_ = nullptr, *f64_partial_ = nullptr;
 	unsigned* f64_counters_ = nullptr;
+	int *f64_items_h_ = nullptr, *f64_items_w_ = nullptr;   // XCD-aware work tables of the passengers (gram_ride_f64_items)
 	int f64_slices_h_ = 0, f64_slices_w_ = 0;        // K slices of the Gram passengers riding in the W^T V / V H^T launch
 	const GramRideF64* ride64_ = nullptr;            // set around a product_h / product_w call
 	unsigned long long* f64_stamps_ = nullptr;       // measurement builds (NMFAMD_F64_STAMPS = file): [4 launches][4096][8] stamps of the LAST fused iteration, written out by the destructor

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <vector>
 
 namespace nmfamd {
 
@@ -17,6 +18,7 @@ struct FactorProductPlan {
 	int splits;       // workgroup slices of the reduction range = number of output slabs
 	int nb;           // 32-wide N-blocks per wave tile: 2, or 1 when only the first 32 panel columns are needed (rank <= 32)
 	int chunks;       // launches needed to cover RP = chunks * 64 factor rows
+	int xhalves = 0;    // fp64 product: 64-row halves of x-tiles that hold valid rows
 	int half_tiles = 0; // fp64 product: 1 = a workgroup takes one 64-row half of an x-tile and eight pieces of its K slice (kernels_f64.hip, RH = 1): small grids
 	int col_split = 0; // split-operand product, RP = 64 only: 2 = a workgroup takes 32 of the 64 panel columns (twice the workgroups, half the MFMAs per K-step and
 	                   // wave; the operand is split twice) -- for small reduction ranges, where the 128 x 64 form leaves most of the chip idle; same bits
@@ -294,12 +296,14 @@ struct GramRideF64 {
 	const double* sumsq_part;   // the pending column scale's source: sumsq_parts vectors of RP partial sums of squares (nullptr: no scale passengers)
 	int sumsq_parts;
 	double* scale_out;          // [RP] d(c) = sum > 0 ? 1 / sqrt(sum) : 1
+	const int* items;           // [super-blocks * slices] which (super-block, slice) passenger pid takes (gram_ride_f64_items; nullptr: pid order)
 	int stop;                   // measurement builds (NMFAMD_RIDE64_STOP): 1 = passengers return at once, 2 = after their partial block, 3 = after counting in (results void)
 	unsigned long long* stamps; // measurement builds: [4096][8] wall-clock stamps (product workgroups from 0, passengers from 2048), tools/stamp_f64.py
 };
-int gram_ride_f64_workgroups(int RP, int slices, bool with_scale);
+int gram_ride_f64_workgroups(int RP, int slices);
 hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
                                      double* slabs, long slab_stride, hipStream_t stream, const GramRideF64* ride = nullptr);
+void gram_ride_f64_items(const FactorProductPlan& p, int RP, int slices, std::vector<int>& items);
 
 // Extras of the fused double-precision iteration (Engine::iterate_fused64): W stays unnormalised in its panel with a pending column scale d (a vector the scale
 // passengers of the W^T V launch leave), and nsNMF's smoothing S = (diag - off) I + off 1 1^T (first r entries) is applied where a row of the panel sits in LDS anyway

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "kernels.h"
 #include "tuning.h"
@@ -108,7 +109,10 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 		}
 		return;
 	}
-	const int sb = pid / g.slices, slice = pid - sb * g.slices;
+	// which (super-block, K slice) this workgroup takes: from the engine's table (XCD-aware: the workgroups an XCD receives take the same K slices, so that every
+	// XCD's L2 pulls its slices' rows of the panel once instead of the whole panel -- gram_ride_f64_items) or in pid order
+	const int item = g.items != nullptr ? g.items[pid] : pid;
+	const int sb = item / g.slices, slice = item - sb * g.slices;
 	int I = 0, rem = sb;
 	while (rem >= nb - I) { rem -= nb - I; ++I; }
 	const int J = I + rem;
@@ -130,7 +134,7 @@ __device__ __forceinline__ void gram_ride_f64(const GramRideF64& g, int RP, int 
 #ifndef RIDE64_RING
 #define RIDE64_RING 8
 #endif
-		constexpr int DG = RIDE64_RING;      // (K-steps in flight; sixteen measured +1 us per launch at the reference example's shape)
+		constexpr int DG = RIDE64_RING;      // (K-steps in flight; sixteen measured no faster)
 		const double* pa = g.P + ((long)4 * s0 + kq) * RP + ca + 2 * l15;
 		const double* pb = g.P + ((long)4 * s0 + kq) * RP + cb + 2 * l15;
 		const long step = 4 * (long)RP;
@@ -242,14 +246,14 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const double* __restrict__ A, long tile_stride,
 	const double* __restrict__ F, int RP,
 	double* __restrict__ slabs, long slab_stride,
-	int steps_total, int splits, int xtiles, GramRideF64 ride) {
+	int steps_total, int splits, int xtiles, int xhalves, GramRideF64 ride) {
 	extern __shared__ __attribute__((aligned(16))) double lds64[];
 	if ((int)blockIdx.x >= xtiles) {
 		// passenger workgroups behind the x-tiles of every (slice, chunk) row of the grid
 		const int extra = (int)gridDim.x - xtiles;
 		const int pid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * extra + ((int)blockIdx.x - xtiles);
 		const int nbk = RP / 64;
-		if (ride.P != nullptr && pid < (nbk * (nbk + 1) / 2) * ride.slices + (ride.sumsq_part != nullptr ? nbk : 0)) gram_ride_f64(ride, RP, pid, lds64);
+		if (ride.P != nullptr && pid < (nbk * (nbk + 1) / 2) * ride.slices + nbk) gram_ride_f64(ride, RP, pid, lds64);
 		return;
 	}
 	const int xt = RH == 2 ? (int)blockIdx.x : (int)blockIdx.x >> 1, sp = blockIdx.y;      // (xtiles counts the product workgroups along x: half tiles when RH = 1)
@@ -266,7 +270,8 @@ __global__ __launch_bounds__(512, 2) void k_factor_product_f64(
 	const int np = splits * KP, pidx = sp * KP + kp;
 	const int s0 = (int)(((long)steps_total * pidx) / np);
 	const int s1 = (int)(((long)steps_total * (pidx + 1)) / np);
-	const int steps = s1 - s0;
+	// (a 64-row half behind the last valid row -- the reference example's H side: 165 rows in two 128-row tiles -- is all padding: no K-steps, its slab rows are zeros)
+	const int steps = 2 * xt + rh < xhalves ? s1 - s0 : 0;
 
 	typedef double fvec __attribute__((ext_vector_type(NC)));
 	f64x4 acc[4][NC];
@@ -407,6 +412,7 @@ FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus) {
 	FactorProductPlan p;
 	p.th = F64_TH;
 	p.xtiles = (X + F64_TH - 1) / F64_TH;
+	p.xhalves = (X + 63) / 64;
 	p.steps_total = (Y + 3) / 4;
 	int min_steps = 16;
 	if (const char* e = tuning_env("NMFAMD_F64_MIN_STEPS")) { if (std::atoi(e) > 0) min_steps = std::atoi(e); }
@@ -423,17 +429,54 @@ FactorProductPlan plan_factor_product_f64(int X, int Y, int RP, int num_cus) {
 	p.half_tiles = (10 * p.xtiles * p.splits * p.chunks <= 4 * num_cus && p.steps_total / 8 >= 4) ? 1 : 0;
 	if (const char* e = tuning_env("NMFAMD_F64_HALF_TILES")) p.half_tiles = std::atoi(e) != 0 ? 1 : 0;
 	if (p.half_tiles) {
+		// (more, shorter slices -- thirteen at the reference example's H side, 156 + 99 workgroups -- measured slower: not every workgroup of a grid that size is
+		//  resident at once, the late ones end the launch)
 		max_splits = std::max(1, p.steps_total / (min_steps * 8));
-		p.splits = std::max(1, std::min(num_cus / std::max(1, 2 * p.xtiles * p.chunks), max_splits));
+		p.splits = std::max(1, std::min(num_cus / std::max(1, p.xhalves * p.chunks), max_splits));
 	}
 	return p;
 }
 
 // A: x-tiled image (launch_tile<double>, tile height 128, the reduction length padded to a multiple of 4 with zeros);
 // F: panel [y][RP]; slabs: plan.splits partial results, panel layout [x][RP].
-int gram_ride_f64_workgroups(int RP, int slices, bool with_scale) {
+// (the RP / 64 scale passengers always have their places in the grid: one layout per engine, whether a scale is pending or not)
+int gram_ride_f64_workgroups(int RP, int slices) {
 	const int nb = RP / 64;
-	return (nb * (nb + 1) / 2) * slices + (with_scale ? nb : 0);
+	return (nb * (nb + 1) / 2) * slices + nb;
+}
+
+static void ride64_grid(const FactorProductPlan& p, int RP, int slices, int* xblocks, int* extra) {
+	*xblocks = p.half_tiles ? 2 * p.xtiles : p.xtiles;
+	const int pass = gram_ride_f64_workgroups(RP, slices), rows = p.splits * p.chunks;
+	*extra = (pass + rows - 1) / rows;
+}
+
+// items[pid] = super-block * slices + slice for the passengers pid < super-blocks * slices of the launch launch_factor_product_f64(p, ..., ride) makes.
+// Model: the hardware deals the workgroups of a grid to the eight XCDs in linear order (x fastest), workgroup L to XCD L mod 8 (what the KL gather and the
+// split-operand product's placement rely on too).  K slice s belongs to XCD s mod 8: an XCD's passengers take its slices' items first (super-blocks in order), what is
+// left over goes to the XCDs with passengers to spare.  Only the traffic depends on the model being right, never the result: every item is taken exactly once.
+void gram_ride_f64_items(const FactorProductPlan& p, int RP, int slices, std::vector<int>& items) {
+	const int nbk = RP / 64, nsuper = nbk * (nbk + 1) / 2, count = nsuper * slices;
+	int xblocks, extra;
+	ride64_grid(p, RP, slices, &xblocks, &extra);
+	const int GX = xblocks + extra, GY = p.splits;
+	items.assign((size_t)count, -1);
+	std::vector<std::vector<int>> wgs(8), work(8);
+	for (int pid = 0; pid < count; ++pid) {
+		const int row = pid / extra, x = xblocks + pid % extra;      // row = z * GY + y
+		const long L = (long)x + (long)GX * ((row % GY) + (long)GY * (row / GY));
+		wgs[(int)(L % 8)].push_back(pid);
+	}
+	for (int sl = 0; sl < slices; ++sl)
+		for (int sb = 0; sb < nsuper; ++sb) work[sl % 8].push_back(sb * slices + sl);
+	std::vector<int> spare_wgs, spare_work;
+	for (int x = 0; x < 8; ++x) {
+		const size_t k = std::min(wgs[x].size(), work[x].size());
+		for (size_t i = 0; i < k; ++i) items[(size_t)wgs[x][i]] = work[x][i];
+		for (size_t i = k; i < wgs[x].size(); ++i) spare_wgs.push_back(wgs[x][i]);
+		for (size_t i = k; i < work[x].size(); ++i) spare_work.push_back(work[x][i]);
+	}
+	for (size_t i = 0; i < spare_wgs.size() && i < spare_work.size(); ++i) items[(size_t)spare_wgs[i]] = spare_work[i];
 }
 
 hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A, long tile_stride, const double* F, int RP,
@@ -446,16 +489,15 @@ hipError_t launch_factor_product_f64(const FactorProductPlan& p, const double* A
 	if (ride_in != nullptr && ride_in->P != nullptr) {
 		if (ride_in->slices < 1 || RP > 512) return hipErrorInvalidValue;
 		ride = *ride_in;
-		const int pass = gram_ride_f64_workgroups(RP, ride.slices, ride.sumsq_part != nullptr), rows = p.splits * p.chunks;
-		extra = (pass + rows - 1) / rows;
 	}
-	const int xblocks = p.half_tiles ? 2 * p.xtiles : p.xtiles;
+	int xblocks = p.half_tiles ? 2 * p.xtiles : p.xtiles;
+	if (ride.P != nullptr) ride64_grid(p, RP, ride.slices, &xblocks, &extra);
 	dim3 grid(xblocks + extra, p.splits, p.chunks), block(512);
 #define NMFAMD_F64_PRODUCT(NCV, RHV)                                                                                                                       \
 	do {                                                                                                                                                  \
 		static std::atomic<unsigned long long> done{0ull};                                                                                                \
 		if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_factor_product_f64<D, NCV, RHV>), (int)lds_bytes, done); e != hipSuccess) return e; \
-		hipLaunchKernelGGL((k_factor_product_f64<D, NCV, RHV>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, xblocks, ride); \
+		hipLaunchKernelGGL((k_factor_product_f64<D, NCV, RHV>), grid, block, lds_bytes, stream, A, tile_stride, F, RP, slabs, slab_stride, p.steps_total, p.splits, xblocks, p.xhalves > 0 ? p.xhalves : 2 * p.xtiles, ride); \
 		return hipGetLastError();                                                                                                                         \
 	} while (0)
 	// ranks <= 32 (nb == 2): the first 32 panel columns only (the rest of every slab stays at its initial zeros)
@@ -716,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		}
 		// (SB slabs requested at a time, added in slab order -- see k_panel_update64_f64)
 #ifndef WIDE64_SB
-#define WIDE64_SB (NE <= 6 ? 8 : (NE <= 12 ? 4 : 2))
+#define WIDE64_SB (NE <= 4 ? 8 : (NE <= 8 ? 4 : 2))      /* at most 32 sixteen-byte loads (128 registers) in flight */
 #endif
 		constexpr int SB = WIDE64_SB;
 		for (int k = 1; k < S; k += SB) {

@@ -142,6 +142,9 @@ typedef struct nmfamd_geometry {
 	/* round 6 */
 	int fused_launches;             /* 4: an iteration is product (+ Gram passengers) / update / product (+ Gram passengers) / update -- fp32 at padded rank 64 and,
 	                                   round 6, double precision (multiplicative update and nsNMF, padded ranks up to 512); 0: the generic launch sequence */
+	int sparse_setup;               /* sparse compute: where the CSR + CSC images of the last upload were built: 1 = on the device (kernels_sparse_setup.hip),
+	                                   0 = on the host (NMFAMD_SPARSE_SETUP=host, or an input the device path hands back: entries outside the matrix, a row or
+	                                   column of more than 8 192 entries, pointer arrays that do not ascend), -1 = not a sparse-compute engine */
 	int gram_ride_slices_h, gram_ride_slices_w;   /* double precision: K slices per 64 x 64 super-block of the Gram passengers riding in W^T V / V H^T (they fix the order of the partial sums) */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);

@@ -24,7 +24,7 @@ LIB = os.path.join(LIBDIR, "libnmfgpu64.so")
 # the measurement build (-DNMFAMD_DIAG_BUILD, csrc/tuning.h): the same library with its A/B switches and stamped kernel variants compiled in; the tests that compare
 # kernel FORMS with each other select them there (tests/conftest.py, fixture diag_build); never loaded by the product path
 DIAG_LIB = os.path.join(LIBDIR, "libnmfgpu64_diag.so")
-SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "kernels_onepass.hip", "kernels_tri.hip", "comm.hip", "engine.cpp", "sharded.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
+SOURCES = ["kernels.hip", "kernels_fast.hip", "kernels_mu64.hip", "kernels_sparse.hip", "kernels_sparse_setup.hip", "kernels_bf16.hip", "kernels_wide.hip", "kernels_f64.hip", "kernels_x3.hip", "kernels_onepass.hip", "kernels_tri.hip", "comm.hip", "engine.cpp", "sharded.cpp", "amd_api.cpp", "abi.cpp", "host_init.cpp"]
 ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 # translation units without device code or HIP runtime calls: plain C++ (function multiversioning
 # is rejected by the device pass of a -x hip compile); no implicit contraction: where the reference's

@@ -347,6 +347,7 @@ int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out) {
 		out->slabs_h = g.slabs_h(); out->slabs_w = g.slabs_w(); out->exchange_count = g.exchange_count();
 		out->product_kernel = g.product_kernel(); out->resident_images = g.resident_images(); out->one_pass = g.one_pass_state();
 		out->kl_blocks_w = g.kl_blocks(true); out->kl_blocks_h = g.kl_blocks(false); out->gram_k_slices = g.gram_k_slices(); out->w_col_split = g.w_col_split() ? 1 : 0;
+		out->sparse_setup = g.sparse_mode() ? (g.sparse_setup_on_device() ? 1 : 0) : -1;
 		out->fused_launches = g.fused_launches(); out->gram_ride_slices_h = g.gram_ride_slices(false); out->gram_ride_slices_w = g.gram_ride_slices(true);
 	};
 	if (e->elem_bytes == 4) fill(*e->f); else fill(*e->d);

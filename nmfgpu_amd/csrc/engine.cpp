@@ -538,6 +538,15 @@ template <typename T>
 Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const int* b, long nnz, int base) {
 	if (format < 1 || format > 3 || nnz < 0 || (nnz > 0 && (!values || !a || !b))) return ST_INVALID;
 	if (sparse_) {
+		// the images are built on the device (kernels_sparse_setup.hip); what that path does not cover -- entries outside the matrix (dropped below), pointer
+		// arrays that do not ascend, a row or column longer than its LDS sort takes, no entries at all -- and NMFAMD_SPARSE_SETUP=host take the host path
+		const char* where = std::getenv("NMFAMD_SPARSE_SETUP");
+		if (!(where != nullptr && std::strcmp(where, "host") == 0) && nnz > 0) {
+			bool fallback = false;
+			const Status st = upload_sparse_device(format, values, a, b, nnz, base, &fallback);
+			if (!fallback) return st;
+		}
+		sparse_setup_on_device_ = false;
 		// expand to 0-based (row, column, value) triplets with the caller's index base applied exactly
 		// (reference: cusparseSetMatIndexBase, Matrix.h:158-160,184-186,215-217); out-of-range entries are dropped
 		std::vector<int> rows, cols; std::vector<T> vals;
@@ -577,6 +586,92 @@ Status Engine<T>::upload_sparse(int format, const T* values, const int* a, const
 	if (d_a) (void)hipFree(d_a);
 	if (d_b) (void)hipFree(d_b);
 	return st;
+}
+
+// The CSR and CSC images built on the device from the caller's arrays as they are (kernels_sparse_setup.hip; reference: the device-side conversions of
+// source/common/Matrix.h:145-232).  *fallback: the input needs the host path (nothing of this engine's state has been touched then, except freed images).
+template <typename T>
+Status Engine<T>::upload_sparse_device(int format, const T* values, const int* a, const int* b, long nnz, int base, bool* fallback) {
+	*fallback = false;
+	if (nnz >= (1l << 31)) return ST_INVALID;
+	const int outer = format == 1 ? m_ : n_;
+	const long na = format == 3 ? nnz : (long)outer + 1;
+	const int segs = std::max(m_, n_);
+	// scratch: freed on every way out
+	T* d_val = nullptr;
+	int *d_a = nullptr, *d_b = nullptr, *row = nullptr, *col = nullptr, *items = nullptr, *rowq = nullptr, *counts = nullptr, *small = nullptr;
+	T* d_vtv = nullptr;
+	double* d_colsum = nullptr;
+	std::vector<void*> owned;
+	auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e == hipSuccess) owned.push_back(*p); else *p = nullptr; return e; };
+	auto disown = [&](void* p) { for (auto& q : owned) if (q == p) q = nullptr; };
+	struct Cleanup { std::vector<void*>& v; ~Cleanup() { for (void* p : v) if (p) (void)hipFree(p); } } cleanup{owned};
+	auto need_host = [&]() { *fallback = true; return ST_OK; };
+
+	void** old[] = {(void**)&csr_ptr_, (void**)&csr_idx_, (void**)&csc_ptr_, (void**)&csc_idx_, (void**)&csc_from_csr_, (void**)&csr_val_, (void**)&csc_val_, (void**)&q_, (void**)&q2_};
+	for (void** o : old) { if (*o) (void)hipFree(*o); *o = nullptr; }
+	nnz_ = 0;
+
+	const size_t ni = sizeof(int) * (size_t)nnz, nv = sizeof(T) * (size_t)nnz;
+	HIPX(alloc((void**)&d_val, nv)); HIPX(alloc((void**)&d_a, sizeof(int) * (size_t)na)); HIPX(alloc((void**)&d_b, ni));
+	HIPX(alloc((void**)&row, ni)); HIPX(alloc((void**)&col, ni));
+	HIPX(alloc((void**)&counts, sizeof(int) * (size_t)segs)); HIPX(alloc((void**)&small, sizeof(int) * 4));
+	HIPX(hipMemcpyAsync(d_val, values, nv, hipMemcpyHostToDevice, stream_));
+	HIPX(hipMemcpyAsync(d_a, a, sizeof(int) * (size_t)na, hipMemcpyHostToDevice, stream_));
+	HIPX(hipMemcpyAsync(d_b, b, ni, hipMemcpyHostToDevice, stream_));
+	HIPX(hipMemsetAsync(small, 0, sizeof(int) * 4, stream_));
+	int* flags = small;                       // [0] flags, [1] longest row, [2] longest column
+	HIPX(launch_sp_expand(format, d_a, d_b, nnz, outer, base, m_, n_, row, col, flags, stream_));
+	HIPX(hipMalloc((void**)&csr_ptr_, sizeof(int) * (size_t)(m_ + 1)));
+	HIPX(hipMalloc((void**)&csc_ptr_, sizeof(int) * (size_t)(n_ + 1)));
+	HIPX(launch_sp_histogram_scan(row, nnz, m_, counts, csr_ptr_, small + 1, stream_));
+	int h_small[4] = {0, 0, 0, 0};
+	HIPX(hipMemcpyAsync(h_small, small, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	if ((h_small[0] & 3) != 0) return need_host();
+	(void)hipFree(d_a); disown(d_a); d_a = nullptr;
+	(void)hipFree(d_b); disown(d_b); d_b = nullptr;
+
+	HIPX(alloc((void**)&items, ni));
+	if ((h_small[0] & 4) != 0) {
+		// not in (row, column) order (COO, CSC, an unsorted CSR): the entries' positions by row, every row by (column, position)
+		if (h_small[1] > sp_segment_sort_capacity()) return need_host();
+		HIPX(alloc((void**)&rowq, ni));
+		HIPX(hipMalloc((void**)&csr_idx_, ni)); HIPX(hipMalloc((void**)&csr_val_, nv));
+		HIPX(launch_sp_scatter_sort(row, nnz, m_, csr_ptr_, counts, items, col, h_small[1], stream_));
+		HIPX(launch_sp_gather_csr<T>(items, row, col, d_val, nnz, csr_idx_, csr_val_, rowq, stream_));
+	} else {
+		// the input IS the CSR image (0-based by now): its buffers are adopted as they are
+		csr_idx_ = col; disown(col);
+		csr_val_ = d_val; disown(d_val); d_val = nullptr;
+		rowq = row;
+	}
+	HIPX(launch_sp_histogram_scan(csr_idx_, nnz, n_, counts, csc_ptr_, small + 2, stream_));
+	HIPX(hipMemcpyAsync(h_small, small, sizeof(int) * 4, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	if (h_small[2] > sp_segment_sort_capacity()) return need_host();
+	// the CSR positions by column, every column's list ascending = ascending row, duplicates in CSR order
+	HIPX(launch_sp_scatter_sort(csr_idx_, nnz, n_, csc_ptr_, counts, items, nullptr, h_small[2], stream_));
+	HIPX(hipMalloc((void**)&csc_idx_, ni)); HIPX(hipMalloc((void**)&csc_val_, nv));
+	HIPX(launch_sp_gather_csc<T>(items, rowq, csr_val_, nnz, csc_idx_, csc_val_, stream_));
+	const bool two_pass = tuning_env("NMFAMD_KL_TWO_PASS") != nullptr;      // (round 1's two-pass KL step, a measurement switch: quotient buffers + the CSR -> CSC permutation)
+	if (two_pass) { csc_from_csr_ = items; disown(items); HIPX(hipMalloc((void**)&q_, nv)); HIPX(hipMalloc((void**)&q2_, nv)); }
+	// tr(V^T V) terms per column (accumulated in T like the trace kernel, in the image's order) and sum(V) for the KL divergence
+	HIPX(alloc((void**)&d_vtv, sizeof(T) * (size_t)n_)); HIPX(alloc((void**)&d_colsum, sizeof(double) * (size_t)n_));
+	HIPX(launch_sp_col_sumsq<T>(csc_ptr_, csc_val_, n_, d_vtv, d_colsum, stream_));
+	h_vtv_.assign(n_, T(0));
+	std::vector<double> colsum((size_t)n_);
+	HIPX(hipMemcpyAsync(h_vtv_.data(), d_vtv, sizeof(T) * (size_t)n_, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipMemcpyAsync(colsum.data(), d_colsum, sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost, stream_));
+	HIPX(hipStreamSynchronize(stream_));
+	std::sort(h_vtv_.begin(), h_vtv_.end());
+	sum_v_ = 0;
+	for (int j = 0; j < n_; ++j) sum_v_ += colsum[j];
+	nnz_ = nnz;
+	sparse_setup_on_device_ = true;
+	if (Status st = setup_kl_blocks()) return st;
+	HIPX(hipStreamSynchronize(stream_));
+	return ST_OK;
 }
 
 template <typename T>
@@ -1835,6 +1930,16 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 		HIPX(hipMemcpyAsync(csr_val_, csr_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 		HIPX(hipMemcpyAsync(csc_val_, csc_val.data(), sizeof(T) * nnz, hipMemcpyHostToDevice, stream_));
 	}
+	nnz_ = nnz;
+	if (Status st = setup_kl_blocks()) return st;
+	HIPX(hipStreamSynchronize(stream_));
+	nnz_ = nnz;
+	return ST_OK;
+}
+
+// Blocked KL gather (kernels_sparse.hip, k_kl_fused): block counts from the shape and the device, per-(row, block) boundary pointers from the images on the device
+template <typename T>
+Status Engine<T>::setup_kl_blocks() {
 	// KL divergence: cut the gathered factor into blocks that stay in an XCD's L2 (4 MiB; NMFAMD_KL_BLOCK_KB sets the block's bytes,
 	// 0 = no blocking) when the whole factor does not: W step gathers rows of H by column index (range n), H step rows of Wt by row index
 	// (range m).  A row's entries are sorted by that index, so its entries of block b are one range: only boundaries are needed.
@@ -1859,24 +1964,14 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)1 << 62; }
 			auto fit = [&](int b, long panel_rows) { while (b > 1 && (double)b * RP_ * (double)panel_rows * sizeof(T) > 0.125 * (double)total_b) b = b > 8 ? ((b / 2 + 7) / 8) * 8 : b / 2; return b; };
 			kl_blocks_w_ = fit(kl_blocks_w_, mpad_); kl_blocks_h_ = fit(kl_blocks_h_, npad_);
-			auto boundaries = [&](const std::vector<int>& ptr, const std::vector<int>& idx, int rows, long range, int blocks, int** dev) -> hipError_t {
+			auto boundaries = [&](const int* ptr, const int* idx, int rows, long range, int blocks, int** dev) -> hipError_t {
 				if (blocks <= 1) return hipSuccess;
-				const long per = (range + blocks - 1) / blocks;
-				std::vector<int> bp((size_t)rows * (blocks + 1));
-				for (int i = 0; i < rows; ++i) {
-					int p = ptr[i];
-					for (int b = 0; b <= blocks; ++b) {
-						const long lim = (long)b * per;                      // first index of block b
-						while (p < ptr[i + 1] && idx[p] < lim) ++p;
-						bp[(size_t)i * (blocks + 1) + b] = b == blocks ? ptr[i + 1] : p;
-					}
-				}
-				hipError_t e = hipMalloc((void**)dev, sizeof(int) * bp.size());
+				hipError_t e = hipMalloc((void**)dev, sizeof(int) * (size_t)rows * (blocks + 1));
 				if (e != hipSuccess) return e;
-				return hipMemcpy(*dev, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice);
+				return launch_sp_boundaries(ptr, idx, rows, range, blocks, *dev, stream_);      // (a row's indices ascend: block b of the row is one range)
 			};
-			HIPX(boundaries(csr_ptr, csr_idx, m_, n_, kl_blocks_w_, &csr_bptr_));
-			HIPX(boundaries(csc_ptr, csc_idx, n_, m_, kl_blocks_h_, &csc_bptr_));
+			HIPX(boundaries(csr_ptr_, csr_idx_, m_, n_, kl_blocks_w_, &csr_bptr_));
+			HIPX(boundaries(csc_ptr_, csc_idx_, n_, m_, kl_blocks_h_, &csc_bptr_));
 			const long pe = std::max<long>(kl_blocks_w_ > 1 ? (long)kl_blocks_w_ * RP_ * mpad_ : 0, kl_blocks_h_ > 1 ? (long)kl_blocks_h_ * RP_ * npad_ : 0);
 			// (no room for the partial panels after all: the unblocked gather needs none)
 			bool ok = pe == 0 || hipMalloc((void**)&kl_part_, sizeof(T) * (size_t)pe) == hipSuccess;
@@ -1888,8 +1983,6 @@ Status Engine<T>::upload_triplets(std::vector<int>& rows, std::vector<int>& cols
 			}
 		}
 	}
-	HIPX(hipStreamSynchronize(stream_));
-	nnz_ = nnz;
 	return ST_OK;
 }
 
@@ -2071,6 +2164,20 @@ Status Engine<T>::debug_read(int which, T* out, long count) {
 		avail = which == 8 ? (long)RP_ * RP_ : which == 9 ? (long)RP_ : which == 10 ? (long)RP_ * mpad_ / 2 : (long)RP_ * npad_ / 2;
 		if (!p || count > avail) return ST_INVALID;
 		HIPX(hipMemcpyAsync(out, p, sizeof(T) * count, hipMemcpyDeviceToHost, stream_));
+		HIPX(hipStreamSynchronize(stream_));
+		return ST_OK;
+	}
+	case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: {
+		// the sparse images (tests/test_gpu_sparse_setup.py compares the device-built ones with the host-built ones): 12 / 13 = CSR / CSC values; 14 .. 19 = CSR
+		// pointers, CSR column indices, CSC pointers, CSC row indices, blocked CSR / CSC boundary pointers as raw 32-bit words (fp32 engines: count = number of ints)
+		if (!sparse_) return ST_INVALID;
+		if (which >= 14 && sizeof(T) != 4) return ST_INVALID;
+		const long bw = kl_blocks_w_ > 1 ? (long)m_ * (kl_blocks_w_ + 1) : 0, bh = kl_blocks_h_ > 1 ? (long)n_ * (kl_blocks_h_ + 1) : 0;
+		const void* ptrs[] = {csr_val_, csc_val_, csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csr_bptr_, csc_bptr_};
+		const long lens[] = {nnz_, nnz_, (long)m_ + 1, nnz_, (long)n_ + 1, nnz_, bw, bh};
+		const void* sp = ptrs[which - 12];
+		if (sp == nullptr || count > lens[which - 12]) return ST_INVALID;
+		HIPX(hipMemcpyAsync(out, sp, sizeof(T) * count, hipMemcpyDeviceToHost, stream_));
 		HIPX(hipStreamSynchronize(stream_));
 		return ST_OK;
 	}

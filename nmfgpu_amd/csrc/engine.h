@@ -135,6 +135,7 @@ public:
 	// that does not look at the error every time (the benchmark loop) never stalls the stream.
 	double kl_divergence() { finalize_error(true); return kl_; }
 	bool sparse_mode() const { return sparse_; }
+	bool sparse_setup_on_device() const { return sparse_setup_on_device_; }
 	long nnz() const { return nnz_; }
 	double frobenius() { finalize_error(true); return frob_; }
 	double frobenius_squared() { finalize_error(true); return frob2_; }      // the resolved sum before the root
@@ -189,7 +190,10 @@ private:
 	bool passengers_ride(const FactorProductPlan& plan) const; // split-operand product, rank 64: the Gram passengers find CUs beside the product blocks
 	bool inverse_rides(const FactorProductPlan& plan) const;   // the inverse can be a passenger workgroup of the product launch
 	Status finish_upload(T* Vcol);
-	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC
+	Status upload_triplets(std::vector<int>& rows, std::vector<int>& cols, std::vector<T>& vals);   // sparse mode: builds CSR + CSC on the host (the fall-back of upload_sparse_device)
+	Status upload_sparse_device(int format, const T* values, const int* a, const int* b, long nnz, int base, bool* fallback);   // ... on the device (kernels_sparse_setup.hip)
+	Status setup_kl_blocks();
+	bool sparse_setup_on_device_ = false;
 	Status iterate_kl(bool compute_error);            // KL-divergence multiplicative update (sparse mode)
 	Status fetch_error_terms(int count_n);            // enqueue the copies, do not wait
 	void finalize_error(bool resolve);

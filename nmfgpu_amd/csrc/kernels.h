@@ -454,4 +454,22 @@ hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pa
 template <typename T>
 hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream);
 
+// ---- the CSR and CSC images of a sparse V built on the device (kernels_sparse_setup.hip) ----------------------------------------
+// flags (one int, zeroed by the caller): bit 0 = an entry outside the matrix or outside every pointer range, bit 1 = pointer array not ascending, bit 2 = the
+// entries are not in (row, column) order.  format: 1 CSR (a = rowPtr, outer = rows), 2 CSC (a = columnPtr, outer = columns), 3 COO (a = rows, b = columns)
+hipError_t launch_sp_expand(int format, const int* a, const int* b, long nnz, int outer, int base, int m, int n, int* row, int* col, int* flags, hipStream_t stream);
+// ptr[0 .. segments] = exclusive scan of the histogram of key[0 .. count) (counts: `segments` ints of scratch), maxlen[0] = the longest segment
+hipError_t launch_sp_histogram_scan(const int* key, long count, int segments, int* counts, int* ptr, int* maxlen, hipStream_t stream);
+long sp_segment_sort_capacity();
+// items <- the positions 0 .. count - 1 grouped by key (segment s at [ptr[s], ptr[s + 1])), every segment ascending by (minor[item], item) -- by item alone
+// when minor == nullptr.  fill: `segments` ints of scratch; maxlen: the longest segment (<= sp_segment_sort_capacity())
+hipError_t launch_sp_scatter_sort(const int* key, long count, int segments, const int* ptr, int* fill, int* items, const int* minor, int maxlen, hipStream_t stream);
+template <typename T>
+hipError_t launch_sp_gather_csr(const int* order, const int* row, const int* col, const T* val, long nnz, int* csr_idx, T* csr_val, int* rowq, hipStream_t stream);
+template <typename T>
+hipError_t launch_sp_gather_csc(const int* cq, const int* rowq, const T* csr_val, long nnz, int* csc_idx, T* csc_val, hipStream_t stream);
+template <typename T>
+hipError_t launch_sp_col_sumsq(const int* csc_ptr, const T* csc_val, int n, T* vtv, double* colsum, hipStream_t stream);
+hipError_t launch_sp_boundaries(const int* ptr, const int* idx, int rows, long range, int blocks, int* bp, hipStream_t stream);
+
 } // namespace nmfamd

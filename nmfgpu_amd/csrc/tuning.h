@@ -5,7 +5,8 @@
 //       NMFAMD_COMM (transport of a numGpus team: rccl / p2p), NMFAMD_SELFTEST (0: skip the peer transport's set-up self-test), NMFAMD_HOST_THREADS (host initialisers),
 //       NMFAMD_MALL_MB (size of the memory-side cache when the device does not report it), NMFAMD_KL_BLOCK_KB (L2 block of the KL gather), NMFAMD_ONE_IMAGE (0 / 1: two
 //       images of V or one), NMFAMD_ONE_PASS (1: the opt-in one-pass iteration), and the cross-check PATHS the parity tests compare with each other -- all of them
-//       complete, correct implementations: NMFAMD_FORCE_VALU, NMFAMD_NO_FUSED_MU, NMFAMD_GRAM_PARTIALS, NMFAMD_FP_TILE;
+//       complete, correct implementations: NMFAMD_FORCE_VALU, NMFAMD_NO_FUSED_MU (fp32 rank 64 and, round 6, double precision: the generic launch sequence),
+//       NMFAMD_GRAM_PARTIALS, NMFAMD_FP_TILE, NMFAMD_SPARSE_SETUP (host: the sparse images are built by the host path, the device path's fall-back);
 //   * A/B switches, forced kernel forms, rehearsal modes and stamped kernel variants that exist for measurements and form-against-form tests only: those go through
 //     tuning_env() and are dead code in the shipped library -- they are compiled in by `python -m nmfgpu_amd.build --diag` (-DNMFAMD_DIAG_BUILD, output
 //     lib/libnmfgpu64_diag.so; tests/conftest.py `diag_build`, tools: NMFAMD_LIBRARY).  Round 5 moved here: NMFAMD_SHARD_REHEARSE (a value > 1 makes a rank update

@@ -28,7 +28,7 @@ class _Geometry(C.Structure):
                 ("padded_m", C.c_long), ("padded_n", C.c_long), ("slabs_h", C.c_int), ("slabs_w", C.c_int),
                 ("exchange_count", C.c_long), ("product_kernel", C.c_int), ("resident_images", C.c_int), ("one_pass", C.c_int),
                 ("kl_blocks_w", C.c_int), ("kl_blocks_h", C.c_int), ("gram_k_slices", C.c_int), ("w_col_split", C.c_int),
-                ("fused_launches", C.c_int), ("gram_ride_slices_h", C.c_int), ("gram_ride_slices_w", C.c_int)]
+                ("fused_launches", C.c_int), ("sparse_setup", C.c_int), ("gram_ride_slices_h", C.c_int), ("gram_ride_slices_w", C.c_int)]
 
 
 def device_count() -> int:

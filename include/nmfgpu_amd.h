@@ -131,7 +131,7 @@ typedef struct nmfamd_geometry {
 	int resident_images;   /* dense images of V kept in HBM: 2 (V and V^T, each streamed along its output index), 1 (only V: W^T V
 	                          reads it along the reduction index; chosen when two would not fit, or by NMFAMD_ONE_IMAGE), 0 sparse */
 	int one_pass;          /* rank-64 multiplicative update: 1 = V is streamed ONCE per iteration (W^T V, the H update and V H^T in one
-	                          persistent launch, kernels_onepass.hip; opt-in: NMFAMD_ONE_PASS=1); 0 = two passes (the default); 2 = a one-pass launch
+	                          persistent launch, kernels_onepass.hip; the MEASUREMENT build only since round 6: NMFAMD_ONE_PASS=1 there); 0 = two passes; 2 = a one-pass launch
 	                          gave up (it could not keep its workgroups resident) and the engine reported the error */
 	/* round 5: the counts that fix the ORDER of partial sums (and so the bits of a result), so that a run can be reproduced: all of them functions of the
 	 * shape and of the device's properties only (never of what else occupies the device) */

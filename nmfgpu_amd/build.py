@@ -30,6 +30,9 @@ ARCH = os.environ.get("NMFAMD_OFFLOAD_ARCH", "gfx950")
 # is rejected by the device pass of a -x hip compile); no implicit contraction: where the reference's
 # nvcc build fuses a multiply-add the source says std::fma)
 HOST_ONLY = {"host_init.cpp"}
+# sources of the MEASUREMENT build only: the one-pass iteration (round 3: built, correct, 1.8 x slower than the two-pass iteration -- a recorded dead end that the
+# shipped library no longer carries; NMFAMD_ONE_PASS=1 selects it in libnmfgpu64_diag.so, tests/test_gpu_onepass.py runs it there)
+DIAG_ONLY = {"kernels_onepass.hip"}
 # per-source extra flags.  kernels_x3.hip: the SLP vectoriser pairs the scalar subtractions of the operand split
 # into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
 # Since round 3 the SLP vectoriser is off for EVERY device source (DEVICE_FLAGS): it also pairs `uniform * x + uniform` into
@@ -97,7 +100,8 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     cc = hipcc()
     objs = []
     procs = []
-    for src in SOURCES:
+    sources = [src for src in SOURCES if diag or src not in DIAG_ONLY]
+    for src in sources:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if src in HOST_ONLY:
@@ -119,7 +123,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
         raise RuntimeError("hipcc failed")
     bad = []
     try:
-        for src, obj in zip(SOURCES, objs):
+        for src, obj in zip(sources, objs):
             if src not in HOST_ONLY and src.endswith(".hip"):
                 bad += [f"{src}: {line}" for line in packed_scalar_sources(obj)]
     except FileNotFoundError as exc:      # (no llvm-objcopy / clang-offload-bundler / llvm-objdump beside hipcc: the flag above still holds, tests/test_abi.py re-checks)

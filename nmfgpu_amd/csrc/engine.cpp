@@ -233,9 +233,13 @@ Status Engine<T>::allocate() {
 	const size_t mall = memory_side_cache_bytes(prop);
 	const bool cache_window = mall > 0 && (double)image_bytes > 0.6 * (double)mall && (double)image_bytes < 1.12 * (double)mall && std::getenv("NMFAMD_ONE_IMAGE") == nullptr;
 	// (the opt-in one-pass iteration runs on the split-operand products whatever the rank)
-	const char* op_env = std::getenv("NMFAMD_ONE_PASS");
+#ifdef NMFAMD_DIAG_BUILD
+	const char* op_env = tuning_env("NMFAMD_ONE_PASS");
 	const bool op_req = op_env != nullptr && std::atoi(op_env) != 0 && one_pass_allowed_ && row_blocks_ == 1 && fused_capable() && RP_ == 64 &&
 	                    std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr && tuning_env("NMFAMD_IMAGE_TILE128") == nullptr && onepass_available(pad128(m_), num_cus_);
+#else
+	const bool op_req = false;      // (kernels_onepass.hip is part of the measurement build only: round 6)
+#endif
 	if (std::is_same<T, float>::value && tiled_ && !bf16_ && !sparse_ && RP_ % 64 == 0 && prm_.precision == 0 && (planH_.nb == 2 || cache_window || op_req) &&
 	    tuning_env("NMFAMD_FP32_NATIVE") == nullptr) {
 		planH_.nb = planW_.nb = 2;
@@ -270,7 +274,7 @@ Status Engine<T>::allocate() {
 		const size_t image_b = sizeof(T) * (size_t)pad128(m_) * (size_t)pad128(n_);
 		const char* force = std::getenv("NMFAMD_ONE_IMAGE");
 		// the one-pass iteration needs ONE image (16-row tiles) and nothing else
-		// (opt-in, NMFAMD_ONE_PASS=1: measured slower than the two-pass iteration)
+		// (measurement build, NMFAMD_ONE_PASS=1: measured slower than the two-pass iteration, docs/HISTORY.md)
 		one_pass_ = op_req && (force == nullptr || std::atoi(force) != 0);
 		if (one_pass_) one_image_ = true;
 		else if (force != nullptr) one_image_ = std::atoi(force) != 0;
@@ -393,6 +397,7 @@ Status Engine<T>::allocate() {
 	}
 	gram_image_ = x3_ && fused_capable() && RP_ == 64 && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr;
 	one_pass_ = one_pass_ && x3_ && gram_image_ && one_image_ && img_th_ == 16;
+#ifdef NMFAMD_DIAG_BUILD
 	if (one_pass_) {
 		HIPX(hipMalloc(&op_part_, onepass_part_bytes()));
 		HIPX(hipMalloc(&op_hfrag_, onepass_hfrag_bytes()));
@@ -414,6 +419,7 @@ Status Engine<T>::allocate() {
 			HIPX(hipMemsetAsync(op_stamps_, 0, sizeof(unsigned long long) * 16 * 8 * ONEPASS_XCDS * ONEPASS_GROUP, stream_));
 		}
 	}
+#endif
 	if (fused_capable() || gram_from_update()) {
 		HIPX(hipMalloc((void**)&gramW_part_, sizeof(float) * 4096 * (size_t)(mpad_ / 64)));
 		HIPX(hipMalloc((void**)&Graw64_, sizeof(float) * 4096));      // the reduced, unscaled W^T W of normalize_w's one-launch form
@@ -1620,6 +1626,7 @@ Status Engine<T>::materialize_w(bool whole_panel) {
 // One pass over V: G = W^T W (split image of W), then ONE persistent launch for W^T V, the H update and V H^T, then U_W.
 template <typename T>
 Status Engine<T>::iterate_onepass(bool compute_error) {
+#ifdef NMFAMD_DIAG_BUILD
 	if constexpr (std::is_same<T, float>::value) {
 		if (!fused_ready_) { normalize_next_ = 0; fused_ready_ = true; }
 		if (!wx3_valid_) { HIPX(launch_pack_panel_x3(Wt_, RP_, m_, Wx3_, ksH_, stream_)); wx3_valid_ = true; }
@@ -1639,7 +1646,11 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 		a.eps = std::numeric_limits<float>::epsilon();
 		a.stamps = op_stamps_;
 		record_begin();
+#ifdef NMFAMD_DIAG_BUILD
 		HIPX(launch_mu64_onepass(a, stream_));
+#else
+		return ST_INVALID;      // (one_pass_ is never set in the shipped library)
+#endif
 		record_end();
 		std::swap(H_, op_H2_);                             // the new H
 		HIPX(launch_reduce_partials<float>(op_hh_part_, ONEPASS_XCDS * ONEPASS_GROUP, 4096, HHt_, 4096, stream_));
@@ -1654,6 +1665,9 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 			if (Status s = onepass_check()) return s;
 		}
 	}
+#else
+	(void)compute_error;
+#endif
 	return ST_OK;
 }
 
@@ -1661,6 +1675,8 @@ Status Engine<T>::iterate_onepass(bool compute_error) {
 // up after bounded waits and leaves the abort word set; its outputs are void.
 template <typename T>
 Status Engine<T>::onepass_check() {
+#ifdef NMFAMD_DIAG_BUILD
+
 	HIPX(hipMemcpyAsync(pin_abort_, op_ctl_ + 8, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
 	HIPX(hipStreamSynchronize(stream_));
 	if (op_stamps_ != nullptr) {
@@ -1675,6 +1691,7 @@ Status Engine<T>::onepass_check() {
 		last_error_ = "the one-pass iteration could not keep its workgroups resident (another kernel on the device?): factors are void; unset NMFAMD_ONE_PASS";
 		return ST_HIP_ERROR;
 	}
+#endif
 	return ST_OK;
 }
 

@@ -471,7 +471,12 @@ void set_factor_product_bf16_stamps(unsigned long long* stamps) { t_bf_stamps = 
 #define BF_STAMP_ARG
 #define BF_STAMP(i) do { } while (0)
 #endif
-template <int NRB, int D, int DF>
+// VAR (measurement builds, NMFAMD_BF_VARIANT; results void, timing only -- profiles/r06_c4_loop.md): the SHIPPED loop with parts taken out --
+//   1 no MFMAs (loads, LDS ring and barriers as they are)   2 only the streamed operand's path (A loads, park, reads; no F loads, no MFMAs)
+//   3 only the factor fragments' loads (no A loads, no LDS traffic, no MFMAs)   4 the whole loop, no slab stores   5 MFMAs and LDS reads only (no global loads in the loop)
+//   6 only the A loads (no LDS ring, no barrier, no F loads, no MFMAs)   7 A and F loads, nothing else
+//   8 / 9 (results valid) the slab epilogue as whole 1 KB rows through LDS / with non-temporal stores
+template <int NRB, int D, int DF, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	const bf16x8* __restrict__ A, long tile_frags, int total_blocks, const bf16x8* __restrict__ F, int NBT,
 	float* __restrict__ slabs, long slab_stride, int RP, int steps_total, int splits, int tiles, GramReduceArgs rg BF_STAMP_ARG) {
@@ -574,24 +579,44 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 #pragma unroll
 		for (int u = 0; u < D; ++u) {
 			const int s = t0 + u;
-			if (!BFD_PAIR || (u & 1) == 0) __syncthreads();      // step s + 1 visible; the slot of step s + AHEAD free
+			if ((!BFD_PAIR || (u & 1) == 0) && VAR != 6 && VAR != 7) __syncthreads();      // step s + 1 visible; the slot of step s + AHEAD free
 			// Everything below is ONE scheduling region: the fourteen MFMAs of step s, and between them (one wave per SIMD
 			// overlaps nothing but its own instruction order; PMC of the first version with the groups in a row: matrix pipe
 			// busy 45 % of the wave's life, 24 % issue stalls outside it) the park of step s + 2, the A loads of step
 			// s + 2 + D, the operand reads of step s + 1 and the F loads of step s + D - 1 (into the ring slot step s - 1 has
 			// just left).
-			l8[wr * 512 + pblk] = stA[(u + AHEAD) % D][0];
-			l8[wr * 512 + pblk + 64] = stA[(u + AHEAD) % D][1];
-			stA[(u + AHEAD) % D][0] = a_src(0, s + AHEAD + D)[lane];
-			stA[(u + AHEAD) % D][1] = a_src(1, s + AHEAD + D)[lane];
+			if (VAR != 3 && VAR != 6 && VAR != 7) {
+				l8[wr * 512 + pblk] = stA[(u + AHEAD) % D][0];
+				l8[wr * 512 + pblk + 64] = stA[(u + AHEAD) % D][1];
+			}
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (VAR == 6 || VAR == 7) asm volatile("" :: "v"(stA[(u + AHEAD) % D][0]), "v"(stA[(u + AHEAD) % D][1]));
+#endif
+			if (VAR != 3 && VAR != 5) {
+				stA[(u + AHEAD) % D][0] = a_src(0, s + AHEAD + D)[lane];
+				stA[(u + AHEAD) % D][1] = a_src(1, s + AHEAD + D)[lane];
+			}
+			if (VAR != 3 && VAR != 6 && VAR != 7) {
 #pragma unroll
-			for (int b = 0; b < NRB; ++b) va[(u + 1) & 1][b] = l8[rd * 512 + b * 64 + lane];
-			stF[(u + DF - 1) % DF][0] = f_src(s + DF - 1)[lane];
-			stF[(u + DF - 1) % DF][1] = f_src(s + DF - 1)[64 + lane];
+				for (int b = 0; b < NRB; ++b) va[(u + 1) & 1][b] = l8[rd * 512 + b * 64 + lane];
+			}
+			if (VAR != 2 && VAR != 5 && VAR != 6) {
+				stF[(u + DF - 1) % DF][0] = f_src(s + DF - 1)[lane];
+				stF[(u + DF - 1) % DF][1] = f_src(s + DF - 1)[64 + lane];
+			}
+			if (VAR == 0 || VAR == 4 || VAR == 5 || VAR >= 8) {
 #pragma unroll
-			for (int b = 0; b < NRB; ++b) {
-				acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][0], acc[b][0], 0, 0, 0);
-				acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][1], acc[b][1], 0, 0, 0);
+				for (int b = 0; b < NRB; ++b) {
+					acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][0], acc[b][0], 0, 0, 0);
+					acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[u & 1][b], stF[u % DF][1], acc[b][1], 0, 0, 0);
+				}
+			} else {
+				// (what was loaded and read stays "used": the compiler keeps the instructions)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+				for (int b = 0; b < NRB; ++b) asm volatile("" :: "v"(va[u & 1][b]));
+				asm volatile("" :: "v"(stF[u % DF][0]), "v"(stF[u % DF][1]));
+#endif
 			}
 			// MFMA, then one memory instruction, fourteen times: 2 LDS writes, 2 + 2 loads, 7 (NRB) LDS reads
 #pragma unroll
@@ -611,9 +636,42 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 	// epilogue: C/D map of the 32 x 32 MFMA: register g of lane l is row (g & 3) + 8 (g >> 2) + 4 (l >> 5), column l & 31
 	BF_STAMP(2);
 	float* slab = slabs + (long)sp * slab_stride;
+	if (VAR == 8) {
+		// sixteen rows of the tile at a time through the (now free) LDS ring: every store instruction of a wave writes one whole row of the 256-column group (1 KB)
+		float* st = reinterpret_cast<float*>(l8);
+		typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+		for (int b = 0; b < NRB; ++b) {
+			const int gb = gb0 + b;
+#pragma unroll
+			for (int h2 = 0; h2 < 2; ++h2) {
+				__syncthreads();
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+					for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+						for (int gl = 0; gl < 4; ++gl) {
+							const int g = 4 * (2 * h2 + gq) + gl;
+							st[(gl + 8 * gq + 4 * half) * 256 + 64 * wave + 32 * nb + l31] = acc[b][nb][g];
+						}
+				__syncthreads();
+				if (gb < total_blocks) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						const int idx = threadIdx.x + 256 * k, row = idx >> 6, c4 = idx & 63;
+						*reinterpret_cast<f32x4v*>(slab + (long)(32 * gb + 16 * h2 + row) * RP + 256 * grp + 4 * c4) = *reinterpret_cast<const f32x4v*>(st + row * 256 + 4 * c4);
+					}
+				}
+			}
+		}
+	} else
 #pragma unroll
 	for (int b = 0; b < NRB; ++b) {
 		const int gb = gb0 + b;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (VAR == 4) { asm volatile("" :: "v"(acc[b][0]), "v"(acc[b][1])); continue; }
+#endif
 		if (gb < total_blocks) {
 #pragma unroll
 			for (int nb = 0; nb < 2; ++nb) {
@@ -621,7 +679,8 @@ __global__ __launch_bounds__(256, 1) void k_factor_product_bf16_r2(
 #pragma unroll
 				for (int g = 0; g < 16; ++g) {
 					const int x = 32 * gb + (g & 3) + 8 * (g >> 2) + 4 * half;
-					slab[(long)x * RP + c] = acc[b][nb][g];
+					if (VAR == 9) __builtin_nontemporal_store(acc[b][nb][g], slab + (long)x * RP + c);
+					else slab[(long)x * RP + c] = acc[b][nb][g];
 				}
 			}
 		}
@@ -655,6 +714,16 @@ static hipError_t launch_fp_bf16_r2(const FactorProductPlan& p, const void* A, i
 	const bool ride = rg != nullptr && rg->tri_frags != nullptr;
 	if (ride && (RP != 256 || rg->G == nullptr || rg->tri_ks < 1 || rg->tri_partial == nullptr || rg->tri_counters == nullptr)) return hipErrorInvalidValue;
 	dim3 grid(tiles * splits + (ride ? TRI_PASSENGERS : 0), RP / 256), block(256);
+#ifdef NMFAMD_DIAG_BUILD
+	if (const char* ve = tuning_env("NMFAMD_BF_VARIANT")) {
+		const int v = std::atoi(ve);
+#define NMFAMD_BF_VAR(V) case V: hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF, V>), grid, block, 0, stream, \
+		reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32, slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none, t_bf_stamps); \
+		t_bf_stamps = nullptr; return hipGetLastError();
+		switch (v) { NMFAMD_BF_VAR(1) NMFAMD_BF_VAR(2) NMFAMD_BF_VAR(3) NMFAMD_BF_VAR(4) NMFAMD_BF_VAR(5) NMFAMD_BF_VAR(6) NMFAMD_BF_VAR(7) NMFAMD_BF_VAR(8) NMFAMD_BF_VAR(9) default: break; }
+#undef NMFAMD_BF_VAR
+	}
+#endif
 	hipLaunchKernelGGL((k_factor_product_bf16_r2<BFD_NRB, BFD_R2_D, BFD_R2_DF>), grid, block, 0, stream,
 	                   reinterpret_cast<const bf16x8*>(A), (long)KS * 256, 4 * p.xtiles, reinterpret_cast<const bf16x8*>(F), RP / 32,
 	                   slabs, slab_stride, RP, KS, splits, tiles, ride ? *rg : none

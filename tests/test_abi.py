@@ -175,7 +175,7 @@ def test_shipped_library_reads_only_the_documented_environment_variables():
     import re
     import subprocess
     from nmfgpu_amd import _lib
-    allowed = {"NMFAMD_COMM", "NMFAMD_SELFTEST", "NMFAMD_HOST_THREADS", "NMFAMD_MALL_MB", "NMFAMD_KL_BLOCK_KB", "NMFAMD_ONE_IMAGE", "NMFAMD_ONE_PASS",
+    allowed = {"NMFAMD_COMM", "NMFAMD_SELFTEST", "NMFAMD_HOST_THREADS", "NMFAMD_MALL_MB", "NMFAMD_KL_BLOCK_KB", "NMFAMD_ONE_IMAGE",
                "NMFAMD_FORCE_VALU", "NMFAMD_NO_FUSED_MU", "NMFAMD_GRAM_PARTIALS", "NMFAMD_FP_TILE", "NMFAMD_SPARSE_SETUP"}
     path = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "lib", "libnmfgpu64.so")
     text = subprocess.run(["strings", "-n", "8", path], check=True, capture_output=True, text=True).stdout

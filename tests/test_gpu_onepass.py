@@ -1,5 +1,5 @@
-"""The one-pass form of the rank-64 multiplicative update (kernels_onepass.hip; opt-in, NMFAMD_ONE_PASS=1) against the fp64 oracle and
-against the default two-pass iteration on the same inputs.
+"""The one-pass form of the rank-64 multiplicative update (kernels_onepass.hip; MEASUREMENT BUILD only since round 6 -- a recorded dead end, 1.8 x slower
+than the two-pass iteration: NMFAMD_ONE_PASS=1 in libnmfgpu64_diag.so) against the fp64 oracle and against the default two-pass iteration on the same inputs.
 
 The H update is column-separable once W^T W is known (reference: source/nmf/AlgorithmMultiplicativeFrobenius.h:176-191,
 source/nmf/KernelMultiplyDivide.cu:29-43), so a column panel of V is fetched once for W^T V, the update of its H columns and
@@ -62,7 +62,7 @@ def run(V, W, H, r, iters, one_pass, monkeypatch):
 # shapes: ragged rows (not a multiple of 16 / 128), ragged columns (not a multiple of 32), fewer panels than XCDs (groups with no
 # panel at all), fewer panels than the pipeline is deep, ranks below the padded 64, the largest row count the cut takes
 @pytest.mark.parametrize("m,n,r,iters", [(1000, 333, 10, 20), (517, 40, 64, 10), (2000, 1100, 33, 20), (4100, 2049, 64, 12), (10240, 300, 64, 10)])
-def test_one_pass_matches_the_oracle(m, n, r, iters, monkeypatch):
+def test_one_pass_matches_the_oracle(m, n, r, iters, monkeypatch, diag_build):
     V, W, H = problem(m, n, r, seed=m + n + r)
     ref = oracle.run("mu", F(V.astype(np.float64)), Wo := F(W.astype(np.float64)), Ho := F(H.astype(np.float64)), iters)
     Wg, Hg, frob, mode = run(V, W, H, r, iters, True, monkeypatch)
@@ -72,7 +72,7 @@ def test_one_pass_matches_the_oracle(m, n, r, iters, monkeypatch):
     assert (Wg >= 0).all() and (Hg >= 0).all()
 
 
-def test_one_pass_equals_two_pass_at_config2(monkeypatch):
+def test_one_pass_equals_two_pass_at_config2(monkeypatch, diag_build):
     """BASELINE configs[1] (10 000 x 5 000, r = 64): both forms of the iteration from the same start, 20 iterations."""
     V, W, H = problem(10000, 5000, 64, seed=1)
     W1, H1, f1, mode1 = run(V, W, H, 64, 20, True, monkeypatch)
@@ -82,7 +82,7 @@ def test_one_pass_equals_two_pass_at_config2(monkeypatch):
     assert f1 == pytest.approx(f2, rel=1e-6)
 
 
-def test_one_pass_is_opt_in_and_deterministic(monkeypatch):
+def test_one_pass_is_opt_in_and_deterministic(monkeypatch, diag_build):
     V, W, H = problem(3000, 700, 20, seed=5)
     a = run(V, W, H, 20, 10, True, monkeypatch)
     b = run(V, W, H, 20, 10, True, monkeypatch)

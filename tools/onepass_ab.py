@@ -2,6 +2,7 @@
 the reported error after ITERS iterations, and time per iteration of both.
 usage: onepass_ab.py [M N R ITERS]"""
 import os, sys, time
+os.environ.setdefault("NMFAMD_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))  # (the one-pass kernel lives in the measurement build)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nmfgpu_amd as na

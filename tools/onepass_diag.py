@@ -1,5 +1,6 @@
 """Which old column did a wrong new column of H come from?  (one iteration, one-pass vs two-pass)"""
 import os, sys
+os.environ.setdefault("NMFAMD_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))  # (the one-pass kernel lives in the measurement build)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nmfgpu_amd as na

@@ -1,5 +1,6 @@
 """Mapping probe of the one-pass kernel: W = [I; 0], H = 1, V(i, j) = i + j / 1024 for i < 64  =>  after one iteration H(c, j) = V(c, j)."""
 import os, sys
+os.environ.setdefault("NMFAMD_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))  # (the one-pass kernel lives in the measurement build)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["NMFAMD_ONE_PASS"] = "1"

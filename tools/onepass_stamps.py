@@ -1,6 +1,7 @@
 """Where a tick of the one-pass kernel spends its cycles (diagnostic build: python -m nmfgpu_amd.build --diag).
 usage: NMFAMD_LIBRARY=nmfgpu_amd/lib/libnmfgpu64_diag.so python tools/onepass_stamps.py [M N]"""
 import os, sys
+os.environ.setdefault("NMFAMD_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nmfgpu_amd", "lib", "libnmfgpu64_diag.so"))  # (the one-pass kernel lives in the measurement build)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "onepass_stamps.bin")

@@ -938,7 +938,8 @@ def main_f64(args):
         avg_s = kernel_ms / 1e3 / kernel_launches
         ach = flops_per_launch / avg_s / 1e12
         roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                    "kernel": "k_factor_product_f64", "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
+                    "kernel": "k_factor_product_f64", "launch_also_carries": "the Gram matrix of the operand as passenger workgroups (kernels_f64.hip, gram_ride_f64)",
+                    "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
                     "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
                     "timed_by": "an event recorded before and one after the launch (over-reports by about idle_event_pair_us), " + TIMED_BY_REPLAY,
                     "hbm_side": {"achieved": bytes_per_launch / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS}}
@@ -949,7 +950,10 @@ def main_f64(args):
            "config": {"workload": ("the reference's example program (example/main.cpp): dense V 4096x165 of multiples of 1/255, r=158, nsNMF theta=0.5, double" if ex else
                                    "configs[1]'s shape in double precision: dense random V 10000x5000, r=64, MU Frobenius, fp64"),
                       "rows": m, "columns": n, "features": r, "error_every": 10, "setup_iterations": setup, "parallelism": "single GPU",
-                      "arithmetic": "fp64 throughout; products on v_mfma_f64_16x16x4_f64"},
+                      "arithmetic": "fp64 throughout; products on v_mfma_f64_16x16x4_f64",
+                      # (round 6) 4: product + Gram passengers / update / product + Gram passengers / update (Engine::iterate_fused64); 0: the generic launch sequence
+                      "launches_per_iteration": eng.geometry()["fused_launches"] or None,
+                      "gram_passenger_k_slices": [eng.geometry()["gram_ride_slices_h"], eng.geometry()["gram_ride_slices_w"]]},
            "frobenius_last": frob, "iter_flops": iter_flops, "achieved_tflops_whole_iteration": iter_flops * (K / elapsed) / 1e12,
            "roofline": whole_iteration(roofline, elapsed / K, floor_flops=2.0 * flops_per_launch, basis="the two products against V at the fp64 MFMA peak")}
     if not args.no_cpu_baseline:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/bench_all.sh TAG  -- every workload's bench line, unprofiled (gpurun_out/TAG_bench_<w>.json) and under rocprofv3 --kernel-trace --stats
 # (gpurun_out/TAG_bench_<w>_profiled.json + TAG_kernel_stats_bench_<w>.csv); copy what is to be judged into profiles/
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $root
 for w in c2 c5 c5-gdcls c4 c3 c2-f64 example; do

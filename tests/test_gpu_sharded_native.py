@@ -437,6 +437,67 @@ def test_team_of_rank_threads_through_the_c_abi_runs_twice_on_one_communicator()
         assert np.array_equal(results[("repl", g)][1], results[("repl again", g)][1])
 
 
+def test_row_block_bf16_run_leaves_whole_fp32_rows_without_a_collective_at_download():
+    """row-block mode at padded rank 256 with bf16 operands exchanges bf16 fragments between W updates; the other ranks' fp32 rows in a rank's panel are
+    stale until gathered.  nmfamd_sharded_iterate gathers them inside the batch that ends on last_iteration (a collective call anyway), so that afterwards ONE rank
+    alone can download its factors -- also after the sharded run is closed -- and every rank holds the same W.  m = 2 000: rows padded to 2 x 1 024 (the fragment
+    all-gather moves 128 K-steps where the product reads 125)."""
+    import threading
+    import torch
+    m, n, r, world, iters = 2000, 2 * 192, 256, 2, 5
+    V, W0, H0 = problem(m, n, r, np.float32, seed=256)
+    group = na.LocalGroup(world)
+    gate = threading.Barrier(world)
+    results, errors = {}, []
+
+    def rank_thread(g):
+        eng = comm = run = None
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            comm = na.LocalComm(group, g)
+            c0, nc = na.shard_columns(n, world, g)
+            eng = na.Engine(m, nc, r, "nsnmf", theta=0.5, precision="bf16", row_blocks=world, stream=stream.cuda_stream)
+            eng.upload(F(V[:, c0:c0 + nc]))
+            eng.set_factors(W0, F(H0[:, c0:c0 + nc]))
+            gate.wait()
+            run = na.ShardedRun(eng, comm, m, n, na.SHARD_ROW_BLOCKS)
+            run.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+            eng.synchronize()
+            gate.wait()
+            run.close(); run = None          # (the gather hook is gone with the run)
+            gate.wait()
+            if g == 0:
+                results[g] = eng.get_factors()          # rank 0 alone: no peer takes part
+            gate.wait()
+            if g != 0:
+                results[g] = eng.get_factors()
+        except BaseException as e:          # noqa: BLE001
+            errors.append((g, e)); group.abort(); gate.abort()
+        finally:
+            for obj in (run, eng, comm):
+                if obj is not None:
+                    try:
+                        obj.close()
+                    except Exception:       # noqa: BLE001
+                        pass
+
+    threads = [threading.Thread(target=rank_thread, args=(g,), daemon=True) for g in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)][:2] or errors[:1]
+    assert np.array_equal(results[0][0], results[1][0])
+    eng1 = na.Engine(m, n, r, "nsnmf", theta=0.5, precision="bf16")
+    eng1.upload(V); eng1.set_factors(W0, H0)
+    eng1.iterate(iters, first_iteration=1, error_every=10, last_iteration=iters)
+    W1, H1 = eng1.get_factors()
+    eng1.close()
+    Hg = np.concatenate([results[g][1] for g in range(world)], axis=1)
+    assert rel(results[0][0], W1) < 2e-2 and rel(Hg, H1) < 2e-2
+
+
 def _join_group(world, env_report=None):
     """`world` rank threads on device 0 join one in-process group; returns (errors, selftest report of the group)."""
     import threading

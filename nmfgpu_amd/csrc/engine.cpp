@@ -140,7 +140,7 @@ Engine<T>::~Engine() {
 	if (inv_work_) (void)hipFree(inv_work_);
 	if (range_flag_) (void)hipFree(range_flag_);
 	{
-		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_, csr_bptr_, csc_bptr_, kl_part_, kl_tpart_};
+		void* sp[] = {csr_ptr_, csr_idx_, csc_ptr_, csc_idx_, csc_from_csr_, csr_val_, csc_val_, q_, q2_, t_vwh_, t_kl_, rowsum_part_, sW_, sH_, kl_scale_, csr_bptr_, csc_bptr_, kl_part_, kl_tpart_};
 		for (void* b : sp) if (b) (void)hipFree(b);
 	}
 	{ void* bb[] = {Vb_, Vtb_, Wtb_, Hb_, Wx3_, Hx3_, qx3_, gram_tri_part_, Gw_raw_, Gh_raw_, colsq_}; for (void* b : bb) if (b) (void)hipFree(b); }
@@ -342,6 +342,7 @@ Status Engine<T>::allocate() {
 		HIPX(dalloc(&rowsum_part_, (std::max(mpad_, npad_) / 128) * RP_));
 		HIPX(dalloc(&sW_, RP_));
 		HIPX(dalloc(&sH_, RP_));
+		HIPX(dalloc(&kl_scale_, RP_));
 		HIPX(hipHostMalloc((void**)&pin_kl_, sizeof(T) * (2 * (size_t)m_ + 3 * (size_t)RP_)));
 	}
 	HIPX(dalloc(&Wt_, panelW));
@@ -684,7 +685,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
+		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
@@ -730,7 +731,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
+	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -1592,6 +1593,11 @@ Status Engine<T>::ensure_w_rows() {
 template <typename T>
 Status Engine<T>::materialize_w(bool whole_panel) {
 	if (whole_panel) { if (Status s = ensure_w_rows()) return s; }
+	if (kl_scale_pending_) {
+		// the KL iteration left W unnormalised (iterate_kl): the pass it skipped
+		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, (int)(mpad_ / 128), stream_));
+		kl_scale_pending_ = false;
+	}
 	if (f64_pending_) {
 		// the fused double-precision iteration left W unnormalised: the second half of kernel::normalizeColumns, as the generic iteration runs it after every W update
 		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
@@ -2015,6 +2021,13 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
 	const int norm_parts = (int)(mpad_ / 128);
 	const bool two_pass = tuning_env("NMFAMD_KL_TWO_PASS") != nullptr;      // A/B: round 1's SDDMM + permute + SpMM per half-step
+	// Round 6: W is left UNNORMALISED by its update, with the column scale d = 1 / sqrt(sum of squares) as a pending factor (kl_scale_, from the update's partial
+	// sums, by the k_kl_sums launch that turns them into the column sums anyway): the pass over the 51 MB panel that normalised it (k_compact_partials +
+	// k_normalize_panel_v2: 25 us at config 3) is gone.  W = Wt D enters the two half-steps through the row each fused kernel loads ONCE per output row
+	// (a_scale), the H update's numerator is D (Wt^T Q), the W update reads its old rows as Wt D.  materialize_w() folds the scale in for everybody else.
+	const bool keep_pending = !two_pass && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
+	if (!keep_pending) { if (Status st = materialize_w()) return st; }
+	const T* dsc = kl_scale_pending_ ? kl_scale_ : nullptr;
 	// H step (no error terms here: they refer to the pair (W_{k-1}, H_k) of the second evaluation).  One pass over the CSC
 	// image: quotient and numerator W^T Q together, one gathered row of W per stored entry (kernels_sparse.hip, k_kl_fused).
 	record_begin();
@@ -2023,15 +2036,15 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		HIPX(launch_permute<T>(q_, csc_from_csr_, q2_, nnz_, stream_));
 		HIPX(launch_spmm_rows<T>(csc_ptr_, csc_idx_, q2_, Wt_, RP_, slabs_, n_, (int)npad_, stream_));
 	} else {
-		if (kl_blocks_h_ > 1) HIPX(launch_kl_fused<T>(csc_bptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, kl_part_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, kl_blocks_h_, (long)RP_ * npad_));
-		else HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_));
+		if (kl_blocks_h_ > 1) HIPX(launch_kl_fused<T>(csc_bptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, kl_part_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, kl_blocks_h_, (long)RP_ * npad_, dsc));
+		else HIPX(launch_kl_fused<T>(csc_ptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, slabs_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, 1, 0, dsc));
 	}
 	record_end();
 	// the column sums of W: from the partial sums its last update left (round 4), or by a pass over the panel when W was set from outside
 	if (!kl_sw_ready_) HIPX(launch_panel_rowsum<T>(Wt_, RP_, (int)mpad_, rowsum_part_, sW_, stream_));
 	// ... and the update of H leaves the partial row sums of the NEW H (the W step's denominators) in rowsum_part_: one small launch instead of a pass over H
-	if (!two_pass && kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_, rowsum_part_));
-	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_, 1, 0, rowsum_part_));
+	if (!two_pass && kl_blocks_h_ > 1) HIPX(launch_kl_update<T>(H_, kl_part_, sW_, RP_, (int)npad_, eps, nullptr, stream_, kl_blocks_h_, (long)RP_ * npad_, rowsum_part_, dsc));
+	else HIPX(launch_kl_update<T>(H_, slabs_, sW_, RP_, (int)npad_, eps, nullptr, stream_, 1, 0, rowsum_part_, dsc));
 	HIPX(launch_kl_sums<T>(rowsum_part_, nullptr, (int)(npad_ / 128), RP_, sH_, stream_));
 	// W step (the quotient is re-evaluated with the new H), over the CSR image; per-row error terms on error iterations only
 	record_begin(1);
@@ -2041,7 +2054,7 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 	} else {
 		if (kl_blocks_w_ > 1) {
 			HIPX(launch_kl_fused<T>(csr_bptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, kl_part_, compute_error ? kl_tpart_ : (T*)nullptr,
-			                        compute_error ? kl_tpart_ + (long)kl_blocks_w_ * mpad_ : (T*)nullptr, m_, (int)mpad_, stream_, kl_blocks_w_, (long)RP_ * mpad_));
+			                        compute_error ? kl_tpart_ + (long)kl_blocks_w_ * mpad_ : (T*)nullptr, m_, (int)mpad_, stream_, kl_blocks_w_, (long)RP_ * mpad_, dsc));
 			if (compute_error) {
 				// the blocks' parts of the per-row error terms, block order
 				HIPX(launch_reduce_partials<T>(kl_tpart_, kl_blocks_w_, mpad_, t_vwh_, m_, stream_));
@@ -2049,14 +2062,14 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 			}
 		} else
 		HIPX(launch_kl_fused<T>(csr_ptr_, csr_idx_, csr_val_, Wt_, H_, RP_, eps, slabs_, compute_error ? t_vwh_ : (T*)nullptr, compute_error ? t_kl_ : (T*)nullptr,
-		                        m_, (int)mpad_, stream_));
+		                        m_, (int)mpad_, stream_, 1, 0, dsc));
 	}
 	record_end();
 	if (compute_error) {
 		// Frobenius error by the reference's trace formula with (W_{k-1}, H_k); KL divergence next to it
 		HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G_, stream_));
 		HIPX(launch_gram<T>(H_, RP_, n_, gram_parts_, gram_part_, HHt_, stream_));
-		HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_));
+		HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_, nullptr, dsc));      // (G_ is the Gram matrix of the panel as it lies: D G D = W^T W of the normalised W)
 		// the terms travel stream-ordered into pinned memory; the sorted host summation (100 000 per-row terms at config 3:
 		// milliseconds) runs when the error is read -- the iteration loop does not wait for the GPU here
 		finalize_error(false);
@@ -2069,12 +2082,14 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 		HIPX(hipEventRecord(err_event_, stream_));
 		kl_pending_ = true;
 	}
-	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_, rowsum_part_));
-	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, 1, 0, rowsum_part_));
-	// colsum of the NORMALISED W = (sum of the new column) / (its norm), both from the update's per-workgroup partials (norm_parts = mpad / 128 of each)
-	HIPX(launch_kl_sums<T>(rowsum_part_, sumsq_part_, norm_parts, RP_, sW_, stream_));
+	if (!two_pass && kl_blocks_w_ > 1) HIPX(launch_kl_update<T>(Wt_, kl_part_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, kl_blocks_w_, (long)RP_ * mpad_, rowsum_part_, dsc));
+	else HIPX(launch_kl_update<T>(Wt_, slabs_, sH_, RP_, (int)mpad_, eps, sumsq_part_, stream_, 1, 0, rowsum_part_, dsc));
+	// colsum of the NORMALISED W = (sum of the new column) / (its norm), both from the update's per-workgroup partials (norm_parts = mpad / 128 of each); and the
+	// pending scale itself
+	HIPX(launch_kl_sums<T>(rowsum_part_, sumsq_part_, norm_parts, RP_, sW_, stream_, keep_pending ? kl_scale_ : nullptr));
 	kl_sw_ready_ = true;
-	HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
+	if (keep_pending) kl_scale_pending_ = true;
+	else HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, norm_parts, stream_));
 	return ST_OK;
 }
 
@@ -2085,6 +2100,7 @@ Status Engine<T>::iterate_kl(bool compute_error) {
 template <typename T>
 Status Engine<T>::kl_h_step() {
 	if (!sparse_ || nnz_ < 0) return ST_INVALID;
+	if (Status st = materialize_w()) return st;      // (the sharded form works on the normalised panel)
 	const T eps = std::numeric_limits<T>::epsilon();
 	record_begin();
 	if (kl_blocks_h_ > 1) HIPX(launch_kl_fused<T>(csc_bptr_, csc_idx_, csc_val_, H_, Wt_, RP_, eps, kl_part_, (T*)nullptr, (T*)nullptr, n_, (int)npad_, stream_, kl_blocks_h_, (long)RP_ * npad_));

@@ -438,7 +438,8 @@ template <typename T>
 // blocks > 1: ptr is the blocked pointer array [rows][blocks + 1] (a row's entries cut at the block boundaries of the gathered index);
 // out then receives `blocks` partial panels out_stride apart (and t_vwh / t_kl `blocks` partial vectors of rows_pad), grid block-major
 hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
-                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks = 1, long out_stride = 0);
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks = 1, long out_stride = 0,
+                           const T* a_scale = nullptr);      // a_scale (RP factors, optional): A(row, :) is read as A(row, c) * a_scale[c] -- W's pending column scale
 template <typename T>
 hipError_t launch_permute(const T* src, const int* perm, T* dst, long count, hipStream_t stream);
 // sums(c) = sum_y P(c, y); partial: (len_pad / 128) * RP elements of scratch
@@ -448,11 +449,12 @@ hipError_t launch_panel_rowsum(const T* P, int RP, int len_pad, T* partial, T* s
 template <typename T>
 // num: `parts` partial numerator panels part_stride apart, added in order
 hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts = 1, long part_stride = 0,
-                            T* sum_part = nullptr);      // sum_part (optional): (len_pad / 128) * RP partial sums of the new values
+                            T* sum_part = nullptr,       // sum_part (optional): (len_pad / 128) * RP partial sums of the new values
+                            const T* scale = nullptr);   // scale (RP factors, optional): P(c, y) <- (P(c, y) scale[c]) num(c, y) / (den(c) + eps)
 // sums(c) = sum of the len_pad / 128 vectors of sum_part, divided by sqrt(sum of sumsq_part) where sumsq_part is given and that is > 0 (the column sums of a panel
 // AFTER its column normalisation, from what its update left behind); RP in {64, 128, 256}
 template <typename T>
-hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream);
+hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream, T* scale_out = nullptr);      // scale_out (optional): 1 / sqrt(sum of squares), 1 where that is 0
 
 // ---- the CSR and CSC images of a sparse V built on the device (kernels_sparse_setup.hip) ----------------------------------------
 // flags (one int, zeroed by the caller): bit 0 = an entry outside the matrix or outside every pointer range, bit 1 = pointer array not ascending, bit 2 = the

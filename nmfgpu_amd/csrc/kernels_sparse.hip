@@ -200,7 +200,7 @@ template <typename T, int VEC, bool TERMS>
 __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                                   const T* __restrict__ A, const T* __restrict__ B, T eps,
                                                   T* __restrict__ out, T* __restrict__ t_vwh, T* __restrict__ t_kl, int rows, int rows_pad,
-                                                  int blocks, long out_stride) {
+                                                  int blocks, long out_stride, const T* __restrict__ a_scale) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int per_block = (rows_pad + 3) >> 2;            // workgroups per block
 	// Which (block, row group) this workgroup is.  blocks % 8 == 0 (the engine cuts long factors that way): workgroup i runs on XCD i % 8, and XCD x takes
@@ -233,6 +233,12 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
 		T a[SEG];
 #pragma unroll
 		for (int e = 0; e < SEG; ++e) a[e] = A[(long)row * RP + sl * SEG + e];
+		// a_scale (round 6): W is carried with a pending column scale d -- W = Wt D -- and every dot product W(i, :) . H(:, j) takes d once, on the row that is
+		// loaded once per output row (the H step's own row of H, the W step's own row of Wt); the gathered rows stay as they lie
+		if (a_scale != nullptr) {
+#pragma unroll
+			for (int e = 0; e < SEG; ++e) a[e] *= a_scale[sl * SEG + e];
+		}
 		const int p_begin = ptr[(long)row * pstride + blk], p_end = ptr[(long)row * pstride + blk + 1];
 		for (int p0 = p_begin; p0 < p_end; p0 += 8) {
 			const int pa = p0 + g, pb = p0 + 4 + g;
@@ -286,13 +292,13 @@ __global__ __launch_bounds__(256) void k_kl_fused(const int* __restrict__ ptr, c
 // out: rows_pad x RP numerator panel (rows in [rows, rows_pad) zeroed); t_vwh == nullptr: no per-row error terms
 template <typename T>
 hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T* A, const T* B, int RP, T eps,
-                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks, long out_stride) {
+                           T* out, T* t_vwh, T* t_kl, int rows, int rows_pad, hipStream_t stream, int blocks, long out_stride, const T* a_scale) {
 	if (blocks < 1) return hipErrorInvalidValue;
 	dim3 grid((unsigned)(((rows_pad + 3) / 4) * blocks)), block(256);
 	const bool terms = t_vwh != nullptr && t_kl != nullptr;
 #define NMFAMD_KLF(VEC)                                                                                                                        \
-	if (terms) hipLaunchKernelGGL((k_kl_fused<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride); \
-	else hipLaunchKernelGGL((k_kl_fused<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride);      \
+	if (terms) hipLaunchKernelGGL((k_kl_fused<T, VEC, true>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride, a_scale); \
+	else hipLaunchKernelGGL((k_kl_fused<T, VEC, false>), grid, block, 0, stream, ptr, idx, val, A, B, eps, out, t_vwh, t_kl, rows, rows_pad, blocks, out_stride, a_scale);      \
 	break
 	switch (RP / 64) {
 	case 1: NMFAMD_KLF(1);
@@ -303,8 +309,8 @@ hipError_t launch_kl_fused(const int* ptr, const int* idx, const T* val, const T
 #undef NMFAMD_KLF
 	return hipGetLastError();
 }
-template hipError_t launch_kl_fused<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, int, hipStream_t, int, long);
-template hipError_t launch_kl_fused<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, int, hipStream_t, int, long);
+template hipError_t launch_kl_fused<float>(const int*, const int*, const float*, const float*, const float*, int, float, float*, float*, float*, int, int, hipStream_t, int, long, const float*);
+template hipError_t launch_kl_fused<double>(const int*, const int*, const double*, const double*, const double*, int, double, double*, double*, double*, int, int, hipStream_t, int, long, const double*);
 
 // dst[p] = src[perm[p]]: the quotients in the other storage order
 template <typename T>
@@ -351,13 +357,16 @@ template hipError_t launch_panel_rowsum<double>(const double*, int, int, double*
 // panel column; the `parts` partial numerators (the blocks of the blocked KL step) are added in block order, eight loads in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* __restrict__ num, const T* __restrict__ den, int RP, T eps,
-                                                   T* __restrict__ sumsq_part, int parts, long part_stride, T* __restrict__ sum_part) {
+                                                   T* __restrict__ sumsq_part, int parts, long part_stride, T* __restrict__ sum_part, const T* __restrict__ scale) {
 	typedef T T4 __attribute__((ext_vector_type(4)));
 	__shared__ T s_ss[256 * 4], s_sv[256 * 4];
 	const long base = (long)blockIdx.x * 128 * RP;
 	const int per_row = RP / 4, c4 = threadIdx.x % per_row, yy = threadIdx.x / per_row, ystep = 256 / per_row;
 	T4 d = *reinterpret_cast<const T4*>(den + 4 * c4);
 	d += in_vgpr(eps);      // (a scalar operand of a packed add otherwise: split3.h)
+	// scale (round 6, W's pending column scale d): the H update's numerator is D (Wt^T Q), the W update's old value is Wt D -- either way one more factor per element
+	T4 sc = {1, 1, 1, 1};
+	if (scale != nullptr) sc = *reinterpret_cast<const T4*>(scale + 4 * c4);
 	T4 ss = {0, 0, 0, 0}, sv = {0, 0, 0, 0};
 	for (int y = yy; y < 128; y += ystep) {
 		const long e = base + (long)y * RP + 4 * c4;
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 		}
 #undef NMFAMD_KL_TAIL
 		const T4 p = *reinterpret_cast<const T4*>(P + e);
-		const T4 v = p * nm / d;
+		const T4 v = (p * sc) * nm / d;
 		*reinterpret_cast<T4*>(P + e) = v;
 		ss += v * v;
 		sv += v;
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(256) void k_kl_update(T* __restrict__ P, const T* _
 // One workgroup of 1024 threads per 16 columns (16 columns x 64 groups of parts, eight loads in flight, groups added in order): a single workgroup pulled the
 // 800 KB of config 3's W-side partials through one CU in 8.4 us.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_kl_sums(const T* __restrict__ sum_part, const T* __restrict__ sumsq_part, int parts, int RP, T* __restrict__ sums) {
+__global__ __launch_bounds__(1024) void k_kl_sums(const T* __restrict__ sum_part, const T* __restrict__ sumsq_part, int parts, int RP, T* __restrict__ sums, T* __restrict__ scale_out) {
 	__shared__ T s_a[1024], s_b[1024];
 	const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
 	T a = 0, b = 0;
@@ -427,25 +436,27 @@ __global__ __launch_bounds__(1024) void k_kl_sums(const T* __restrict__ sum_part
 		T sa = 0, sb = 0;
 		for (int k = 0; k < 64; ++k) { sa += s_a[k * 16 + cl]; sb += s_b[k * 16 + cl]; }
 		sums[c] = sumsq_part == nullptr ? sa : (sb > T(0) ? sa / (T)sqrt((double)sb) : sa);
+		// the pending column scale itself (kernel::normalizeColumns as a factor, KernelNormalizeColumns.cu:37-58): 1 / sqrt(sum of squares), 1 for an all-zero column
+		if (scale_out != nullptr) scale_out[c] = sb > T(0) ? (T)(1.0 / sqrt((double)sb)) : T(1);
 	}
 }
 
 template <typename T>
-hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream) {
+hipError_t launch_kl_sums(const T* sum_part, const T* sumsq_part, int parts, int RP, T* sums, hipStream_t stream, T* scale_out) {
 	if (RP < 64 || RP > 256 || RP % 16 != 0) return hipErrorInvalidValue;
-	hipLaunchKernelGGL((k_kl_sums<T>), dim3(RP / 16), dim3(1024), 0, stream, sum_part, sumsq_part, parts, RP, sums);
+	hipLaunchKernelGGL((k_kl_sums<T>), dim3(RP / 16), dim3(1024), 0, stream, sum_part, sumsq_part, parts, RP, sums, scale_out);
 	return hipGetLastError();
 }
-template hipError_t launch_kl_sums<float>(const float*, const float*, int, int, float*, hipStream_t);
-template hipError_t launch_kl_sums<double>(const double*, const double*, int, int, double*, hipStream_t);
+template hipError_t launch_kl_sums<float>(const float*, const float*, int, int, float*, hipStream_t, float*);
+template hipError_t launch_kl_sums<double>(const double*, const double*, int, int, double*, hipStream_t, double*);
 
 template <typename T>
-hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts, long part_stride, T* sum_part) {
+hipError_t launch_kl_update(T* P, const T* num, const T* den, int RP, int len_pad, T eps, T* sumsq_part, hipStream_t stream, int parts, long part_stride, T* sum_part, const T* scale) {
 	if (RP % 64 != 0 || RP > 256 || parts < 1) return hipErrorInvalidValue;
-	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part, parts, part_stride, sum_part);
+	hipLaunchKernelGGL((k_kl_update<T>), dim3(len_pad / 128), dim3(256), 0, stream, P, num, den, RP, eps, sumsq_part, parts, part_stride, sum_part, scale);
 	return hipGetLastError();
 }
-template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t, int, long, float*);
-template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t, int, long, double*);
+template hipError_t launch_kl_update<float>(float*, const float*, const float*, int, int, float, float*, hipStream_t, int, long, float*, const float*);
+template hipError_t launch_kl_update<double>(double*, const double*, const double*, int, int, double, double*, hipStream_t, int, long, double*, const double*);
 
 } // namespace nmfamd

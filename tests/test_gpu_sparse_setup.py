@@ -143,3 +143,37 @@ def test_inputs_the_device_path_hands_back(monkeypatch):
     W2 = F((1.0 - rng.random((m2, r))).astype(np.float32))
     long_col.set_factors(W2, H); long_col.iterate(2, last_iteration=2)
     assert np.isfinite(long_col.frobenius)
+
+
+def test_kl_iteration_with_the_pending_column_scale_equals_normalising_every_iteration(monkeypatch):
+    """Round 6: the KL iteration leaves W unnormalised with its column scale as a pending factor (no pass over the panel per iteration); NMFAMD_NO_FUSED_MU=1 keeps
+    the normalising pass.  Same arithmetic up to where the factor 1 / sqrt(sum) is applied: factors, divergence and Frobenius error agree to fp32 rounding, the
+    columns of the downloaded W are unit vectors, and stepping one iteration at a time with a download after each step (which folds the scale in) ends in the same place."""
+    monkeypatch.delenv("NMFAMD_SPARSE_SETUP", raising=False)
+    m, n, r, iters = 3000, 900, 70, 12
+    rows, cols, vals = triplets(m, n, 0.02, seed=77)
+    arrays = as_format(1, rows, cols, vals, m, n, 0, "sorted")
+    rng = np.random.default_rng(8)
+    W, H = F((1.0 - rng.random((m, r))).astype(np.float32)), F((1.0 - rng.random((r, n))).astype(np.float32))
+
+    def run(stepwise=False):
+        eng = na.Engine(m, n, r, "mu", divergence="kl")
+        eng.upload_sparse(1, *arrays, 0)
+        eng.set_factors(W, H)
+        if stepwise:
+            for k in range(1, iters + 1):
+                eng.iterate(1, first_iteration=k, error_every=4, last_iteration=iters)
+                Wk, _ = eng.get_factors()
+                np.testing.assert_allclose(np.linalg.norm(Wk, axis=0), 1.0, rtol=1e-5)
+        else:
+            eng.iterate(iters, first_iteration=1, error_every=4, last_iteration=iters)
+        return eng.get_factors() + (eng.kl_divergence, eng.frobenius)
+
+    Wp, Hp, klp, fp = run()
+    Ws, Hs, kls, fs = run(stepwise=True)
+    monkeypatch.setenv("NMFAMD_NO_FUSED_MU", "1")
+    Wn, Hn, kln, fn = run()
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+    assert rel(Wp, Wn) < 2e-5 and rel(Hp, Hn) < 2e-5 and rel(Ws, Wn) < 2e-5 and rel(Hs, Hn) < 2e-5
+    assert klp == pytest.approx(kln, rel=1e-5) and fp == pytest.approx(fn, rel=1e-5) and kls == pytest.approx(kln, rel=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(Wp, axis=0), 1.0, rtol=1e-5)

@@ -37,7 +37,7 @@ DIAG_ONLY = {"kernels_onepass.hip"}
 # into v2f32 values, which costs a v_mov per element to line the pairs up and re-serialises the chain
 # Since round 3 the SLP vectoriser is off for EVERY device source (DEVICE_FLAGS): it also pairs `uniform * x + uniform` into
 # v_pk_fma_f32 with a scalar-register source, which gave wrong low halves in lanes 48..63 whenever waves of another kernel shared
-# the SIMD (csrc/split3.h in_vgpr; check_packed_scalar_sources below).
+# the SIMD (docs/DESIGN_r05.md section 11; csrc/split3.h in_vgpr; check_packed_scalar_sources below).
 EXTRA_FLAGS = {}
 DEVICE_FLAGS = ["-fno-slp-vectorize"]
 # experiment switches: NMFAMD_CXXFLAGS="-DNAME=1 ..." is appended to every compile (and forces nothing: use --force)
@@ -67,7 +67,7 @@ _PACKED_SCALAR = re.compile(r"\bv_pk_\w+_[fb]32\b.*(?<![\w.])s(\d+|\[\d+:\d+\])"
 def packed_scalar_sources(obj: str) -> list:
     """Disassembles the gfx950 code object inside a compiled .hip object and returns "kernel: instruction" for every packed 32-bit
     instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32) that reads a scalar register -- the form that misbehaved
-    when other kernels' waves shared the SIMD.  Empty list = clean."""
+    when other kernels' waves shared the SIMD (docs/DESIGN_r05.md section 11).  Empty list = clean."""
     llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")

@@ -152,7 +152,7 @@ def test_package_does_not_import_the_oracle():
 
 
 def test_no_packed_fp32_instruction_reads_a_scalar_register():
-    """gfx950 rule found in round 3: v_pk_fma / mul / add_f32 with a scalar-register source returned wrong low
+    """gfx950 rule found in round 3 (docs/DESIGN_r05.md section 11): v_pk_fma / mul / add_f32 with a scalar-register source returned wrong low
     halves in lanes 48..63 whenever another kernel's waves shared the SIMD.  The build refuses such code (nmfgpu_amd/build.py);
     this re-checks the objects the loaded library was linked from, and that the check itself still sees the offending form."""
     from nmfgpu_amd import build as b

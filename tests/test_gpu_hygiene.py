@@ -53,7 +53,7 @@ def test_one_image_window_follows_the_memory_side_cache(monkeypatch):
 
 
 def test_split_product_edges_are_the_documented_ones():
-    """kernels_x3.hip at its edges (DESIGN section 4.9): exact wherever every operand is 0 or within 2^-100 .. 2^126; outside
+    """kernels_x3.hip at its edges (DESIGN section 4.1): exact wherever every operand is 0 or within 2^-100 .. 2^126; outside
     that the result is NOT the fp32 product -- which is why the engine does not run this kernel on such a V (next test)."""
     rng = np.random.default_rng(0)
     X, Y, r = 256, 320, 64

@@ -368,7 +368,7 @@ def test_config4_as_stated_eight_shards_on_one_device():
         assert f == pytest.approx(out["single"][2], rel=2e-2)
     assert rel(out["rows"][0], out["repl"][0]) < 1e-3 and rel(out["rows"][1], out["repl"][1]) < 1e-3
     # eight rank threads with a stream each on one device: the same bits every time (round 3 found one or two ranks per run going wrong by a few
-    # per cent -- packed fp32 instructions with a scalar source misbehaving beside other kernels' waves; tests/test_gpu_shared_device.py)
+    # per cent -- packed fp32 instructions with a scalar source misbehaving beside other kernels' waves, docs/DESIGN_r05.md section 11; tests/test_gpu_shared_device.py)
     for _ in range(2):
         W, H = W0.copy(order="F"), H0.copy(order="F")
         assert na.compute(V, W, H, algorithm=na.NmfAlgorithm.nsNMF, iterations=iters, parameters=dict(base, numGpus=8, shardMode=1)) == na.ResultType.Success

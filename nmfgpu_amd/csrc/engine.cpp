@@ -1496,6 +1496,14 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		const double diag = ns ? (1.0 - prm_.theta) + off : 1.0;
 		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 		struct RideGuard { const GramRideF64*& p; ~RideGuard() { p = nullptr; } } guard{ride64_};
+		// Error iterations of a single engine: the H update writes its n terms and the W update's trace workgroups their r terms straight into the pinned host
+		// buffer (its device address): no k_trace_small launch, no copy launch (as iterate_mu64 does since round 5) -- 1.2 us per iteration on average at the
+		// reference example's shape.  The previous error iteration's values leave the buffer first.
+		ps_direct_ = compute_error && !error_terms_stay_ && pin_psN_dev_ != nullptr && tuning_env("NMFAMD_ERROR_COPY_KERNEL") == nullptr;
+		if (ps_direct_) finalize_error(false);
+		struct DirectGuard { bool& f; ~DirectGuard() { f = false; } } direct_guard{ps_direct_};
+		T* const ps_n = ps_direct_ ? pin_psN_dev_ : psN_;
+		T* const ps_r = ps_direct_ ? pin_psN_dev_ + ps_stride_ : psR_;
 		// 1
 		GramRideF64 gw = {};
 		gw.P = Wt_; gw.len = m_; gw.slices = f64_slices_h_; gw.partial = f64_partial_; gw.counters = f64_counters_; gw.G = G_;
@@ -1513,8 +1521,8 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		fh.scale = dscale; fh.r = r_;
 		if (ns) { fh.smooth = 1; fh.off = off; fh.diag = diag; fh.smooth_out = Hs_; }
 		fh.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 1l * 4096 * 8 : nullptr;
-		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
-		else HIPX(launch_panel_update_wide_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr, stream_, &fh));
+		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, (int)npad_, eps, compute_error ? ps_n : nullptr, n_, nullptr, nullptr, stream_, &fh));
+		else HIPX(launch_panel_update_wide_f64(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, G_, RP_, (int)npad_, eps, compute_error ? ps_n : nullptr, n_, nullptr, nullptr, stream_, &fh));
 		// 3
 		const double* Fh = ns ? Hs_ : H_;
 		GramRideF64 gh = {};
@@ -1525,12 +1533,12 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		ride64_ = &gh;
 		if (Status s = product_w(Fh)) return s;
 		ride64_ = nullptr;
-		// tr((S H)(S H)^T W^T W) with the W^T W of this iteration's H step, unsmoothed (AlgorithmNonSmoothNMF.h:201-202; AlgorithmMultiplicativeFrobenius.h:212)
-		// (G_ is the Gram matrix of the panel as it lies: the pending scale is applied on the way, D G D = W^T W of the normalised W)
-		if (compute_error) HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_, nullptr, dscale));
-		// 4
+		// 4 -- and, on error iterations, tr((S H)(S H)^T W^T W) with the W^T W of this iteration's H step, unsmoothed (AlgorithmNonSmoothNMF.h:201-202;
+		// AlgorithmMultiplicativeFrobenius.h:212) by extra workgroups of the same launch (G_ is the Gram matrix of the panel as it lies: the pending scale is applied
+		// on the way, D G D = W^T W of the normalised W)
 		PanelFusedF64 fw = {};
 		fw.old_scale = dscale;
+		if (compute_error) { fw.trace_a = HHt_; fw.trace_b = G_; fw.trace_scale = dscale; fw.trace_out = ps_r; fw.trace_r = r_; }
 		fw.stamps = f64_stamps_ != nullptr ? f64_stamps_ + 3l * 4096 * 8 : nullptr;
 		if (RP_ == 64) HIPX(launch_panel_update64_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));
 		else HIPX(launch_panel_update_wide_f64(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, HHt_, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr, stream_, &fw));

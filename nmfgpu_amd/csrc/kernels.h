@@ -315,8 +315,16 @@ struct PanelFusedF64 {
 	double off, diag;
 	int r;
 	double* smooth_out;         // H update: a second panel that receives S new(y, :) (the operand of V (S H)^T and of its Gram matrix)
+	// W update on error iterations: ceil(trace_r / 4) extra workgroups behind the panel's compute the r terms of tr(H H^T W^T W) (k_trace_small's arithmetic:
+	// trace_out[d] = sum_i A(i, d) B(d, i) f(d) f(i), f = trace_scale or ones) -- the launch of its own and the boundary around it are gone
+	const double* trace_a;
+	const double* trace_b;
+	const double* trace_scale;
+	double* trace_out;
+	int trace_r;
 	unsigned long long* stamps; // measurement builds: [workgroups][8] wall-clock stamps (wide kernel)
 };
+inline int panel_fused_f64_extra_workgroups(const PanelFusedF64* fx) { return (fx != nullptr && fx->trace_out != nullptr) ? (fx->trace_r + 3) / 4 : 0; }
 // fp64 / padded rank 64 panel update on the fp64 MFMA pipe (32 panel rows per workgroup: len_pad / 32 norm partials)
 hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, int S, long slab_stride, const double* Q, int len_pad,
                                      double eps, double* ps, int len_valid, double* sumsq_part, double* num_out, hipStream_t stream, const PanelFusedF64* fused = nullptr);

@@ -453,8 +453,12 @@ static void ride64_grid(const FactorProductPlan& p, int RP, int slices, int* xbl
 
 // items[pid] = super-block * slices + slice for the passengers pid < super-blocks * slices of the launch launch_factor_product_f64(p, ..., ride) makes.
 // Model: the hardware deals the workgroups of a grid to the eight XCDs in linear order (x fastest), workgroup L to XCD L mod 8 (what the KL gather and the
-// split-operand product's placement rely on too).  K slice s belongs to XCD s mod 8: an XCD's passengers take its slices' items first (super-blocks in order), what is
-// left over goes to the XCDs with passengers to spare.  Only the traffic depends on the model being right, never the result: every item is taken exactly once.
+// split-operand product's placement rely on too).  SUPER-BLOCK b belongs to XCD b mod 8: an XCD's passengers take the slices of its super-blocks first, what is
+// left over goes to the XCDs with passengers to spare -- the last arriver of a super-block then finds most of the partial blocks it adds in its own XCD's L2
+// (plain-stored slabs are read at 104 - 122 GB/s per workgroup from the same XCD against 62 - 70 across XCDs: the guide's split-K figures; the reduction of
+// sixteen 32 KB partial blocks is what ends the H-side launch at the reference example's shape).  A first table kept a K SLICE on one XCD (every L2 pulling only
+// its slices' rows of the panel): no change -- the passengers' loop is bound by the fp64 matrix pipe.  Only the speed depends on the model being right, never
+// the result: every item is taken exactly once.
 void gram_ride_f64_items(const FactorProductPlan& p, int RP, int slices, std::vector<int>& items) {
 	const int nbk = RP / 64, nsuper = nbk * (nbk + 1) / 2, count = nsuper * slices;
 	int xblocks, extra;
@@ -467,8 +471,8 @@ void gram_ride_f64_items(const FactorProductPlan& p, int RP, int slices, std::ve
 		const long L = (long)x + (long)GX * ((row % GY) + (long)GY * (row / GY));
 		wgs[(int)(L % 8)].push_back(pid);
 	}
-	for (int sl = 0; sl < slices; ++sl)
-		for (int sb = 0; sb < nsuper; ++sb) work[sl % 8].push_back(sb * slices + sl);
+	for (int sb = 0; sb < nsuper; ++sb)
+		for (int sl = 0; sl < slices; ++sl) work[sb % 8].push_back(sb * slices + sl);
 	std::vector<int> spare_wgs, spare_work;
 	for (int x = 0; x < 8; ++x) {
 		const size_t k = std::min(wgs[x].size(), work[x].size());
@@ -552,6 +556,23 @@ __device__ __forceinline__ void fused64_h_prepare(double* s_num, const double* s
 		if (sub == 0) s_rs[y] = osum;
 	} else if (sub == 0) s_rs[y] = 0.0;
 }
+// the trace workgroups behind a W update's panel workgroups (PanelFusedF64::trace_*): one wave per term, lanes stride the inner index, butterfly sum --
+// k_trace_small's order (kernels.hip), hence its bits
+__device__ __forceinline__ void fused64_trace(const PanelFusedF64& fx, int RP, int block) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int d = block * 4 + wave;
+	if (d >= fx.trace_r) return;
+	double s = 0.0;
+	if (fx.trace_scale != nullptr) {
+		const double fd = fx.trace_scale[d];
+		for (int i = lane; i < fx.trace_r; i += 64) s += fx.trace_a[(long)i * RP + d] * (fx.trace_b[(long)d * RP + i] * (fd * fx.trace_scale[i]));
+	} else {
+		for (int i = lane; i < fx.trace_r; i += 64) s += fx.trace_a[(long)i * RP + d] * fx.trace_b[(long)d * RP + i];
+	}
+	for (int w = 32; w > 0; w >>= 1) s += __shfl_xor(s, w);
+	if (lane == 0) fx.trace_out[d] = s;
+}
+
 template <int YB>
 __device__ __forceinline__ void fused64_smooth_out(const double* s_new, int LD, int RP, long base, const PanelFusedF64& fx) {
 	constexpr int TPR = 256 / YB;
@@ -571,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update64_f64(
 	const double* __restrict__ Q, double eps, double* __restrict__ ps, int len_valid,
 	double* __restrict__ sumsq_part, double* __restrict__ num_out, PanelFusedF64 fx) {
 	constexpr int YB = 32, LD = 68;
+	if (fx.trace_out != nullptr && (int)blockIdx.x >= (int)gridDim.x - (fx.trace_r + 3) / 4) { fused64_trace(fx, 64, (int)blockIdx.x - ((int)gridDim.x - (fx.trace_r + 3) / 4)); return; }
 	__shared__ __attribute__((aligned(16))) double s_num[YB * LD];
 	__shared__ __attribute__((aligned(16))) double s_old[YB * LD];      // old values, then the new ones
 	__shared__ double s_ps[4][YB];
@@ -727,6 +749,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 	double* __restrict__ sumsq_part, double* __restrict__ num_out, PanelFusedF64 fx) {
 	extern __shared__ __attribute__((aligned(16))) double ldsw[];
 	constexpr int YB = 16;
+	if (fx.trace_out != nullptr && (int)blockIdx.x >= (int)gridDim.x - (fx.trace_r + 3) / 4) { fused64_trace(fx, RP, (int)blockIdx.x - ((int)gridDim.x - (fx.trace_r + 3) / 4)); return; }
 	const int LD = RP + 4;
 	double* s_num = ldsw;                  // [16][LD]
 	double* s_old = ldsw + YB * LD;        // [16][LD]
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f64(
 		}
 		// (SB slabs requested at a time, added in slab order -- see k_panel_update64_f64)
 #ifndef WIDE64_SB
-#define WIDE64_SB (NE <= 4 ? 8 : (NE <= 8 ? 4 : 2))      /* at most 32 sixteen-byte loads (128 registers) in flight */
+#define WIDE64_SB (NE <= 4 ? 8 : (NE <= 8 ? 4 : 2))      /* at most 32 sixteen-byte loads (128 registers) in flight; 48 at the narrow panels measured the same */
 #endif
 		constexpr int SB = WIDE64_SB;
 		for (int k = 1; k < S; k += SB) {
@@ -901,7 +924,7 @@ static hipError_t launch_wide_f64(double* P, const double* slabs, int S, long sl
 	const size_t max_bytes = sizeof(double) * (2 * 16 * (size_t)(64 * NCT + 4) + 64 + (HS ? 64 + 16 + 64 * (size_t)NCT : 0));
 	static std::atomic<unsigned long long> lds_done{0ull};
 	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f64<MODE, NCT, HS>), (int)max_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT, HS>), dim3(len_pad / 16), dim3(256), lds_bytes, stream,
+	hipLaunchKernelGGL((k_panel_update_wide_f64<MODE, NCT, HS>), dim3(len_pad / 16 + panel_fused_f64_extra_workgroups(&fx)), dim3(256), lds_bytes, stream,
 	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, fx);
 	return hipGetLastError();
 }
@@ -937,7 +960,7 @@ hipError_t launch_panel_update64_f64(int mode, double* P, const double* slabs, i
 	if (fused != nullptr) fx = *fused;
 	if (fx.h_side && mode != PANEL_MU) return hipErrorInvalidValue;
 	if (!fx.smooth) { fx.off = 0.0; fx.diag = 1.0; }
-	dim3 grid(len_pad / 32), block(256);
+	dim3 grid(len_pad / 32 + panel_fused_f64_extra_workgroups(&fx)), block(256);
 	if (fx.h_side) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU, true>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);
 	else if (mode == PANEL_MU) hipLaunchKernelGGL((k_panel_update64_f64<PANEL_MU, false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);
 	else hipLaunchKernelGGL((k_panel_update64_f64<PANEL_LS, false>), grid, block, 0, stream, P, slabs, S, slab_stride, Q, eps, ps, len_valid, sumsq_part, num_out, fx);

@@ -485,7 +485,7 @@ Status Engine<T>::allocate() {
 template <typename T>
 Status Engine<T>::finish_upload(T* Vcol) {
 	int odd_values = 0;
-	h_product_ahead_ = false;
+	h_product_ahead_ = false; f64_product_ahead_ = false;
 	HIPX(hipMemsetAsync(range_flag_, 0, sizeof(int), stream_));
 	HIPX(launch_column_sumsq<T>(Vcol, mpad_, m_, n_, psN_, stream_, x3_ ? range_flag_ : nullptr));
 	h_vtv_.resize(n_);
@@ -685,7 +685,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
+		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
@@ -731,7 +731,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { h_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
+	if (w) { h_product_ahead_ = false; f64_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -1089,7 +1089,7 @@ Status Engine<T>::h_step(bool compute_error) {
 template <typename T>
 Status Engine<T>::h_step_impl(bool compute_error) {
 	const T eps = std::numeric_limits<T>::epsilon();
-	h_product_ahead_ = false;                           // (the three-phase API enqueues its own W^T V)
+	h_product_ahead_ = false; f64_product_ahead_ = false;                           // (the three-phase API enqueues its own W^T V)
 	if constexpr (std::is_same<T, float>::value) {
 		if (fused_capable()) {
 			// sharded form of the four-launch iteration (kernels_mu64.hip): K_H + U_H here
@@ -1487,6 +1487,23 @@ bool Engine<T>::fused64_capable() const {
 //   4. W update: old rows read as W d, result left unnormalised + per-workgroup sums of squares (the first half of kernel::normalizeColumns)
 // References: AlgorithmMultiplicativeFrobenius.h:165-248, AlgorithmNonSmoothNMF.h:174-218 (same operation order per element; the column scale is a factor
 // 1 / sqrt(sum) where the reference divides by sqrt(sum): 1 ulp, inside the 1e-9 the fp64 tests ask).
+// launch 1 of the fused double-precision iteration: W^T V from the panel as it lies + the Gram passengers (W^T W, the pending column scale)
+template <typename T>
+Status Engine<T>::fused64_product_h() {
+	if constexpr (std::is_same<T, double>::value) {
+		struct RideGuard { const GramRideF64*& p; ~RideGuard() { p = nullptr; } } guard{ride64_};
+		GramRideF64 gw = {};
+		gw.P = Wt_; gw.len = m_; gw.slices = f64_slices_h_; gw.partial = f64_partial_; gw.counters = f64_counters_; gw.G = G_;
+		gw.sumsq_part = f64_pending_ ? sumsq_part_ : nullptr; gw.sumsq_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_); gw.scale_out = f64_scale_;
+		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gw.stop = std::atoi(e);
+		gw.stamps = f64_stamps_;
+		gw.items = f64_items_h_;
+		ride64_ = &gw;
+		return product_h(Wt_);
+	}
+	return ST_OK;
+}
+
 template <typename T>
 Status Engine<T>::iterate_fused64(bool compute_error) {
 	if constexpr (std::is_same<T, double>::value) {
@@ -1494,7 +1511,6 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		const bool ns = alg_ == ALG_NSNMF;
 		const double off = ns ? prm_.theta / (double)(unsigned)r_ : 0.0;
 		const double diag = ns ? (1.0 - prm_.theta) + off : 1.0;
-		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 		struct RideGuard { const GramRideF64*& p; ~RideGuard() { p = nullptr; } } guard{ride64_};
 		// Error iterations of a single engine: the H update writes its n terms and the W update's trace workgroups their r terms straight into the pinned host
 		// buffer (its device address): no k_trace_small launch, no copy launch (as iterate_mu64 does since round 5) -- 1.2 us per iteration on average at the
@@ -1504,16 +1520,9 @@ Status Engine<T>::iterate_fused64(bool compute_error) {
 		struct DirectGuard { bool& f; ~DirectGuard() { f = false; } } direct_guard{ps_direct_};
 		T* const ps_n = ps_direct_ ? pin_psN_dev_ : psN_;
 		T* const ps_r = ps_direct_ ? pin_psN_dev_ + ps_stride_ : psR_;
-		// 1
-		GramRideF64 gw = {};
-		gw.P = Wt_; gw.len = m_; gw.slices = f64_slices_h_; gw.partial = f64_partial_; gw.counters = f64_counters_; gw.G = G_;
-		gw.sumsq_part = f64_pending_ ? sumsq_part_ : nullptr; gw.sumsq_parts = norm_parts; gw.scale_out = f64_scale_;
-		if (const char* e = tuning_env("NMFAMD_RIDE64_STOP")) gw.stop = std::atoi(e);
-		gw.stamps = f64_stamps_;
-		gw.items = f64_items_h_;
-		ride64_ = &gw;
-		if (Status s = product_h(Wt_)) return s;
-		ride64_ = nullptr;
+		// 1 (already enqueued by begin_next_iteration() behind the previous error iteration: nothing has touched W, V or the scratch since)
+		if (f64_product_ahead_) f64_product_ahead_ = false;
+		else if (Status s = fused64_product_h()) return s;
 		// 2
 		PanelFusedF64 fh = {};
 		const double* dscale = f64_pending_ ? f64_scale_ : nullptr;
@@ -1610,6 +1619,7 @@ Status Engine<T>::materialize_w(bool whole_panel) {
 		// the fused double-precision iteration left W unnormalised: the second half of kernel::normalizeColumns, as the generic iteration runs it after every W update
 		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
 		f64_pending_ = false;
+		f64_product_ahead_ = false;      // (an ahead launch multiplied with the unnormalised panel and its pending scale)
 		gram_w_ready_ = false;
 	}
 	if constexpr (std::is_same<T, float>::value) {
@@ -1620,7 +1630,7 @@ Status Engine<T>::materialize_w(bool whole_panel) {
 			HIPX(launch_mu64_apply_scale(Wt_, (int)mpad_, scale_, stream_));
 			w_pending_ = false;
 			fused_ready_ = false;
-			h_product_ahead_ = false;
+			h_product_ahead_ = false; f64_product_ahead_ = false;
 			wx3_valid_ = false;
 		}
 		if (tri_scale_pending_) {
@@ -1745,6 +1755,17 @@ Status Engine<T>::iterate_mu64(bool compute_error) {
 
 template <typename T>
 Status Engine<T>::begin_next_iteration() {
+	if constexpr (std::is_same<T, double>::value) {
+		// the fused double-precision iteration: its first launch writes the split-K slabs, G_ and the scale vector -- scratch the next iterate() overwrites anyway
+		if (!fused64_capable() || f64_partial_ == nullptr || !f64_pending_ || f64_product_ahead_ || prm_.divergence != 0) return ST_OK;
+		const bool sampled = timing_now_;
+		timing_now_ = false;
+		const Status s = fused64_product_h();
+		timing_now_ = sampled;
+		if (s != ST_OK) return s;
+		f64_product_ahead_ = true;
+		return ST_OK;
+	}
 	if constexpr (std::is_same<T, float>::value) {
 		if (!fused_capable() || one_pass_ || !fused_ready_ || h_product_ahead_ || prm_.divergence != 0 || !x3_ || !wx3_valid_) return ST_OK;
 		GramReduceArgs rgW = gram_args(true, G_, scale_, normalize_next_);

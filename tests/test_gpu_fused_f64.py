@@ -135,3 +135,27 @@ def test_repeated_runs_are_bit_identical():
     for _ in range(3):
         _, Wb, Hb = run_engine(V, W, H, "nsnmf", iters, theta=0.5)
         assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+
+
+def test_compute_in_double_with_the_next_launch_enqueued_ahead():
+    """nmfgpu::compute's loop enqueues the next iteration's first launch before it waits for an error value (abi.cpp; round 6: also for the double-precision fused
+    iteration).  Runs that end on their last iteration, on the threshold mid-way, and right behind an error iteration return the factors of an engine stepped one
+    iteration at a time; the reported error is the oracle's."""
+    m, n, r = 700, 260, 90
+    V, W, H = problem(m, n, r, seed=41)
+    assert na.initialize() in (na.ResultType.Success, na.ResultType.ErrorAlreadyInitialized)
+    na.set_verbosity(na.Verbosity.Nothing)
+    for iters, threshold in ((37, 0.0), (40, 0.0), (200, 1e9)):      # (1e9: the threshold test passes at the second error iteration -- the launch enqueued ahead there is wasted)
+        Wc, Hc = W.copy(order="F"), H.copy(order="F")
+        s = na.Summary()
+        assert na.compute(V, Wc, Hc, algorithm=na.NmfAlgorithm.nsNMF, iterations=iters, summary=s, parameters={"theta": 0.5},
+                          threshold=threshold) == na.ResultType.Success
+        done = s.record(0).numIterations
+        assert done == (iters if threshold == 0.0 else 20)
+        eng = na.Engine(m, n, r, "nsnmf", dtype=np.float64, theta=0.5)
+        eng.upload(V); eng.set_factors(W, H)
+        for k in range(1, done + 1):
+            eng.iterate(1, first_iteration=k, error_every=10, last_iteration=done)
+        We, He = eng.get_factors()
+        assert rel(Wc, We) < 1e-12 and rel(Hc, He) < 1e-12, (iters, rel(Wc, We), rel(Hc, He))
+        assert s.record(0).frobenius == pytest.approx(eng.frobenius, rel=1e-12)

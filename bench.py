@@ -937,7 +937,10 @@ def main_f64(args):
     if kernel_launches > 0:
         avg_s = kernel_ms / 1e3 / kernel_launches
         ach = flops_per_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+        # (counter traffic of the product launch WITH its Gram passengers, measured at config 2's shape: tools/pmc_traffic.py, sha-stamped; null for the example's shape)
+        f64_traffic, f64_traffic_source = measured_traffic("factor_product_f64", "nmfgpu_amd/csrc/kernels_f64.hip") if not ex else (None, "not measured at this shape")
+        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": f64_traffic,
+                    "traffic_source": f64_traffic_source,
                     "kernel": "k_factor_product_f64", "launch_also_carries": "the Gram matrix of the operand as passenger workgroups (kernels_f64.hip, gram_ride_f64)",
                     "avg_launch_us": avg_s * 1e6, "idle_event_pair_us": pair_overhead_ms * 1e3, "launches": kernel_launches,
                     "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,

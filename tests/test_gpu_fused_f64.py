@@ -159,3 +159,18 @@ def test_compute_in_double_with_the_next_launch_enqueued_ahead():
         We, He = eng.get_factors()
         assert rel(Wc, We) < 1e-12 and rel(Hc, He) < 1e-12, (iters, rel(Wc, We), rel(Hc, He))
         assert s.record(0).frobenius == pytest.approx(eng.frobenius, rel=1e-12)
+
+
+def test_config2_shape_in_double_full_size_against_the_fp64_oracle():
+    """BASELINE configs[1]'s shape (10 000 x 5 000, r = 64) in double precision -- `bench.py --workload c2-f64` -- at full size: 12 iterations of the four-launch
+    iteration (237 / 240 product workgroups + 16 Gram passengers per launch, 6 / 3 K slices) against the fp64 oracle, 1e-9 on factors and error."""
+    m, n, r, iters = 10000, 5000, 64, 12
+    V, W, H = problem(m, n, r, seed=2)
+    Wo, Ho = W.copy(order="F"), H.copy(order="F")
+    ref = oracle.run("mu", V, Wo, Ho, iters)
+    eng, Wg, Hg = run_engine(V, W, H, "mu", iters)
+    g = eng.geometry()
+    assert g["fused_launches"] == 4 and g["padded_rank"] == 64 and 8 <= g["gram_ride_slices_h"] <= 16
+    assert rel(Wg, Wo) < 1e-9 and rel(Hg, Ho) < 1e-9, (rel(Wg, Wo), rel(Hg, Ho))
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-9)
+    np.testing.assert_allclose(np.linalg.norm(Wg, axis=0), 1.0, rtol=1e-12)

@@ -141,7 +141,8 @@ typedef struct nmfamd_geometry {
 	int w_col_split;                /* 1: V H^T runs as 128 x 32 workgroups (narrow column shards) */
 	/* round 6 */
 	int fused_launches;             /* 4: an iteration is product (+ Gram passengers) / update / product (+ Gram passengers) / update -- fp32 at padded rank 64 and,
-	                                   round 6, double precision (multiplicative update and nsNMF, padded ranks up to 512); 0: the generic launch sequence */
+	                                   round 6, double precision (multiplicative update and nsNMF, padded ranks up to 512); 8: fp32 at padded ranks 128 ... 512
+	                                   (Gram slices, reduction + split image + scale, product, update -- twice; the generic sequence: 14); 0: the generic launch sequence */
 	int sparse_setup;               /* sparse compute: where the CSR + CSC images of the last upload were built: 1 = on the device (kernels_sparse_setup.hip),
 	                                   0 = on the host (NMFAMD_SPARSE_SETUP=host, or an input the device path hands back: entries outside the matrix, a row or
 	                                   column of more than 8 192 entries, pointer arrays that do not ascend), -1 = not a sparse-compute engine */

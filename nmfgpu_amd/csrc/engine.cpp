@@ -151,6 +151,7 @@ Engine<T>::~Engine() {
 		}
 		(void)hipFree(f64_stamps_);
 	}
+	if (f32w_scale_) (void)hipFree(f32w_scale_);
 	{ void* fb[] = {f64_scale_, f64_partial_, f64_counters_, f64_items_h_, f64_items_w_}; for (void* b : fb) if (b) (void)hipFree(b); }
 	if (gramW_part_) (void)hipFree(gramW_part_);
 	if (wsq_part_) (void)hipFree(wsq_part_);
@@ -437,6 +438,10 @@ Status Engine<T>::allocate() {
 		HIPX(hipMalloc((void**)&wsq_part_, sizeof(float) * 64 * (size_t)(mpad_ / 32)));
 		HIPX(hipMemsetAsync(wsq_part_, 0, sizeof(float) * 64 * (size_t)(mpad_ / 32), stream_));
 	}
+	if (fused32w_capable()) {
+		HIPX(hipMalloc((void**)&f32w_scale_, sizeof(float) * (size_t)RP_));
+		HIPX(hipMemsetAsync(f32w_scale_, 0, sizeof(float) * (size_t)RP_, stream_));
+	}
 	if (fused64_capable()) {
 		// Gram passengers of the two product launches (kernels_f64.hip, gram_ride_f64): as many K slices per 64 x 64 super-block as the product's grid leaves CUs for,
 		// at most 16 (the level-1 finisher adds them one after the other), at least 4 (a grid that fills the chip: the passengers queue behind the product blocks)
@@ -685,7 +690,7 @@ template <typename T>
 Status Engine<T>::set_factors(const T* W, long ldw, const T* H, long ldh) {
 	if (W) {
 		if (ldw < m_) return ST_INVALID;
-		fused_ready_ = false; w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
+		fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; h_product_ahead_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; kl_sw_ready_ = false; w_rows_stale_ = false;
 		// host m x r (column-major) -> staging m x r (ld mpad) -> Wt panel (element (c, i) at [i * RP + c])
 		HIPX(hipMemcpy2DAsync(stage_, mpad_ * sizeof(T), W, ldw * sizeof(T), m_ * sizeof(T), r_, hipMemcpyHostToDevice, stream_));
@@ -731,7 +736,7 @@ Status Engine<T>::get_factors(T* W, long ldw, T* H, long ldh) {
 template <typename T>
 Status Engine<T>::randomize_factors(unsigned seed, bool w, bool h, long h_first_column) {
 	// The reference seeds W's and H's generators identically (RandomValueStrategy.cpp:53-69).
-	if (w) { h_product_ahead_ = false; f64_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
+	if (w) { h_product_ahead_ = false; f64_product_ahead_ = false; kl_sw_ready_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; kl_scale_pending_ = false; gram_w_ready_ = false; wx3_valid_ = false; hx3_valid_ = false; wtb_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; w_rows_stale_ = false; }
 	if (h) { gram_h_partials_ = false; hx3_valid_ = false; hb_valid_ = false; }
 	if (w) HIPX(launch_fill_uniform<T>(Wt_, RP_, r_, m_, mpad_, seed, stream_));
 	if (h) HIPX(launch_fill_uniform<T>(H_, RP_, r_, n_, npad_, seed, stream_, h_first_column));
@@ -1470,6 +1475,60 @@ bool Engine<T>::fused_capable() const {
 	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;   // (evaluated before allocate(): no tiled_ here)
 }
 
+// fp32 at padded ranks 128 ... 512 on the split-operand products (ranks 65 ... 512 in float: what rounds 1 - 5 ran as the generic sequence of 14 launches):
+// multiplicative update and nsNMF.  Long panels (the 64-row update kernel of kernels_wide.hip) and the bf16 mode keep their own paths.
+template <typename T>
+bool Engine<T>::fused32w_capable() const {
+	return std::is_same<T, float>::value && x3_ && tiled_ && !bf16_ && !sparse_ && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && RP_ >= 128 && panel_update_wide_available(RP_) &&
+	       gram_wide_available(RP_) && qx3_ != nullptr && !panel_update_long_available(RP_, (int)mpad_) && !panel_update_long_available(RP_, (int)npad_) &&
+	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
+}
+
+// One iteration in EIGHT launches, none of them a pack, a smoothing pass or a normalisation (the generic sequence: 14.2 at r = 128):
+//   Gram slices of Wt (k_gram_wide_x3) -> k_gram_reduce_x3: Wt^T Wt, ITS split image (the update's operand) and the pending column scale d
+//   Wt^T V from the split image the W update left
+//   H update (FX): num <- S D (sum of the slabs), den = S D (Wt^T Wt) D S h around the MFMA product; writes H, S H and the split image of the next product's operand
+//   the same for S H: Gram slices -> reduction + split image; V (S H)^T; W update (old rows read as Wt d, result unnormalised, its split image, sums of squares)
+// The float counterpart of iterate_fused64 without passengers: the split-operand product kernel is the headline's and stays as it is.
+template <typename T>
+Status Engine<T>::iterate_fused32w(bool compute_error) {
+	if constexpr (std::is_same<T, float>::value) {
+		const float eps = std::numeric_limits<float>::epsilon();
+		const bool ns = alg_ == ALG_NSNMF;
+		const float off = ns ? (float)prm_.theta / (float)(unsigned)r_ : 0.f;
+		const float diag = ns ? (float)((1.0 - (float)prm_.theta) + off) : 1.f;
+		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
+		const float* dscale = f32w_pending_ ? f32w_scale_ : nullptr;
+		// H step
+		HIPX(launch_gram_wide_fused_f32(Wt_, RP_, m_, gram_parts_, gram_part_, G_, qx3_, f32w_pending_ ? sumsq_part_ : nullptr, norm_parts, f32w_scale_, stream_));
+		if (Status s = product_h(Wt_, nullptr, wx3_valid_)) return s;
+		wx3_valid_ = true;
+		PanelFusedF32 fh;
+		fh.h_side = 1; fh.scale = dscale; fh.r = r_;
+		if (ns) { fh.smooth = 1; fh.off = off; fh.diag = diag; fh.smooth_out = Hs_; }
+		fh.x3_out = Hx3_; fh.x3_ks = ksW_;
+		HIPX(launch_panel_update_wide_f32(PANEL_MU, H_, slabs_, planH_.splits, slab_stride_, nullptr, RP_, (int)npad_, eps, compute_error ? psN_ : nullptr, n_, nullptr, nullptr,
+		                                  stream_, qx3_, nullptr, &fh));
+		// W step
+		const float* Fh = ns ? Hs_ : H_;
+		HIPX(launch_gram_wide_fused_f32(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, qx3_, nullptr, 0, nullptr, stream_));
+		if (Status s = product_w(Fh, nullptr, nullptr, true)) return s;
+		hx3_valid_ = !ns;
+		// tr((S H)(S H)^T W^T W) with the W^T W of this iteration's H step (the pending scale applied on the way: D G D)
+		if (compute_error) HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_, nullptr, dscale));
+		PanelFusedF32 fw;
+		fw.old_scale = dscale;
+		fw.x3_out = Wx3_; fw.x3_ks = ksH_;
+		HIPX(launch_panel_update_wide_f32(PANEL_MU, Wt_, slabs_, planW_.splits, slab_stride_, nullptr, RP_, (int)mpad_, eps, nullptr, m_, sumsq_part_, nullptr,
+		                                  stream_, qx3_, nullptr, &fw));
+		f32w_pending_ = true;
+		wx3_valid_ = true;          // (of the panel as it lies)
+		gram_w_ready_ = false;
+		if (compute_error) { if (Status s = fetch_error_terms(n_)) return s; }
+	}
+	return ST_OK;
+}
+
 // Double precision, multiplicative update and nsNMF on the MFMA kernels of kernels_f64.hip at any padded rank they cover: what the reference's own callers run
 // (example/main.cpp: NmfDescription<double>, nsNMF, r = 158; the R binding).  NMFAMD_NO_FUSED_MU=1 keeps the generic launch sequence (the cross-check path).
 template <typename T>
@@ -1610,6 +1669,13 @@ Status Engine<T>::ensure_w_rows() {
 template <typename T>
 Status Engine<T>::materialize_w(bool whole_panel) {
 	if (whole_panel) { if (Status s = ensure_w_rows()) return s; }
+	if (f32w_pending_) {
+		// the fused fp32 iteration at padded ranks >= 128 left W unnormalised (and the split image of THAT panel in Wx3_)
+		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, panel_update_parts(RP_, sizeof(T), (int)mpad_), stream_));
+		f32w_pending_ = false;
+		wx3_valid_ = false;
+		gram_w_ready_ = false;
+	}
 	if (kl_scale_pending_) {
 		// the KL iteration left W unnormalised (iterate_kl): the pass it skipped
 		HIPX(launch_normalize_panel<T>(Wt_, RP_, (int)mpad_, sumsq_part_, (int)(mpad_ / 128), stream_));
@@ -1787,6 +1853,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 	if (prm_.divergence != 0) return constant_w ? ST_INVALID : iterate_kl(compute_error);
 	if (fused_capable() && !constant_w) return iterate_mu64(compute_error);
 	if (fused64_capable() && !constant_w) return iterate_fused64(compute_error);
+	if (f32w_scale_ != nullptr && fused32w_capable() && !constant_w) return iterate_fused32w(compute_error);
 	const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 	h_partials_unneeded_ = !constant_w;              // (the fused iteration: H H^T rides the product where it can)
 	const Status hs = h_step_impl(compute_error);

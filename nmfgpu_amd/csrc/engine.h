@@ -98,12 +98,12 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	int kl_blocks(bool w_step) const { return prm_.divergence != 0 ? (w_step ? kl_blocks_w_ : kl_blocks_h_) : 0; }
 	int gram_k_slices() const { return gram_spread_ ? GRAM_REDUCE_BLOCKS : gram_ksplit_; }      // (16: the spread form)
 	bool w_col_split() const { return w_col_split_; }
-	int fused_launches() const { return (fused_capable() && !one_pass_ && gram_image_) || (f64_partial_ != nullptr && fused64_capable()) ? 4 : 0; }
+	int fused_launches() const { return (fused_capable() && !one_pass_ && gram_image_) || (f64_partial_ != nullptr && fused64_capable()) ? 4 : (f32w_scale_ != nullptr && fused32w_capable() ? 8 : 0); }
 	int gram_ride_slices(bool w_side) const { return f64_partial_ == nullptr ? 0 : (w_side ? f64_slices_w_ : f64_slices_h_); }
 	// Row-block form at padded rank 256 with bf16 operands (config 4): between two W updates the OTHER ranks read only the bf16 fragments of a rank's rows (the next
 	// W^T V's operand and the Gram matrix are made from them) -- so the all-gather carries the fragments w_normalize_rows() left for this rank's rows (RP / 2 four-byte
@@ -114,7 +114,7 @@ public:
 	long w_fragment_words_per_row() const { return RP_ / 2; }
 	// the fragments of every rank's rows have been gathered into w_fragments(); stale: the fp32 rows of the other ranks were not
 	void w_fragments_gathered(bool stale) {
-		kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
+		kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; wtb_valid_ = true; w_rows_stale_ = stale;
 	}
 	void set_w_gather_hook(std::function<Status()> hook) { w_gather_hook_ = std::move(hook); }
@@ -175,6 +175,8 @@ private:
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false);   // slabs_ <- partials of F V   (r x n)
 	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
 	bool fused_capable() const;                      // fp32, padded rank 64, MU
+	bool fused32w_capable() const;                   // fp32, split-operand products, MU / nsNMF, padded ranks 128 ... 512: the eight-launch iteration of iterate_fused32w
+	Status iterate_fused32w(bool compute_error);     // (Gram slices + reduce) / product / update, twice; W carried unnormalised with a pending column scale, no pack / smooth / normalise launches
 	bool fused64_capable() const;                    // fp64, MU / nsNMF, any padded rank up to 512: the four-launch iteration of iterate_fused64
 	Status iterate_fused64(bool compute_error);      // product (+ Gram passengers) / update / product (+ Gram passengers) / update, W carried unnormalised with a pending column scale
 	bool gram_from_update() const;                   // GDCLS / ALS family at fp32, padded rank 64: Gram matrices from the update kernel's partials
@@ -311,6 +313,8 @@ private:
 	Status tri_update_w(const T* num, int S, long stride, const T* hht);   // W update + normalisation + everything tri_prepare_w() would do
 	// fused double-precision iteration (round 6, iterate_fused64): Wt_ holds the UNNORMALISED result of the last W update, sumsq_part_ its per-workgroup sums of squares;
 	// the column scale is applied by the consumers (kernels_f64.hip: gram_ride_f64 -> f64_scale_, PanelFusedF64) -- materialize_w() folds it into the panel
+	bool f32w_pending_ = false;                      // fused fp32 iteration at padded ranks >= 128: Wt_ unnormalised, sumsq_part_ holds its sums of squares, Wx3_ its split image
+	float* f32w_scale_ = nullptr;                    // ... the pending column scale (k_gram_reduce_x3)
 	bool f64_pending_ = false;
 	bool f64_product_ahead_ = false;                 // begin_next_iteration() has enqueued launch 1 of the next iterate_fused64 (cleared by whatever changes W, H or V)
 	Status fused64_product_h();

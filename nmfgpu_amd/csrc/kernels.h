@@ -220,9 +220,24 @@ bool gram_wide_available(int RP);
 hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, float* partial, float* G, hipStream_t stream);
 // q_split (optional): 3 * 16 * (RP / 16 + 1) * (RP / 32) * 64 bytes of scratch; when given, the r x r product runs on the bf16
 // matrix pipe with exactly split operands (fp32 accuracy, kernels_x3.hip) instead of the fp32 MFMA instructions
+// Extras of the fused fp32 iteration at padded ranks 128 ... 512 (Engine::iterate_fused32w; the float counterpart of PanelFusedF64)
+struct PanelFusedF32 {
+	const float* old_scale = nullptr;   // W update: every old value is read as old(y, c) * old_scale[c]
+	int h_side = 0;                     // H update with W = Wt D (S): Q is the RAW Gram matrix of the panel Wt, and
+	const float* scale = nullptr;       //   d (nullptr: ones):  num <- S D num,  den = S D Q D S old
+	int smooth = 0;                     //   0: S = I
+	float off = 0.f, diag = 1.f;
+	int r = 0;
+	float* smooth_out = nullptr;        // H update with smoothing: a second panel that receives S new(y, :)
+	void* x3_out = nullptr;             // the split image (k_pack_panel_x3's layout) of what the next product multiplies with: S new where there is smoothing, else new
+	long x3_ks = 0;                     // ... K-steps >= x3_ks are not written
+};
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
-                                        void* q_split = nullptr, const PanelTriExtras* tri = nullptr);
+                                        void* q_split = nullptr, const PanelTriExtras* tri = nullptr, const PanelFusedF32* fused = nullptr);
+// G = P P^T, its split image (the update kernel's operand: launch_panel_update_wide_f32 with Q == nullptr) and, W side, the pending column scale -- two launches
+hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts, float* partial, float* G, void* qx3, const float* sumsq_part, int sq_parts,
+                                      float* scale_out, hipStream_t stream);
 template <typename T>
 hipError_t launch_reduce_partials(const T* partial, int parts, long stride, T* out, long count, hipStream_t stream);
 template <typename T>

@@ -35,16 +35,28 @@ constexpr int WIDE_MAX_RP = 512;
 //   A operand: lane (c = l & 31, h) holds Q(8u + 4h + gi, 32 cb + c): 128 B per half-wave from L2.
 // The MFMA C/D map gives lane (y, h) the rows c = 32 cb + 8q + 4h + gi -- four consecutive c per q, so
 // the element-wise step reads old / num and writes new as b128 LDS accesses.
-template <int MODE, int NCB>      // NCB = column blocks per wave = RP / 128
+// FX (round 6, PanelFusedF32, kernels.h; the fp32 counterpart of kernels_f64.hip's HS path): W is carried unnormalised with a pending column scale d and nsNMF's S
+// is applied around the r x r product -- num <- S D (sum of the slabs), u = D S old as the B operand leaves LDS, den = S D (Q u) with the row's sum through LDS --
+// and the update writes what its consumers read: the smoothed panel S H and the SPLIT IMAGE of the next product's operand (k_pack_panel_x3's layout), so that
+// no pack, smoothing or normalisation launch is left in the iteration.  Any padded rank of the kernel (NCB = 1 .. 4); Q as its split image only.
+template <int MODE, int NCB, bool FX = false>      // NCB = column blocks per wave = RP / 128
 __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, int RP, float eps, float* __restrict__ ps, int len_valid,
-	float* __restrict__ sumsq_part, float* __restrict__ num_out, const bf16x8* __restrict__ Qx3, const PanelTriExtras tri) {
+	float* __restrict__ sumsq_part, float* __restrict__ num_out, const bf16x8* __restrict__ Qx3, const PanelTriExtras tri, const PanelFusedF32 fx) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	const int LD = RP + 4;
 	float* s_num = lds;                       // [32][LD]
 	float* s_old = lds + WIDE_YB * LD;        // [32][LD]   old values, then the new ones
 	float* s_ps = s_old + WIDE_YB * LD;       // [4][32] error terms, [4][32] row sums of the new rows
+	// FX: the RP factors (zero from r on when smoothing), [4][32] partial sums of D (Q u), the 32 row sums of the old rows, the 32 row sums of the new rows
+	float* s_fd = s_ps + 256;                 // [RP]
+	float* s_fsig = s_fd + RP;                // [4][32]
+	float* s_frs = s_fsig + 128;              // [32]
+	float* s_fns = s_frs + 32;                // [32]
+	const bool fxh = FX && fx.h_side != 0;
+	// (uniforms that meet vector values go through a VGPR: no packed fp32 instruction may read a scalar register, split3.h)
+	const float f_off = FX ? in_vgpr(fx.off) : 0.f, f_diag = FX ? in_vgpr(fx.diag) : 1.f, f_ha = FX ? in_vgpr(fx.diag - fx.off) : 1.f;
 	// PanelTriExtras::den_transform (rank 256; the launcher sizes the LDS for it): the product's operand u = D S old, the factors D, partial sums of D (G u)
 	const bool dent = NCB == 2 && tri.den_transform;
 	float* s_u = s_ps + 256;                  // [32][LD]
@@ -56,6 +68,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 	const long base = (long)blockIdx.x * WIDE_YB * RP;
 	const int q4 = RP / 4;                    // float4 per panel row
 	if (dent) s_dg[tid] = tri.den_colsq != nullptr ? tri_pending_scale(tri.den_colsq, tri.den_colsq_parts, 256, tid) : 1.0f;      // (256 threads, 256 columns)
+	if (fxh) {
+		const int r_eff = fx.smooth ? fx.r : RP;
+		for (int c = tid; c < RP; c += 256) s_fd[c] = c < r_eff ? (fx.scale != nullptr ? fx.scale[c] : 1.0f) : 0.0f;
+	}
 
 	// 1. numerator = sum of the split-K slabs (slab order), old panel values.  All of a thread's loads of one
 	//    slab are issued together (NE independent 16-byte loads): one memory latency per slab, not per element.
@@ -77,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			for (int i = 0; i < NE; ++i) {
 				const int e = tid + 256 * i, y = e / q4, c4 = e - y * q4;
 				if (NCB == 2 && tri.old_colsq != nullptr) old[i] *= od;
+				if (FX && fx.old_scale != nullptr) old[i] *= *reinterpret_cast<const f32x4*>(fx.old_scale + 4 * c4);      // (the panel's own pending column scale)
 				*reinterpret_cast<f32x4*>(s_old + y * LD + 4 * c4) = old[i];
 			}
 			if (dent) {
@@ -155,6 +172,25 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 		}
 	}
 	__syncthreads();
+	if (fxh) {
+		// num(y, c) <- d(c) num(y, c), then S on the first r entries of the row (k_smooth_panel's formula); the old row's sum for the B operand.  Eight threads per row.
+		const int y = tid >> 3, sub = tid & 7;
+		float* row = s_num + y * LD;
+		float sum = 0.f, osum = 0.f;
+		for (int c = sub; c < RP; c += 8) {
+			const float x = row[c] * s_fd[c];      // (zero from r_eff on)
+			row[c] = x;
+			sum += x;
+			if (s_fd[c] != 0.f) osum += s_old[y * LD + c];
+		}
+		if (fx.smooth) {
+#pragma unroll
+			for (int w = 1; w < 8; w <<= 1) { sum += __shfl_xor(sum, w); osum += __shfl_xor(osum, w); }
+			for (int c = sub; c < fx.r; c += 8) { const float x = row[c]; row[c] = f_off * (sum - x) + f_diag * x; }
+			if (sub == 0) s_frs[y] = osum;
+		} else if (sub == 0) s_frs[y] = 0.f;
+		__syncthreads();
+	}
 
 	// 2. the r x r product
 	const float* vec = (dent ? s_u : MODE == PANEL_MU ? s_old : s_num) + l31 * LD + 4 * half;
@@ -187,6 +223,13 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 				const f32x4 b1 = *reinterpret_cast<const f32x4*>(vb + 16 * (u + d) + 4);
 #pragma unroll
 				for (int j = 0; j < 4; ++j) { v[j] = b0[j]; v[4 + j] = b1[j]; }
+				if (fxh) {
+					// u = D S old, formed as the value leaves LDS: u(k) = d(k) ((diag - off) old(k) + off rowsum), k = 16 (u + d) + 8 half + j
+					const float h_a = f_ha, h_b = f_off * s_frs[l31];
+					const f32x4 d0 = *reinterpret_cast<const f32x4*>(s_fd + 16 * (u + d) + 8 * half), d1 = *reinterpret_cast<const f32x4*>(s_fd + 16 * (u + d) + 8 * half + 4);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { v[j] = d0[j] * (h_a * v[j] + h_b); v[4 + j] = d1[j] * (h_a * v[4 + j] + h_b); }
+				}
 				bf16x8 hi, mid, lo;
 				const bool b16 = NCB == 2 && tri.old_as_bf16;      // (PanelTriExtras: the panel's rows enter the product rounded to bf16; uniform)
 				if (b16) {
@@ -271,6 +314,29 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 			for (int g = 0; g < 16; ++g) acc[i][g] = tri.den_a * acc[i][g] + tri.den_b * tau;
 	}
 
+	if (fxh) {
+		// den = S D t: v(c) = d(c) t(c); den(c) = off (sigma - v(c)) + diag v(c), sigma = the row's sum of v over all column blocks and waves
+		float tl = 0.f;
+#pragma unroll
+		for (int i = 0; i < NCB; ++i)
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const int c = 32 * (wave + 4 * i) + 8 * (g >> 2) + 4 * half + (g & 3);
+				acc[i][g] *= s_fd[c];
+				tl += acc[i][g];
+			}
+		if (fx.smooth) {
+			tl += __shfl_xor(tl, 32);
+			if (half == 0) s_fsig[wave * 32 + l31] = tl;
+			__syncthreads();
+			const float sigma = ((s_fsig[l31] + s_fsig[32 + l31]) + s_fsig[64 + l31]) + s_fsig[96 + l31];
+#pragma unroll
+			for (int i = 0; i < NCB; ++i)
+#pragma unroll
+				for (int g = 0; g < 16; ++g) acc[i][g] = f_off * (sigma - acc[i][g]) + f_diag * acc[i][g];
+		}
+	}
+
 	// 3. element-wise step in the C/D layout; new values replace the old ones in LDS once every wave
 	//    has finished reading them as B operands
 	f32x4 nv[NCB][4];
@@ -323,6 +389,43 @@ __global__ __launch_bounds__(256, 2) void k_panel_update_wide_f32(
 #pragma unroll 8
 			for (int y = 0; y < WIDE_YB; ++y) { const float v = s_old[y * LD + c]; s += v * v; }
 			sumsq_part[(long)blockIdx.x * RP + c] = s;
+		}
+	}
+	if (FX && (fx.smooth_out != nullptr || fx.x3_out != nullptr)) {
+		// what the consumers of the new rows read: the smoothed panel S new (the operand of V (S H)^T and of its Gram matrix) and the split image of the next
+		// product's operand -- of the smoothed rows where there is smoothing, of the rows as they lie otherwise (W: unnormalised, its scale stays pending)
+		const float* src = s_old;
+		if (fxh && fx.smooth) {
+			const int y = tid >> 3, sub = tid & 7;
+			const float* row = s_old + y * LD;
+			float sum = 0.f;
+			for (int c = sub; c < fx.r; c += 8) sum += row[c];
+#pragma unroll
+			for (int w = 1; w < 8; w <<= 1) sum += __shfl_xor(sum, w);
+			float* sm = s_num + y * LD;                  // (the numerators have been consumed)
+			for (int c = sub; c < RP; c += 8) { const float x = row[c]; sm[c] = c < fx.r ? f_off * (sum - x) + f_diag * x : 0.f; }
+			__syncthreads();
+			src = s_num;
+			if (fx.smooth_out != nullptr) {
+				for (int e = tid; e < WIDE_YB * q4; e += 256) {
+					const int y2 = e / q4, c4 = e - y2 * q4;
+					*reinterpret_cast<f32x4*>(fx.smooth_out + base + 4l * e) = *reinterpret_cast<const f32x4*>(s_num + y2 * LD + 4 * c4);
+				}
+			}
+		}
+		if (fx.x3_out != nullptr) {
+			// slot (kk, nb, h, r) of the workgroup's two K-steps: the eight rows 16 kk + 8 h + j of column 32 nb + r, split exactly into three bf16 planes
+			const int NBT = RP / 32;
+			for (int t = tid; t < 128 * NBT; t += 256) {
+				const int r = t & 31, h = (t >> 5) & 1, rest = t >> 6, nb = rest % NBT, kk = rest / NBT;
+				const long ks = (long)blockIdx.x * 2 + kk;
+				if (ks < fx.x3_ks) {
+					float v[8];
+#pragma unroll
+					for (int j = 0; j < 8; ++j) v[j] = src[(16 * kk + 8 * h + j) * LD + 32 * nb + r];
+					store_split3(reinterpret_cast<bf16x8*>(fx.x3_out), ks, NBT, nb, h, r, v);
+				}
+			}
 		}
 	}
 	if (NCB == 2 && tri.frag_out != nullptr) {
@@ -585,6 +688,88 @@ hipError_t launch_gram_wide_f32(const float* P, int RP, int len, int parts, floa
 	if (e != hipSuccess) return e;
 	return launch_reduce_partials<float>(partial, parts, (long)RP * RP, G, (long)RP * RP, stream);
 }
+
+// The slices of k_gram_wide_x3 reduced, and in the same launch what the update kernel reads: the matrix's split image (A(c, k) = G(k, c): k_pack_panel_x3's layout
+// of G as a panel -- launch_panel_update_wide_f32 with Q == nullptr) and, W side, the pending column scale d(c) = 1 / sqrt(sum of the W update's per-workgroup sums
+// of squares) (kernel::normalizeColumns as a factor, KernelNormalizeColumns.cu:37-58).  The generic sequence ran k_reduce_partials, k_pack_panel_x3 (and, for W,
+// k_compact_partials + k_normalize_panel_v2) for this.  One workgroup per 8 x 32 tile of G (a first version with 32 x 32 tiles -- 16 workgroups at rank 128, 0.5 MB
+// of partials through each CU -- took 21.6 us): the four waves add a quarter of the slices each, eight loads in flight, quarters added in order; RP / 64 more
+// workgroups for the scale.
+__global__ __launch_bounds__(256) void k_gram_reduce_x3(const float* __restrict__ partial, int parts, int RP, float* __restrict__ G, bf16x8* __restrict__ qx3,
+                                                        const float* __restrict__ sumsq_part, int sq_parts, float* __restrict__ scale_out) {
+	__shared__ __attribute__((aligned(16))) float s_p[4 * 8 * 32];
+	__shared__ float s_t[8 * 33];
+	const int tid = threadIdx.x;
+	const int nbt = RP / 32, tiles = (RP / 8) * nbt;
+	const int g = tid >> 6, t64 = tid & 63;
+	if ((int)blockIdx.x >= tiles) {
+		if (sumsq_part == nullptr) return;
+		const int c = 64 * ((int)blockIdx.x - tiles) + t64;
+		const int p0 = (int)(((long)sq_parts * g) / 4), p1 = (int)(((long)sq_parts * (g + 1)) / 4);
+		float s = 0.f;
+		for (int p = p0; p < p1; p += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = sumsq_part[(long)(p + u < p1 ? p + u : p0) * RP + c];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (p + u < p1) s += v[u];
+		}
+		s_p[tid] = s;
+		__syncthreads();
+		if (g == 0) {
+			const float t = ((s_p[tid] + s_p[64 + tid]) + s_p[128 + tid]) + s_p[192 + tid];
+			scale_out[c] = t > 0.f ? 1.0f / sqrtf(t) : 1.0f;
+		}
+		return;
+	}
+	// tile = eight rows k x 32 columns c of G (one (K-step, half) of one column block of the split image); the four waves take a quarter of the slices each
+	const int ti = (int)blockIdx.x / nbt, tj = (int)blockIdx.x % nbt;
+	const int rr = t64 >> 3, c4 = 4 * (t64 & 7);
+	const long e = (long)(8 * ti + rr) * RP + 32 * tj + c4, stride = (long)RP * RP;
+	const int p0 = (int)(((long)parts * g) / 4), p1 = (int)(((long)parts * (g + 1)) / 4);
+	f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+	for (int p = p0; p < p1; p += 8) {
+		f32x4 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(partial + (long)(p + u < p1 ? p + u : p0) * stride + e);
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			if (p + u < p1) sum += v[u];
+	}
+	*reinterpret_cast<f32x4*>(s_p + g * 256 + 4 * t64) = sum;
+	__syncthreads();
+	if (g == 0) {
+		f32x4 o = *reinterpret_cast<const f32x4*>(s_p + 4 * t64);
+#pragma unroll
+		for (int k = 1; k < 4; ++k) o += *reinterpret_cast<const f32x4*>(s_p + k * 256 + 4 * t64);
+		*reinterpret_cast<f32x4*>(G + e) = o;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) s_t[rr * 33 + c4 + k] = o[k];
+	}
+	__syncthreads();
+	if (qx3 != nullptr && tid < 32) {
+		float v8[8];
+#pragma unroll
+		for (int kk = 0; kk < 8; ++kk) v8[kk] = s_t[kk * 33 + tid];            // rows k = 8 ti + kk of column c = 32 tj + tid
+		store_split3(qx3, (8 * ti) >> 4, nbt, tj, ti & 1, tid, v8);
+	}
+}
+
+// G, its split image and (sumsq_part != nullptr) the pending column scale in TWO launches: slices, then k_gram_reduce_x3
+hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts, float* partial, float* G, void* qx3, const float* sumsq_part, int sq_parts,
+                                      float* scale_out, hipStream_t stream) {
+	if (!gram_wide_available(RP) || qx3 == nullptr) return hipErrorInvalidValue;
+	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
+	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
+	hipLaunchKernelGGL((k_gram_wide_x3<2>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
+	if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+	const int nbt = RP / 32;
+	hipLaunchKernelGGL(k_gram_reduce_x3, dim3((RP / 8) * nbt + (sumsq_part != nullptr ? RP / 64 : 0)), dim3(256), 0, stream, partial, parts, RP, G, reinterpret_cast<bf16x8*>(qx3),
+	                   sumsq_part, sq_parts, scale_out);
+	return hipGetLastError();
+}
+
 
 // ------------------------------------------------------------------------------------------
 // The same at padded rank 64 (nsNMF, GDCLS and the least-squares family at r <= 64; the multiplicative update has
@@ -1179,24 +1364,41 @@ hipError_t launch_panel_update_long_mu(const float* P_in, float* P_out, const fl
 
 bool panel_update_wide_available(int RP) { return RP >= 128 && RP % 128 == 0 && RP <= WIDE_MAX_RP; }
 
-template <int MODE, int NCB>
+template <int MODE, int NCB, bool FX = false>
 static hipError_t launch_wide(float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3, const PanelTriExtras& tri) {
-	// two panels + [4][32] error terms + [4][32] row sums; PanelTriExtras::den_transform (rank 256): a third panel, the RP factors, [4][32] partial sums
+                              float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, const void* qx3, const PanelTriExtras& tri,
+                              const PanelFusedF32& fx = PanelFusedF32()) {
+	// two panels + [4][32] error terms + [4][32] row sums; PanelTriExtras::den_transform (rank 256): a third panel, the RP factors, [4][32] partial sums;
+	// FX: the RP factors, [4][32] partial sums, two vectors of 32 row sums
 	const size_t extra = NCB == 2 ? (size_t)WIDE_YB * (RP + 4) + RP + 128 : 0;
-	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 256 + (tri.den_transform ? extra : 0));
-	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 256 + extra);
+	const size_t fxe = FX ? (size_t)RP + 128 + 64 : 0, fxmax = FX ? (size_t)128 * NCB + 128 + 64 : 0;
+	const size_t lds_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (RP + 4) + 256 + (tri.den_transform ? extra : 0) + fxe);
+	const size_t max_bytes = sizeof(float) * (2 * (size_t)WIDE_YB * (128 * NCB + 4) + 256 + extra + fxmax);
 	static std::atomic<unsigned long long> lds_done{0ull};
-	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB>), (int)max_bytes, lds_done); e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
-	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3), tri);
+	if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_panel_update_wide_f32<MODE, NCB, FX>), (int)max_bytes, lds_done); e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_panel_update_wide_f32<MODE, NCB, FX>), dim3(len_pad / WIDE_YB), dim3(256), lds_bytes, stream,
+	                   P, slabs, S, slab_stride, Q, RP, eps, ps, len_valid, sumsq_part, num_out, reinterpret_cast<const bf16x8*>(qx3), tri, fx);
 	return hipGetLastError();
 }
 
 hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, int S, long slab_stride, const float* Q, int RP, int len_pad,
-                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, void* q_split, const PanelTriExtras* tri) {
+                                        float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream, void* q_split, const PanelTriExtras* tri,
+                                        const PanelFusedF32* fused) {
 	if (!panel_update_wide_available(RP) || (mode != PANEL_MU && mode != PANEL_LS) || len_pad % WIDE_YB != 0) return hipErrorInvalidValue;
 	if (tri != nullptr && (RP != 256 || mode != PANEL_MU)) return hipErrorInvalidValue;
+	if (fused != nullptr) {
+		// the fused fp32 iteration at padded ranks 128 ... 512 (Engine::iterate_fused32w): 32-row kernel, multiplicative update, Q as its split image in q_split
+		if (tri != nullptr || mode != PANEL_MU || q_split == nullptr || Q != nullptr || num_out != nullptr) return hipErrorInvalidValue;
+		PanelFusedF32 fx = *fused;
+		if (!fx.smooth) { fx.off = 0.f; fx.diag = 1.f; }
+		const PanelTriExtras none = PanelTriExtras();
+		switch (RP / 128) {
+		case 1: return launch_wide<PANEL_MU, 1, true>(P, slabs, S, slab_stride, nullptr, RP, len_pad, eps, ps, len_valid, sumsq_part, nullptr, stream, q_split, none, fx);
+		case 2: return launch_wide<PANEL_MU, 2, true>(P, slabs, S, slab_stride, nullptr, RP, len_pad, eps, ps, len_valid, sumsq_part, nullptr, stream, q_split, none, fx);
+		case 3: return launch_wide<PANEL_MU, 3, true>(P, slabs, S, slab_stride, nullptr, RP, len_pad, eps, ps, len_valid, sumsq_part, nullptr, stream, q_split, none, fx);
+		default: return launch_wide<PANEL_MU, 4, true>(P, slabs, S, slab_stride, nullptr, RP, len_pad, eps, ps, len_valid, sumsq_part, nullptr, stream, q_split, none, fx);
+		}
+	}
 	const PanelTriExtras ext = tri ? *tri : PanelTriExtras();
 	const void* qx3 = nullptr;
 	if (q_split != nullptr) {

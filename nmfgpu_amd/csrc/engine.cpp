@@ -1480,7 +1480,7 @@ bool Engine<T>::fused_capable() const {
 template <typename T>
 bool Engine<T>::fused32w_capable() const {
 	return std::is_same<T, float>::value && x3_ && tiled_ && !bf16_ && !sparse_ && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && RP_ >= 128 && panel_update_wide_available(RP_) &&
-	       gram_wide_available(RP_) && qx3_ != nullptr && !panel_update_long_available(RP_, (int)mpad_) && !panel_update_long_available(RP_, (int)npad_) &&
+	       gram_wide_available(RP_) && qx3_ != nullptr &&
 	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
 }
 

@@ -43,6 +43,8 @@ def run_engine(V, W, H, alg, iters, error_every=10, **kw):
     ("nsnmf", 640, 900, 300, dict(theta=0.3)),        # 384
     ("mu", 410, 1300, 500, {}),                       # 512
     ("nsnmf", 70, 45, 65, dict(theta=0.8)),           # one row block and a half
+    ("mu", 33000, 260, 100, {}),                      # panels of 32 768 rows and more (the generic sequence switches to the 128-row update there)
+    ("nsnmf", 300, 32800, 140, dict(theta=0.6)),      # ... on the H side, rank 256
 ])
 def test_fused_wide_iteration_against_the_oracle_and_the_generic_sequence(alg, m, n, r, kw, monkeypatch):
     iters = 12

@@ -1,6 +1,6 @@
 """usage: python tools/launches_per_iteration.py M N R ALG DTYPE [theta]      (on the GPU box; ALG mu | nsnmf | gdcls | als | acls | ahcls, DTYPE f32 | f64)
 Kernel launches and kernel time per steady-state iteration of the resident engine at any shape: two child runs under `rocprofv3 --kernel-trace` (100 and 300
-iterations, error terms every 10th), the difference divided by 200 -- set-up, upload and the first launches cancel.  Prints the per-kernel table of the difference."""
+iterations, error terms every 10th), the difference divided by 200 -- set-up, upload and the first launches cancel; a third child without the profiler gives the wall time per iteration.  Prints the per-kernel table of the difference."""
 import collections
 import csv
 import glob
@@ -55,7 +55,9 @@ def main():
         return child(m, n, r, alg, dtype, float(sys.argv[8]) if len(sys.argv) > 8 else 0.5, iters)
     args = sys.argv[1:]
     a, _ = trace(args, 100)
-    b, wall = trace(args, 300)
+    b, _ = trace(args, 300)
+    out = subprocess.run(["python3", os.path.abspath(__file__), "--child", "300", *args], capture_output=True, text=True, timeout=600)   # no profiler attached
+    wall = next((float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("WALL")), float("nan"))
     rows = []
     for name in b:
         dc = (b[name][0] - a.get(name, [0, 0])[0]) / 200.0

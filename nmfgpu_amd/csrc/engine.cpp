@@ -847,8 +847,14 @@ Status Engine<T>::mu64_update(bool is_w, const T* slabs, int S, long slab_stride
 		void* xo = x3_ ? (is_w ? Wx3_ : Hx3_) : nullptr;
 		const int xks = is_w ? ksH_ : ksW_;
 		if (peers != nullptr && !gram_image_) return ST_INVALID;
+		// nsNMF: the smoothing matrix goes around the H update's r x r product (the launches on either side work on the unsmoothed W image and on the image of S H)
+		SmoothAround ns;
+		ns.off = (float)prm_.theta / (float)(unsigned)r_; ns.diag = (float)((1.0 - (float)prm_.theta) + ns.off); ns.r = r_;
+		const bool smooth = alg_ == ALG_NSNMF && !is_w;
+		if (alg_ == ALG_NSNMF && !gram_image_) return ST_INVALID;
 		if (gram_image_) HIPX(launch_mu64_update32(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? G_ : nullptr, compute_error ? 1 : 0, stream_, xo, xks, peers,
-		                                           is_w ? wsq_part_ : nullptr, (!is_w && (const void*)Q == (const void*)Gpart_) ? gram_ksplit_ : 0, (!is_w && (const void*)Q == (const void*)Gpart_) ? G_ : nullptr));
+		                                           is_w ? wsq_part_ : nullptr, (!is_w && (const void*)Q == (const void*)Gpart_) ? gram_ksplit_ : 0, (!is_w && (const void*)Q == (const void*)Gpart_) ? G_ : nullptr,
+		                                           smooth ? &ns : nullptr));
 		else HIPX(launch_mu64_update(is_w ? 1 : 0, P, slabs, S, slab_stride, Q, scale_, eps, ps, len, len_pad, is_w ? gramW_part_ : gramH_part_, is_w ? G_ : nullptr,
 		                             compute_error ? 1 : 0, stream_, xo, xks));
 	}
@@ -1204,9 +1210,16 @@ Status Engine<T>::w_products(T* exchange) {
 			// workgroups, then the local split-K slabs summed into the exchange panel
 			GramReduceArgs rgH = gram_args(false, ex_hht, nullptr, 0);
 			// a team of one: w_finish() sums the split-K slabs itself, as iterate_mu64() does -- no pass over the panel in between
-			if (sole_rank_ && gram_image_) return product_w(H_, &rgH, nullptr, x3_ && hx3_valid_);
+			// (nsNMF: the H update of h_step left the split image of S H; without it -- no H step since the factors were set -- the smoothed panel is packed here)
+			const T* Fh = H_;
+			if (alg_ == ALG_NSNMF && !(x3_ && hx3_valid_)) {
+				const T off = (T)prm_.theta / (T)(unsigned)r_;
+				HIPX(launch_smooth_panel<T>(H_, Hs_, RP_, r_, npad_, off, (T)((1.0 - (T)prm_.theta) + off), stream_));
+				Fh = Hs_;
+			}
+			if (sole_rank_ && gram_image_) return product_w(Fh, &rgH, nullptr, x3_ && hx3_valid_);
 			// one K slice (short column shards) writes the exchange panel itself
-			if (Status s = product_w(H_, &rgH, exchange, x3_ && hx3_valid_)) return s;
+			if (Status s = product_w(Fh, &rgH, exchange, x3_ && hx3_valid_)) return s;
 			if (planW_.splits > 1) HIPX(launch_reduce_slabs<T>(slabs_, planW_.splits, slab_stride_, exchange, (long)RP_ * mpad_, stream_));
 			return ST_OK;
 		}
@@ -1471,12 +1484,15 @@ Status Engine<T>::tri_update_w(const T* num, int S, long stride, const T* hht) {
 
 template <typename T>
 bool Engine<T>::fused_capable() const {
-	return std::is_same<T, float>::value && RP_ == 64 && alg_ == ALG_MU &&
-	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;   // (evaluated before allocate(): no tiled_ here)
+	// (evaluated before allocate(): no tiled_ here.  nsNMF (round 6): only on the split-operand products with the Gram matrices taken from the images -- x3_ is false
+	//  until the plan has chosen that path, so the one-pass request and the native-fp32 plan never see it)
+	return std::is_same<T, float>::value && RP_ == 64 &&
+	       (alg_ == ALG_MU || (alg_ == ALG_NSNMF && x3_ && !bf16_ && !sparse_ && std::getenv("NMFAMD_GRAM_PARTIALS") == nullptr)) &&
+	       std::getenv("NMFAMD_FORCE_VALU") == nullptr && std::getenv("NMFAMD_NO_FUSED_MU") == nullptr;
 }
 
 // fp32 at padded ranks 128 ... 512 on the split-operand products (ranks 65 ... 512 in float: what rounds 1 - 5 ran as the generic sequence of 14 launches):
-// multiplicative update and nsNMF.  Long panels (the 64-row update kernel of kernels_wide.hip) and the bf16 mode keep their own paths.
+// multiplicative update and nsNMF.  The bf16 mode keeps its own path.
 template <typename T>
 bool Engine<T>::fused32w_capable() const {
 	return std::is_same<T, float>::value && x3_ && tiled_ && !bf16_ && !sparse_ && (alg_ == ALG_MU || alg_ == ALG_NSNMF) && RP_ >= 128 && panel_update_wide_available(RP_) &&
@@ -1894,6 +1910,7 @@ Status Engine<T>::iterate(bool compute_error, bool constant_w) {
 			const T* wtw = tri_ ? reinterpret_cast<const T*>(Gw_raw_) : G_;      // MU: W^T W of this iteration's H step (rank-256 bf16 path: the unscaled Gram matrix + tri_trace_scale())
 			if (alg_ == ALG_NSNMF) {                            // unsmoothed W^T W (AlgorithmNonSmoothNMF.h:201-202)
 				if (tri_) wtw = reinterpret_cast<const T*>(Gw_raw_);
+				else if (fused_capable()) wtw = G_;             // (rank 64: the H step's passengers took it from the unsmoothed image, pending scale applied)
 				else { HIPX(launch_gram<T>(Wt_, RP_, m_, gram_parts_, gram_part_, G2_, stream_)); wtw = G2_; }
 			} else if (alg_ != ALG_MU) wtw = G2_;               // LS algorithms: copy saved before the regulariser
 			HIPX(launch_trace_small<T>(HHt_, wtw, RP_, r_, psR_, stream_, tri_trace_scale()));

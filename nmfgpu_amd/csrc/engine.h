@@ -174,7 +174,7 @@ private:
 	// prepacked: the split (x3) image of F is already in Wx3_ / Hx3_ (emitted by the update kernel that wrote F)
 	Status product_h(const T* F, const GramReduceArgs* rg = nullptr, bool prepacked = false);   // slabs_ <- partials of F V   (r x n)
 	Status product_w(const T* F, const GramReduceArgs* rg = nullptr, T* single_slab_out = nullptr, bool prepacked = false);   // slabs_ (or the caller's panel when there is one K slice) <- partials of (V F^T)^T (r x m)
-	bool fused_capable() const;                      // fp32, padded rank 64, MU
+	bool fused_capable() const;                      // fp32, padded rank 64, MU (and nsNMF on the split-operand products)
 	bool fused32w_capable() const;                   // fp32, split-operand products, MU / nsNMF, padded ranks 128 ... 512: the eight-launch iteration of iterate_fused32w
 	Status iterate_fused32w(bool compute_error);     // (Gram slices + reduce) / product / update, twice; W carried unnormalised with a pending column scale, no pack / smooth / normalise launches
 	bool fused64_capable() const;                    // fp64, MU / nsNMF, any padded rank up to 512: the four-launch iteration of iterate_fused64

@@ -124,9 +124,13 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 // device or in a peer's memory) instead of S slabs slab_stride apart
 constexpr int PEER_SLABS_MAX = 16;
 struct PeerSlabs { const float* p[PEER_SLABS_MAX]; int count; };
+// nsNMF's smoothing matrix S = (diag - off) I + off 1 1^T over the first r rank rows, applied AROUND the H update's r x r product (k_mu64_update32<.., NS>)
+struct SmoothAround { float off, diag; int r; };
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
-                                void* x3_out, int x3_ks, const PeerSlabs* peers = nullptr, float* colsq_part = nullptr, int qsplit = 0, float* q_out = nullptr);
+                                void* x3_out, int x3_ks, const PeerSlabs* peers = nullptr, float* colsq_part = nullptr, int qsplit = 0, float* q_out = nullptr,
+                                const SmoothAround* ns = nullptr);
+// (ns, H update only: num = S D sum(slabs), den = S Q (S h), the split image written is that of S h_new -- the operand of nsNMF's V (S H)^T; the panel keeps h_new)
 // (qsplit > 1, H update: Q holds qsplit unscaled partial matrices 4096 elements apart -- the K-split Gram passengers' output, GramReduceArgs::ksplit; every
 //  workgroup adds them in order and scales the sum by `scale` on both sides, workgroup 0 also stores the finished matrix to q_out)
 // (colsq_part, W update only: len_pad / 32 vectors of 64 partial sums of squares of the new rows, one per workgroup -- what the next Gram passengers turn into

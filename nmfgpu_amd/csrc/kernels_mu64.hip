@@ -226,16 +226,26 @@ hipError_t launch_mu64_update(int is_w, float* P, const float* slabs, int S, lon
 #define U32_Q_EARLY 0               // (A/B switch, tools/build_variant.sh: 1 = request the finished r x r operand behind the slabs' first batch as the K-slice forms do)
 #endif
 // QS: K slices the r x r operand arrives in (H update; 1: the finished matrix)
-template <bool IS_W, int U = 7, int QS = 1>
+// NS (H update of nsNMF, AlgorithmNonSmoothNMF.h:174-218): the smoothing matrix S = ns_a I + ns_b 1 1^T (r x r) goes AROUND the r x r product instead of over the
+// panels -- the launch before this one multiplied the UNSMOOTHED W image against V and took the unsmoothed Gram matrix, so
+//   num = S D (sum of the slabs)      ((W D S)^T V = S D (W^T V)),
+//   den = S (D G D) (S h)             ((W D S)^T (W D S) h),
+// and what leaves for the next product is the split image of S h_new (the operand of V (S H)^T, :194); the panel itself keeps h_new.  S x = ns_a x + ns_b sum(x):
+// three sums over the 64 rank rows of a column (shuffles over a column's 16 lanes in the linear pass; per-wave partials through LDS for the MFMA's C/D map).
+template <bool IS_W, int U = 7, int QS = 1, bool NS = false>
 __global__ __launch_bounds__(256) void k_mu64_update32(
 	float* __restrict__ P, const float* __restrict__ slabs, int S, long slab_stride,
 	const float* __restrict__ Q, const float* __restrict__ scale, float eps,
 	float* __restrict__ ps, int len_valid, const float* __restrict__ Gprev, int compute_error, bf16x8* __restrict__ x3_out, int x3_ks, PeerSlabs peers,
-	float* __restrict__ colsq_part, int qsplit, float* __restrict__ q_out) {
+	float* __restrict__ colsq_part, int qsplit, float* __restrict__ q_out, float ns_a_arg, float ns_b_arg, int ns_r) {
+	static_assert(!(NS && IS_W), "the smoothing matrix rides the H update only");
 	typedef float f32x4v __attribute__((ext_vector_type(4)));
 	__shared__ __attribute__((aligned(16))) float s_num[32][68];   // reduced numerator, later the new values
 	__shared__ __attribute__((aligned(16))) float s_old[32][68];   // old values (scaled for the W update)
+	__shared__ __attribute__((aligned(16))) float s_sm[NS ? 32 : 1][68];   // NS: S h, the B operand of the r x r product
 	__shared__ float s_ps[4][32];
+	__shared__ float s_dsum[NS ? 4 : 1][32], s_osum[NS ? 4 : 1][32];      // NS: per-wave parts of a column's sums over the rank rows (denominator, new values)
+	const float ns_a = NS ? in_vgpr(ns_a_arg) : 1.f, ns_b = NS ? in_vgpr(ns_b_arg) : 0.f;   // (VGPRs: a packed multiply must not take a scalar source, split3.h)
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int q = lane >> 4, l15 = lane & 15;
@@ -326,6 +336,21 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 	for (int j = 0; j < 2; ++j) {
 		// the pending column scale of W goes on the numerator W^T V (H update) or on W itself (W update)
 		if (IS_W) ol[j] *= sc; else nl[j] *= sc;
+		if (NS) {
+			// S over the rank rows of column yl0 + 16 j: its 64 rows lie in the 16 lanes tid & 15 of this wave (rows past r: zero in, zero out)
+			float sn = (nl[j][0] + nl[j][1]) + (nl[j][2] + nl[j][3]);
+			float so = (ol[j][0] + ol[j][1]) + (ol[j][2] + ol[j][3]);
+#pragma unroll
+			for (int w = 1; w < 16; w <<= 1) { sn += __shfl_xor(sn, w); so += __shfl_xor(so, w); }
+			f32x4v sm;
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const bool in = c4 + g < ns_r;
+				nl[j][g] = in ? ns_a * nl[j][g] + ns_b * sn : 0.f;
+				sm[g] = in ? ns_a * ol[j][g] + ns_b * so : 0.f;
+			}
+			*reinterpret_cast<f32x4v*>(&s_sm[yl0 + 16 * j][c4]) = sm;
+		}
 		*reinterpret_cast<f32x4v*>(&s_num[yl0 + 16 * j][c4]) = nl[j];
 		*reinterpret_cast<f32x4v*>(&s_old[yl0 + 16 * j][c4]) = ol[j];
 	}
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 #pragma unroll
 	for (int yt = 0; yt < 2; ++yt)
 #pragma unroll
-		for (int u = 0; u < 4; ++u) ob[yt][u] = *reinterpret_cast<const f32x4v*>(&s_old[16 * yt + l15][16 * q + 4 * u]);
+		for (int u = 0; u < 4; ++u) ob[yt][u] = *reinterpret_cast<const f32x4v*>(NS ? &s_sm[16 * yt + l15][16 * q + 4 * u] : &s_old[16 * yt + l15][16 * q + 4 * u]);
 	f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
 	for (int u = 0; u < 4; ++u)
@@ -347,6 +372,24 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		}
 	// C/D map: register g of lane (q, l15) is row c = 16 wave + 4 q + g, column y = 16 yt + l15
 	f32x4v sq = {0.f, 0.f, 0.f, 0.f};
+	if (NS) {
+		// den = S t: the sum of t over all 64 rows of a column = over g, the four lane groups and the four waves
+#pragma unroll
+		for (int yt = 0; yt < 2; ++yt) {
+			float v = (acc[yt][0] + acc[yt][1]) + (acc[yt][2] + acc[yt][3]);
+			v += __shfl_xor(v, 16);
+			v += __shfl_xor(v, 32);
+			if (q == 0) s_dsum[wave][16 * yt + l15] = v;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int yt = 0; yt < 2; ++yt) {
+			const int y = 16 * yt + l15;
+			const float tsum = ((s_dsum[0][y] + s_dsum[1][y]) + s_dsum[2][y]) + s_dsum[3][y];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) acc[yt][g] = ns_a * acc[yt][g] + ns_b * tsum;     // (rows past r: old value 0, the quotient is never used)
+		}
+	}
 #pragma unroll
 	for (int yt = 0; yt < 2; ++yt) {
 		const int y = 16 * yt + l15;
@@ -362,6 +405,12 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 		}
 		// each (column, four rows) of s_num is read and then overwritten by exactly one lane
 		*reinterpret_cast<f32x4v*>(&s_num[y][16 * wave + 4 * q]) = o;
+		if (NS) {
+			float v = (o[0] + o[1]) + (o[2] + o[3]);
+			v += __shfl_xor(v, 16);
+			v += __shfl_xor(v, 32);
+			if (q == 0) s_osum[wave][y] = v;
+		}
 		if (!IS_W && compute_error) {
 			psum += __shfl_xor(psum, 16);
 			psum += __shfl_xor(psum, 32);
@@ -406,24 +455,29 @@ __global__ __launch_bounds__(256) void k_mu64_update32(
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				const int yl = 16 * kk + 8 * h + j;
-				v[j] = blockIdx.x * 32 + yl < len_valid ? s_num[yl][32 * nb + r] : 0.f;
+				float x = s_num[yl][32 * nb + r];
+				// NS: the image is that of S h_new, the operand of V (S H)^T (rows past the rank stay zero)
+				if (NS) x = 32 * nb + r < ns_r ? ns_a * x + ns_b * (((s_osum[0][yl] + s_osum[1][yl]) + s_osum[2][yl]) + s_osum[3][yl]) : 0.f;
+				v[j] = blockIdx.x * 32 + yl < len_valid ? x : 0.f;
 			}
 			store_split3(x3_out, ks, 2, nb, h, r, v);
 		}
 	}
 }
 
-template <bool IS_W, int U, int QS>
+template <bool IS_W, int U, int QS, bool NS = false>
 static void launch_update32_inst(dim3 grid, hipStream_t stream, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale, float eps, float* ps,
-                                 int len_valid, const float* Gprev, int compute_error, bf16x8* xo, int x3_ks, const PeerSlabs& peers, float* colsq_part, float* q_out) {
-	hipLaunchKernelGGL((k_mu64_update32<IS_W, U, QS>), grid, dim3(256), 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, peers,
-	                   colsq_part, QS, q_out);
+                                 int len_valid, const float* Gprev, int compute_error, bf16x8* xo, int x3_ks, const PeerSlabs& peers, float* colsq_part, float* q_out,
+                                 const SmoothAround* ns = nullptr) {
+	hipLaunchKernelGGL((k_mu64_update32<IS_W, U, QS, NS>), grid, dim3(256), 0, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, peers,
+	                   colsq_part, QS, q_out, NS ? ns->diag - ns->off : 1.f, NS ? ns->off : 0.f, NS ? ns->r : 0);
 }
 
 hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, long slab_stride, const float* Q, const float* scale,
                                 float eps, float* ps, int len_valid, int len_pad, const float* Gprev, int compute_error, hipStream_t stream,
-                                void* x3_out, int x3_ks, const PeerSlabs* peers, float* colsq_part, int qsplit, float* q_out) {
+                                void* x3_out, int x3_ks, const PeerSlabs* peers, float* colsq_part, int qsplit, float* q_out, const SmoothAround* ns) {
 	if (x3_out == nullptr || len_pad % 32 != 0 || (qsplit > 1 && is_w) || (qsplit > 1 && qsplit != 2 && qsplit != 4 && qsplit != 8)) return hipErrorInvalidValue;
+	if (ns != nullptr && (is_w || ns->r < 1 || ns->r > 64)) return hipErrorInvalidValue;
 	PeerSlabs pa = {};
 	if (peers != nullptr) {
 		if (peers->count < 1 || peers->count > PEER_SLABS_MAX) return hipErrorInvalidValue;
@@ -433,6 +487,13 @@ hipError_t launch_mu64_update32(int is_w, float* P, const float* slabs, int S, l
 	dim3 grid(len_pad / 32);
 	bf16x8* xo = reinterpret_cast<bf16x8*>(x3_out);
 #define NMFAMD_U32(ISW, UU, QQ) launch_update32_inst<ISW, UU, QQ>(grid, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, pa, colsq_part, q_out)
+#define NMFAMD_U32NS(UU, QQ) launch_update32_inst<false, UU, QQ, true>(grid, stream, P, slabs, S, slab_stride, Q, scale, eps, ps, len_valid, Gprev, compute_error, xo, x3_ks, pa, colsq_part, q_out, ns)
+	if (ns != nullptr) {
+		if (S > 8) { if (qsplit == 2) NMFAMD_U32NS(13, 2); else if (qsplit == 4) NMFAMD_U32NS(13, 4); else if (qsplit == 8) NMFAMD_U32NS(13, 8); else NMFAMD_U32NS(13, 1); }
+		else { if (qsplit == 2) NMFAMD_U32NS(7, 2); else if (qsplit == 4) NMFAMD_U32NS(7, 4); else if (qsplit == 8) NMFAMD_U32NS(7, 8); else NMFAMD_U32NS(7, 1); }
+#undef NMFAMD_U32NS
+		return hipGetLastError();
+	}
 	if (is_w) { if (S > 8) NMFAMD_U32(true, 13, 1); else NMFAMD_U32(true, 7, 1); }
 	else if (S > 8) { if (qsplit == 2) NMFAMD_U32(false, 13, 2); else if (qsplit == 4) NMFAMD_U32(false, 13, 4); else if (qsplit == 8) NMFAMD_U32(false, 13, 8); else NMFAMD_U32(false, 13, 1); }
 	else { if (qsplit == 2) NMFAMD_U32(false, 7, 2); else if (qsplit == 4) NMFAMD_U32(false, 7, 4); else if (qsplit == 8) NMFAMD_U32(false, 7, 8); else NMFAMD_U32(false, 7, 1); }

@@ -98,7 +98,7 @@ public:
 	// blocks of every rank have been gathered into w_panel(), w_rows_replaced() drops what was derived from the old W.
 	Status w_update_rows(const T* num_rows, const T* hht, long row0, long rows, bool compute_error, T* colsq);
 	Status w_normalize_rows(long row0, long rows, T* colsq);
-	void w_rows_replaced() { kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
+	void w_rows_replaced() { kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; h_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false; tri_scale_pending_ = false; tri_scale_from_gram_ = false; if (!tri_rows_cover_) wtb_valid_ = false; }
 	T* w_panel() { return Wt_; }
 	int kl_blocks(bool w_step) const { return prm_.divergence != 0 ? (w_step ? kl_blocks_w_ : kl_blocks_h_) : 0; }
 	int gram_k_slices() const { return gram_spread_ ? GRAM_REDUCE_BLOCKS : gram_ksplit_; }      // (16: the spread form)
@@ -114,7 +114,7 @@ public:
 	long w_fragment_words_per_row() const { return RP_ / 2; }
 	// the fragments of every rank's rows have been gathered into w_fragments(); stale: the fp32 rows of the other ranks were not
 	void w_fragments_gathered(bool stale) {
-		kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
+		kl_sw_ready_ = false; kl_scale_pending_ = false; fused_ready_ = false; w_pending_ = false; f32w_pending_ = false; f64_pending_ = false; f64_product_ahead_ = false; h_product_ahead_ = false; gram_w_ready_ = false; wx3_valid_ = false; tri_gw_ready_ = false; qx3_holds_g_ = false;
 		tri_scale_pending_ = false; tri_scale_from_gram_ = false; wtb_valid_ = true; w_rows_stale_ = stale;
 	}
 	void set_w_gather_hook(std::function<Status()> hook) { w_gather_hook_ = std::move(hook); }

@@ -579,7 +579,15 @@ __global__ __launch_bounds__(512) void k_mu64_gram_reduce(GramReduceArgs rg) {
 			const int c = tid & 63, g = tid >> 6;
 			const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
 			float sum = 0.f;
-			for (int p = p0; p < p1; ++p) sum += rg.partials[(long)p * 4096 + c * 65];
+			// (eight loads in flight, added in order: one load per round trip made this launch a chain of parts / 2 dependent loads -- 20 us at 64 parts)
+			for (int p = p0; p < p1; p += 8) {
+				float v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) v[u] = rg.partials[(long)(p + u < p1 ? p + u : p0) * 4096 + c * 65];
+#pragma unroll
+				for (int u = 0; u < 8; ++u)
+					if (p + u < p1) sum += v[u];
+			}
 			s_tmp[g * 64 + c] = sum;
 		}
 		__syncthreads();
@@ -596,7 +604,14 @@ __global__ __launch_bounds__(512) void k_mu64_gram_reduce(GramReduceArgs rg) {
 		const int e = blk * 256 + el;
 		const int p0 = (parts * g) / 2, p1 = (parts * (g + 1)) / 2;
 		float sum = 0.f;
-		for (int p = p0; p < p1; ++p) sum += rg.partials[(long)p * 4096 + e];
+		for (int p = p0; p < p1; p += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = rg.partials[(long)(p + u < p1 ? p + u : p0) * 4096 + e];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (p + u < p1) sum += v[u];
+		}
 		s_tmp[g * 256 + el] = sum;
 	}
 	__syncthreads();

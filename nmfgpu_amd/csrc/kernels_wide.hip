@@ -555,7 +555,24 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_f32(const float* __restric
 // (c = l & 31, h = l >> 5) gathers P(16 s + 8 h + j, block + c), j = 0..7, with eight coalesced 4-byte loads and splits
 // them exactly into three bf16 terms; six 32x32x16 MFMAs per tile and K-step replace eight 32x32x2 fp32 ones at a quarter of
 // their cycles each.  Rows past len are zero up to the padded length (a multiple of 128).
-template <int D>
+#ifndef GW_VAR
+#define GW_VAR 0        // measurement variants (tools/build_variant.sh): 1 no mirrored stores, 2 one accumulator element kept (the compiler drops three quarters of the kernel), 3 no MFMAs, 4 no operand split
+#endif
+#if GW_VAR == 4
+#define GW_SPLIT(v, o) do { f32x4 q_ = {v[0], v[1], v[2], v[3]}; f32x4 q2_ = {v[4], v[5], v[6], v[7]}; o[0] = __builtin_bit_cast(bf16x8, q_); o[1] = __builtin_bit_cast(bf16x8, q2_); o[2] = o[0]; } while (0)
+#else
+#define GW_SPLIT(v, o) split3(v, o[0], o[1], o[2])
+#endif
+#if GW_VAR == 3
+__device__ inline f32x16 gw_no_mfma(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) { c[0] += (float)a[0] * (float)b[0]; return c; }
+#define GW_MFMA(...) gw_no_mfma(__VA_ARGS__)
+#else
+#define GW_MFMA(...) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__VA_ARGS__)
+#endif
+// MIRROR = false (the fused sequence, k_gram_reduce_x3 behind it): only 32 x 32 blocks ON the diagonal are mirrored here; the reduction mirrors the blocks above it
+// once instead of every slice doing it with 4-byte stores a row apart (measured, GW_VAR: of 15.6 us per launch at padded rank 256 the mirrored stores were 6.4, the direct
+// ones 4.1, the MFMAs 3.4, the operand split 0.7; a launch without stores takes 5.0).
+template <int D, bool MIRROR = true>
 __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict__ P, int RP, int len, int parts, float* __restrict__ partial) {
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int half = lane >> 5, l31 = lane & 31;
@@ -602,8 +619,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict
 				bf16x8 ah[2][3], bh[2][3];
 #pragma unroll
 				for (int k = 0; k < 2; ++k) {
-					split3(va[d][k], ah[k][0], ah[k][1], ah[k][2]);
-					split3(vb[d][k], bh[k][0], bh[k][1], bh[k][2]);
+					GW_SPLIT(va[d][k], ah[k]);
+					GW_SPLIT(vb[d][k], bh[k]);
 				}
 				int tn = t + D + d;
 				tn = tn < last ? tn : last;
@@ -618,12 +635,12 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict
 				for (int a = 0; a < 2; ++a)
 #pragma unroll
 					for (int b = 0; b < 2; ++b) {
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
 					}
 				__builtin_amdgcn_sched_barrier(0);
 			}
@@ -635,19 +652,19 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict
 				bf16x8 ah[2][3], bh[2][3];
 #pragma unroll
 				for (int k = 0; k < 2; ++k) {
-					split3(va[d][k], ah[k][0], ah[k][1], ah[k][2]);
-					split3(vb[d][k], bh[k][0], bh[k][1], bh[k][2]);
+					GW_SPLIT(va[d][k], ah[k]);
+					GW_SPLIT(vb[d][k], bh[k]);
 				}
 #pragma unroll
 				for (int a = 0; a < 2; ++a)
 #pragma unroll
 					for (int b = 0; b < 2; ++b) {
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
+						acc[a][b] = GW_MFMA(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
 					}
 			}
 		}
@@ -664,9 +681,10 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict
 			for (int g = 0; g < 16; ++g) {
 				const int r = ca + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * half;
 				const int c = cb + 32 * b + l31;
+				if (GW_VAR == 2 && !(a == 0 && b == 0 && g == 0)) continue;
 				if (r <= c) {
 					out[(long)r * RP + c] = acc[a][b][g];
-					if (r != c) out[(long)c * RP + r] = acc[a][b][g];
+					if (r != c && GW_VAR != 1 && (MIRROR || ca + 32 * a == cb + 32 * b)) out[(long)c * RP + r] = acc[a][b][g];
 				}
 			}
 }
@@ -725,6 +743,10 @@ __global__ __launch_bounds__(256) void k_gram_reduce_x3(const float* __restrict_
 	}
 	// tile = eight rows k x 32 columns c of G (one (K-step, half) of one column block of the split image); the four waves take a quarter of the slices each
 	const int ti = (int)blockIdx.x / nbt, tj = (int)blockIdx.x % nbt;
+	// The slices hold the 32 x 32 blocks on and above the diagonal (k_gram_wide_x3<.., false>): a tile above the diagonal blocks also writes its mirror image --
+	// G(c, k) and the image slots of those rows -- and the tiles below have nothing to do.
+	if ((ti >> 2) > tj) return;
+	const bool mirror = (ti >> 2) < tj;
 	const int rr = t64 >> 3, c4 = 4 * (t64 & 7);
 	const long e = (long)(8 * ti + rr) * RP + 32 * tj + c4, stride = (long)RP * RP;
 	const int p0 = (int)(((long)parts * g) / 4), p1 = (int)(((long)parts * (g + 1)) / 4);
@@ -754,6 +776,22 @@ __global__ __launch_bounds__(256) void k_gram_reduce_x3(const float* __restrict_
 		for (int kk = 0; kk < 8; ++kk) v8[kk] = s_t[kk * 33 + tid];            // rows k = 8 ti + kk of column c = 32 tj + tid
 		store_split3(qx3, (8 * ti) >> 4, nbt, tj, ti & 1, tid, v8);
 	}
+	if (mirror) {
+		// G(k' = 32 tj + j, c' = 8 ti + i) = tile(i, j): 32 rows of eight values; image slots: K-step 2 tj + jg / 2, half jg & 1 of column block ti / 4, lane 8 (ti % 4) + i
+		if (tid < 64) {
+			const int j = tid >> 1, i4 = 4 * (tid & 1);
+			f32x4 o;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) o[k] = s_t[(i4 + k) * 33 + j];
+			*reinterpret_cast<f32x4*>(G + (long)(32 * tj + j) * RP + 8 * ti + i4) = o;
+		} else if (qx3 != nullptr && tid < 96) {
+			const int t = tid - 64, i = t & 7, jg = t >> 3;
+			float v8[8];
+#pragma unroll
+			for (int kk = 0; kk < 8; ++kk) v8[kk] = s_t[i * 33 + 8 * jg + kk];
+			store_split3(qx3, 2 * tj + (jg >> 1), nbt, ti >> 2, jg & 1, 8 * (ti & 3) + i, v8);
+		}
+	}
 }
 
 // G, its split image and (sumsq_part != nullptr) the pending column scale in TWO launches: slices, then k_gram_reduce_x3
@@ -762,7 +800,7 @@ hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts
 	if (!gram_wide_available(RP) || qx3 == nullptr) return hipErrorInvalidValue;
 	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
 	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
-	hipLaunchKernelGGL((k_gram_wide_x3<2>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
+	hipLaunchKernelGGL((k_gram_wide_x3<2, false>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
 	if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
 	const int nbt = RP / 32;
 	hipLaunchKernelGGL(k_gram_reduce_x3, dim3((RP / 8) * nbt + (sumsq_part != nullptr ? RP / 64 : 0)), dim3(256), 0, stream, partial, parts, RP, G, reinterpret_cast<bf16x8*>(qx3),

@@ -441,6 +441,25 @@ Status Engine<T>::allocate() {
 	if (fused32w_capable()) {
 		HIPX(hipMalloc((void**)&f32w_scale_, sizeof(float) * (size_t)RP_));
 		HIPX(hipMemsetAsync(f32w_scale_, 0, sizeof(float) * (size_t)RP_, stream_));
+		// The Gram slices as passengers of the product launch (gram_wide.h) where the product's first round of workgroups leaves CUs free for them and their chain --
+		// a slice's K-steps at ~0.75 us each under the product's memory stream (measured: 625 steps in one slice made a 330 us launch 460) -- stays inside the launch,
+		// or is shorter than the launch of their own it replaces (~10 us); otherwise k_gram_wide_x3.  Measured (profiles/r06_f32w_ride_ab.txt), 10 000 x 5 000:
+		// r = 128 184.4 -> 166.7 us per iteration, r = 158 336.3 -> 309.7; 4096 x 165, r = 158: 103.7 -> 83.6; forced at r = 500 (one slice per super-block): 709 -> 967.
+		// NMFAMD_F32W_RIDE = 0 / 1 (measurement builds): never / wherever a CU is free.
+		const int nbk = RP_ / 128, nsuper = nbk * (nbk + 1) / 2;
+		const char* force = tuning_env("NMFAMD_F32W_RIDE");
+		auto ride = [&](const FactorProductPlan& p, long len) {
+			const int wgs = p.xtiles * p.splits;      // (per layer of 128 columns; the passengers sit in the first layer)
+			if (wgs >= num_cus_ || (force != nullptr && std::atoi(force) == 0)) return 0;
+			const int slices = std::min((num_cus_ - wgs) / nsuper, gram_wide_fused_parts(RP_, (int)len, gram_parts_));
+			if (slices < 1) return 0;
+			const long steps = ((len + 15) / 16 + slices - 1) / slices;
+			const double chain_us = 5.0 + 0.75 * (double)steps;
+			const double product_us = 6.0 + (double)nbk * sizeof(T) * (double)mpad_ * (double)npad_ / 3.2e6;      // (65 us per layer of 128 columns at config 2's shape)
+			return (chain_us <= 0.8 * product_us || steps <= 8 || (force != nullptr && std::atoi(force) == 1)) ? slices : 0;
+		};
+		f32w_ride_h_ = ride(planHx_, m_);
+		f32w_ride_w_ = ride(planWx_, n_);
 	}
 	if (fused64_capable()) {
 		// Gram passengers of the two product launches (kernels_f64.hip, gram_ride_f64): as many K slices per 64 x 64 super-block as the product's grid leaves CUs for,
@@ -886,7 +905,7 @@ Status Engine<T>::product_h(const T* F, const GramReduceArgs* rg, bool prepacked
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, m_, Wx3_, ksH_, stream_));
-			if (rg && !passengers_ride(planHx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && rg->wide_P == nullptr && !passengers_ride(planHx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			hipEvent_t e0, e1;
 			const bool timed = timed_launch_events(0, &e0, &e1);
 			if (one_image_) HIPX(launch_factor_product_x3(planHx_, V_, strideV_, Wx3_, RP_, slabs_, slab_stride_, stream_, rg, nullptr, true, img_th_, e0, e1));
@@ -941,7 +960,7 @@ Status Engine<T>::product_w(const T* F, const GramReduceArgs* rg, T* single_slab
 		}
 		if (x3_) {
 			if (!prepacked) HIPX(launch_pack_panel_x3(F, RP_, n_, Hx3_, ksW_, stream_));
-			if (rg && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
+			if (rg && rg->wide_P == nullptr && !passengers_ride(planWx_)) { if (Status st = standalone_gram(*rg)) return st; rg = nullptr; }
 			hipEvent_t e0, e1;
 			const bool timed = timed_launch_events(1, &e0, &e1);
 			HIPX(launch_factor_product_x3(planWx_, V_, strideV_, Hx3_, RP_, dest, slab_stride_, stream_, rg, nullptr, false, img_th_, e0, e1));
@@ -1516,8 +1535,15 @@ Status Engine<T>::iterate_fused32w(bool compute_error) {
 		const int norm_parts = panel_update_parts(RP_, sizeof(T), (int)mpad_);
 		const float* dscale = f32w_pending_ ? f32w_scale_ : nullptr;
 		// H step
-		HIPX(launch_gram_wide_fused_f32(Wt_, RP_, m_, gram_parts_, gram_part_, G_, qx3_, f32w_pending_ ? sumsq_part_ : nullptr, norm_parts, f32w_scale_, stream_));
-		if (Status s = product_h(Wt_, nullptr, wx3_valid_)) return s;
+		if (f32w_ride_h_ > 0) {
+			GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
+			rg.wide_P = Wt_; rg.wide_len = m_; rg.wide_parts = f32w_ride_h_; rg.wide_partial = gram_part_;
+			if (Status s = product_h(Wt_, &rg, wx3_valid_)) return s;
+			HIPX(launch_gram_reduce_x3(gram_part_, f32w_ride_h_, RP_, G_, qx3_, f32w_pending_ ? sumsq_part_ : nullptr, norm_parts, f32w_scale_, stream_));
+		} else {
+			HIPX(launch_gram_wide_fused_f32(Wt_, RP_, m_, gram_parts_, gram_part_, G_, qx3_, f32w_pending_ ? sumsq_part_ : nullptr, norm_parts, f32w_scale_, stream_));
+			if (Status s = product_h(Wt_, nullptr, wx3_valid_)) return s;
+		}
 		wx3_valid_ = true;
 		PanelFusedF32 fh;
 		fh.h_side = 1; fh.scale = dscale; fh.r = r_;
@@ -1527,8 +1553,15 @@ Status Engine<T>::iterate_fused32w(bool compute_error) {
 		                                  stream_, qx3_, nullptr, &fh));
 		// W step
 		const float* Fh = ns ? Hs_ : H_;
-		HIPX(launch_gram_wide_fused_f32(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, qx3_, nullptr, 0, nullptr, stream_));
-		if (Status s = product_w(Fh, nullptr, nullptr, true)) return s;
+		if (f32w_ride_w_ > 0) {
+			GramReduceArgs rg = {nullptr, 0, nullptr, nullptr, 0};
+			rg.wide_P = Fh; rg.wide_len = n_; rg.wide_parts = f32w_ride_w_; rg.wide_partial = gram_part_;
+			if (Status s = product_w(Fh, &rg, nullptr, true)) return s;
+			HIPX(launch_gram_reduce_x3(gram_part_, f32w_ride_w_, RP_, HHt_, qx3_, nullptr, 0, nullptr, stream_));
+		} else {
+			HIPX(launch_gram_wide_fused_f32(Fh, RP_, n_, gram_parts_, gram_part_, HHt_, qx3_, nullptr, 0, nullptr, stream_));
+			if (Status s = product_w(Fh, nullptr, nullptr, true)) return s;
+		}
 		hx3_valid_ = !ns;
 		// tr((S H)(S H)^T W^T W) with the W^T W of this iteration's H step (the pending scale applied on the way: D G D)
 		if (compute_error) HIPX(launch_trace_small<T>(HHt_, G_, RP_, r_, psR_, stream_, nullptr, dscale));

@@ -103,8 +103,11 @@ public:
 	int kl_blocks(bool w_step) const { return prm_.divergence != 0 ? (w_step ? kl_blocks_w_ : kl_blocks_h_) : 0; }
 	int gram_k_slices() const { return gram_spread_ ? GRAM_REDUCE_BLOCKS : gram_ksplit_; }      // (16: the spread form)
 	bool w_col_split() const { return w_col_split_; }
-	int fused_launches() const { return (fused_capable() && !one_pass_ && gram_image_) || (f64_partial_ != nullptr && fused64_capable()) ? 4 : (f32w_scale_ != nullptr && fused32w_capable() ? 8 : 0); }
-	int gram_ride_slices(bool w_side) const { return f64_partial_ == nullptr ? 0 : (w_side ? f64_slices_w_ : f64_slices_h_); }
+	int fused_launches() const {
+		if ((fused_capable() && !one_pass_ && gram_image_) || (f64_partial_ != nullptr && fused64_capable())) return 4;
+		return f32w_scale_ != nullptr && fused32w_capable() ? 8 - (f32w_ride_h_ > 0 ? 1 : 0) - (f32w_ride_w_ > 0 ? 1 : 0) : 0;
+	}
+	int gram_ride_slices(bool w_side) const { return f64_partial_ != nullptr ? (w_side ? f64_slices_w_ : f64_slices_h_) : (f32w_scale_ != nullptr ? (w_side ? f32w_ride_w_ : f32w_ride_h_) : 0); }
 	// Row-block form at padded rank 256 with bf16 operands (config 4): between two W updates the OTHER ranks read only the bf16 fragments of a rank's rows (the next
 	// W^T V's operand and the Gram matrix are made from them) -- so the all-gather carries the fragments w_normalize_rows() left for this rank's rows (RP / 2 four-byte
 	// words per row: 25.6 MB at config 4 instead of 51.2 MB of fp32 rows) and the fp32 rows of the other ranks stay STALE in w_panel() until somebody needs them
@@ -315,6 +318,7 @@ private:
 	// the column scale is applied by the consumers (kernels_f64.hip: gram_ride_f64 -> f64_scale_, PanelFusedF64) -- materialize_w() folds it into the panel
 	bool f32w_pending_ = false;                      // fused fp32 iteration at padded ranks >= 128: Wt_ unnormalised, sumsq_part_ holds its sums of squares, Wx3_ its split image
 	float* f32w_scale_ = nullptr;                    // ... the pending column scale (k_gram_reduce_x3)
+	int f32w_ride_h_ = 0, f32w_ride_w_ = 0;         // ... K slices per super-block of W^T W / H H^T that ride the product launches as passenger workgroups (0: a launch of their own)
 	bool f64_pending_ = false;
 	bool f64_product_ahead_ = false;                 // begin_next_iteration() has enqueued launch 1 of the next iterate_fused64 (cleared by whatever changes W, H or V)
 	Status fused64_product_h();

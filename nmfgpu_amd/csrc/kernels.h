@@ -81,6 +81,12 @@ struct GramReduceArgs {
 	float* tri_diag = nullptr;
 	float* tri_partial = nullptr;       // [TRI_PASSENGERS / 2][36][1024] partial tiles
 	unsigned* tri_counters = nullptr;   // two counters, zero between launches
+	// fifth kind (split-operand product at padded ranks 128 ... 512, gram_wide.h): wide_parts K slices of every 128 x 128 super-block of the Gram matrix of the
+	// fp32 panel wide_P (wide_len valid rows) as passenger workgroups -- what k_gram_wide_x3 does as a launch of its own; wide_partial: [wide_parts][RP][RP]
+	// (blocks on and above the diagonal), reduced by launch_gram_reduce_x3 behind the product launch
+	const float* wide_P = nullptr;
+	int wide_len = 0, wide_parts = 0;
+	float* wide_partial = nullptr;
 };
 constexpr int GRAM_REDUCE_BLOCKS = 16;
 constexpr int TRI_PASSENGERS = 32;                 // tri_gram_tile.h: 16 K slices x 2 halves of the 36 upper-triangle tiles
@@ -240,6 +246,10 @@ hipError_t launch_panel_update_wide_f32(int mode, float* P, const float* slabs, 
                                         float eps, float* ps, int len_valid, float* sumsq_part, float* num_out, hipStream_t stream,
                                         void* q_split = nullptr, const PanelTriExtras* tri = nullptr, const PanelFusedF32* fused = nullptr);
 // G = P P^T, its split image (the update kernel's operand: launch_panel_update_wide_f32 with Q == nullptr) and, W side, the pending column scale -- two launches
+// the second half of launch_gram_wide_fused_f32 on its own: the slices came from passenger workgroups of a product launch (GramReduceArgs::wide_P)
+hipError_t launch_gram_reduce_x3(const float* partial, int parts, int RP, float* G, void* qx3, const float* sumsq_part, int sq_parts, float* scale_out, hipStream_t stream);
+// the slice count launch_gram_wide_fused_f32 settles on (at most `parts`)
+int gram_wide_fused_parts(int RP, int len, int parts);
 hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts, float* partial, float* G, void* qx3, const float* sumsq_part, int sq_parts,
                                       float* scale_out, hipStream_t stream);
 template <typename T>

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "tuning.h"
 #include "split3.h"
+#include "gram_wide.h"
 
 namespace nmfamd {
 
@@ -551,142 +552,10 @@ __global__ __launch_bounds__(256, 2) void k_gram_wide_f32(const float* __restric
 			}
 }
 
-// The same Gram matrix at fp32 accuracy on the bf16 matrix pipe (kernels_x3.hip): K-step = 16 panel rows, a lane
-// (c = l & 31, h = l >> 5) gathers P(16 s + 8 h + j, block + c), j = 0..7, with eight coalesced 4-byte loads and splits
-// them exactly into three bf16 terms; six 32x32x16 MFMAs per tile and K-step replace eight 32x32x2 fp32 ones at a quarter of
-// their cycles each.  Rows past len are zero up to the padded length (a multiple of 128).
-#ifndef GW_VAR
-#define GW_VAR 0        // measurement variants (tools/build_variant.sh): 1 no mirrored stores, 2 one accumulator element kept (the compiler drops three quarters of the kernel), 3 no MFMAs, 4 no operand split
-#endif
-#if GW_VAR == 4
-#define GW_SPLIT(v, o) do { f32x4 q_ = {v[0], v[1], v[2], v[3]}; f32x4 q2_ = {v[4], v[5], v[6], v[7]}; o[0] = __builtin_bit_cast(bf16x8, q_); o[1] = __builtin_bit_cast(bf16x8, q2_); o[2] = o[0]; } while (0)
-#else
-#define GW_SPLIT(v, o) split3(v, o[0], o[1], o[2])
-#endif
-#if GW_VAR == 3
-__device__ inline f32x16 gw_no_mfma(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) { c[0] += (float)a[0] * (float)b[0]; return c; }
-#define GW_MFMA(...) gw_no_mfma(__VA_ARGS__)
-#else
-#define GW_MFMA(...) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__VA_ARGS__)
-#endif
-// MIRROR = false (the fused sequence, k_gram_reduce_x3 behind it): only 32 x 32 blocks ON the diagonal are mirrored here; the reduction mirrors the blocks above it
-// once instead of every slice doing it with 4-byte stores a row apart (measured, GW_VAR: of 15.6 us per launch at padded rank 256 the mirrored stores were 6.4, the direct
-// ones 4.1, the MFMAs 3.4, the operand split 0.7; a launch without stores takes 5.0).
+// (the slice's body: gram_wide.h -- shared with the passenger workgroups of the product launch)
 template <int D, bool MIRROR = true>
 __global__ __launch_bounds__(256, 2) void k_gram_wide_x3(const float* __restrict__ P, int RP, int len, int parts, float* __restrict__ partial) {
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-	const int half = lane >> 5, l31 = lane & 31;
-	const int nb = RP / 128;
-	int I = 0, rem = blockIdx.y;
-	while (rem >= nb - I) { rem -= nb - I; ++I; }
-	const int J = I + rem;
-	const int wi = wave >> 1, wj = wave & 1;
-	const int ca = 128 * I + 64 * wi, cb = 128 * J + 64 * wj;
-	const int steps_total = (len + 15) / 16;
-	const int s0 = (int)(((long)steps_total * blockIdx.x) / parts);
-	const int s1 = (int)(((long)steps_total * (blockIdx.x + 1)) / parts);
-	const int steps = s1 - s0;
-
-	f32x16 acc[2][2];
-#pragma unroll
-	for (int a = 0; a < 2; ++a)
-#pragma unroll
-		for (int b = 0; b < 2; ++b)
-#pragma unroll
-			for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
-
-	if (steps > 0) {
-		const float* pa = P + ((long)16 * s0 + 8 * half) * RP + ca + l31;
-		const float* pb = P + ((long)16 * s0 + 8 * half) * RP + cb + l31;
-		const int last = steps - 1;
-		float va[D][2][8], vb[D][2][8];
-#pragma unroll
-		for (int d = 0; d < D; ++d) {
-			const int t = d < last ? d : last;
-#pragma unroll
-			for (int k = 0; k < 2; ++k)
-#pragma unroll
-				for (int j = 0; j < 8; ++j) {
-					va[d][k][j] = pa[((long)16 * t + j) * RP + 32 * k];
-					vb[d][k][j] = pb[((long)16 * t + j) * RP + 32 * k];
-				}
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		int t = 0;
-		for (; t + D <= steps; t += D) {
-#pragma unroll
-			for (int d = 0; d < D; ++d) {
-				bf16x8 ah[2][3], bh[2][3];
-#pragma unroll
-				for (int k = 0; k < 2; ++k) {
-					GW_SPLIT(va[d][k], ah[k]);
-					GW_SPLIT(vb[d][k], bh[k]);
-				}
-				int tn = t + D + d;
-				tn = tn < last ? tn : last;
-#pragma unroll
-				for (int k = 0; k < 2; ++k)
-#pragma unroll
-					for (int j = 0; j < 8; ++j) {
-						va[d][k][j] = pa[((long)16 * tn + j) * RP + 32 * k];
-						vb[d][k][j] = pb[((long)16 * tn + j) * RP + 32 * k];
-					}
-#pragma unroll
-				for (int a = 0; a < 2; ++a)
-#pragma unroll
-					for (int b = 0; b < 2; ++b) {
-						acc[a][b] = GW_MFMA(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
-					}
-				__builtin_amdgcn_sched_barrier(0);
-			}
-		}
-		const int remn = steps - t;
-#pragma unroll
-		for (int d = 0; d < D; ++d) {
-			if (d < remn) {
-				bf16x8 ah[2][3], bh[2][3];
-#pragma unroll
-				for (int k = 0; k < 2; ++k) {
-					GW_SPLIT(va[d][k], ah[k]);
-					GW_SPLIT(vb[d][k], bh[k]);
-				}
-#pragma unroll
-				for (int a = 0; a < 2; ++a)
-#pragma unroll
-					for (int b = 0; b < 2; ++b) {
-						acc[a][b] = GW_MFMA(ah[a][2], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][2], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][1], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][1], bh[b][0], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][1], acc[a][b], 0, 0, 0);
-						acc[a][b] = GW_MFMA(ah[a][0], bh[b][0], acc[a][b], 0, 0, 0);
-					}
-			}
-		}
-	}
-	// Only the upper triangle (r <= c) is taken from the accumulators and mirrored: the six-term sum of (r, c) and of
-	// (c, r) adds the same products in a different order, and G must be exactly symmetric (the reference computes one
-	// triangle, syrk, and reads it through symm).
-	float* out = partial + (long)blockIdx.x * RP * RP;
-#pragma unroll
-	for (int a = 0; a < 2; ++a)
-#pragma unroll
-		for (int b = 0; b < 2; ++b)
-#pragma unroll
-			for (int g = 0; g < 16; ++g) {
-				const int r = ca + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * half;
-				const int c = cb + 32 * b + l31;
-				if (GW_VAR == 2 && !(a == 0 && b == 0 && g == 0)) continue;
-				if (r <= c) {
-					out[(long)r * RP + c] = acc[a][b][g];
-					if (r != c && GW_VAR != 1 && (MIRROR || ca + 32 * a == cb + 32 * b)) out[(long)c * RP + r] = acc[a][b][g];
-				}
-			}
+	gram_wide_slice<D, MIRROR>(P, RP, len, parts, partial, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 bool gram_wide_available(int RP) { return RP >= 128 && RP % 128 == 0; }
@@ -795,17 +664,27 @@ __global__ __launch_bounds__(256) void k_gram_reduce_x3(const float* __restrict_
 }
 
 // G, its split image and (sumsq_part != nullptr) the pending column scale in TWO launches: slices, then k_gram_reduce_x3
-hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts, float* partial, float* G, void* qx3, const float* sumsq_part, int sq_parts,
-                                      float* scale_out, hipStream_t stream) {
-	if (!gram_wide_available(RP) || qx3 == nullptr) return hipErrorInvalidValue;
+int gram_wide_fused_parts(int RP, int len, int parts) {
 	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
-	parts = std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
-	hipLaunchKernelGGL((k_gram_wide_x3<2, false>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
-	if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+	return std::max(1, std::min(std::min(parts, std::max(16, 512 / nsuper)), std::max(1, len / 64)));
+}
+
+hipError_t launch_gram_reduce_x3(const float* partial, int parts, int RP, float* G, void* qx3, const float* sumsq_part, int sq_parts, float* scale_out, hipStream_t stream) {
+	if (!gram_wide_available(RP) || qx3 == nullptr || parts < 1) return hipErrorInvalidValue;
 	const int nbt = RP / 32;
 	hipLaunchKernelGGL(k_gram_reduce_x3, dim3((RP / 8) * nbt + (sumsq_part != nullptr ? RP / 64 : 0)), dim3(256), 0, stream, partial, parts, RP, G, reinterpret_cast<bf16x8*>(qx3),
 	                   sumsq_part, sq_parts, scale_out);
 	return hipGetLastError();
+}
+
+hipError_t launch_gram_wide_fused_f32(const float* P, int RP, int len, int parts, float* partial, float* G, void* qx3, const float* sumsq_part, int sq_parts,
+                                      float* scale_out, hipStream_t stream) {
+	if (!gram_wide_available(RP) || qx3 == nullptr) return hipErrorInvalidValue;
+	const int nb = RP / 128, nsuper = nb * (nb + 1) / 2;
+	parts = gram_wide_fused_parts(RP, len, parts);
+	hipLaunchKernelGGL((k_gram_wide_x3<2, false>), dim3(parts, nsuper), dim3(256), 0, stream, P, RP, len, parts, partial);
+	if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+	return launch_gram_reduce_x3(partial, parts, RP, G, qx3, sumsq_part, sq_parts, scale_out, stream);
 }
 
 

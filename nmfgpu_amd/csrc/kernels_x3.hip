@@ -25,6 +25,7 @@
 #include "split3.h"
 #include "inverse_gj64.h"
 #include "gram_image.h"
+#include "gram_wide.h"
 
 namespace nmfamd {
 
@@ -172,6 +173,14 @@ __global__ __launch_bounds__(64 * X3_WAVES, NBW == 1 ? 2 : 1) void k_factor_prod
 	const int pblocks = xtiles * splits * (FOLD ? 2 : 1);
 	if (blockIdx.x >= (unsigned)pblocks) {
 		if (blockIdx.y != 0) return;                            // (one set of passengers, whatever the number of column chunks)
+		if constexpr (NBW == 4) {
+			// padded ranks 128 ... 512: K slices of the panel's Gram matrix (gram_wide.h; ring of four K-steps -- under the product's memory stream a load comes back late)
+			if (rg.wide_P != nullptr) {
+				const int pid = (int)blockIdx.x - pblocks;
+				gram_wide_slice<4, false>(rg.wide_P, RP, rg.wide_len, rg.wide_parts, rg.wide_partial, pid % rg.wide_parts, pid / rg.wide_parts);
+			}
+			return;
+		}
 		// the 64 x 64 inverse of the least-squares algorithms rides as ONE block right behind the product's last one
 		if (rg.inv_a != nullptr) inverse_gj64_body<float, X3_WAVES>(rg.inv_a, 64, rg.inv_r, rg.inv_out, rg.inv_offdiag, rg.inv_diag);
 		else if (rg.image != nullptr) { if (X3_WAVES == 4) gram_image_block(rg, blockIdx.x - pblocks, lds); }
@@ -485,12 +494,15 @@ template <int D, int WAVES, int DIAG = 0, int NBW = 2, bool TR = false, int IMG 
 static hipError_t launch_fp_x3(const FactorProductPlan& p, const float* A, long tile_stride, const void* F, int RP,
                                float* slabs, long slab_stride, hipStream_t stream, const GramReduceArgs* rg, unsigned long long* stamps = nullptr) {
 	GramReduceArgs none = {nullptr, 0, nullptr, nullptr, 0};
-	const bool wanted = rg != nullptr && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
+	const bool wide = rg != nullptr && rg->wide_P != nullptr;
+	if (wide && (NBW != 4 || RP % 128 != 0 || rg->wide_parts < 1 || rg->wide_partial == nullptr)) return hipErrorInvalidValue;
+	const bool wanted = rg != nullptr && !wide && (rg->partials != nullptr || rg->inv_a != nullptr || rg->image != nullptr);
 	// (the passengers sit behind the product blocks in the grid, whatever the number of x-tiles; the caller sees to it that they find a CU
 	//  while the product runs -- Engine::passengers_ride)
-	const bool with_reduce = wanted && RP == 64;
+	const bool with_reduce = (wanted && RP == 64) || wide;
 	if (wanted && !with_reduce) return hipErrorInvalidValue;
-	const int passengers = !with_reduce ? 0 : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
+	const int passengers = !with_reduce ? 0 : wide ? rg->wide_parts * ((RP / 128) * (RP / 128 + 1) / 2)
+	                                    : (rg->inv_a != nullptr ? 1 : (rg->image != nullptr && rg->ksplit > 1) ? GRAM_IMAGE_TILES * rg->ksplit : GRAM_REDUCE_BLOCKS);
 	if (NBW == 1 && RP != 64) return hipErrorInvalidValue;
 	dim3 grid(p.xtiles * p.splits * (NBW == 1 ? 2 : 1) + passengers, NBW == 1 ? 1 : RP / (32 * NBW), 1), block(64 * WAVES);
 	const size_t lds_bytes = std::max<size_t>(std::max<size_t>(WAVES * ((X3_EPILOGUE_ONE_ROUND && NBW == 2 && !YLDS) ? 8 : 4) * 4 * 64 * sizeof(f32x4), 1024 * sizeof(float)),

@@ -14,7 +14,8 @@
 //     NMFAMD_TRI_FP32_DEN, NMFAMD_NORMALIZE_TWO_LAUNCHES; also NMFAMD_ERROR_COPY_KERNEL (error terms through k_copy_small instead of written by the update kernels) and
 //     NMFAMD_GRAM_SPREAD (0: a tile per Gram passenger instead of the spread form).  Round 6 moved here: NMFAMD_ONE_PASS with its kernel (kernels_onepass.hip is
 //     compiled into the measurement build only), and added NMFAMD_RIDE64_STOP / NMFAMD_F64_STAMPS / NMFAMD_F64_MIN_STEPS / NMFAMD_F64_HALF_TILES /
-//     NMFAMD_RIDE64_PID_ORDER (double-precision fused iteration) and NMFAMD_BF_VARIANT (the config-4 product's loop with parts taken out).
+//     NMFAMD_RIDE64_PID_ORDER (double-precision fused iteration), NMFAMD_BF_VARIANT (the config-4 product's loop with parts taken out) and NMFAMD_F32W_RIDE
+//     (0 / 1: the wide fp32 Gram slices never / always as passengers of the product launch).
 #pragma once
 
 #include <cstdlib>

@@ -53,7 +53,8 @@ def test_fused_wide_iteration_against_the_oracle_and_the_generic_sequence(alg, m
     ref = oracle.run(alg, V64, W64, H64, iters, **kw)
     eng, Wg, Hg = run_engine(V, W, H, alg, iters, error_every=4, **kw)
     g = eng.geometry()
-    assert g["fused_launches"] == 8 and g["product_kernel"] == 2 and g["padded_rank"] == 128 * ((r + 127) // 128)
+    # (eight launches; seven or six where the Gram slices of a side ride its product launch as passenger workgroups)
+    assert g["fused_launches"] == 8 - (g["gram_ride_slices_h"] > 0) - (g["gram_ride_slices_w"] > 0) and g["product_kernel"] == 2 and g["padded_rank"] == 128 * ((r + 127) // 128)
     assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4, (rel(Wg, W64), rel(Hg, H64))
     assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)
     monkeypatch.setenv("NMFAMD_NO_FUSED_MU", "1")
@@ -92,3 +93,24 @@ def test_repeated_fused_wide_runs_are_bit_identical():
     for _ in range(2):
         _, Wb, Hb = run_engine(V, W, H, "mu", iters)
         assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+
+
+@pytest.mark.parametrize("ride", ["0", "1"])
+@pytest.mark.parametrize("alg,m,n,r,kw", [("mu", 1500, 610, 100, {}), ("nsnmf", 2100, 900, 158, dict(theta=0.5)), ("mu", 410, 1300, 500, {})])
+def test_gram_slices_as_passengers_and_as_a_launch_give_the_same_bits(alg, m, n, r, kw, ride, monkeypatch, diag_build):
+    """The Gram slices of the wide fp32 iteration run as passenger workgroups of the product launch where its first round leaves CUs free (csrc/gram_wide.h), as a
+    launch of their own otherwise.  The slice count differs between the two forms, so G differs by rounding; both forms against the oracle at the fp32 tolerance, and
+    the form the measurement build is forced into is the one reported."""
+    iters = 10
+    V, W, H = problem(m, n, r, seed=r + m)
+    V64, W64, H64 = (F(x.astype(np.float64)) for x in (V, W, H))
+    ref = oracle.run(alg, V64, W64, H64, iters, **kw)
+    monkeypatch.setenv("NMFAMD_F32W_RIDE", ride)
+    eng, Wg, Hg = run_engine(V, W, H, alg, iters, error_every=5, **kw)
+    g = eng.geometry()
+    if ride == "0":
+        assert g["fused_launches"] == 8 and g["gram_ride_slices_h"] == 0 and g["gram_ride_slices_w"] == 0
+    else:
+        assert g["gram_ride_slices_h"] > 0 and g["gram_ride_slices_w"] > 0 and g["fused_launches"] == 6
+    assert rel(Wg, W64) < 2e-4 and rel(Hg, H64) < 2e-4, (rel(Wg, W64), rel(Hg, H64))
+    assert eng.frobenius == pytest.approx(ref["frobenius"], rel=1e-5)

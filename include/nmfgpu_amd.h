@@ -140,13 +140,15 @@ typedef struct nmfamd_geometry {
 	                                   to the sixteen passengers of a whole problem's W^T V launch (up to three pieces per tile, added in order) */
 	int w_col_split;                /* 1: V H^T runs as 128 x 32 workgroups (narrow column shards) */
 	/* round 6 */
-	int fused_launches;             /* 4: an iteration is product (+ Gram passengers) / update / product (+ Gram passengers) / update -- fp32 at padded rank 64 and,
-	                                   round 6, double precision (multiplicative update and nsNMF, padded ranks up to 512); 8: fp32 at padded ranks 128 ... 512
-	                                   (Gram slices, reduction + split image + scale, product, update -- twice; the generic sequence: 14); 0: the generic launch sequence */
+	int fused_launches;             /* 4: an iteration is product (+ Gram passengers) / update / product (+ Gram passengers) / update -- fp32 at padded rank 64
+	                                   (multiplicative update; nsNMF on the split-operand products) and, round 6, double precision (multiplicative update and nsNMF,
+	                                   padded ranks up to 512); 8: fp32 at padded ranks 128 ... 512 (Gram slices, reduction + split image + scale, product, update --
+	                                   twice; the generic sequence: 14), 7 or 6 where the Gram slices of a side ride its product launch; 0: the generic launch sequence */
 	int sparse_setup;               /* sparse compute: where the CSR + CSC images of the last upload were built: 1 = on the device (kernels_sparse_setup.hip),
 	                                   0 = on the host (NMFAMD_SPARSE_SETUP=host, or an input the device path hands back: entries outside the matrix, a row or
 	                                   column of more than 8 192 entries, pointer arrays that do not ascend), -1 = not a sparse-compute engine */
-	int gram_ride_slices_h, gram_ride_slices_w;   /* double precision: K slices per 64 x 64 super-block of the Gram passengers riding in W^T V / V H^T (they fix the order of the partial sums) */
+	int gram_ride_slices_h, gram_ride_slices_w;   /* K slices per super-block of the Gram passengers riding in W^T V / V H^T -- double precision (64 x 64 super-blocks) and
+	                                                 fp32 at padded ranks 128 ... 512 (128 x 128; 0: the slices are a launch of their own); they fix the order of the partial sums */
 } nmfamd_geometry;
 NMFAMD_API int nmfamd_engine_geometry(const nmfamd_engine* e, nmfamd_geometry* out);
 /* The same for a caller compiled against an older (shorter) or newer (longer) nmfamd_geometry: writes min(struct_size, sizeof(nmfamd_geometry)) bytes, never
